@@ -1,0 +1,262 @@
+"""Generate tests/golden/*.pt by running the UNMODIFIED reference (/root/reference) on CPU.
+
+TEST INFRASTRUCTURE ONLY.  Run in the build container (the reference tree is absent on the
+GPU box):   python -m oracle.gen_golden
+While generating, every case is also replayed through the CPU restatement (oracle/ref_ops.py,
+oracle/ref_model.py) and must agree (logits bit-identical, token streams identical, top-k
+tie-tolerant) — that is how the oracle is pinned (the reference has no
+golden vectors of its own for this path).
+"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import _refshim, specs, ref_ops as R, ref_model as M  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def build_reference_model(ref, cfg, sd, draft=False):
+    """Constructor + load_state_dict (never from_pretrained: SURVEY §8c pitfall (i))."""
+    kw = {k: v for k, v in cfg.items() if not k.startswith("_")}
+    hf_cfg = ref.config_yarn.LlamaConfig(**kw)
+    hf_cfg._name_or_path = cfg["_name_or_path"]
+    cls = ref.modeling_llama_68m.LlamaForCausalLM if draft else ref.modeling_llama.LlamaForCausalLM
+    m = cls(hf_cfg)
+    m = m.to(torch.float16)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("rotary_emb" in k for k in missing), missing
+    return m.eval()
+
+
+def triforce_case(name, tcfg, dcfg, tseed, dseed, pseed, prefill, budget, gamma, chunk, gen_len,
+                  temperature, top_p, rng_seed=None, repeats=1, head_std=0.05):
+    ref = _refshim.load_reference()
+    tsd = specs.random_state_dict(tcfg, tseed, head_std=head_std)
+    dsd = specs.random_state_dict(dcfg, dseed, head_std=head_std)
+    prompt = specs.random_prompt(tcfg["vocab_size"], prefill, pseed)
+    recent = 256 - 16 - gamma                                    # on_chip.py:76-80
+
+    # ---------------- reference ----------------
+    target = build_reference_model(ref, tcfg, tsd)
+    draft = build_reference_model(ref, dcfg, dsd, draft=True)
+    cache = ref.cache.FlashSimpleCache(target, prefill + gen_len + 16)
+    gcache = ref.cache.RetrievalCache(target, max_budget=budget, prefill=prefill, gamma=gamma, chunk_size=chunk)
+    dcache = ref.cache.StreamingLLMEvictionCache(draft, start_size=16, recent_size=recent, gamma=gamma)
+    eng = _refshim.EagerEngine(ref, target, cache, gcache, draft, dcache, temperature, top_p)
+    tok = _refshim.FakeTokenizer()
+
+    # record the retrieval build (scores fed to torch.topk and the indices it returned)
+    topk_log = []
+    real_topk = torch.topk
+
+    def spy_topk(x, k, dim=-1, **kw):
+        out = real_topk(x, k=k, dim=dim, **kw)
+        if x.dim() == 3 and x.dtype == torch.float16:
+            topk_log.append((x.clone(), out[1].clone()))
+        return out
+
+    streams = []
+    ref_dec = ref.decoding
+    emitted = []
+    orig_stream = ref_dec.spec_stream
+
+    def record(t, tokenizer, color="blue"):
+        emitted.append(int(torch.as_tensor(t).reshape(-1)[0]))
+
+    ref_dec.spec_stream = record
+
+    def run_ref_triforce():
+        emitted.clear()
+        if rng_seed is not None:
+            torch.manual_seed(rng_seed)
+        torch.topk = spy_topk
+        try:
+            acc, _ = ref_dec.TriForce(tok, eng, prompt, gamma=gamma, max_len=gen_len, top_k=-1, top_p=top_p,
+                                      temperature=temperature, verbose=True)
+        finally:
+            torch.topk = real_topk
+        return list(emitted), acc
+
+    def run_ref_ar():
+        emitted.clear()
+        if rng_seed is not None:
+            torch.manual_seed(rng_seed)
+        ref_dec.Autoregressive(tok, eng, prompt, max_len=gen_len, top_k=-1, top_p=top_p,
+                               temperature=temperature, verbose=True)
+        return list(emitted)
+
+    t0 = time.time()
+    ar_tokens = run_ref_ar()
+    for _ in range(repeats):
+        topk_log.clear()
+        toks, acc = run_ref_triforce()
+        streams.append(dict(tokens=toks, acceptance_rate=acc,
+                            final_seq_len=cache.seq_len, draft_seq_len=dcache.seq_len))
+    ref_dec.spec_stream = orig_stream
+    t_ref = time.time() - t0
+    ref_scores = torch.stack([s[0][0] for s in topk_log])       # (L, H, C-1) fp16 (chunk 0 dropped)
+    ref_topk_rest = torch.stack([s[1][0] for s in topk_log])     # (L, H, sets-1) (0-based into [:,1:])
+    ref_retr_k = gcache.key_cache[:, 0].clone()
+    ref_retr_v = gcache.value_cache[:, 0].clone()
+
+    # ---------------- oracle restatement ----------------
+    ot, od = M.OracleTarget(tcfg, tsd), M.OracleDraft(dcfg, dsd)
+    okv = M.FullCache(tcfg, prefill + gen_len + 16)
+    ogc = M.RetrievalCacheO(tcfg, budget, prefill, chunk, gamma)
+    odc = M.StreamingCacheO(dcfg, gamma=gamma, start_size=16, recent_size=recent)
+    oeng = M.OracleEngine(ot, okv, ogc, od, odc, temperature, top_p)
+    if rng_seed is not None:
+        torch.manual_seed(rng_seed)
+    o_ar = M.autoregressive(oeng, prompt, gen_len, temperature, top_p)
+    assert o_ar == ar_tokens, f"[{name}] AR stream mismatch\n{o_ar}\n{ar_tokens}"
+    o_streams = []
+    for rep in range(repeats):
+        if rng_seed is not None:
+            torch.manual_seed(rng_seed)
+        trace = []
+        res = M.triforce(oeng, prompt, gamma, gen_len, temperature, top_p, trace=trace)
+        o_streams.append(res)
+        assert res["tokens"] == streams[rep]["tokens"], \
+            f"[{name}] TriForce stream mismatch (rep {rep})\n{res['tokens']}\n{streams[rep]['tokens']}"
+        assert abs(res["acceptance_rate"] - streams[rep]["acceptance_rate"]) < 1e-12
+        assert okv.seq_len == streams[rep]["final_seq_len"] and odc.seq_len == streams[rep]["draft_seq_len"]
+    # stage-wise: scores bit-identical, top-k tie-tolerant, and (given the canonical tie rule)
+    # gathered cache identical wherever the index sets agree
+    o_scores = torch.stack(ogc.last_scores)                      # (L,H,C)
+    assert torch.equal(o_scores[:, :, 1:], ref_scores), f"[{name}] retrieval scores differ"
+    o_idx = torch.stack(ogc.last_idx)                            # (L,H,sets)
+    ref_idx = torch.cat([torch.zeros_like(ref_topk_rest[:, :, :1]), ref_topk_rest + 1], dim=-1)
+    for l in range(o_idx.shape[0]):
+        assert R.topk_matches_reference(o_scores[l], o_idx[l], ref_idx[l]), f"[{name}] top-k layer {l}"
+    same_order = torch.equal(o_idx, ref_idx)
+    if same_order:
+        assert torch.equal(ogc.key_cache, ref_retr_k) and torch.equal(ogc.value_cache, ref_retr_v)
+    if temperature == 1.0 and top_p < 1e-6:
+        # known-answer invariant: greedy TriForce == greedy autoregressive
+        n = min(len(ar_tokens), len(streams[0]["tokens"]))
+        assert streams[0]["tokens"][:n] == ar_tokens[:n], f"[{name}] greedy invariant violated"
+
+    out = dict(
+        name=name, tcfg=tcfg, dcfg=dcfg, tseed=tseed, dseed=dseed, pseed=pseed, head_std=head_std,
+        prefill=prefill, budget=budget, gamma=gamma, chunk=chunk, gen_len=gen_len,
+        temperature=temperature, top_p=top_p, rng_seed=rng_seed, repeats=repeats,
+        ar_tokens=ar_tokens, triforce=streams, counts=[s["counts"] for s in o_streams],
+        retrieval_scores=ref_scores, retrieval_idx=ref_idx, topk_order_identical=same_order,
+        retr_k_digest=ref_retr_k.float().sum(dim=(1, 3)), retr_v_digest=ref_retr_v.float().sum(dim=(1, 3)),
+        first_verify_logits=trace[0]["logits"] if trace else None,
+        first_verify_tokens=trace[0]["verify_tokens"] if trace else None,
+    )
+    torch.save(out, os.path.join(GOLDEN, f"{name}.pt"))
+    print(f"[{name}] ok: ref+oracle {t_ref:.1f}s, {len(ar_tokens)} AR tokens, acc "
+          f"{[round(s['acceptance_rate'], 3) for s in streams]}, topk order identical: {same_order}")
+
+
+def forward_case(name="forward_small"):
+    """One target prefill+decode step and one draft spec step: logits must be bit-identical."""
+    ref = _refshim.load_reference()
+    tcfg = specs.tiny_target_config(vocab_size=512, layers=2, hidden=256, heads=2, max_pos=1024)
+    dcfg = specs.llama_config(128, 256, 2, 2, vocab_size=512, max_position_embeddings=512, name="tiny-draft")
+    tsd, dsd = specs.random_state_dict(tcfg, 11), specs.random_state_dict(dcfg, 12)
+    prompt = specs.random_prompt(512, 200, 13)
+    target = build_reference_model(ref, tcfg, tsd)
+    draft = build_reference_model(ref, dcfg, dsd, draft=True)
+    cache = ref.cache.FlashSimpleCache(target, 256)
+    with torch.inference_mode():
+        l1 = target(input_ids=prompt[:, :128], kv_cache=cache, graph_cache=None).logits
+        l2 = target(input_ids=prompt[:, 128:200], kv_cache=cache, graph_cache=None).logits
+        l3 = target(input_ids=prompt[:, :5], kv_cache=cache, graph_cache=None).logits
+    ot = M.OracleTarget(tcfg, tsd)
+    okv = M.FullCache(tcfg, 256)
+    o1 = ot.forward(prompt[:, :128], okv)
+    o2 = ot.forward(prompt[:, 128:200], okv)
+    o3 = ot.forward(prompt[:, :5], okv)
+    assert torch.equal(l1, o1) and torch.equal(l2, o2) and torch.equal(l3, o3), "target logits differ"
+    dcache = ref.cache.StreamingLLMEvictionCache(draft, start_size=16, recent_size=100, gamma=4)
+    odc = M.StreamingCacheO(dcfg, gamma=4, start_size=16, recent_size=100)
+    od = M.OracleDraft(dcfg, dsd)
+    with torch.inference_mode():
+        for i in range(4):
+            dcache.evict_prefill(50)
+            dl = draft(input_ids=prompt[:, i * 50:(i + 1) * 50], kv_cache=dcache, graph_cache=None).logits
+            odc.evict_prefill(50)
+            ol = od.forward(prompt[:, i * 50:(i + 1) * 50], odc, None)
+            assert torch.equal(dl, ol), f"draft prefill logits differ at block {i}"
+        ds = draft(input_ids=prompt[:, :3], kv_cache=dcache, graph_cache=dcache, gamma_offset=2).logits
+    os_ = od.forward(prompt[:, :3], odc, odc, gamma_offset=2)
+    assert torch.equal(ds, os_), "draft spec logits differ"
+    # sampling helpers
+    g = torch.Generator().manual_seed(5)
+    lg = torch.randn(6, 512, generator=g) * 3
+    cases = [(0.6, 0.9), (1.0, 1e-9), (1.0, 1.0), (0.3, 0.5)]
+    sm = {}
+    for T, P in cases:
+        a = ref.sampling.norm_logits(lg.clone(), temperature=T, top_k=-1, top_p=P)
+        b = R.norm_logits(lg.clone(), temperature=T, top_k=-1, top_p=P)
+        assert torch.equal(a, b), f"norm_logits({T},{P}) differs"
+        sm[(T, P)] = a
+    # exact ties: torch.sort(descending=True) is not stable (sampling.py:20), so WHICH of the tied
+    # entries survives top-p is implementation-defined; the oracle's canonical rule is the stable
+    # order (lowest index first).  Pin the tie-independent part: the sorted probability values.
+    lt = lg.clone()
+    lt[3, :7] = lt[3].max()
+    lt[2] = lt[2].half().float()
+    for T, P in cases:
+        a = ref.sampling.norm_logits(lt.clone(), temperature=T, top_k=-1, top_p=P)
+        b = R.norm_logits(lt.clone(), temperature=T, top_k=-1, top_p=P)
+        assert torch.equal(torch.sort(a, dim=-1)[0], torch.sort(b, dim=-1)[0]), f"tie case ({T},{P})"
+    x = torch.randn(512, generator=g)
+    assert torch.equal(ref.sampling.max_fn(x), R.max_fn(x))
+    torch.save(dict(tcfg=tcfg, dcfg=dcfg, tseed=11, dseed=12, pseed=13,
+                    target_logits=[l1[:, -1].clone(), l2[:, -1].clone(), l3.clone()],
+                    draft_spec_logits=ds.clone(), draft_prefill_last=dl[:, -1].clone(),
+                    sampling_logits=lg, sampling_probs=sm, maxfn_in=x, maxfn_out=R.max_fn(x)),
+               os.path.join(GOLDEN, f"{name}.pt"))
+    print(f"[{name}] ok")
+
+
+def rope_case(name="rope_tables"):
+    ref = _refshim.load_reference()
+    y = ref.modeling_llama.LlamaYaRNRotaryEmbedding(dim=128, max_position_embeddings=131072, base=10000,
+                                                    scaling_factor=32.0, original_max_position_embeddings=4096)
+    cos, sin = R.rope_tables_yarn(128, 131072, 32.0, 4096)
+    assert torch.equal(y.cos_cached, cos) and torch.equal(y.sin_cached, sin), "yarn tables differ"
+    p = ref.modeling_llama.LlamaRotaryEmbedding(128, max_position_embeddings=131072, base=1e7)
+    pc, ps = R.rope_tables_plain(128, 131072, 1e7)
+    assert torch.equal(p.cos_cached.half(), pc) and torch.equal(p.sin_cached.half(), ps), "plain tables differ"
+    rows = torch.tensor([0, 1, 7, 4095, 4096, 65535, 124927, 131071])
+    torch.save(dict(rows=rows, yarn_cos=cos[rows], yarn_sin=sin[rows], plain_cos=pc[rows], plain_sin=ps[rows],
+                    yarn_mscale=float(y.mscale)), os.path.join(GOLDEN, f"{name}.pt"))
+    print(f"[{name}] ok (mscale {y.mscale:.5f})")
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.set_num_threads(8)
+    rope_case()
+    forward_case()
+    # BASELINE.json configs[0]: Llama-68M-shaped draft + tiny target, prefill 2048, budget 256, gamma 4, greedy
+    triforce_case("cfg1_greedy", specs.tiny_target_config(), specs.draft_68m_config(), 101, 102, 103,
+                  prefill=2048, budget=256, gamma=4, chunk=8, gen_len=48, temperature=1.0, top_p=1e-9, repeats=2)
+    # same plumbing, stochastic sampling (cfg3-style T=0.6/top_p=0.9), seeded torch RNG replayed exactly
+    triforce_case("cfg1_stochastic", specs.tiny_target_config(), specs.draft_68m_config(), 101, 102, 103,
+                  prefill=2048, budget=256, gamma=4, chunk=8, gen_len=32, temperature=0.6, top_p=0.9, rng_seed=77)
+    # small-vocab, D=64 heads, gamma 6 (cfg2's gamma), ragged prompt length (not a multiple of 128)
+    triforce_case("small_gamma6",
+                  specs.llama_config(256, 512, 3, 4, vocab_size=1024, max_position_embeddings=4096,
+                                     rope_scaling=dict(type="yarn", factor=8.0, original_max_position_embeddings=512),
+                                     name="tiny-d64"),
+                  specs.llama_config(128, 256, 2, 2, vocab_size=1024, max_position_embeddings=2048, name="tiny-draft"),
+                  201, 202, 203, prefill=1000, budget=128, gamma=6, chunk=8, gen_len=40,
+                  temperature=1.0, top_p=1e-9, repeats=1)
+
+
+if __name__ == "__main__":
+    main()
