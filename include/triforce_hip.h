@@ -1,0 +1,152 @@
+/*
+ * triforce_hip.h — C ABI of libtriforce_hip.so (hand-written gfx950 / CDNA4 kernels for the
+ * TriForce hierarchical draft/verify decode path).
+ *
+ * The reference (Infini-AI-Lab/TriForce @ 2024-10-08) has no FFI layer: its native boundary is
+ * the third-party op flash_attn.flash_attn_with_kvcache plus torch kernels called from Python
+ * (SURVEY.md §8b, B4).  Each entry point below replaces one such native call site; the citation
+ * on every declaration is the reference file:line it stands in for.  INTEGRATION.md shows the
+ * ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - fp16 tensors are passed as `const void*` / `void*` (IEEE binary16, last dim contiguous);
+ *   - KV caches are addressed as base + token*stride_t + head*stride_h + d  (strides in ELEMENTS),
+ *     so both the reference layout [T][H][D] and the head-major layout [H][T][D] used by
+ *     triforce_amd are valid inputs;
+ *   - every function enqueues work on `stream` (a hipStream_t passed as void*), allocates nothing,
+ *     never synchronises and is hipGraph-capturable; workspaces are caller-provided;
+ *   - return value: 0 on success, a negative errno-style code on bad arguments (TF_E*), or the
+ *     positive hipError_t of a failed launch.
+ */
+#ifndef TRIFORCE_HIP_H
+#define TRIFORCE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TF_OK        0
+#define TF_EINVAL  (-22)   /* bad argument (shape / alignment / unsupported head_dim)        */
+#define TF_ENOSPC  (-28)   /* caller-provided workspace too small                           */
+#define TF_ERANGE  (-34)   /* size exceeds what the kernel supports (e.g. chunks > 32768)    */
+
+/* ABI version; bumped on any signature change. */
+int tf_abi_version(void);
+
+/* -------------------------------------------------------------------------------------------
+ * Verify / decode attention  (replaces flash_attn_with_kvcache(q, k_cache, v_cache,
+ * softmax_scale, causal=True): models/modeling_llama.py:240, models/tensor_op.py:168,316)
+ *
+ * Split-KV attention of sq <= 32 query rows against sk cached keys per head, bottom-right
+ * aligned causal mask (query i sees keys [0, sk - sq + i]).  QK^T and PV run on MFMA
+ * (v_mfma_f32_16x16x32_f16 / 16x16x16_f16), softmax in fp32, output fp16.
+ *   q        [sq][H][D] fp16 (post-RoPE)
+ *   k, v     layer base of the cache, see stride convention above; keys [0, sk) are read
+ *   out      [sq][H*D] fp16
+ *   sk_dev   optional device int32: if non-NULL the key count is read from it at run time (lets a
+ *            captured hipGraph follow a growing cache); `sk` is then the upper bound used to size
+ *            the launch
+ *   ws       float workspace, at least tf_attn_decode_ws_floats(H, sq, D, nsplit) floats
+ *   nsplit   number of KV splits per head (>=1); tf_attn_decode_pick_nsplit gives a default
+ * D must be 64 or 128.
+ * ------------------------------------------------------------------------------------------- */
+int64_t tf_attn_decode_ws_floats(int H, int sq, int D, int nsplit);
+int tf_attn_decode_pick_nsplit(int H, int sk);
+int tf_attn_decode(const void* q, const void* k, const void* v, void* out,
+                   int64_t stride_t, int64_t stride_h,
+                   int sq, int sk, const int32_t* sk_dev, int H, int D, float scale,
+                   int nsplit, float* ws, int64_t ws_floats, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Draft (Llama-68M) attention with RoPE applied to the cached keys on read
+ * (models/modeling_llama_68m.py:151-190): keys are cached UN-rotated and rotated with
+ * cache-relative positions 0..kv_len-1 at every call; q arrives already rotated.
+ *   q [sq][H][D] fp16, k/v cache rows [0,kv_len), cos/sin [max_pos][D] fp16, out [sq][H*D].
+ * D must be 64.  Bottom-right causal.
+ * ------------------------------------------------------------------------------------------- */
+int tf_attn_rope_on_read(const void* q, const void* k, const void* v, const void* cos, const void* sin,
+                         void* out, int64_t stride_t, int64_t stride_h,
+                         int sq, int kv_len, int H, int D, float scale, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Retrieval-cache build (models/cache.py:146-178 == :517-556): chunk-mean scoring, per-head
+ * top-k, chunk gather.
+ * tf_retrieval_score : scores[h][c] = fp16( q[h] . fp16(mean_{t in chunk c} K[t][h]) ), un-scaled
+ *                      (cache.py:154-157).  k rows [0, C*chunk) are read once.
+ * tf_retrieval_topk  : idx[h][0] = 0, idx[h][1..sets-1] = the sets-1 best chunks of [1,C),
+ *                      descending score, ascending chunk index among equal scores
+ *                      (cache.py:159-162; torch.topk leaves the tie order undefined).  C <= 32768.
+ * tf_retrieval_gather: dst slot j of head h <- chunk idx[h][j] (chunk rows of D), K and V
+ *                      (cache.py:163-175).
+ * ------------------------------------------------------------------------------------------- */
+int tf_retrieval_score(const void* k, int64_t stride_t, int64_t stride_h, const void* q,
+                       void* scores, int C, int chunk, int H, int D, void* stream);
+int tf_retrieval_topk(const void* scores, int32_t* idx, int C, int sets, int H, void* stream);
+int tf_retrieval_gather(const void* k_src, const void* v_src, int64_t src_stride_t, int64_t src_stride_h,
+                        const int32_t* idx, void* k_dst, void* v_dst, int64_t dst_stride_t,
+                        int64_t dst_stride_h, int sets, int chunk, int H, int D, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * KV row movement.
+ * tf_kv_copy_rows : dst[l][h][dst_t0+i] = src[l][h][src_t0+i], i<n, for L layers x H heads of
+ *                   D elements — RetrievalCache.update_graph_cache (cache.py:180-182, :566-575).
+ *                   Source and destination must not overlap.
+ * tf_kv_shift_rows: in-place move of rows [src_t0, src_t0+n) to [dst_t0, dst_t0+n), dst_t0 <=
+ *                   src_t0, overlap allowed — StreamingLLMEvictionCache.evict_for_spec /
+ *                   evict_prefill (cache.py:252-265).
+ * ------------------------------------------------------------------------------------------- */
+int tf_kv_copy_rows(const void* src, int64_t src_stride_l, int64_t src_stride_t, int64_t src_stride_h,
+                    void* dst, int64_t dst_stride_l, int64_t dst_stride_t, int64_t dst_stride_h,
+                    int src_t0, int dst_t0, int n, int L, int H, int D, void* stream);
+int tf_kv_shift_rows(void* cache, int64_t stride_l, int64_t stride_t, int64_t stride_h,
+                     int src_t0, int dst_t0, int n, int L, int H, int D, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Dense-block glue (models/modeling_llama.py:132-159,221-238; models/tensor_op.py:25-64).
+ * tf_rmsnorm    : optional fused residual add: s = fp16(x + res) (written to sum_out when
+ *                 non-NULL), y = w * fp16(s * rsqrt(mean(s^2)+eps))  — the cast precedes the
+ *                 weight multiply exactly as modeling_llama.py:138-143.
+ * tf_rope_append: split a fused qkv row [q | k | v] (each H*D), rotate q (and k unless
+ *                 rotate_k==0) at positions[i] with fp16 tables, write q to q_out [rows][H][D]
+ *                 and the k/v rows into the cache at token slot0+i (slot0 read from slot0_dev
+ *                 when non-NULL).  fp16 arithmetic order = (x*cos) + (rotate_half(x)*sin).
+ * tf_silu_mul   : out = fp16(silu(gate)) * up for a fused [gate | up] row of 2*I.
+ * ------------------------------------------------------------------------------------------- */
+int tf_rmsnorm(const void* x, const void* res, const void* w, void* y, void* sum_out,
+               int rows, int hidden, float eps, void* stream);
+int tf_rope_append(const void* qkv, int64_t qkv_row_stride, const void* cos, const void* sin,
+                   const int64_t* positions, void* q_out, void* k_cache, void* v_cache,
+                   int64_t stride_t, int64_t stride_h, int slot0, const int32_t* slot0_dev,
+                   int rows, int H, int D, int rotate_k, void* stream);
+int tf_silu_mul(const void* gate_up, void* out, int rows, int I, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Sampling / accept-rollback (utils/sampling.py:63-75, utils/decoding.py:97-134,190-220).
+ * tf_sample_inverse_cdf: token = first index whose inclusive cumulative sum of probs exceeds
+ *                        u * sum(probs)  (stand-in for torch.multinomial with an explicit uniform).
+ * tf_accept_chain      : sequential speculative accept test of g2 drafted tokens against the
+ *                        target distribution rows p[0..g2] and the drafting rows q[0..g2-1]:
+ *                        flag_i = u_i < min(1, p_i[x_i]/q_i[x_i])  (<= when inclusive), count =
+ *                        accepted prefix (wave ballot + ffs), stop at an accepted eos; then the
+ *                        correction token: residual max_fn(p_count - q_count) on rejection, bonus
+ *                        p_g2 when everything passed.  The sample uses uniforms[examined].
+ *                        out[0]=count, out[1]=next token, out[2]=reason (0 rejected, 1 all
+ *                        accepted, 2 eos accepted), out[3]=number of uniforms consumed.
+ * tf_middle_accept     : one inner TriForce step (decoding.py:190-220): test drafted token d
+ *                        (= tokens[n+1]) with p[n], q_d; sample the follow-up token from p[n+acc].
+ *                        out[0]=accepted(0/1), out[1]=follow-up token.  Also writes the follow-up
+ *                        token into tokens[n+1+acc] when that index is <= gamma.
+ * ------------------------------------------------------------------------------------------- */
+int tf_sample_inverse_cdf(const float* probs, const float* u, int64_t* token_out, int V, void* stream);
+int tf_accept_chain(const float* p, const float* q, const int64_t* tokens, const float* uniforms,
+                    int g2, int V, int inclusive, int64_t eos_token_id, int64_t* out, void* stream);
+int tf_middle_accept(const float* p, const float* q_d, int64_t* tokens, const float* uniforms,
+                     int n, int gamma, int V, int64_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRIFORCE_HIP_H */

@@ -256,3 +256,36 @@ def accept_chain(target_probs, spec_probs, tokens, uniforms, inclusive=False):
             break
         count += 1
     return count, flags
+
+
+def accept_and_correct(target_probs, spec_probs, tokens, uniforms, inclusive=False, eos_token_id=-1):
+    """Whole outer-step decision of utils/decoding.py:96-134 as one function (the checker for
+    tf_accept_chain): accept chain, stop right after an accepted eos unless it is the last drafted
+    token, residual resample on rejection (max_fn(p-q), :114), bonus sample when all passed (:130).
+    The sample uses uniforms[examined].  Returns (count, next_token, reason, consumed) with
+    reason 0 = rejected, 1 = all accepted, 2 = eos accepted."""
+    g2 = len(tokens)
+    count, flags = accept_chain(target_probs, spec_probs, tokens, uniforms, inclusive)
+    reason = 1 if count == g2 else 0
+    for i in range(count):
+        if int(tokens[i]) == eos_token_id and i + 1 < g2:
+            count, reason = i + 1, 2
+            break
+    examined = count + 1 if reason == 0 else count
+    if reason == 2:
+        return count, int(eos_token_id), 2, examined
+    if reason == 0:
+        nxt = sample_inverse_cdf(max_fn(target_probs[count] - spec_probs[count]), uniforms[examined])
+    else:
+        nxt = sample_inverse_cdf(target_probs[g2], uniforms[examined])
+    return count, nxt, reason, examined + 1
+
+
+def middle_accept(p, q_d, d, n, uniforms):
+    """One inner step of utils/decoding.py:190-220: accept test of drafted token d against p[n], then
+    the follow-up sample from p[n+acc].  Returns (accepted, follow_up_token)."""
+    ratio = p[n, d] / q_d[d]
+    m = torch.min(torch.tensor([1.0]), ratio.reshape(1))
+    acc = bool(torch.as_tensor(uniforms[0], dtype=torch.float32).reshape(1) < m)
+    b = sample_inverse_cdf(p[n + (1 if acc else 0)], uniforms[1])
+    return int(acc), b

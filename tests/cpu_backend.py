@@ -1,0 +1,96 @@
+"""CPU stand-ins for triforce_amd.ops built on the oracle (TEST-ONLY; installed by the ``cpu_ops``
+fixture).  They take the product's head-major (H,T,D) layer views and call oracle/ref_ops.py."""
+import torch
+
+from oracle import ref_ops as R
+
+PATCHED = ["rmsnorm", "rope_append", "silu_mul", "attn_decode", "attn_prefill", "attn_rope_on_read", "retrieval_score",
+           "retrieval_topk", "retrieval_gather", "kv_copy_rows", "kv_shift_rows", "sample_inverse_cdf",
+           "accept_chain", "middle_accept"]
+
+
+def rmsnorm(x, w, eps, residual=None, sum_out=None):
+    if residual is not None:
+        s = x + residual
+        if sum_out is not None:
+            sum_out.copy_(s)
+        x = s
+    return R.rms_norm(x, w, eps)
+
+
+def rope_append(qkv, cos, sin, positions, k_layer, v_layer, slot0, H, D, rotate_k=True, slot0_dev=None):
+    rows = qkv.shape[0]
+    q = qkv[:, :H * D].reshape(rows, H, D)
+    k = qkv[:, H * D:2 * H * D].reshape(rows, H, D)
+    v = qkv[:, 2 * H * D:].reshape(rows, H, D)
+    qr = R.apply_rope(q, cos, sin, positions)
+    kr = R.apply_rope(k, cos, sin, positions) if rotate_k else k
+    k_layer[:, slot0:slot0 + rows] = kr.permute(1, 0, 2)
+    v_layer[:, slot0:slot0 + rows] = v.permute(1, 0, 2)
+    return qr.contiguous()
+
+
+def silu_mul(gate_up):
+    I = gate_up.shape[1] // 2
+    return R.silu_mul(gate_up[:, :I], gate_up[:, I:])
+
+
+def attn_decode(q, k_layer, v_layer, sk, scale, sk_dev=None, nsplit=None):
+    sq, H, D = q.shape
+    k = k_layer[:, :sk].permute(1, 0, 2)
+    v = v_layer[:, :sk].permute(1, 0, 2)
+    return R.attn_kvcache(q, k, v, scale).reshape(sq, H * D)
+
+
+def attn_prefill(q, k_layer, v_layer, sk, scale):
+    # one shot (the product cuts a block into <=32-row slabs; same math, different fp32 summation order)
+    return attn_decode(q, k_layer, v_layer, sk, scale)
+
+
+def attn_rope_on_read(q, k_layer, v_layer, cos, sin, kv_len, scale):
+    sq, H, D = q.shape
+    k = R.apply_rope(k_layer[:, :kv_len].permute(1, 0, 2), cos, sin, torch.arange(kv_len))
+    v = v_layer[:, :kv_len].permute(1, 0, 2)
+    return R.attn_kvcache(q, k, v, scale).reshape(sq, H * D)
+
+
+def retrieval_score(k_layer, q, chunks, chunk):
+    return R.retrieval_scores(k_layer.permute(1, 0, 2), q, chunks * chunk, chunk)
+
+
+def retrieval_topk(scores, sets):
+    return R.retrieval_topk(scores, sets).to(torch.int32)
+
+
+def retrieval_gather(k_src, v_src, idx, k_dst, v_dst, chunk):
+    n = idx.shape[1] * chunk
+    k_dst[:, :n] = R.retrieval_gather(k_src.permute(1, 0, 2), idx.long(), chunk).permute(1, 0, 2)
+    v_dst[:, :n] = R.retrieval_gather(v_src.permute(1, 0, 2), idx.long(), chunk).permute(1, 0, 2)
+
+
+def kv_copy_rows(src, dst, src_t0, dst_t0, n):
+    if n > 0:
+        dst[:, :, dst_t0:dst_t0 + n] = src[:, :, src_t0:src_t0 + n]
+
+
+def kv_shift_rows(cache, src_t0, dst_t0, n):
+    if n > 0 and src_t0 != dst_t0:
+        cache[:, :, dst_t0:dst_t0 + n] = cache[:, :, src_t0:src_t0 + n].clone()
+
+
+def sample_inverse_cdf(probs, u, token_out):
+    token_out[0] = R.sample_inverse_cdf(probs, float(u[0]))
+
+
+def accept_chain(p, q, tokens, uniforms, g2, inclusive, eos_token_id, out):
+    c, nxt, reason, consumed = R.accept_and_correct(p[:g2 + 1], q[:g2], tokens[:g2].tolist(),
+                                                    uniforms[:g2 + 1].tolist(), inclusive, eos_token_id)
+    out[:4] = torch.tensor([c, nxt, reason, consumed])
+
+
+def middle_accept(p, q_d, tokens, uniforms, n, gamma, out):
+    d = int(tokens[n + 1])
+    acc, b = R.middle_accept(p, q_d, d, n, uniforms[:2].tolist())
+    out[:3] = torch.tensor([acc, b, d])
+    if n + 1 + acc <= gamma:
+        tokens[n + 1 + acc] = b

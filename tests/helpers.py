@@ -1,0 +1,68 @@
+"""Shared builders for the parity tests (oracle side and product side from the same seeds)."""
+import os
+
+import torch
+
+from oracle import ref_model as M
+from oracle import specs
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    return torch.load(os.path.join(GOLDEN, f"{name}.pt"), weights_only=False)
+
+
+class FakeTokenizer:
+    eos_token_id = 2
+
+    def decode(self, ids, **kw):
+        return ""
+
+
+def build_oracle(g, temperature=None, top_p=None):
+    tsd = specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g.get("head_std", 0.05))
+    dsd = specs.random_state_dict(g["dcfg"], g["dseed"], head_std=g.get("head_std", 0.05))
+    recent = 256 - 16 - g["gamma"]
+    ot, od = M.OracleTarget(g["tcfg"], tsd), M.OracleDraft(g["dcfg"], dsd)
+    okv = M.FullCache(g["tcfg"], g["prefill"] + g["gen_len"] + 16)
+    ogc = M.RetrievalCacheO(g["tcfg"], g["budget"], g["prefill"], g["chunk"], g["gamma"])
+    odc = M.StreamingCacheO(g["dcfg"], gamma=g["gamma"], start_size=16, recent_size=recent)
+    eng = M.OracleEngine(ot, okv, ogc, od, odc, g["temperature"] if temperature is None else temperature,
+                         g["top_p"] if top_p is None else top_p)
+    return eng, tsd, dsd
+
+
+def build_product(g, device, tsd=None, dsd=None, temperature=None, top_p=None, graphs=False):
+    """The product engine (triforce_amd) from the same seeded weights."""
+    from triforce_amd.models.cache import FlashSimpleCache, RetrievalCache, StreamingLLMEvictionCache
+    from triforce_amd.models.config_yarn import LlamaConfig
+    from triforce_amd.models.modeling_llama import LlamaForCausalLM
+    from triforce_amd.models.modeling_llama_68m import LlamaForCausalLM as LlamaForCausalLM_68M
+    from triforce_amd.utils.graph_infer import GraphInferenceEngine
+    if tsd is None:
+        tsd = specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g.get("head_std", 0.05))
+        dsd = specs.random_state_dict(g["dcfg"], g["dseed"], head_std=g.get("head_std", 0.05))
+    target = LlamaForCausalLM.from_state_dict(LlamaConfig.from_dict(g["tcfg"]), tsd, device)
+    draft = LlamaForCausalLM_68M.from_state_dict(LlamaConfig.from_dict(g["dcfg"]), dsd, device)
+    gamma = g["gamma"]
+    cache = FlashSimpleCache(target, g["prefill"] + g["gen_len"] + 16)
+    gcache = RetrievalCache(target, max_budget=g["budget"], prefill=g["prefill"], gamma=gamma, chunk_size=g["chunk"])
+    dcache = StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - gamma, gamma=gamma)
+    ge = GraphInferenceEngine(target, cache, gcache, draft, dcache)
+    T = g["temperature"] if temperature is None else temperature
+    P = g["top_p"] if top_p is None else top_p
+    if graphs:
+        ge.initialize_cuda_graph(gamma, probs=True, temperature=T, top_p=P, verbose=False)
+    else:
+        ge.initialize_eager(gamma, probs=True, temperature=T, top_p=P)
+    return ge
+
+
+def prompt_of(g):
+    return specs.random_prompt(g["tcfg"]["vocab_size"], g["prefill"], g["pseed"])
+
+
+def fixed_uniforms(n=4096, seed=99):
+    gen = torch.Generator().manual_seed(seed)
+    return torch.rand(n, generator=gen).tolist()

@@ -1,0 +1,66 @@
+"""Host logic of triforce_amd (caches, engine routing, decode loops) on CPU, with every HIP op swapped
+for its oracle restatement (cpu_ops fixture).  Checks the product's control flow reproduces the
+reference's golden token streams — nothing here measures or validates a kernel."""
+import pytest
+import torch
+
+from oracle import ref_model as M
+from tests import helpers as Hh
+
+
+@pytest.mark.parametrize("name", ["small_gamma6", "cfg1_greedy"])
+def test_triforce_greedy_matches_golden(cpu_ops, name):
+    from triforce_amd.utils.decoding import Autoregressive, TriForce
+    g = Hh.load_golden(name)
+    ge = Hh.build_product(g, "cpu")
+    prompt = Hh.prompt_of(g)
+    tok = Hh.FakeTokenizer()
+    _, ar = Autoregressive(tok, ge, prompt, max_len=g["gen_len"], top_k=-1, top_p=g["top_p"],
+                           temperature=g["temperature"], return_tokens=True)
+    assert ar == g["ar_tokens"]
+    for rep in range(g["repeats"]):
+        res = TriForce(tok, ge, prompt, gamma=g["gamma"], max_len=g["gen_len"], top_k=-1, top_p=g["top_p"],
+                       temperature=g["temperature"], return_details=True)
+        ref = g["triforce"][rep]
+        assert res["tokens"] == ref["tokens"]
+        assert abs(res["acceptance_rate"] - ref["acceptance_rate"]) < 1e-12
+        assert res["counts"] == g["counts"][rep]
+        assert ge.engine.kv_cache.seq_len == ref["final_seq_len"]
+        assert ge.engine.draft_cache.seq_len == ref["draft_seq_len"]
+
+
+def test_triforce_stochastic_matches_oracle_with_injected_uniforms(cpu_ops):
+    """T=0.6 / top_p=0.9 (cfg3-style): product and oracle consume the same explicit uniform stream."""
+    from triforce_amd.utils.decoding import TriForce
+    from triforce_amd.utils.sampling import UniformSource
+    g = Hh.load_golden("small_gamma6")
+    us = Hh.fixed_uniforms()
+    oeng, tsd, dsd = Hh.build_oracle(g, temperature=0.6, top_p=0.9)
+    prompt = Hh.prompt_of(g)
+    want = M.triforce(oeng, prompt, g["gamma"], 24, 0.6, 0.9, rng=M.InjectedRng(us))
+    ge = Hh.build_product(g, "cpu", tsd, dsd, temperature=0.6, top_p=0.9)
+    got = TriForce(Hh.FakeTokenizer(), ge, prompt, gamma=g["gamma"], max_len=24, top_k=-1, top_p=0.9, temperature=0.6,
+                   rng=UniformSource("cpu", values=us), return_details=True)
+    assert got["tokens"] == want["tokens"]
+    assert got["counts"] == want["counts"]
+    assert abs(got["acceptance_rate"] - want["acceptance_rate"]) < 1e-12
+    assert want["accepted"] > 0      # the stochastic path actually accepts something
+
+
+def test_product_logits_equal_oracle_logits(cpu_ops):
+    """Same weights, fused qkv / gate-up GEMMs and fused residual+norm must not change a bit on CPU."""
+    g = Hh.load_golden("forward_small")
+    from oracle import specs
+    from triforce_amd.models.cache import FlashSimpleCache
+    from triforce_amd.models.config_yarn import LlamaConfig
+    from triforce_amd.models.modeling_llama import LlamaForCausalLM
+    tsd = specs.random_state_dict(g["tcfg"], g["tseed"])
+    prompt = specs.random_prompt(512, 200, g["pseed"])
+    m = LlamaForCausalLM.from_state_dict(LlamaConfig.from_dict(g["tcfg"]), tsd, "cpu")
+    cache = FlashSimpleCache(m, 256)
+    l1 = m(input_ids=prompt[:, :128], kv_cache=cache).logits
+    l2 = m(input_ids=prompt[:, 128:200], kv_cache=cache).logits
+    l3 = m(input_ids=prompt[:, :5], kv_cache=cache).logits
+    assert torch.equal(l1[:, -1], g["target_logits"][0])
+    assert torch.equal(l2[:, -1], g["target_logits"][1])
+    assert torch.equal(l3, g["target_logits"][2])

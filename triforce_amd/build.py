@@ -1,0 +1,46 @@
+"""Build libtriforce_hip.so (gfx950) in-tree with hipcc.  No JIT cache: the .so travels with the tree."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libtriforce_hip.so")
+SOURCES = ["attn.hip", "retrieval.hip", "elementwise.hip", "sampling.hip", "gemv.hip", "abi.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fno-gpu-rdc", "-Wno-unused-result"]
+
+
+def hipcc_path():
+    p = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(p):
+        raise RuntimeError("hipcc not found: cannot build libtriforce_hip.so")
+    return p
+
+
+def sources():
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "triforce_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_library(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc_path()] + FLAGS + sources() + ["-o", LIB_PATH]
+    if verbose:
+        print("[triforce_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build_library(force=True)

@@ -1,0 +1,351 @@
+// Split-KV verify/decode attention for gfx950 (MI355X).
+//
+// Replaces flash_attn_with_kvcache at models/modeling_llama.py:240, models/tensor_op.py:168,316
+// (target verify over the full KV, retrieval verify over the retrieval cache, q=1 decode) and,
+// in the rope-on-read variant, models/modeling_llama_68m.py:151-190 (Llama-68M draft).
+//
+// Design (HBM-bound: q <= 32 rows against 4K..130K keys, arithmetic intensity ~ q flop/B):
+//   * grid = (nsplit, H); a workgroup = 4 waves; the key range of a split is walked in tiles of
+//     16 keys, wave w taking tiles w, w+4, ... so the 4 waves stream adjacent 4 KiB pieces.
+//   * K and V tiles go global -> VGPR directly in MFMA operand shape (lane (i, g) = key i,
+//     8 contiguous d at 32c+8g: one 16-B load), two tiles deep (8 KiB in flight per wave);
+//     no LDS and no barrier in the main loop.
+//   * S^T = K Q^T with v_mfma_f32_16x16x32_f16 ("swapped" QK^T): a lane then owns 4 keys of one
+//     query, so the exponentiated tile is already the B operand of the PV MFMA — P never
+//     leaves registers.
+//   * V must be contracted over keys, but its memory order is d-contiguous.  The tile is
+//     transposed on the matrix core itself: V_tile x Sel (a constant 0/1 selection operand)
+//     returns V in C-layout = 4 consecutive keys of one d per lane = the A operand of
+//     v_mfma_f32_16x16x16_f16.  The extra MFMAs are free (the kernel uses a few % of MFMA peak).
+//   * online softmax in fp32 (running max / sum per query column), partial (m, l, O) per split
+//     merged by a second tiny kernel.
+#include "common.h"
+
+#define NEG_BIG (-1.0e30f)
+
+template <int D, int QT>
+struct AttnState {
+    static constexpr int NC = D / 32;
+    static constexpr int NT = D / 16;
+    half8 qf[QT][NC];
+    f32x4 acc[QT][NT];
+    float m[QT];
+    float l[QT];
+};
+
+template <int D>
+__device__ __forceinline__ void load_kv_tile(const h16* __restrict__ kbase, const h16* __restrict__ vbase,
+                                             int64_t stride_t, int tile, int sk, int li, int g,
+                                             half8 (&kf)[D / 32], half8 (&vf)[D / 32]) {
+    int key = tile * 16 + li;
+    key = key < sk ? key : sk - 1;                     // clamp: masked below, but must stay in-bounds
+    const int64_t off = (int64_t)key * stride_t + 8 * g;
+#pragma unroll
+    for (int c = 0; c < D / 32; ++c) {
+        kf[c] = load_half8(kbase + off + 32 * c);
+        vf[c] = load_half8(vbase + off + 32 * c);
+    }
+}
+
+template <int D, int QT>
+__device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf)[D / 32],
+                                          const half8 (&vf)[D / 32], half8 sel0, half8 sel1, int tile,
+                                          int sk, int sq, float scale, int li, int g) {
+    constexpr int NC = D / 32, NT = D / 16;
+    // V tile -> key-contiguous fragments through the matrix core (exact: multiplies by 0/1)
+    half4 va[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[t >> 1], (t & 1) ? sel1 : sel0, z, 0, 0, 0);
+        va[t] = half4{(h16)r[0], (h16)r[1], (h16)r[2], (h16)r[3]};
+    }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[c], st.qf[qt][c], s, 0, 0, 0);
+        // lane holds S^T[key = tile*16 + 4g + r][q = qt*16 + li]
+        const int qrow = qt * 16 + li;
+        const int kmax = (qrow < sq) ? (sk - sq + qrow) : (sk - 1);   // bottom-right causal
+        float x[4];
+        bool ok[4];
+        float tmax = NEG_BIG;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kidx = tile * 16 + 4 * g + r;
+            ok[r] = kidx <= kmax;
+            x[r] = s[r] * scale;
+            tmax = ok[r] ? fmaxf(tmax, x[r]) : tmax;
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(st.m[qt], tmax);
+        const float alpha = __expf(st.m[qt] - mnew);
+        float psum = 0.f;
+        half4 pb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = ok[r] ? __expf(x[r] - mnew) : 0.f;
+            psum += p;
+            pb[r] = (h16)p;
+        }
+        st.l[qt] = st.l[qt] * alpha + psum;
+        st.m[qt] = mnew;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 a = st.acc[qt][t];
+            a[0] *= alpha; a[1] *= alpha; a[2] *= alpha; a[3] *= alpha;
+            st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(va[t], pb, a, 0, 0, 0);
+        }
+    }
+}
+
+// ws layout: o[H][nsplit][QR][D] | m[H][nsplit][QR] | l[H][nsplit][QR],  QR = QT*16
+template <int D, int QT>
+__global__ __launch_bounds__(256) void attn_split_kernel(
+    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
+    int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
+    float* __restrict__ ws) {
+    constexpr int NC = D / 32, NT = D / 16, QR = QT * 16;
+    const int split = blockIdx.x, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    int sk = sk_dev ? *sk_dev : sk_host;
+    if (sk > sk_host) sk = sk_host;
+    if (sk < 1) sk = 1;
+
+    const int ntiles = (sk + 15) >> 4;
+    const int tps = (ntiles + nsplit - 1) / nsplit;
+    const int t_begin = split * tps;
+    const int t_end = min(ntiles, t_begin + tps);
+
+    AttnState<D, QT> st;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int row = qt * 16 + li;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            st.qf[qt][c] = (row < sq) ? load_half8(q + ((int64_t)row * H + h) * D + 32 * c + 8 * g) : z;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) st.acc[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        st.m[qt] = NEG_BIG;
+        st.l[qt] = 0.f;
+    }
+    half8 sel0, sel1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sel0[e] = (8 * g + e == li) ? (h16)1.0f : (h16)0.0f;
+        sel1[e] = (8 * g + e == 16 + li) ? (h16)1.0f : (h16)0.0f;
+    }
+
+    const h16* kbase = k + (int64_t)h * stride_h;
+    const h16* vbase = v + (int64_t)h * stride_h;
+
+    // two tiles deep: the loads of tile t+4 are in flight while tile t is on the matrix core
+    half8 ka[NC], va_[NC], kb[NC], vb[NC];
+    int t = t_begin + wave;
+    if (t < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t, sk, li, g, ka, va_);
+    while (t < t_end) {
+        const int t1 = t + 4;
+        if (t1 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t1, sk, li, g, kb, vb);
+        attn_tile<D, QT>(st, ka, va_, sel0, sel1, t, sk, sq, scale, li, g);
+        if (t1 >= t_end) break;
+        const int t2 = t1 + 4;
+        if (t2 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t2, sk, li, g, ka, va_);
+        attn_tile<D, QT>(st, kb, vb, sel0, sel1, t1, sk, sq, scale, li, g);
+        t = t2;
+    }
+
+    // ---- merge the 4 waves of this split through LDS, one q-tile at a time ----
+    __shared__ float sm_o[4][16][D + 1];
+    __shared__ float sm_m[4][16];
+    __shared__ float sm_l[4][16];
+    float* ws_o = ws;
+    float* ws_m = ws + (int64_t)H * nsplit * QR * D;
+    float* ws_l = ws_m + (int64_t)H * nsplit * QR;
+    const int64_t pbase = ((int64_t)h * nsplit + split) * QR;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float lsum = st.l[qt];
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm_o[wave][li][16 * tt + 4 * g + r] = st.acc[qt][tt][r];
+        if (g == 0) {
+            sm_m[wave][li] = st.m[qt];
+            sm_l[wave][li] = lsum;
+        }
+        __syncthreads();
+        for (int e = tid; e < 16 * D; e += 256) {
+            const int qq = e / D, d = e - qq * D;
+            const float m0 = sm_m[0][qq], m1 = sm_m[1][qq], m2 = sm_m[2][qq], m3 = sm_m[3][qq];
+            const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+            const float w0 = __expf(m0 - mm), w1 = __expf(m1 - mm), w2 = __expf(m2 - mm), w3 = __expf(m3 - mm);
+            const float o = sm_o[0][qq][d] * w0 + sm_o[1][qq][d] * w1 + sm_o[2][qq][d] * w2 + sm_o[3][qq][d] * w3;
+            ws_o[(pbase + qt * 16 + qq) * D + d] = o;
+            if (d == 0) {
+                ws_m[pbase + qt * 16 + qq] = mm;
+                ws_l[pbase + qt * 16 + qq] = sm_l[0][qq] * w0 + sm_l[1][qq] * w1 + sm_l[2][qq] * w2 + sm_l[3][qq] * w3;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int D>
+__global__ void attn_combine_kernel(const float* __restrict__ ws, h16* __restrict__ out, int sq, int H, int nsplit,
+                                    int QR) {
+    const int h = blockIdx.x, qq = blockIdx.y, d = threadIdx.x;
+    const float* ws_o = ws;
+    const float* ws_m = ws + (int64_t)H * nsplit * QR * D;
+    const float* ws_l = ws_m + (int64_t)H * nsplit * QR;
+    const int64_t base = (int64_t)h * nsplit * QR + qq;
+    float mm = NEG_BIG;
+    for (int s = 0; s < nsplit; ++s) mm = fmaxf(mm, ws_m[base + (int64_t)s * QR]);
+    float o = 0.f, l = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float w = __expf(ws_m[base + (int64_t)s * QR] - mm);
+        o += ws_o[(base + (int64_t)s * QR) * D + d] * w;
+        l += ws_l[base + (int64_t)s * QR] * w;
+    }
+    out[((int64_t)qq * H + h) * D + d] = (h16)(o / l);
+}
+
+// ------------------------------------------------------------------------------------------
+// Draft attention, RoPE applied to cached keys on read (modeling_llama_68m.py:151-190).
+// Tiny problem (12 heads, <=259 keys, D=64): one wave per (head, query row); latency-bound.
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_rope_on_read_kernel(
+    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, const h16* __restrict__ cosb,
+    const h16* __restrict__ sinb, h16* __restrict__ out, int64_t stride_t, int64_t stride_h, int sq, int kv_len,
+    int H, float scale) {
+    constexpr int NV = D / 8, HV = NV / 2;          // half8 vectors per row / per half row
+    extern __shared__ float smem[];                 // [4 waves][kv_len] scores -> probabilities
+    const int h = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qrow = blockIdx.y * 4 + wave;
+    const bool active = qrow < sq;
+    float* pw = smem + (size_t)wave * kv_len;
+    const int kmax = active ? (kv_len - sq + qrow) : -1;    // last visible key (bottom-right causal)
+    float lsum = 0.f;
+    if (active) {
+        const h16* qp = q + ((int64_t)qrow * H + h) * D;
+        half8 qv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) qv[i] = load_half8(qp + 8 * i);
+        const h16* kb = k + (int64_t)h * stride_h;
+        float mloc = NEG_BIG;
+        for (int j = lane; j <= kmax; j += 64) {
+            const h16* kp = kb + (int64_t)j * stride_t;
+            const h16* cp = cosb + (int64_t)j * D;
+            const h16* sp = sinb + (int64_t)j * D;
+            half8 kv[NV], cv[NV], sv[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                kv[i] = load_half8(kp + 8 * i);
+                cv[i] = load_half8(cp + 8 * i);
+                sv[i] = load_half8(sp + 8 * i);
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < HV; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const h16 x1 = kv[i][e], x2 = kv[i + HV][e];
+                    // (x*cos) + (rotate_half(x)*sin), every op rounded to fp16 like the reference
+                    const h16 lo = hadd_rn(hmul_rn(x1, cv[i][e]), hmul_rn((h16)(-(float)x2), sv[i][e]));
+                    const h16 hi = hadd_rn(hmul_rn(x2, cv[i + HV][e]), hmul_rn(x1, sv[i + HV][e]));
+                    s = fmaf((float)qv[i][e], (float)lo, s);
+                    s = fmaf((float)qv[i + HV][e], (float)hi, s);
+                }
+            s *= scale;
+            pw[j] = s;
+            mloc = fmaxf(mloc, s);
+        }
+        const float mx = wave_max(mloc);
+        for (int j = lane; j <= kmax; j += 64) {
+            const float p = __expf(pw[j] - mx);     // same lane wrote pw[j]
+            pw[j] = p;
+            lsum += p;
+        }
+        lsum = wave_sum(lsum);
+    }
+    __syncthreads();
+    if (active) {
+        const h16* vb = v + (int64_t)h * stride_h;
+        for (int d = lane; d < D; d += 64) {
+            float o = 0.f;
+            for (int j = 0; j <= kmax; ++j) o = fmaf(pw[j], (float)vb[(int64_t)j * stride_t + d], o);
+            out[((int64_t)qrow * H + h) * D + d] = (h16)(o / lsum);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" int64_t tf_attn_decode_ws_floats(int H, int sq, int D, int nsplit) {
+    const int QR = ((sq + 15) / 16) * 16;
+    return (int64_t)H * nsplit * QR * (D + 2);
+}
+
+extern "C" int tf_attn_decode_pick_nsplit(int H, int sk) {
+    const int tiles = (sk + 15) / 16;
+    int by_work = tiles / 32;                        // >= 8 tiles per wave
+    int by_grid = 1024 / (H > 0 ? H : 1);            // ~4 workgroups per CU on 256 CUs
+    int n = by_work < by_grid ? by_work : by_grid;
+    if (n < 1) n = 1;
+    if (n > 128) n = 128;
+    return n;
+}
+
+template <int D, int QT>
+static int launch_attn(const void* q, const void* k, const void* v, void* out, int64_t stride_t, int64_t stride_h,
+                       int sq, int sk, const int32_t* sk_dev, int H, float scale, int nsplit, float* ws,
+                       hipStream_t st) {
+    dim3 grid(nsplit, H), block(256);
+    hipLaunchKernelGGL((attn_split_kernel<D, QT>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
+                       stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws);
+    TF_LAUNCH_CHECK();
+    hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(H, sq), dim3(D), 0, st, (const float*)ws, (h16*)out, sq, H,
+                       nsplit, QT * 16);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}
+
+extern "C" int tf_attn_decode(const void* q, const void* k, const void* v, void* out, int64_t stride_t,
+                              int64_t stride_h, int sq, int sk, const int32_t* sk_dev, int H, int D, float scale,
+                              int nsplit, float* ws, int64_t ws_floats, void* stream) {
+    if (!q || !k || !v || !out || !ws) return TF_EINVAL;
+    if (sq < 1 || sq > 32 || sk < 1 || H < 1 || nsplit < 1) return TF_EINVAL;
+    if ((stride_t % 8) || (stride_h % 8)) return TF_EINVAL;          // 16-B loads
+    if (ws_floats < tf_attn_decode_ws_floats(H, sq, D, nsplit)) return TF_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    const int QT = (sq + 15) / 16;
+    if (D == 128 && QT == 1) return launch_attn<128, 1>(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, st);
+    if (D == 128 && QT == 2) return launch_attn<128, 2>(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, st);
+    if (D == 64 && QT == 1) return launch_attn<64, 1>(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, st);
+    if (D == 64 && QT == 2) return launch_attn<64, 2>(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, st);
+    return TF_EINVAL;
+}
+
+extern "C" int tf_attn_rope_on_read(const void* q, const void* k, const void* v, const void* cosb, const void* sinb,
+                                    void* out, int64_t stride_t, int64_t stride_h, int sq, int kv_len, int H, int D,
+                                    float scale, void* stream) {
+    if (!q || !k || !v || !cosb || !sinb || !out) return TF_EINVAL;
+    if (D != 64 || sq < 1 || kv_len < sq || H < 1) return TF_EINVAL;
+    const size_t lds = (size_t)4 * kv_len * sizeof(float);
+    if (lds > 64 * 1024) return TF_ERANGE;
+    dim3 grid(H, (sq + 3) / 4), block(256);
+    hipLaunchKernelGGL((attn_rope_on_read_kernel<64>), grid, block, lds, (hipStream_t)stream, (const h16*)q,
+                       (const h16*)k, (const h16*)v, (const h16*)cosb, (const h16*)sinb, (h16*)out, stride_t, stride_h,
+                       sq, kv_len, H, scale);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}

@@ -1,0 +1,66 @@
+"""ctypes binding of libtriforce_hip.so (C ABI in include/triforce_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a symbol is absent the
+import of any op raises.  Build it with ``python -m triforce_amd.build`` (hipcc, gfx950).
+"""
+import ctypes
+import os
+
+from .build import LIB_PATH
+
+_c = ctypes
+_vp, _i32, _i64, _f32 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
+
+# name -> (restype, argtypes); mirrors include/triforce_hip.h one to one
+SIGNATURES = {
+    "tf_abi_version": (_i32, []),
+    "tf_attn_decode_ws_floats": (_i64, [_i32, _i32, _i32, _i32]),
+    "tf_attn_decode_pick_nsplit": (_i32, [_i32, _i32]),
+    "tf_attn_decode": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _i32, _f32, _i32, _vp, _i64, _vp]),
+    "tf_attn_rope_on_read": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "tf_retrieval_score": (_i32, [_vp, _i64, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "tf_retrieval_topk": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "tf_retrieval_gather": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "tf_kv_copy_rows": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "tf_kv_shift_rows": (_i32, [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "tf_rmsnorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
+    "tf_rope_append": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "tf_silu_mul": (_i32, [_vp, _vp, _i32, _i32, _vp]),
+    "tf_sample_inverse_cdf": (_i32, [_vp, _vp, _vp, _i32, _vp]),
+    "tf_accept_chain": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
+    "tf_middle_accept": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class TriforceHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it cannot be loaded."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TriforceHipError(
+                f"{LIB_PATH} not found: the HIP extension is required (python -m triforce_amd.build); "
+                "there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:
+                raise TriforceHipError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype, fn.argtypes = res, args
+        if L.tf_abi_version() != ABI_VERSION:
+            raise TriforceHipError(f"ABI mismatch: library {L.tf_abi_version()} != binding {ABI_VERSION}")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-22: "TF_EINVAL", -28: "TF_ENOSPC", -34: "TF_ERANGE"}.get(rc, f"hipError {rc}" if rc > 0 else str(rc))
+        raise TriforceHipError(f"{what} failed: {kind}")

@@ -1,0 +1,102 @@
+"""Target model (Llama-2-7B/13B-128K, LWM-Text-Chat-128K) on the HIP ops — host-side mirror of
+the reference's models/modeling_llama.py: same call signature
+``model(input_ids=, kv_cache=, graph_cache=, position_ids=, spec=).logits`` (:384-414), same
+dispatch between full-cache forward, retrieval-cache (spec) forward and the q_len==1 retrieval
+build (:226-238), same numerics.
+
+Per layer the forward is 4 skinny GEMMs (fused qkv, o, fused gate-up, down — hipBLASLt through
+torch) and 5 hand-written kernels: RMSNorm(+residual), RoPE+KV-append, split-KV MFMA attention
+(+merge), SwiGLU.
+"""
+import torch
+
+from .. import ops
+from .cache import RetrievalCache
+from .config_yarn import LlamaConfig
+from .llama_core import (CausalLMOutput, LlamaWeights, load_checkpoint_state_dict, parse_random_spec,
+                         rope_tables_for, softmax_scale_for)
+
+
+class LlamaForCausalLM:
+    def __init__(self, config: LlamaConfig, device="cuda:0"):
+        self.config = config
+        self.device = torch.device(device)
+        self.dtype = torch.float16
+        self.weights = LlamaWeights(config, self.device)
+        cos, sin = rope_tables_for(config)
+        self.cos, self.sin = cos.to(self.device), sin.to(self.device)
+        self.scale = softmax_scale_for(config.hidden_size // config.num_attention_heads)
+        self.vocab_size = config.vocab_size
+
+    # -- construction ------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, name_or_path, torch_dtype=torch.float16, device_map="cuda:0", config=None, **_):
+        """Local HF directory, or ``random:<seed>`` with an explicit ``config`` (no hub access offline)."""
+        assert torch_dtype == torch.float16, "the TriForce path is fp16"
+        seed = parse_random_spec(name_or_path)
+        if seed is not None:
+            assert config is not None, "random:<seed> needs config="
+            return cls(config, device_map).init_random(seed)
+        cfg = config or LlamaConfig.from_pretrained(name_or_path)
+        m = cls(cfg, device_map)
+        m.weights.load_state_dict(load_checkpoint_state_dict(name_or_path))
+        return m
+
+    @classmethod
+    def from_state_dict(cls, config, sd, device="cuda:0"):
+        m = cls(config, device)
+        m.weights.load_state_dict(sd)
+        return m
+
+    def init_random(self, seed):
+        self.weights.init_random(seed)
+        return self
+
+    def eval(self):
+        return self
+
+    # -- forward -----------------------------------------------------------------------------
+    @torch.inference_mode()
+    def __call__(self, input_ids, kv_cache=None, graph_cache=None, position_ids=None, spec=False,
+                 attention_mask=None, storage_ids=None, gamma_offset=0):
+        return self.forward(input_ids, kv_cache, graph_cache, position_ids, spec)
+
+    def forward(self, input_ids, kv_cache, graph_cache=None, position_ids=None, spec=False):
+        W = self.weights
+        H, D = W.H, W.D
+        q_len = input_ids.shape[1]
+        if position_ids is None:                        # reference modeling_llama.py:345-349
+            position_ids = torch.arange(kv_cache.seq_len, kv_cache.seq_len + q_len, dtype=torch.long,
+                                        device=self.device).unsqueeze(0)
+        pos = position_ids.reshape(-1).contiguous()
+        x = W.embed[input_ids.reshape(-1)]              # (q, hidden) fp16 gather
+        build = (not spec) and q_len == 1 and isinstance(graph_cache, RetrievalCache)
+        d = None
+        for i in range(W.L):
+            if d is None:
+                h = ops.rmsnorm(x, W.ln1[i], W.eps)
+            else:                                       # x += mlp_out of the previous layer, fused into the norm
+                h = ops.rmsnorm(d, W.ln1[i], W.eps, residual=x, sum_out=x)
+            qkv = ops.linear(h, W.wqkv[i])
+            if spec:                                    # :226-227  retrieval-cache forward
+                kl, vl = graph_cache.layer_kv(i)
+                assert q_len == graph_cache.gamma + 1, "spec forward takes exactly gamma+1 tokens (cache.py:184-189)"
+                q = ops.rope_append(qkv, self.cos, self.sin, pos, kl, vl, graph_cache.spec_slot, H, D)
+                a = ops.attn_decode(q, kl, vl, graph_cache.real_budget, self.scale)
+            else:                                       # :228-238  full-cache forward
+                kl, vl = kv_cache.layer_kv(i)
+                slot = kv_cache.append_slot(i, q_len)
+                q = ops.rope_append(qkv, self.cos, self.sin, pos, kl, vl, slot, H, D)
+                if build:
+                    if not graph_cache.init_graph:
+                        graph_cache.init_graph_cache(kv_cache, q, i)
+                    else:
+                        graph_cache.update_graph_cache_retrieval(kv_cache, q, i)
+                a = ops.attn_prefill(q, kl, vl, slot + q_len, self.scale)
+            o = ops.linear(a, W.wo[i])
+            h = ops.rmsnorm(o, W.ln2[i], W.eps, residual=x, sum_out=x)       # x += attn_out
+            act = ops.silu_mul(ops.linear(h, W.wgu[i]))
+            d = ops.linear(act, W.wd[i])
+        h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)
+        logits = ops.linear(h, W.lm_head).float().unsqueeze(0)               # (1, q, V) fp32  (:408-409)
+        return CausalLMOutput(logits)

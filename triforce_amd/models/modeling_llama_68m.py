@@ -1,0 +1,91 @@
+"""Draft model (JackFram/llama-68m shape) on the HIP ops — mirror of the reference's
+models/modeling_llama_68m.py: keys are cached UN-rotated in a StreamingLLM cache and RoPE is
+re-applied to every cached key on read with cache-relative positions (:151-178); a decode call with
+``gamma_offset=n`` recomputes all n+1 speculative tokens (:151-162).
+"""
+import torch
+
+from .. import ops
+from .config_yarn import LlamaConfig
+from .llama_core import (CausalLMOutput, LlamaWeights, load_checkpoint_state_dict, parse_random_spec,
+                         rope_tables_plain, softmax_scale_for)
+
+
+class LlamaForCausalLM:
+    def __init__(self, config: LlamaConfig, device="cuda:0"):
+        self.config = config
+        self.device = torch.device(device)
+        self.dtype = torch.float16
+        self.weights = LlamaWeights(config, self.device)
+        D = config.hidden_size // config.num_attention_heads
+        cos, sin = rope_tables_plain(D, config.max_position_embeddings, config.rope_theta)   # 68m.py:123-128
+        self.cos, self.sin = cos.to(self.device), sin.to(self.device)
+        self.scale = softmax_scale_for(D)
+        self.vocab_size = config.vocab_size
+
+    @classmethod
+    def from_pretrained(cls, name_or_path, torch_dtype=torch.float16, device_map="cuda:0", config=None, **_):
+        assert torch_dtype == torch.float16
+        seed = parse_random_spec(name_or_path)
+        if seed is not None:
+            assert config is not None, "random:<seed> needs config="
+            return cls(config, device_map).init_random(seed)
+        cfg = config or LlamaConfig.from_pretrained(name_or_path)
+        m = cls(cfg, device_map)
+        m.weights.load_state_dict(load_checkpoint_state_dict(name_or_path))
+        return m
+
+    @classmethod
+    def from_state_dict(cls, config, sd, device="cuda:0"):
+        m = cls(config, device)
+        m.weights.load_state_dict(sd)
+        return m
+
+    def init_random(self, seed):
+        self.weights.init_random(seed)
+        return self
+
+    def eval(self):
+        return self
+
+    @torch.inference_mode()
+    def __call__(self, input_ids, kv_cache=None, graph_cache=None, position_ids=None, gamma_offset=-1,
+                 attention_mask=None, storage_ids=None):
+        return self.forward(input_ids, kv_cache, graph_cache, gamma_offset)
+
+    def forward(self, input_ids, kv_cache, graph_cache=None, gamma_offset=-1):
+        W = self.weights
+        H, D = W.H, W.D
+        q_len = input_ids.shape[1]
+        x = W.embed[input_ids.reshape(-1)]
+        spec = gamma_offset >= 0
+        if spec:                                                          # 68m.py:151-162
+            c = graph_cache
+            assert q_len == gamma_offset + 1 and q_len <= c.gamma + 3
+            slot0 = c.spec_slot
+            kv_len = gamma_offset + c.start_size + c.recent_size + 1
+            pos = torch.arange(slot0, slot0 + q_len, dtype=torch.long, device=self.device)
+        else:                                                             # 68m.py:164-178, :286-291
+            c = kv_cache
+            slot0 = c.seq_len
+            kv_len = slot0 + q_len
+            pos = torch.arange(slot0, slot0 + q_len, dtype=torch.long, device=self.device)
+        d = None
+        for i in range(W.L):
+            if d is None:
+                h = ops.rmsnorm(x, W.ln1[i], W.eps)
+            else:
+                h = ops.rmsnorm(d, W.ln1[i], W.eps, residual=x, sum_out=x)
+            qkv = ops.linear(h, W.wqkv[i])
+            kl, vl = c.layer_kv(i)
+            if not spec:
+                c.append_slot(i, q_len)
+            q = ops.rope_append(qkv, self.cos, self.sin, pos, kl, vl, slot0, H, D, rotate_k=False)
+            a = ops.attn_rope_on_read(q, kl, vl, self.cos, self.sin, kv_len, self.scale)
+            o = ops.linear(a, W.wo[i])
+            h = ops.rmsnorm(o, W.ln2[i], W.eps, residual=x, sum_out=x)
+            act = ops.silu_mul(ops.linear(h, W.wgu[i]))
+            d = ops.linear(act, W.wd[i])
+        h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)
+        logits = ops.linear(h, W.lm_head).float().unsqueeze(0)
+        return CausalLMOutput(logits)

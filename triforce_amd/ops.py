@@ -1,0 +1,226 @@
+"""Tensor-level wrappers over the C ABI (include/triforce_hip.h).
+
+PyTorch here is plumbing only: it owns device memory and the stream; every function below
+validates its tensors, takes raw device pointers and enqueues hand-written gfx950 kernels on
+torch's current HIP stream (so they are captured by ``torch.cuda.graph`` like any torch op).
+No CPU path exists: tensors that are not on a HIP device raise.
+
+KV "layer views" are 3-D tensors (H, T, D) with unit stride on D and arbitrary H/T strides, so
+the physical layout (head-major [L][H][T][D] in triforce_amd, token-major in the reference)
+is the caller's choice.  Other modules must call these as ``ops.<name>(...)``.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import hip
+
+_HALF = torch.float16
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise hip.TriforceHipError("triforce_amd ops need HIP device tensors (no CPU fallback)")
+
+
+def _kv(t):
+    assert t.dim() == 3 and t.stride(2) == 1 and t.dtype == _HALF, "KV layer view must be (H,T,D) fp16, D contiguous"
+    return t.stride(1), t.stride(0)          # stride_t, stride_h
+
+
+# ------------------------------------------------------------------------------------------
+def linear(x, w):
+    """fp16 GEMM with fp32 accumulation (hipBLASLt through torch) — the reference's nn.Linear/F.linear."""
+    return F.linear(x, w)
+
+
+def rmsnorm(x, w, eps, residual=None, sum_out=None):
+    """y = w * fp16((x [+ residual]) * rsqrt(mean(.^2)+eps)); writes the fp16 sum to sum_out if given."""
+    _dev(x, w, residual, sum_out)
+    assert x.dtype == _HALF and x.is_contiguous() and x.dim() == 2
+    y = torch.empty_like(x)
+    hip.check(hip.lib().tf_rmsnorm(_ptr(x), _ptr(residual), _ptr(w), _ptr(y), _ptr(sum_out), x.shape[0], x.shape[1],
+                                   float(eps), _stream()), "tf_rmsnorm")
+    return y
+
+
+def rope_append(qkv, cos, sin, positions, k_layer, v_layer, slot0, H, D, rotate_k=True, slot0_dev=None):
+    """Split fused qkv rows, rotate q (and k), append k/v rows to the cache at slot0+i.  Returns q (rows,H,D)."""
+    _dev(qkv, cos, sin, positions, k_layer, v_layer)
+    rows = qkv.shape[0]
+    assert qkv.dtype == _HALF and qkv.stride(1) == 1 and qkv.shape[1] == 3 * H * D
+    assert positions.dtype == torch.int64 and positions.numel() == rows and positions.is_contiguous()
+    assert cos.dtype == _HALF and cos.is_contiguous() and cos.shape[1] == D
+    st, sh = _kv(k_layer)
+    assert _kv(v_layer) == (st, sh)
+    q = torch.empty(rows, H, D, dtype=_HALF, device=qkv.device)
+    hip.check(hip.lib().tf_rope_append(_ptr(qkv), qkv.stride(0), _ptr(cos), _ptr(sin), _ptr(positions), _ptr(q),
+                                       _ptr(k_layer), _ptr(v_layer), st, sh, int(slot0), _ptr(slot0_dev), rows, H, D,
+                                       1 if rotate_k else 0, _stream()), "tf_rope_append")
+    return q
+
+
+def silu_mul(gate_up):
+    _dev(gate_up)
+    rows, two_i = gate_up.shape
+    assert gate_up.dtype == _HALF and gate_up.is_contiguous()
+    out = torch.empty(rows, two_i // 2, dtype=_HALF, device=gate_up.device)
+    hip.check(hip.lib().tf_silu_mul(_ptr(gate_up), _ptr(out), rows, two_i // 2, _stream()), "tf_silu_mul")
+    return out
+
+
+def _workspace(device, floats):
+    # per-call allocation from torch's caching allocator: no hipMalloc after warm-up, and inside a
+    # hipGraph capture the block comes from the graph's private pool, so replays stay valid
+    return torch.empty(int(floats), dtype=torch.float32, device=device)
+
+
+def attn_decode(q, k_layer, v_layer, sk, scale, sk_dev=None, nsplit=None):
+    """flash_attn_with_kvcache(q, k, v, softmax_scale, causal=True) for sq<=32 rows (bottom-right causal).
+    q (sq,H,D); returns (sq, H*D) fp16."""
+    _dev(q, k_layer, v_layer, sk_dev)
+    sq, H, D = q.shape
+    assert q.dtype == _HALF and q.is_contiguous()
+    st, sh = _kv(k_layer)
+    assert _kv(v_layer) == (st, sh)
+    L = hip.lib()
+    if nsplit is None:
+        nsplit = L.tf_attn_decode_pick_nsplit(H, int(sk))
+    need = L.tf_attn_decode_ws_floats(H, sq, D, nsplit)
+    ws = _workspace(q.device, need)
+    out = torch.empty(sq, H * D, dtype=_HALF, device=q.device)
+    hip.check(L.tf_attn_decode(_ptr(q), _ptr(k_layer), _ptr(v_layer), _ptr(out), st, sh, sq, int(sk), _ptr(sk_dev),
+                               H, D, float(scale), nsplit, _ptr(ws), ws.numel(), _stream()), "tf_attn_decode")
+    return out
+
+
+def attn_prefill(q, k_layer, v_layer, sk, scale):
+    """Causal attention for a prefill block of any length: the block is cut into <=32-row slabs, slab j
+    seeing keys [0, sk - sq + end_j) — each slab is one bottom-right-aligned tf_attn_decode call."""
+    sq = q.shape[0]
+    if sq <= 32:
+        return attn_decode(q, k_layer, v_layer, sk, scale)
+    outs = []
+    for r0 in range(0, sq, 32):
+        r1 = min(sq, r0 + 32)
+        outs.append(attn_decode(q[r0:r1].contiguous(), k_layer, v_layer, sk - (sq - r1), scale))
+    return torch.cat(outs, dim=0)
+
+
+def attn_rope_on_read(q, k_layer, v_layer, cos, sin, kv_len, scale):
+    """Draft attention: cached keys are un-rotated and rotated on read with positions 0..kv_len-1."""
+    _dev(q, k_layer, v_layer, cos, sin)
+    sq, H, D = q.shape
+    assert q.dtype == _HALF and q.is_contiguous()
+    st, sh = _kv(k_layer)
+    assert _kv(v_layer) == (st, sh)
+    out = torch.empty(sq, H * D, dtype=_HALF, device=q.device)
+    hip.check(hip.lib().tf_attn_rope_on_read(_ptr(q), _ptr(k_layer), _ptr(v_layer), _ptr(cos), _ptr(sin), _ptr(out),
+                                             st, sh, sq, int(kv_len), H, D, float(scale), _stream()),
+              "tf_attn_rope_on_read")
+    return out
+
+
+def retrieval_score(k_layer, q, chunks, chunk):
+    """(H, chunks) fp16 un-scaled scores q . mean(K chunk)."""
+    _dev(k_layer, q)
+    H, T, D = k_layer.shape
+    st, sh = _kv(k_layer)
+    assert q.shape == (H, D) and q.dtype == _HALF and q.is_contiguous() and chunks * chunk <= T
+    scores = torch.empty(H, chunks, dtype=_HALF, device=q.device)
+    hip.check(hip.lib().tf_retrieval_score(_ptr(k_layer), st, sh, _ptr(q), _ptr(scores), chunks, chunk, H, D,
+                                           _stream()), "tf_retrieval_score")
+    return scores
+
+
+def retrieval_topk(scores, sets):
+    """(H, sets) int32: chunk 0 first, then the sets-1 best of [1,C), descending, ties -> lowest chunk."""
+    _dev(scores)
+    H, C = scores.shape
+    assert scores.dtype == _HALF and scores.is_contiguous()
+    idx = torch.empty(H, sets, dtype=torch.int32, device=scores.device)
+    hip.check(hip.lib().tf_retrieval_topk(_ptr(scores), _ptr(idx), C, sets, H, _stream()), "tf_retrieval_topk")
+    return idx
+
+
+def retrieval_gather(k_src, v_src, idx, k_dst, v_dst, chunk):
+    _dev(k_src, v_src, idx, k_dst, v_dst)
+    H, _, D = k_src.shape
+    sst, ssh = _kv(k_src)
+    assert _kv(v_src) == (sst, ssh)
+    dst_t, dsh = _kv(k_dst)
+    assert _kv(v_dst) == (dst_t, dsh)
+    assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.shape[0] == H
+    hip.check(hip.lib().tf_retrieval_gather(_ptr(k_src), _ptr(v_src), sst, ssh, _ptr(idx), _ptr(k_dst), _ptr(v_dst),
+                                            dst_t, dsh, idx.shape[1], chunk, H, D, _stream()), "tf_retrieval_gather")
+
+
+def _lhtd(t):
+    assert t.dim() == 4 and t.stride(3) == 1 and t.dtype == _HALF, "(L,H,T,D) fp16 expected"
+    return t.stride(0), t.stride(2), t.stride(1)     # stride_l, stride_t, stride_h
+
+
+def kv_copy_rows(src, dst, src_t0, dst_t0, n):
+    """dst[l,h,dst_t0+i] = src[l,h,src_t0+i] for all layers/heads; src/dst are (L,H,T,D) views."""
+    if n <= 0:
+        return
+    _dev(src, dst)
+    L, H, _, D = src.shape
+    assert dst.shape[0] == L and dst.shape[1] == H and dst.shape[3] == D
+    ssl, sst, ssh = _lhtd(src)
+    dsl, dst_t, dsh = _lhtd(dst)
+    hip.check(hip.lib().tf_kv_copy_rows(_ptr(src), ssl, sst, ssh, _ptr(dst), dsl, dst_t, dsh, int(src_t0), int(dst_t0),
+                                        int(n), L, H, D, _stream()), "tf_kv_copy_rows")
+
+
+def kv_shift_rows(cache, src_t0, dst_t0, n):
+    """In-place move of rows [src_t0, src_t0+n) down to [dst_t0, ...) (overlap allowed), all layers/heads."""
+    if n <= 0 or src_t0 == dst_t0:
+        return
+    _dev(cache)
+    L, H, _, D = cache.shape
+    sl, st, sh = _lhtd(cache)
+    hip.check(hip.lib().tf_kv_shift_rows(_ptr(cache), sl, st, sh, int(src_t0), int(dst_t0), int(n), L, H, D,
+                                         _stream()), "tf_kv_shift_rows")
+
+
+def sample_inverse_cdf(probs, u, token_out):
+    """token_out[0] <- first index with inclusive cumsum(probs) > u[0]*sum(probs).  All device tensors."""
+    _dev(probs, u, token_out)
+    assert probs.dtype == torch.float32 and probs.is_contiguous() and probs.dim() == 1
+    assert u.dtype == torch.float32 and token_out.dtype == torch.int64
+    hip.check(hip.lib().tf_sample_inverse_cdf(_ptr(probs), _ptr(u), _ptr(token_out), probs.numel(), _stream()),
+              "tf_sample_inverse_cdf")
+
+
+def accept_chain(p, q, tokens, uniforms, g2, inclusive, eos_token_id, out):
+    """out[4] int64 <- (count, next_token, reason, uniforms_consumed); see include/triforce_hip.h."""
+    _dev(p, q, tokens, uniforms, out)
+    V = p.shape[-1]
+    assert p.dtype == torch.float32 and p.is_contiguous() and p.shape[0] >= g2 + 1
+    assert q.dtype == torch.float32 and q.is_contiguous() and q.shape[0] >= g2 and q.shape[-1] == V
+    assert tokens.dtype == torch.int64 and tokens.numel() >= g2 and uniforms.numel() >= g2 + 1
+    assert out.dtype == torch.int64 and out.numel() >= 4
+    hip.check(hip.lib().tf_accept_chain(_ptr(p), _ptr(q), _ptr(tokens), _ptr(uniforms), int(g2), V,
+                                        1 if inclusive else 0, int(eos_token_id), _ptr(out), _stream()),
+              "tf_accept_chain")
+
+
+def middle_accept(p, q_d, tokens, uniforms, n, gamma, out):
+    """One Middle_Spec step on device: out[3] int64 <- (accepted, follow_up_token, drafted_token)."""
+    _dev(p, q_d, tokens, uniforms, out)
+    V = p.shape[-1]
+    assert p.dtype == torch.float32 and p.is_contiguous() and q_d.dtype == torch.float32 and q_d.numel() == V
+    assert tokens.dtype == torch.int64 and tokens.numel() >= gamma + 1 and uniforms.numel() >= 2
+    hip.check(hip.lib().tf_middle_accept(_ptr(p), _ptr(q_d), _ptr(tokens), _ptr(uniforms), int(n), int(gamma), V,
+                                         _ptr(out), _stream()), "tf_middle_accept")

@@ -1,0 +1,232 @@
+"""Decode algorithms of the TriForce path — same entry points as the reference's utils/decoding.py:
+Autoregressive (:14-37), TriForce (:41-160), Middle_Spec (:163-223) (+ the TP variants in
+decoding_dist.py).  Same algorithm, same quirks, different execution:
+
+  * every accept/reject decision, residual resample and bonus sample runs on the device
+    (tf_accept_chain / tf_middle_accept / tf_sample_inverse_cdf); the host reads back ONE small int64
+    record per inner step and ONE per outer step instead of >= gamma+2 blocking ``.item()`` /
+    ``if r < ...`` syncs (decoding.py:97-121,190-193);
+  * randomness comes from an explicit uniform stream (utils.sampling.UniformSource) consumed in
+    the reference's decision order, so a run is reproducible and comparable across devices;
+  * timing brackets the decode loop with device synchronisation (the reference omits it on-chip).
+"""
+import time
+
+import numpy as np
+import torch
+
+from .. import ops
+from .misc import log_csv, spec_stream
+from .sampling import UniformSource, norm_logits, sample
+
+PAD_TOKEN = 100            # filler id of verify_tokens / pass_tokens (decoding.py:94,177)
+
+
+def _sync(device):
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def _eos(tokenizer):
+    e = getattr(tokenizer, "eos_token_id", None)
+    return -1 if e is None else int(e)
+
+
+@torch.inference_mode()
+def Autoregressive(tokenizer, graph_engine, input_ids, max_len=256, top_k=-1, top_p=0.9, temperature=0.6, verbose=False,
+                   rng=None, return_tokens=False):
+    eng = graph_engine.engine
+    device = eng.model.device
+    rng = rng or UniformSource(device)
+    eng.kv_cache.reset()
+    logits = graph_engine.inference(input_ids=input_ids)
+    next_token = sample(norm_logits(logits[:, -1, :], temperature=temperature, top_k=top_k, top_p=top_p), rng=rng)
+    toks = [next_token]
+    n = 0
+    _sync(device)
+    time1 = time.time()
+    while n < max_len:      # no host sync inside the loop: the sampled token never leaves the device
+        logits = eng.model(input_ids=next_token, kv_cache=eng.kv_cache, graph_cache=None).logits
+        next_token = sample(norm_logits(logits[:, -1, :], temperature=temperature, top_k=top_k, top_p=top_p), rng=rng)
+        toks.append(next_token)
+        n += 1
+    _sync(device)
+    time2 = time.time()
+    if verbose or return_tokens:
+        ids = torch.cat(toks, dim=1)[0].tolist()
+        if verbose:
+            for t in ids:
+                spec_stream(t, tokenizer, "cyan")
+        if return_tokens:
+            return n / (time2 - time1), ids
+    return n / (time2 - time1)
+
+
+class _SpecBuffers:
+    """Per-engine device scratch reused across iterations (allocated once)."""
+
+    def __init__(self, device, gamma, vocab):
+        self.verify_tokens = torch.full((1, gamma + 1), PAD_TOKEN, dtype=torch.long, device=device)
+        self.spec_rows = torch.empty(gamma + 2, vocab, dtype=torch.float32, device=device)
+        self.mid_out = torch.zeros(4, dtype=torch.int64, device=device)
+        self.chain_out = torch.zeros(4, dtype=torch.int64, device=device)
+
+
+def _buffers(graph_engine, gamma, vocab, device):
+    b = getattr(graph_engine, "_tf_spec_buffers", None)
+    if b is None or b.verify_tokens.shape[1] != gamma + 1 or b.spec_rows.shape[1] != vocab:
+        b = _SpecBuffers(device, gamma, vocab)
+        graph_engine._tf_spec_buffers = b
+    return b
+
+
+@torch.inference_mode()
+def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, buffers=None):
+    """Inner loop: the 68M drafts one token at a time for the retrieval-cache model (decoding.py:163-223).
+    Returns (ids [next, t1..t_g2], rows = device (g2, V) view of the retrieval-model prob rows, acceptance)."""
+    eng = graph_engine.engine
+    device = eng.model.device
+    rng = rng or UniformSource(device)
+    if buffers is None:
+        buffers = _buffers(graph_engine, gamma, eng.model.config.vocab_size, device)
+    S = eng.kv_cache.seq_len
+    n = accepted = drafted = 0
+    ids = [int(next_token)]
+    vt = buffers.verify_tokens
+    vt.fill_(PAD_TOKEN)
+    vt[0, 0] = ids[0]
+    position_ids = torch.arange(S, S + gamma + 1, device=device).unsqueeze(0)
+    while n < gamma:
+        q_d = graph_engine.graph_draft_inference(input_ids=vt[:, :n + 1], gamma_offset=n)
+        flat = vt.view(-1)
+        u = rng.take(3)
+        ops.sample_inverse_cdf(q_d, u[0:1], flat[n + 1:n + 2])               # d ~ q_d, written into verify_tokens
+        p = graph_engine.graph_verify(input_ids=vt, position_ids=position_ids)
+        ops.middle_accept(p, q_d, flat, u[1:3], n, gamma, buffers.mid_out)   # accept test + follow-up sample
+        acc, b, d = buffers.mid_out[:3].tolist()                              # the one host sync of this step
+        rng.advance(3)
+        drafted += 1
+        g = len(ids) - 1
+        if acc:                                                               # decoding.py:193-209
+            buffers.spec_rows[g].copy_(p[n])
+            buffers.spec_rows[g + 1].copy_(p[n + 1])
+            ids += [d, b]
+            accepted += 1
+            n += 2
+            if verbose:
+                spec_stream(d, tokenizer, "green")
+                spec_stream(b, tokenizer, "blue")
+        else:                                                                 # decoding.py:211-220
+            buffers.spec_rows[g].copy_(p[n])
+            ids.append(b)
+            n += 1
+            if verbose:
+                spec_stream(b, tokenizer, "red")
+    return ids, buffers.spec_rows[:len(ids) - 1], accepted / drafted
+
+
+@torch.inference_mode()
+def TriForce(tokenizer, graph_engine, input_ids, gamma=4, max_len=256, top_k=-1, top_p=0.9, temperature=0.6, verbose=False,
+             file_path=None, dataset=None, spec_args=None, rng=None, return_details=False):
+    eng = graph_engine.engine
+    device = eng.model.device
+    rng = rng or UniformSource(device)
+    eos = _eos(tokenizer)
+    vocab = eng.model.config.vocab_size
+
+    eng.kv_cache.reset()
+    eng.graph_cache.reset()
+    eng.draft_cache.reset()
+    graph_engine.inference(input_ids=input_ids[:, :-1])
+    logits = graph_engine.inference(input_ids=input_ids[:, -1:])          # q_len==1 -> retrieval cache is built here
+    graph_engine.graph_draft_prefill(input_ids=input_ids)
+    if verbose:
+        eng.kv_cache.print_status()
+        eng.graph_cache.print_status()
+        eng.draft_cache.print_status()
+
+    bufs = _buffers(graph_engine, gamma, vocab, device)
+    resample_count = accepted_count = target_sample_count = draft_count = 0
+    next_token = int(sample(norm_logits(logits[:, -1, :], temperature=temperature, top_k=top_k, top_p=top_p), rng=rng))
+    if verbose:
+        spec_stream(next_token, tokenizer, "cyan")
+    emitted = [next_token]
+    counts, acc_rate_middle_list = [], []
+    n = 0
+    _sync(device)
+    time1 = time.time()
+    while n < max_len:
+        ids, spec_rows, acc_mid = Middle_Spec(next_token, graph_engine, gamma, False, tokenizer, rng=rng, buffers=bufs)
+        acc_rate_middle_list.append(acc_mid)
+        generated = ids[1:]
+        g2 = len(generated)
+        draft_count += g2
+
+        # target model verifies [next, t1..t_g2] against the full KV cache
+        verify_tokens = torch.tensor([ids], dtype=torch.long, device=device)
+        logits = graph_engine.inference(input_ids=verify_tokens)
+        probs = norm_logits(logits[0], temperature=temperature, top_k=top_k, top_p=top_p)
+        ops.accept_chain(probs, spec_rows, verify_tokens.view(-1)[1:], rng.take(g2 + 1), g2, False, eos, bufs.chain_out)
+        count, pred, reason, consumed = bufs.chain_out.tolist()          # the one host sync of the outer step
+        rng.advance(consumed)
+
+        pass_tokens = [next_token] + generated[:count] + [PAD_TOKEN] * (g2 + 1 - count)
+        accepted_count += count
+        n += count
+        emitted += generated[:count]
+        if verbose:
+            for t in generated[:count]:
+                spec_stream(t, tokenizer, "green")
+        if reason == 0:                                                   # rejection -> residual resample (:111-118)
+            resample_count += 1
+            n += 1
+            pass_tokens[count + 1] = pred
+            emitted.append(pred)
+            if verbose:
+                spec_stream(pred, tokenizer, "red")
+        elif reason == 2:                                                 # accepted eos (:108-110)
+            draft_count -= g2 - count
+
+        eng.kv_cache.seq_len -= (g2 - count)                              # rollback (:124)
+        graph_engine.update_graph_cache()                                 # refresh the retrieval tail (:125)
+
+        if reason == 1:                                                   # everything accepted -> bonus token (:127-134)
+            target_sample_count += 1
+            n += 1
+            pass_tokens[count + 1] = pred
+            emitted.append(pred)
+            if verbose:
+                spec_stream(pred, tokenizer, "blue")
+            count += 1
+        counts.append(count)
+
+        # bring the 68M cache up to date (:137-139)
+        graph_engine.graph_draft_inference(input_ids=torch.tensor([pass_tokens], dtype=torch.long, device=device),
+                                           gamma_offset=g2 + 1)
+        dc = eng.draft_cache
+        dc.evict_for_spec(dc.start_size + dc.recent_size + count)
+        next_token = pred
+    _sync(device)
+    time2 = time.time()
+
+    acceptance_rate = accepted_count / draft_count
+    avg_tokens = accepted_count / draft_count * gamma
+    if verbose:
+        print(f"Use {time2 - time1} sec to generate {n} tokens (now {eng.kv_cache.seq_len} tokens), "
+              f"Tokens/s: {n / (time2 - time1)}", flush=True)
+        print(f"accepted rate {acceptance_rate}, avg generated tokens {avg_tokens}")
+    if file_path is not None:
+        header = "target,acceptance_rate,token/s,avg_tokens,prefill,gen_len,dataset,acc_rate_middle,latency\n"
+        entry = (f"{eng.model.config._name_or_path},{acceptance_rate},{n / (time2 - time1)},{avg_tokens},"
+                 f"{input_ids.shape[1]},{n},{dataset},{np.array(acc_rate_middle_list).mean()},{(time2 - time1) / n}\n")
+        if spec_args is not None:
+            for k, v in spec_args.items():
+                header = header.replace("\n", f",{k}\n")
+                entry = entry.replace("\n", f",{v}\n")
+        log_csv(file_path, header, entry)
+    if return_details:
+        return dict(acceptance_rate=acceptance_rate, tokens_per_s=n / (time2 - time1), tokens=emitted, n=n,
+                    counts=counts, accepted=accepted_count, drafted=draft_count, avg_tokens=avg_tokens,
+                    resampled=resample_count, bonus=target_sample_count, seconds=time2 - time1,
+                    outer_steps=len(counts), acc_rate_middle=float(np.mean(acc_rate_middle_list)))
+    return acceptance_rate, n / (time2 - time1)

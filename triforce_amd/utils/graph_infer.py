@@ -1,0 +1,171 @@
+"""Single-GPU engine — mirror of the reference's utils/graph_infer.py: InferenceEngine (:14-72)
+routes prefill vs verify vs draft; GraphInferenceEngine (:129-194) captures gamma+3 draft hipGraphs
+(one per gamma_offset) and one retrieval-verify hipGraph and replays them.
+
+On ROCm ``torch.cuda.CUDAGraph`` is a hipGraph; our kernels are enqueued on torch's current stream
+through the C ABI, so they are captured together with the hipBLASLt GEMMs.
+"""
+import gc
+import math
+from typing import Optional
+
+import torch
+
+from .sampling import norm_logits
+
+
+class InferenceEngine:
+    def __init__(self, model, cache, graph_cache, draft, draft_cache) -> None:
+        self.model = model.eval()                  # target (7B)
+        self.kv_cache = cache
+        self.graph_cache = graph_cache
+        self.draft = draft.eval()                  # 68M
+        self.draft_cache = draft_cache
+
+    @torch.inference_mode()
+    def model_run(self, input_ids: torch.LongTensor):
+        n = input_ids.shape[-1]
+        if n > 64:                                 # chunked prefill, 128 tokens per forward (graph_infer.py:30-37)
+            for i in range(math.ceil(n / 128)):
+                logits = self.model(input_ids=input_ids[:, i * 128:(i + 1) * 128], kv_cache=self.kv_cache,
+                                    graph_cache=None).logits
+        else:                                      # verification / q_len==1 retrieval build
+            logits = self.model(input_ids=input_ids, kv_cache=self.kv_cache, graph_cache=self.graph_cache).logits
+        return logits
+
+    @torch.inference_mode()
+    def draft_run(self, input_ids: torch.LongTensor, gamma_offset: int = 0, probs=False, temperature=0.6, top_p=0.9):
+        n = input_ids.shape[-1]
+        if n > 64:                                 # draft prefill, 64 tokens per forward with eviction (:44-52)
+            for i in range(math.ceil(n / 64)):
+                self.draft_cache.evict_prefill(64)
+                logits = self.draft(input_ids=input_ids[:, i * 64:(i + 1) * 64], kv_cache=self.draft_cache,
+                                    graph_cache=None).logits
+        else:
+            logits = self.draft(input_ids=input_ids, kv_cache=self.draft_cache, graph_cache=self.draft_cache,
+                                gamma_offset=gamma_offset).logits
+        if probs:
+            return norm_logits(logits[0], temperature=temperature, top_k=-1, top_p=top_p)[-1]
+        return logits
+
+    @torch.inference_mode()
+    def model_verify(self, input_ids: torch.LongTensor, position_ids: Optional[torch.LongTensor] = None, probs=False,
+                     temperature=0.6, top_p=0.9):
+        logits = self.model(input_ids=input_ids, kv_cache=self.kv_cache, graph_cache=self.graph_cache,
+                            position_ids=position_ids, spec=True).logits
+        if probs:
+            return norm_logits(logits[0], temperature=temperature, top_k=-1, top_p=top_p)
+        return logits
+
+    def clear_kv(self):
+        self.kv_cache.reset()
+        self.graph_cache.reset()
+        self.draft_cache.reset()
+
+
+def _capture(fn, static_inputs, mempool, n_warmups):
+    """Warm up on a side stream, then capture ``fn(*static_inputs)`` into one hipGraph."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(n_warmups):
+            static_out = fn(*static_inputs)
+        side.synchronize()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, pool=mempool):
+        static_out = fn(*static_inputs)
+    return graph, static_out
+
+
+def draft_run_capture_graph(engine: InferenceEngine, gamma_offset: int = 0, mempool=None, n_warmups: int = 3, probs=False,
+                            temperature=0.6, top_p=0.9, verbose=True):
+    device = engine.draft.device
+    static_input_ids = torch.zeros((1, gamma_offset + 1), dtype=torch.long, device=device)
+    if verbose:
+        print(f"[draft run] capturing graph for {gamma_offset} (probs={probs}, temp={temperature}, top_p={top_p})...")
+    graph, static_out = _capture(
+        lambda ids: engine.draft_run(input_ids=ids, gamma_offset=gamma_offset, probs=probs, temperature=temperature,
+                                     top_p=top_p), (static_input_ids,), mempool, n_warmups)
+
+    def run(input_ids):
+        static_input_ids.copy_(input_ids)
+        graph.replay()
+        return static_out.clone()
+
+    return run
+
+
+def model_verify_capture_graph(engine: InferenceEngine, mempool=None, n_warmups: int = 3, gamma: int = 6, probs=False,
+                               temperature=0.6, top_p=0.9, verbose=True):
+    device = engine.model.device
+    static_input_ids = torch.zeros((1, gamma + 1), dtype=torch.long, device=device)
+    static_position_ids = torch.arange(gamma + 1, device=device).unsqueeze(0)
+    if verbose:
+        print(f"[model verify] capturing graph for spec len {gamma} (probs={probs}, temp={temperature}, top_p={top_p})...")
+    graph, static_out = _capture(
+        lambda ids, pos: engine.model_verify(input_ids=ids, position_ids=pos, probs=probs, temperature=temperature,
+                                             top_p=top_p), (static_input_ids, static_position_ids), mempool, n_warmups)
+
+    def run(input_ids, position_ids):
+        static_input_ids.copy_(input_ids)
+        static_position_ids.copy_(position_ids)
+        graph.replay()
+        return static_out.clone()
+
+    return run
+
+
+class GraphInferenceEngine:
+    def __init__(self, model, cache, graph_cache, draft, draft_cache) -> None:
+        self.engine = InferenceEngine(model, cache, graph_cache, draft, draft_cache)
+        self.callables = {}
+        self.callable_model_verify = None
+        self.mempool = None
+        self.sampling = dict(probs=False, temperature=0.6, top_p=0.9)
+
+    @torch.inference_mode()
+    def initialize_cuda_graph(self, gamma=6, probs=False, temperature=0.6, top_p=0.9, verbose=True):
+        gc.collect()
+        self.mempool = torch.cuda.graphs.graph_pool_handle()
+        self.sampling = dict(probs=probs, temperature=temperature, top_p=top_p)
+        for gamma_offset in range(gamma + 3):
+            self.callables[gamma_offset] = draft_run_capture_graph(
+                engine=self.engine, gamma_offset=gamma_offset, mempool=self.mempool, n_warmups=3, verbose=verbose,
+                **self.sampling)
+        self.callable_model_verify = model_verify_capture_graph(
+            engine=self.engine, mempool=self.mempool, n_warmups=3, gamma=gamma, verbose=verbose, **self.sampling)
+        self.engine.clear_kv()
+
+    def initialize_eager(self, gamma=6, probs=True, temperature=0.6, top_p=0.9):
+        """Same surface without graph capture (debugging / parity bisecting)."""
+        self.sampling = dict(probs=probs, temperature=temperature, top_p=top_p)
+        eng = self.engine
+        for off in range(gamma + 3):
+            self.callables[off] = (lambda ids, off=off: eng.draft_run(input_ids=ids, gamma_offset=off, **self.sampling))
+        self.callable_model_verify = lambda ids, pos: eng.model_verify(input_ids=ids, position_ids=pos, **self.sampling)
+
+    def clear_kv(self):
+        self.engine.clear_kv()
+
+    @torch.inference_mode()
+    def graph_draft_inference(self, input_ids: torch.LongTensor, gamma_offset: int = 0):
+        return self.callables[gamma_offset](input_ids)
+
+    @torch.inference_mode()
+    def graph_draft_prefill(self, input_ids: torch.LongTensor):
+        return self.engine.draft_run(input_ids=input_ids)
+
+    @torch.inference_mode()
+    def inference(self, input_ids: torch.LongTensor):
+        return self.engine.model_run(input_ids=input_ids)
+
+    @torch.inference_mode()
+    def graph_verify(self, input_ids: torch.LongTensor, position_ids: torch.LongTensor):
+        return self.callable_model_verify(input_ids, position_ids)
+
+    def init_graph_cache(self):
+        self.engine.graph_cache.init_graph_cache(kv_cache=self.engine.kv_cache)
+
+    def update_graph_cache(self):
+        self.engine.graph_cache.update_graph_cache(kv_cache=self.engine.kv_cache)

@@ -1,0 +1,41 @@
+"""Console / CSV helpers (role of the reference's utils/misc.py: spec_stream :5-16, log_csv :23-35,
+print_config :37-50).  ANSI colours directly — no termcolor dependency."""
+_ANSI = {"red": 31, "green": 32, "yellow": 33, "blue": 34, "magenta": 35, "cyan": 36}
+
+
+def colored(text, color=None):
+    code = _ANSI.get(color)
+    return f"\033[{code}m{text}\033[0m" if code else str(text)
+
+
+def spec_stream(pred_token_idx, tokenizer, color="blue"):
+    if tokenizer is None:
+        return
+    decoded = tokenizer.decode(pred_token_idx, skip_special_tokens=True, clean_up_tokenization_spaces=True)
+    print(colored(decoded.replace("<0x0A>", "\n"), color), flush=True, end=" ")
+
+
+def log_csv(file_path, header, entry):
+    try:
+        with open(file_path, "r") as f:
+            contents = f.read()
+    except FileNotFoundError:
+        contents = ""
+    with open(file_path, "a") as f:
+        if not contents:
+            f.write(header)
+        f.write(entry)
+
+
+def print_config(draft, target, prefill, gen_len, gamma, top_k, top_p, temperature, file_path, method,
+                 spec_args=None, dataset=None):
+    bar = "#" * 39
+    print(colored(f"{bar} Config {bar}", "blue"), flush=True)
+    print(colored(f"Method: {method}", "red"), flush=True)
+    for line in (f"Dataset: {dataset}", f"Spec Args: {spec_args}", f"Draft: {draft.config._name_or_path}",
+                 f"Target: {target.config._name_or_path}", f"Prefill Length: {prefill}",
+                 f"Generation Length: {gen_len}", f"Gamma: {gamma}",
+                 f"Sampling Method: top_k = {top_k}, top_p = {top_p}, temperature = {temperature}",
+                 f"Log CSV: {file_path}"):
+        print(colored(line, "blue"), flush=True)
+    print(colored("#" * 86 + "\n", "blue"), flush=True)
