@@ -1,0 +1,59 @@
+"""The C-ABI library loads, exports every symbol include/triforce_hip.h declares, and rejects bad
+arguments before launching anything (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "triforce_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from triforce_amd import hip
+    lib = hip.lib()
+    names = _header_symbols()
+    assert len(names) >= 16
+    for n in names:
+        assert hasattr(lib, n), f"libtriforce_hip.so does not export {n}"
+    assert set(names) == set(hip.SIGNATURES), "ctypes binding and header disagree"
+    assert lib.tf_abi_version() == hip.ABI_VERSION
+
+
+def test_host_side_helpers():
+    from triforce_amd import hip
+    lib = hip.lib()
+    assert lib.tf_attn_decode_pick_nsplit(32, 124928) == 32
+    assert lib.tf_attn_decode_pick_nsplit(32, 4103) == 8
+    assert lib.tf_attn_decode_pick_nsplit(2, 16) == 1
+    assert lib.tf_attn_decode_ws_floats(32, 8, 128, 32) == 32 * 32 * 16 * 130
+    assert lib.tf_attn_decode_ws_floats(16, 18, 128, 4) == 16 * 4 * 32 * 130
+
+
+def test_bad_arguments_are_rejected_without_launching():
+    from triforce_amd import hip
+    lib = hip.lib()
+    null = ctypes.c_void_p(0)
+    assert lib.tf_attn_decode(null, null, null, null, 128, 128, 1, 1, null, 1, 128, 1.0, 1, null, 0, null) == -22
+    assert lib.tf_rmsnorm(null, null, null, null, null, 1, 8, 1e-6, null) == -22
+    assert lib.tf_retrieval_topk(null, null, 10, 2, 1, null) == -22
+    assert lib.tf_kv_copy_rows(null, 0, 0, 0, null, 0, 0, 0, 0, 0, 0, 1, 1, 8, null) == 0      # n == 0 is a no-op
+    with pytest.raises(hip.TriforceHipError):
+        hip.check(-22, "x")
+
+
+def test_ops_refuse_cpu_tensors():
+    """No CPU fallback: the product ops raise on non-device tensors instead of computing."""
+    import torch
+    from triforce_amd import hip, ops
+    x = torch.zeros(2, 8, dtype=torch.float16)
+    with pytest.raises(hip.TriforceHipError):
+        ops.rmsnorm(x, torch.ones(8, dtype=torch.float16), 1e-6)
+    with pytest.raises(hip.TriforceHipError):
+        ops.silu_mul(torch.zeros(2, 16, dtype=torch.float16))

@@ -1,0 +1,379 @@
+"""Op-level parity on a real MI355X: every HIP kernel, called through the C ABI (triforce_amd.ops ->
+ctypes -> libtriforce_hip.so), against its CPU oracle on the same seeded inputs.
+
+Bars: bit-exact for integer / index / copy / fp16-elementwise work; for reductions in fp32 whose
+summation order legitimately differs from the CPU's the tolerance is written next to the assert.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _ops():
+    from triforce_amd import ops
+    return ops
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def ulp_report(name, got, want, max_ulp_frac=2e-3, atol=0.0):
+    """fp16 results that may differ by rounding of an fp32 reduction: at most `max_ulp_frac` of the
+    elements may differ at all, and none by more than 1 fp16 ulp (+atol)."""
+    got, want = got.float().cpu(), want.float().cpu()
+    diff = (got - want).abs()
+    ulp = torch.maximum(want.abs(), torch.tensor(6.1e-5)) * 2 ** -10
+    bad = diff > (ulp * 1.01 + atol)
+    frac = (diff > 0).float().mean().item()
+    assert not bad.any(), f"{name}: {int(bad.sum())} elements off by >1 ulp, max diff {diff.max().item():.3e}"
+    assert frac <= max_ulp_frac, f"{name}: {frac:.4%} elements differ (allowed {max_ulp_frac:.2%})"
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,hidden", [(1, 256), (7, 768), (128, 4096), (3, 5120)])
+@pytest.mark.parametrize("residual", [False, True])
+def test_rmsnorm(rows, hidden, residual):
+    ops = _ops()
+    x, w = rnd(rows, hidden, seed=1), (1 + 0.1 * rnd(hidden, seed=2).float()).half()
+    res = rnd(rows, hidden, seed=3) if residual else None
+    xs = x + res if residual else x
+    want = R.rms_norm(xs, w, 1e-5)
+    xd = x.to(DEV)
+    so = torch.empty_like(xd) if residual else None
+    got = ops.rmsnorm(xd, w.to(DEV), 1e-5, residual=res.to(DEV) if residual else None, sum_out=so)
+    if residual:
+        assert torch.equal(so.cpu(), xs), "residual sum must be bit-exact (fp16 add)"
+    # fp32 sum of squares is reduced in a different order than torch CPU: the normalised value may
+    # round differently for a handful of elements -> <=1 ulp on <=1% of them
+    ulp_report("rmsnorm", got, want, max_ulp_frac=1e-2)
+
+
+def test_rmsnorm_inplace_residual_accumulate():
+    ops = _ops()
+    x, d, w = rnd(8, 512, seed=4).to(DEV), rnd(8, 512, seed=5).to(DEV), torch.ones(512, dtype=torch.float16, device=DEV)
+    want_sum = (x.cpu() + d.cpu())
+    ops.rmsnorm(d, w, 1e-6, residual=x, sum_out=x)
+    assert torch.equal(x.cpu(), want_sum)
+
+
+@pytest.mark.parametrize("H,D", [(4, 64), (2, 128), (32, 128)])
+@pytest.mark.parametrize("rotate_k", [True, False])
+@pytest.mark.parametrize("head_major", [True, False])
+def test_rope_append_bit_exact(H, D, rotate_k, head_major):
+    ops = _ops()
+    rows, T, slot0 = 9, 64, 17
+    qkv = rnd(rows, 3 * H * D, seed=6)
+    cos, sin = R.rope_tables_yarn(D, 4096, 16.0, 256) if D == 128 else R.rope_tables_plain(D, 4096)
+    pos = torch.tensor([4000, 0, 1, 77, 2048, 5, 6, 7, 4095])
+    q = qkv[:, :H * D].view(rows, H, D)
+    k = qkv[:, H * D:2 * H * D].view(rows, H, D)
+    v = qkv[:, 2 * H * D:].view(rows, H, D)
+    want_q = R.apply_rope(q, cos, sin, pos)
+    want_k = R.apply_rope(k, cos, sin, pos) if rotate_k else k
+    if head_major:
+        kc = torch.zeros(H, T, D, dtype=torch.float16, device=DEV)
+        vc = torch.zeros(H, T, D, dtype=torch.float16, device=DEV)
+        kl, vl = kc, vc
+    else:
+        kc = torch.zeros(T, H, D, dtype=torch.float16, device=DEV)
+        vc = torch.zeros(T, H, D, dtype=torch.float16, device=DEV)
+        kl, vl = kc.permute(1, 0, 2), vc.permute(1, 0, 2)
+    got_q = ops.rope_append(qkv.to(DEV), cos.to(DEV), sin.to(DEV), pos.to(DEV), kl, vl, slot0, H, D, rotate_k=rotate_k)
+    assert torch.equal(got_q.cpu(), want_q)
+    assert torch.equal(kl[:, slot0:slot0 + rows].permute(1, 0, 2).cpu(), want_k)
+    assert torch.equal(vl[:, slot0:slot0 + rows].permute(1, 0, 2).cpu(), v)
+    assert kl[:, :slot0].abs().sum() == 0 and kl[:, slot0 + rows:].abs().sum() == 0
+    # device-side slot (graph-capturable form)
+    kl.zero_()
+    sdev = torch.tensor([3], dtype=torch.int32, device=DEV)
+    ops.rope_append(qkv.to(DEV), cos.to(DEV), sin.to(DEV), pos.to(DEV), kl, vl, 0, H, D, rotate_k=rotate_k, slot0_dev=sdev)
+    assert torch.equal(kl[:, 3:3 + rows].permute(1, 0, 2).cpu(), want_k)
+
+
+@pytest.mark.parametrize("rows,I", [(1, 768), (7, 11008), (128, 3072)])
+def test_silu_mul(rows, I):
+    ops = _ops()
+    gu = rnd(rows, 2 * I, seed=7, scale=2.0)
+    want = R.silu_mul(gu[:, :I], gu[:, I:])
+    got = ops.silu_mul(gu.to(DEV))
+    # expf on the device vs the CPU's vectorised exp: <=1 ulp on a small fraction
+    ulp_report("silu_mul", got, want, max_ulp_frac=2e-2)
+
+
+# ------------------------------------------------------------------------------------------
+ATTN_CASES = [
+    # sq, sk, H, D, nsplit
+    (1, 1, 2, 128, None), (1, 17, 2, 128, None), (7, 16, 4, 128, 1), (7, 261, 4, 128, None), (8, 300, 2, 64, 2),
+    (5, 1000, 4, 64, 3), (16, 4103, 4, 128, None), (17, 12305, 2, 128, None), (18, 2049, 4, 128, 5),
+    (32, 333, 2, 128, None), (32, 32, 2, 64, None), (19, 4096, 4, 64, 7), (7, 4103, 32, 128, None),
+]
+
+
+def _attn_inputs(sq, sk, H, D, seed, head_major=True, cap=None):
+    cap = cap or sk
+    q, k, v = rnd(sq, H, D, seed=seed), rnd(cap, H, D, seed=seed + 1), rnd(cap, H, D, seed=seed + 2)
+    if head_major:
+        kd, vd = k.permute(1, 0, 2).contiguous().to(DEV), v.permute(1, 0, 2).contiguous().to(DEV)
+    else:
+        kd, vd = k.to(DEV).permute(1, 0, 2), v.to(DEV).permute(1, 0, 2)
+    return q, k, v, kd, vd
+
+
+# attention tolerance: P is rounded to fp16 before the PV MFMA (like flash-attn) and exp is the fast
+# hardware exp2 path; the oracle keeps P in fp32.  |out| <= max|v| ~ 4, so 2e-3 abs + 2e-3 rel.
+ATTN_ATOL, ATTN_RTOL = 2e-3, 2e-3
+
+
+@pytest.mark.parametrize("sq,sk,H,D,nsplit", ATTN_CASES)
+def test_attn_decode_matches_oracle(sq, sk, H, D, nsplit):
+    ops = _ops()
+    scale = R.softmax_scale_for(D)
+    q, k, v, kd, vd = _attn_inputs(sq, sk, H, D, seed=10 + sq + sk)
+    want = R.attn_kvcache(q, k, v, scale).reshape(sq, H * D)
+    got = ops.attn_decode(q.to(DEV), kd, vd, sk, scale, nsplit=nsplit)
+    torch.testing.assert_close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+
+
+def test_attn_decode_token_major_and_device_seqlen():
+    ops = _ops()
+    sq, sk, H, D, cap = 7, 777, 4, 128, 1024
+    scale = R.softmax_scale_for(D)
+    q, k, v, kd, vd = _attn_inputs(sq, sk, H, D, seed=99, head_major=False, cap=cap)
+    want = R.attn_kvcache(q, k[:sk], v[:sk], scale).reshape(sq, H * D)
+    got = ops.attn_decode(q.to(DEV), kd, vd, sk, scale)
+    torch.testing.assert_close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+    # key count read from device memory, launch sized by the capacity
+    skd = torch.tensor([sk], dtype=torch.int32, device=DEV)
+    got2 = ops.attn_decode(q.to(DEV), kd, vd, cap, scale, sk_dev=skd, nsplit=4)
+    torch.testing.assert_close(got2.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+
+
+def test_attn_decode_online_softmax_rescale_is_exercised():
+    """One key far above the rest, placed late in the stream of one split and early in another, forces
+    the running-max rescale branch (a rare data-dependent path needs its own test)."""
+    ops = _ops()
+    sq, sk, H, D = 8, 2000, 2, 128
+    scale = R.softmax_scale_for(D)
+    q, k, v, _, _ = _attn_inputs(sq, sk, H, D, seed=5)
+    k[1500] = q[3] * 3.0            # huge score for query 3 at key 1500
+    k[40, 1] = q[6, 1] * 2.5
+    kd, vd = k.permute(1, 0, 2).contiguous().to(DEV), v.permute(1, 0, 2).contiguous().to(DEV)
+    want = R.attn_kvcache(q, k, v, scale).reshape(sq, H * D)
+    for ns in (1, 2, 5):
+        got = ops.attn_decode(q.to(DEV), kd, vd, sk, scale, nsplit=ns)
+        torch.testing.assert_close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+
+
+def test_attn_prefill_block_equals_oracle():
+    ops = _ops()
+    sq, sk, H, D = 128, 640, 2, 128
+    scale = R.softmax_scale_for(D)
+    q, k, v, kd, vd = _attn_inputs(sq, sk, H, D, seed=3)
+    want = R.attn_kvcache(q, k, v, scale).reshape(sq, H * D)
+    got = ops.attn_prefill(q.to(DEV), kd, vd, sk, scale)
+    torch.testing.assert_close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+
+
+def test_attn_decode_full_size_cfg2_layer():
+    """BASELINE configs[1] shape for one layer: 8 queries x 124 935 keys x 32 heads x 128 (2 GB of KV)."""
+    ops = _ops()
+    sq, sk, H, D = 8, 124928 + 7, 32, 128
+    scale = R.softmax_scale_for(D)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    kd = torch.randn(H, sk, D, generator=g, device=DEV, dtype=torch.float16)
+    vd = torch.randn(H, sk, D, generator=g, device=DEV, dtype=torch.float16)
+    q = torch.randn(sq, H, D, generator=g, device=DEV, dtype=torch.float16)
+    got = ops.attn_decode(q, kd, vd, sk, scale)
+    want = R.attn_kvcache(q.cpu(), kd.permute(1, 0, 2).cpu(), vd.permute(1, 0, 2).cpu(), scale).reshape(sq, H * D)
+    torch.testing.assert_close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+    # size-independent property: attention is linear in V
+    got2 = ops.attn_decode(q, kd, vd * 2, sk, scale)
+    torch.testing.assert_close(got2.float(), got.float() * 2, atol=2 * ATTN_ATOL, rtol=ATTN_RTOL)
+
+
+@pytest.mark.parametrize("sq,kv_len,H", [(1, 5, 2), (3, 64, 12), (9, 259, 12), (64, 200, 12), (7, 130, 3)])
+def test_attn_rope_on_read(sq, kv_len, H):
+    ops = _ops()
+    D = 64
+    scale = R.softmax_scale_for(D)
+    cos, sin = R.rope_tables_plain(D, 2048)
+    q, k, v, kd, vd = _attn_inputs(sq, kv_len, H, D, seed=20 + sq, cap=kv_len + 3)
+    kr = R.apply_rope(k[:kv_len], cos, sin, torch.arange(kv_len))
+    want = R.attn_kvcache(q, kr, v[:kv_len], scale).reshape(sq, H * D)
+    got = ops.attn_rope_on_read(q.to(DEV), kd, vd, cos.to(DEV), sin.to(DEV), kv_len, scale)
+    torch.testing.assert_close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,H,D,chunk", [(1000, 4, 64, 8), (2048, 2, 128, 8), (124928, 32, 128, 8), (640, 3, 128, 16)])
+def test_retrieval_score(T, H, D, chunk):
+    ops = _ops()
+    C = T // chunk
+    k, q = rnd(T + 5, H, D, seed=30), rnd(H, D, seed=31)
+    want = R.retrieval_scores(k, q, C * chunk, chunk)
+    kd = k.permute(1, 0, 2).contiguous().to(DEV)
+    got = ops.retrieval_score(kd, q.to(DEV), C, chunk)
+    # two fp16 rounding points (mean, dot) with fp32 sums in a different order than torch CPU:
+    # <= 1 ulp (SURVEY §7 "scores (<=1 ulp fp16)"); most elements identical
+    ulp_report("retrieval_score", got, want, max_ulp_frac=0.25, atol=2e-3)
+
+
+@pytest.mark.parametrize("H,C,sets", [(1, 9, 4), (4, 125, 16), (2, 256, 32), (32, 15616, 512), (16, 16256, 1536), (3, 3000, 2999)])
+def test_retrieval_topk_bit_exact_with_ties(H, C, sets):
+    ops = _ops()
+    # coarse quantisation -> thousands of exact ties, including at the k-th value
+    s = (rnd(H, C, seed=40).float() * 4).round().div(4).half()
+    s[0, 3] = float("inf")
+    s[-1, C - 1] = float("-inf")
+    want = R.retrieval_topk(s, sets)
+    got = ops.retrieval_topk(s.to(DEV), sets)
+    assert got.dtype == torch.int32
+    assert torch.equal(got.cpu().long(), want), "top-k indices (descending score, ties -> lowest chunk) must be bit-exact"
+
+
+@pytest.mark.parametrize("H,D,chunk,C,sets", [(4, 64, 8, 125, 16), (32, 128, 8, 1000, 512), (2, 128, 16, 40, 8)])
+def test_retrieval_gather_bit_exact(H, D, chunk, C, sets):
+    ops = _ops()
+    T = C * chunk
+    k, v = rnd(T, H, D, seed=50), rnd(T, H, D, seed=51)
+    g = torch.Generator().manual_seed(52)
+    idx = torch.stack([torch.randperm(C, generator=g)[:sets] for _ in range(H)])
+    want_k, want_v = R.retrieval_gather(k, idx, chunk), R.retrieval_gather(v, idx, chunk)
+    kd, vd = k.permute(1, 0, 2).contiguous().to(DEV), v.permute(1, 0, 2).contiguous().to(DEV)
+    R_ = sets * chunk + 7
+    kr = torch.zeros(H, R_, D, dtype=torch.float16, device=DEV)
+    vr = torch.zeros(H, R_, D, dtype=torch.float16, device=DEV)
+    ops.retrieval_gather(kd, vd, idx.to(torch.int32).to(DEV), kr, vr, chunk)
+    assert torch.equal(kr[:, :sets * chunk].permute(1, 0, 2).cpu(), want_k)
+    assert torch.equal(vr[:, :sets * chunk].permute(1, 0, 2).cpu(), want_v)
+    assert kr[:, sets * chunk:].abs().sum() == 0
+
+
+def test_retrieval_build_round_trip_full_size():
+    """cfg2 layer shape: score -> top-k -> gather; property checks that do not need the CPU oracle:
+    chunk 0 first, indices unique, scores of selected chunks sorted descending, every selected score >=
+    every unselected one, gathered rows equal the source rows."""
+    ops = _ops()
+    H, D, chunk, P, B = 32, 128, 8, 124928, 4096
+    C, sets = P // chunk, B // chunk
+    g = torch.Generator(device=DEV).manual_seed(7)
+    kd = torch.randn(H, P, D, generator=g, device=DEV, dtype=torch.float16)
+    vd = torch.randn(H, P, D, generator=g, device=DEV, dtype=torch.float16)
+    q = torch.randn(H, D, generator=g, device=DEV, dtype=torch.float16)
+    scores = ops.retrieval_score(kd, q, C, chunk)
+    idx = ops.retrieval_topk(scores, sets)
+    kr = torch.zeros(H, B + 7, D, dtype=torch.float16, device=DEV)
+    vr = torch.zeros(H, B + 7, D, dtype=torch.float16, device=DEV)
+    ops.retrieval_gather(kd, vd, idx, kr, vr, chunk)
+    idxl = idx.long()
+    assert (idxl[:, 0] == 0).all()
+    assert all(len(set(r.tolist())) == sets for r in idxl.cpu())
+    sel = torch.gather(scores.float(), 1, idxl[:, 1:])
+    assert (sel[:, :-1] >= sel[:, 1:]).all(), "selected chunks must come in descending score order"
+    mask = torch.ones_like(scores, dtype=torch.bool).scatter(1, idxl, False)
+    mask[:, 0] = False
+    unsel_max = scores.float().masked_fill(~mask, float("-inf")).max(dim=1).values
+    assert (sel[:, -1] >= unsel_max).all()
+    tok = (idxl.unsqueeze(-1) * chunk + torch.arange(chunk, device=DEV)).reshape(H, B)
+    src = torch.gather(kd, 1, tok.unsqueeze(-1).expand(H, B, D))
+    assert torch.equal(kr[:, :B], src)
+    assert torch.equal(ops.retrieval_topk(scores, sets), idx)          # idempotent / deterministic
+    # oracle on one head at full size (bit-exact top-k given identical scores)
+    want = R.retrieval_topk(scores[:1].cpu(), sets)
+    assert torch.equal(idxl[:1].cpu(), want)
+
+
+def test_kv_copy_and_shift_rows():
+    ops = _ops()
+    L, H, D = 3, 4, 64
+    src = rnd(L, H, 50, D, seed=60).to(DEV)
+    dst = torch.zeros(L, H, 40, D, dtype=torch.float16, device=DEV)
+    ops.kv_copy_rows(src, dst, 20, 7, 13)
+    want = torch.zeros(L, H, 40, D, dtype=torch.float16)
+    want[:, :, 7:20] = src.cpu()[:, :, 20:33]
+    assert torch.equal(dst.cpu(), want)
+    ops.kv_copy_rows(src[1:2], dst[1:2], 0, 0, 1)                       # layer slice views
+    assert torch.equal(dst[1, :, 0].cpu(), src[1, :, 0].cpu())
+    for n, shift in [(234, 5), (236, 1), (10, 30), (100, 0)]:
+        c = rnd(2, 12, 300, D, seed=61 + n).to(DEV)
+        ref = c.cpu().clone()
+        ref[:, :, 16:16 + n] = ref[:, :, 16 + shift:16 + shift + n].clone()
+        ops.kv_shift_rows(c, 16 + shift, 16, n)
+        assert torch.equal(c.cpu(), ref), f"overlapping shift n={n} shift={shift}"
+
+
+# ------------------------------------------------------------------------------------------
+def _probs(rows, V, seed, sparse=False):
+    lg = rnd(rows, V, seed=seed, dtype=torch.float32) * 3
+    return R.norm_logits(lg, 0.6, -1, 0.9) if sparse else torch.softmax(lg, dim=-1)
+
+
+@pytest.mark.parametrize("V", [512, 32000])
+@pytest.mark.parametrize("sparse", [False, True])
+def test_sample_inverse_cdf(V, sparse):
+    ops = _ops()
+    p = _probs(1, V, 70, sparse)[0]
+    out = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for u in [0.0, 1e-7, 0.13, 0.5, 0.77, 0.999, 0.9999999]:
+        ops.sample_inverse_cdf(p.to(DEV), torch.tensor([u], device=DEV), out)
+        want = R.sample_inverse_cdf(p, u)
+        got = int(out.item())
+        assert p[got] > 0
+        if got != want:        # only a cumulative-sum rounding tie may move the boundary by one non-zero bin
+            c = torch.cumsum(p.double(), 0)
+            assert abs(float(c[min(got, want)]) - u * float(c[-1])) < 1e-5, (u, got, want)
+    onehot = torch.zeros(V)
+    onehot[V - 3] = 1.0
+    ops.sample_inverse_cdf(onehot.to(DEV), torch.tensor([0.42], device=DEV), out)
+    assert int(out.item()) == V - 3
+
+
+def test_accept_chain_and_middle_accept_match_oracle():
+    ops = _ops()
+    V = 32000
+    out = torch.zeros(4, dtype=torch.int64, device=DEV)
+    gen = torch.Generator().manual_seed(80)
+    for trial in range(24):
+        g2 = [1, 4, 6, 7, 17, 18][trial % 6]
+        p = _probs(g2 + 1, V, 100 + trial, sparse=True)
+        q = _probs(g2, V, 200 + trial, sparse=True)
+        toks = torch.stack([torch.multinomial(q[i], 1, generator=gen)[0] for i in range(g2)])
+        if trial % 3 == 0:                                    # make the drafted tokens likely under p too
+            for i in range(g2):
+                p[i, toks[i]] = p[i].max()
+                p[i] /= p[i].sum()
+        u = torch.rand(g2 + 1, generator=gen)
+        eos = int(toks[min(1, g2 - 1)]) if trial % 4 == 0 else -1
+        for inclusive in (False, True):
+            want = R.accept_and_correct(p, q, toks.tolist(), u.tolist(), inclusive, eos)
+            ops.accept_chain(p.to(DEV), q.to(DEV), toks.to(DEV), u.to(DEV), g2, inclusive, eos, out)
+            got = tuple(out.tolist())
+            assert got[0] == want[0] and got[2] == want[2] and got[3] == want[3], (trial, got, want)
+            assert got[1] == want[1], (trial, got, want)
+    # one inner step
+    gamma = 6
+    for n in range(gamma):
+        p = _probs(gamma + 1, V, 300 + n, sparse=True)
+        qd = _probs(1, V, 400 + n, sparse=True)[0]
+        tokens = torch.full((gamma + 1,), 100, dtype=torch.int64)
+        d = int(torch.multinomial(qd, 1, generator=gen))
+        tokens[n + 1] = d
+        if n % 2 == 0:
+            p[n, d] = p[n].max()
+            p[n] /= p[n].sum()
+        u = torch.rand(2, generator=gen)
+        acc, b = R.middle_accept(p, qd, d, n, u.tolist())
+        td = tokens.to(DEV)
+        ops.middle_accept(p.to(DEV), qd.to(DEV), td, u.to(DEV), n, gamma, out)
+        assert out[:3].tolist() == [acc, b, d]
+        if n + 1 + acc <= gamma:
+            assert int(td[n + 1 + acc]) == b

@@ -1,0 +1,85 @@
+"""The CPU oracle (oracle/ref_ops.py, oracle/ref_model.py) against the golden fixtures that
+oracle/gen_golden.py recorded from the UNMODIFIED reference (tests/golden/*.pt).  This is what pins
+the oracle: the reference itself ships no golden vectors for this path."""
+import pytest
+import torch
+
+from oracle import ref_model as M
+from oracle import ref_ops as R
+from oracle import specs
+from tests import helpers as Hh
+
+
+def test_rope_tables_match_reference():
+    g = Hh.load_golden("rope_tables")
+    cos, sin = R.rope_tables_yarn(128, 131072, 32.0, 4096)
+    assert torch.equal(cos[g["rows"]], g["yarn_cos"]) and torch.equal(sin[g["rows"]], g["yarn_sin"])
+    pc, ps = R.rope_tables_plain(128, 131072, 1e7)
+    assert torch.equal(pc[g["rows"]], g["plain_cos"]) and torch.equal(ps[g["rows"]], g["plain_sin"])
+    assert abs(g["yarn_mscale"] - 1.34657) < 1e-5
+
+
+def test_forward_and_sampling_match_reference():
+    g = Hh.load_golden("forward_small")
+    tsd, dsd = specs.random_state_dict(g["tcfg"], g["tseed"]), specs.random_state_dict(g["dcfg"], g["dseed"])
+    prompt = specs.random_prompt(512, 200, g["pseed"])
+    ot, okv = M.OracleTarget(g["tcfg"], tsd), M.FullCache(g["tcfg"], 256)
+    assert torch.equal(ot.forward(prompt[:, :128], okv)[:, -1], g["target_logits"][0])
+    assert torch.equal(ot.forward(prompt[:, 128:200], okv)[:, -1], g["target_logits"][1])
+    assert torch.equal(ot.forward(prompt[:, :5], okv), g["target_logits"][2])
+    od, odc = M.OracleDraft(g["dcfg"], dsd), M.StreamingCacheO(g["dcfg"], gamma=4, start_size=16, recent_size=100)
+    for i in range(4):
+        odc.evict_prefill(50)
+        last = od.forward(prompt[:, i * 50:(i + 1) * 50], odc, None)
+    assert torch.equal(last[:, -1], g["draft_prefill_last"])
+    assert torch.equal(od.forward(prompt[:, :3], odc, odc, gamma_offset=2), g["draft_spec_logits"])
+    for (T, P), want in g["sampling_probs"].items():
+        assert torch.equal(R.norm_logits(g["sampling_logits"].clone(), T, -1, P), want)
+    assert torch.equal(R.max_fn(g["maxfn_in"]), g["maxfn_out"])
+
+
+@pytest.mark.parametrize("name", ["small_gamma6", "cfg1_greedy", "cfg1_stochastic"])
+def test_triforce_streams_match_reference(name):
+    g = Hh.load_golden(name)
+    eng, _, _ = Hh.build_oracle(g)
+    prompt = Hh.prompt_of(g)
+    if g["rng_seed"] is not None:
+        torch.manual_seed(g["rng_seed"])
+    assert M.autoregressive(eng, prompt, g["gen_len"], g["temperature"], g["top_p"]) == g["ar_tokens"]
+    for rep in range(g["repeats"]):
+        if g["rng_seed"] is not None:
+            torch.manual_seed(g["rng_seed"])
+        res = M.triforce(eng, prompt, g["gamma"], g["gen_len"], g["temperature"], g["top_p"])
+        assert res["tokens"] == g["triforce"][rep]["tokens"]
+        assert abs(res["acceptance_rate"] - g["triforce"][rep]["acceptance_rate"]) < 1e-12
+    # stage-wise: retrieval scores bit-identical to the reference, top-k equal up to the tie order
+    scores = torch.stack(eng.graph_cache.last_scores)
+    assert torch.equal(scores[:, :, 1:], g["retrieval_scores"])
+    for l in range(scores.shape[0]):
+        assert R.topk_matches_reference(scores[l], eng.graph_cache.last_idx[l], g["retrieval_idx"][l])
+    if g["temperature"] == 1.0:
+        n = min(len(g["ar_tokens"]), len(g["triforce"][0]["tokens"]))
+        assert g["triforce"][0]["tokens"][:n] == g["ar_tokens"][:n]     # lossless: greedy TriForce == greedy AR
+
+
+def test_topk_canonical_tie_rule():
+    s = torch.tensor([[9.0, 1, 3, 3, 2, 3, -1, 3]], dtype=torch.float16)
+    assert R.retrieval_topk(s, 4).tolist() == [[0, 2, 3, 5]]           # ties -> lowest chunk first
+    assert R.retrieval_topk(s, 8).tolist() == [[0, 2, 3, 5, 7, 4, 1, 6]]
+
+
+def test_accept_chain_edge_cases():
+    V = 16
+    p = torch.full((4, V), 1.0 / V)
+    q = torch.full((3, V), 1.0 / V)
+    q[1, 5] = 0.0                                                       # p/q = inf -> min(1,inf)=1 -> accept
+    p[2, 7] = 0.0
+    q[2, 7] = 0.0                                                       # 0/0 = nan -> `r < nan` is False -> reject
+    count, flags = R.accept_chain(p, q, [1, 5, 7], [0.5, 0.999, 0.0])
+    assert flags == [True, True, False] and count == 2
+    assert R.accept_chain(p, q, [1, 2, 3], [1.0, 0.0, 0.0], inclusive=True)[0] == 3    # r<=1 (TP variant)
+    assert R.accept_chain(p, q, [1, 2, 3], [1.0, 0.0, 0.0], inclusive=False)[0] == 0
+    c, nxt, reason, used = R.accept_and_correct(p, q, [1, 2, 3], [0.1, 0.1, 0.1, 0.5], eos_token_id=2)
+    assert (c, nxt, reason, used) == (2, 2, 2, 2)                       # accepted eos stops the chain, no resample
+    c, nxt, reason, used = R.accept_and_correct(p, q, [1, 3, 2], [0.1, 0.1, 0.1, 0.5], eos_token_id=2)
+    assert (c, reason, used) == (3, 1, 4)                               # eos as the LAST token: bonus path still runs
