@@ -66,3 +66,28 @@ def prompt_of(g):
 def fixed_uniforms(n=4096, seed=99):
     gen = torch.Generator().manual_seed(seed)
     return torch.rand(n, generator=gen).tolist()
+
+
+def teacher_forced_gaps(g, stream, tsd=None, dsd=None):
+    """Feed `stream` (first token + generated tokens) through the CPU oracle's greedy autoregressive path and
+    return, for every token, how far its oracle logit is below the oracle's best logit given the same
+    prefix (0 = it IS the oracle's argmax).  This is the device-independent statement of 'token-for-token
+    at temp=0': rounding may only ever pick a token whose oracle logit is within fp16 noise of the best."""
+    eng, _, _ = build_oracle(g)
+    prompt = prompt_of(g)
+    eng.kv_cache.reset()
+    logits = eng.inference(prompt)[0, -1]
+    gaps = [float(logits.max() - logits[stream[0]])]
+    for i in range(len(stream) - 1):
+        logits = eng.model.forward(torch.tensor([[stream[i]]]), eng.kv_cache, None)[0, -1]
+        gaps.append(float(logits.max() - logits[stream[i + 1]]))
+    return gaps
+
+
+def common_prefix(a, b):
+    n = 0
+    for x, y in zip(a, b):
+        if x != y:
+            break
+        n += 1
+    return n

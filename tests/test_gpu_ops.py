@@ -26,15 +26,15 @@ def rnd(*shape, seed=0, scale=1.0, dtype=torch.float16):
     return (torch.randn(*shape, generator=g) * scale).to(dtype)
 
 
-def ulp_report(name, got, want, max_ulp_frac=2e-3, atol=0.0):
+def ulp_report(name, got, want, max_ulp_frac=2e-3, atol=0.0, ulps=1):
     """fp16 results that may differ by rounding of an fp32 reduction: at most `max_ulp_frac` of the
-    elements may differ at all, and none by more than 1 fp16 ulp (+atol)."""
+    elements may differ at all, and none by more than `ulps` fp16 ulp (+atol)."""
     got, want = got.float().cpu(), want.float().cpu()
     diff = (got - want).abs()
     ulp = torch.maximum(want.abs(), torch.tensor(6.1e-5)) * 2 ** -10
-    bad = diff > (ulp * 1.01 + atol)
+    bad = diff > (ulp * (ulps + 0.01) + atol)
     frac = (diff > 0).float().mean().item()
-    assert not bad.any(), f"{name}: {int(bad.sum())} elements off by >1 ulp, max diff {diff.max().item():.3e}"
+    assert not bad.any(), f"{name}: {int(bad.sum())} elements off by >{ulps} ulp, max diff {diff.max().item():.3e}"
     assert frac <= max_ulp_frac, f"{name}: {frac:.4%} elements differ (allowed {max_ulp_frac:.2%})"
 
 
@@ -52,9 +52,10 @@ def test_rmsnorm(rows, hidden, residual):
     got = ops.rmsnorm(xd, w.to(DEV), 1e-5, residual=res.to(DEV) if residual else None, sum_out=so)
     if residual:
         assert torch.equal(so.cpu(), xs), "residual sum must be bit-exact (fp16 add)"
-    # fp32 sum of squares is reduced in a different order than torch CPU: the normalised value may
-    # round differently for a handful of elements -> <=1 ulp on <=1% of them
-    ulp_report("rmsnorm", got, want, max_ulp_frac=1e-2)
+    # fp32 sum of squares is reduced in a different order than torch CPU: the normalised value may round
+    # to the neighbouring fp16 for a handful of elements, and the following fp16 weight multiply (|w|~1.1)
+    # can carry that to 2 ulp of the product -> <=2 ulp on <=1% of the elements
+    ulp_report("rmsnorm", got, want, max_ulp_frac=1e-2, ulps=2)
 
 
 def test_rmsnorm_inplace_residual_accumulate():
@@ -224,7 +225,7 @@ def test_retrieval_score(T, H, D, chunk):
     got = ops.retrieval_score(kd, q.to(DEV), C, chunk)
     # two fp16 rounding points (mean, dot) with fp32 sums in a different order than torch CPU:
     # <= 1 ulp (SURVEY §7 "scores (<=1 ulp fp16)"); most elements identical
-    ulp_report("retrieval_score", got, want, max_ulp_frac=0.25, atol=2e-3)
+    ulp_report("retrieval_score", got, want, max_ulp_frac=0.05, atol=2e-3)
 
 
 @pytest.mark.parametrize("H,C,sets", [(1, 9, 4), (4, 125, 16), (2, 256, 32), (32, 15616, 512), (16, 16256, 1536), (3, 3000, 2999)])

@@ -39,10 +39,22 @@ class TriforceHipError(RuntimeError):
     pass
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64.so.7.  Our library must bind to THAT runtime instance (the one
+    that owns torch's device context and streams): load it first so the dynamic linker reuses it for our
+    NEEDED libamdhip64.so.7 instead of opening the system copy as a second, uninitialised runtime
+    (symptom: every launch fails with hipErrorNoDevice)."""
+    import torch  # noqa: F401  (imports libtorch_hip -> torch/lib/libamdhip64.so)
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 def lib():
     """The loaded library; raises (never falls back) when it cannot be loaded."""
     global _lib
     if _lib is None:
+        _preload_torch_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise TriforceHipError(
                 f"{LIB_PATH} not found: the HIP extension is required (python -m triforce_amd.build); "

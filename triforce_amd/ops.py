@@ -85,6 +85,11 @@ def _workspace(device, floats):
     return torch.empty(int(floats), dtype=torch.float32, device=device)
 
 
+# When set to a list, every eager attn_decode call appends (start_event, end_event, sk, H, D): HIP events on
+# the stream the kernel is launched on, used by bench.py for the live roofline figure.
+ATTN_TIMER = None
+
+
 def attn_decode(q, k_layer, v_layer, sk, scale, sk_dev=None, nsplit=None):
     """flash_attn_with_kvcache(q, k, v, softmax_scale, causal=True) for sq<=32 rows (bottom-right causal).
     q (sq,H,D); returns (sq, H*D) fp16."""
@@ -99,8 +104,15 @@ def attn_decode(q, k_layer, v_layer, sk, scale, sk_dev=None, nsplit=None):
     need = L.tf_attn_decode_ws_floats(H, sq, D, nsplit)
     ws = _workspace(q.device, need)
     out = torch.empty(sq, H * D, dtype=_HALF, device=q.device)
+    timed = ATTN_TIMER is not None and not torch.cuda.is_current_stream_capturing()
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     hip.check(L.tf_attn_decode(_ptr(q), _ptr(k_layer), _ptr(v_layer), _ptr(out), st, sh, sq, int(sk), _ptr(sk_dev),
                                H, D, float(scale), nsplit, _ptr(ws), ws.numel(), _stream()), "tf_attn_decode")
+    if timed:
+        ev1.record()
+        ATTN_TIMER.append((ev0, ev1, int(sk), H, D))
     return out
 
 

@@ -125,92 +125,131 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
     return ids, buffers.spec_rows[:len(ids) - 1], accepted / drafted
 
 
-@torch.inference_mode()
-def TriForce(tokenizer, graph_engine, input_ids, gamma=4, max_len=256, top_k=-1, top_p=0.9, temperature=0.6, verbose=False,
-             file_path=None, dataset=None, spec_args=None, rng=None, return_details=False):
-    eng = graph_engine.engine
-    device = eng.model.device
-    rng = rng or UniformSource(device)
-    eos = _eos(tokenizer)
-    vocab = eng.model.config.vocab_size
+class TriForceRunner:
+    """The TriForce outer loop (decoding.py:41-160) as prefill() + step(): ``TriForce`` below drives it to
+    ``max_len`` tokens, bench.py drives it for an exact number of steps."""
 
-    eng.kv_cache.reset()
-    eng.graph_cache.reset()
-    eng.draft_cache.reset()
-    graph_engine.inference(input_ids=input_ids[:, :-1])
-    logits = graph_engine.inference(input_ids=input_ids[:, -1:])          # q_len==1 -> retrieval cache is built here
-    graph_engine.graph_draft_prefill(input_ids=input_ids)
-    if verbose:
-        eng.kv_cache.print_status()
-        eng.graph_cache.print_status()
-        eng.draft_cache.print_status()
+    def __init__(self, tokenizer, graph_engine, gamma, top_k=-1, top_p=0.9, temperature=0.6, verbose=False, rng=None):
+        self.tokenizer, self.ge, self.eng = tokenizer, graph_engine, graph_engine.engine
+        self.gamma, self.top_k, self.top_p, self.temperature, self.verbose = gamma, top_k, top_p, temperature, verbose
+        self.device = self.eng.model.device
+        self.rng = rng or UniformSource(self.device)
+        self.eos = _eos(tokenizer)
+        self.bufs = _buffers(graph_engine, gamma, self.eng.model.config.vocab_size, self.device)
+        self.resample_count = self.accepted_count = self.target_sample_count = self.draft_count = 0
+        self.n = 0
+        self.inner_iters = 0          # Middle_Spec iterations = 68M draft calls = retrieval-verify replays
+        self.emitted, self.counts, self.acc_rate_middle_list = [], [], []
+        self.next_token = None
 
-    bufs = _buffers(graph_engine, gamma, vocab, device)
-    resample_count = accepted_count = target_sample_count = draft_count = 0
-    next_token = int(sample(norm_logits(logits[:, -1, :], temperature=temperature, top_k=top_k, top_p=top_p), rng=rng))
-    if verbose:
-        spec_stream(next_token, tokenizer, "cyan")
-    emitted = [next_token]
-    counts, acc_rate_middle_list = [], []
-    n = 0
-    _sync(device)
-    time1 = time.time()
-    while n < max_len:
-        ids, spec_rows, acc_mid = Middle_Spec(next_token, graph_engine, gamma, False, tokenizer, rng=rng, buffers=bufs)
-        acc_rate_middle_list.append(acc_mid)
+    @torch.inference_mode()
+    def prefill(self, input_ids):
+        eng, ge = self.eng, self.ge
+        eng.kv_cache.reset()
+        eng.graph_cache.reset()
+        eng.draft_cache.reset()
+        ge.inference(input_ids=input_ids[:, :-1])
+        logits = ge.inference(input_ids=input_ids[:, -1:])         # q_len==1 -> the retrieval cache is built here
+        ge.graph_draft_prefill(input_ids=input_ids)
+        if self.verbose:
+            eng.kv_cache.print_status()
+            eng.graph_cache.print_status()
+            eng.draft_cache.print_status()
+        self.start(logits)
+
+    @torch.inference_mode()
+    def start(self, logits):
+        probs = norm_logits(logits[:, -1, :], temperature=self.temperature, top_k=self.top_k, top_p=self.top_p)
+        self.next_token = int(sample(probs, rng=self.rng))
+        if self.verbose:
+            spec_stream(self.next_token, self.tokenizer, "cyan")
+        self.emitted = [self.next_token]
+
+    @torch.inference_mode()
+    def step(self):
+        """One outer iteration: Middle_Spec drafting, target verify over the full KV, device-side
+        accept/rollback, cache fix-ups.  Returns the number of tokens emitted."""
+        eng, ge, gamma, device, bufs, rng = self.eng, self.ge, self.gamma, self.device, self.bufs, self.rng
+        tokenizer, verbose = self.tokenizer, self.verbose
+        next_token = self.next_token
+        n0 = self.n
+        ids, spec_rows, acc_mid = Middle_Spec(next_token, ge, gamma, False, tokenizer, rng=rng, buffers=bufs)
+        self.acc_rate_middle_list.append(acc_mid)
         generated = ids[1:]
         g2 = len(generated)
-        draft_count += g2
+        self.draft_count += g2
+        self.inner_iters += int(round(g2 / (1.0 + acc_mid)))        # g2 = iterations + accepted drafts
 
         # target model verifies [next, t1..t_g2] against the full KV cache
         verify_tokens = torch.tensor([ids], dtype=torch.long, device=device)
-        logits = graph_engine.inference(input_ids=verify_tokens)
-        probs = norm_logits(logits[0], temperature=temperature, top_k=top_k, top_p=top_p)
-        ops.accept_chain(probs, spec_rows, verify_tokens.view(-1)[1:], rng.take(g2 + 1), g2, False, eos, bufs.chain_out)
+        logits = ge.inference(input_ids=verify_tokens)
+        probs = norm_logits(logits[0], temperature=self.temperature, top_k=self.top_k, top_p=self.top_p)
+        ops.accept_chain(probs, spec_rows, verify_tokens.view(-1)[1:], rng.take(g2 + 1), g2, False, self.eos,
+                         bufs.chain_out)
         count, pred, reason, consumed = bufs.chain_out.tolist()          # the one host sync of the outer step
         rng.advance(consumed)
 
         pass_tokens = [next_token] + generated[:count] + [PAD_TOKEN] * (g2 + 1 - count)
-        accepted_count += count
-        n += count
-        emitted += generated[:count]
+        self.accepted_count += count
+        self.n += count
+        self.emitted += generated[:count]
         if verbose:
             for t in generated[:count]:
                 spec_stream(t, tokenizer, "green")
         if reason == 0:                                                   # rejection -> residual resample (:111-118)
-            resample_count += 1
-            n += 1
+            self.resample_count += 1
+            self.n += 1
             pass_tokens[count + 1] = pred
-            emitted.append(pred)
+            self.emitted.append(pred)
             if verbose:
                 spec_stream(pred, tokenizer, "red")
         elif reason == 2:                                                 # accepted eos (:108-110)
-            draft_count -= g2 - count
+            self.draft_count -= g2 - count
 
         eng.kv_cache.seq_len -= (g2 - count)                              # rollback (:124)
-        graph_engine.update_graph_cache()                                 # refresh the retrieval tail (:125)
+        ge.update_graph_cache()                                           # refresh the retrieval tail (:125)
 
         if reason == 1:                                                   # everything accepted -> bonus token (:127-134)
-            target_sample_count += 1
-            n += 1
+            self.target_sample_count += 1
+            self.n += 1
             pass_tokens[count + 1] = pred
-            emitted.append(pred)
+            self.emitted.append(pred)
             if verbose:
                 spec_stream(pred, tokenizer, "blue")
             count += 1
-        counts.append(count)
+        self.counts.append(count)
 
         # bring the 68M cache up to date (:137-139)
-        graph_engine.graph_draft_inference(input_ids=torch.tensor([pass_tokens], dtype=torch.long, device=device),
-                                           gamma_offset=g2 + 1)
+        ge.graph_draft_inference(input_ids=torch.tensor([pass_tokens], dtype=torch.long, device=device),
+                                 gamma_offset=g2 + 1)
         dc = eng.draft_cache
         dc.evict_for_spec(dc.start_size + dc.recent_size + count)
-        next_token = pred
+        self.next_token = pred
+        return self.n - n0
+
+    def stats(self, seconds):
+        acceptance_rate = self.accepted_count / max(self.draft_count, 1)
+        return dict(acceptance_rate=acceptance_rate, tokens_per_s=self.n / seconds, tokens=self.emitted, n=self.n,
+                    counts=self.counts, accepted=self.accepted_count, drafted=self.draft_count,
+                    avg_tokens=acceptance_rate * self.gamma, resampled=self.resample_count,
+                    bonus=self.target_sample_count, seconds=seconds, outer_steps=len(self.counts),
+                    acc_rate_middle=float(np.mean(self.acc_rate_middle_list)) if self.acc_rate_middle_list else 0.0)
+
+
+@torch.inference_mode()
+def TriForce(tokenizer, graph_engine, input_ids, gamma=4, max_len=256, top_k=-1, top_p=0.9, temperature=0.6, verbose=False,
+             file_path=None, dataset=None, spec_args=None, rng=None, return_details=False):
+    run = TriForceRunner(tokenizer, graph_engine, gamma, top_k, top_p, temperature, verbose, rng)
+    run.prefill(input_ids)
+    eng, device = run.eng, run.device
+    _sync(device)
+    time1 = time.time()
+    while run.n < max_len:
+        run.step()
     _sync(device)
     time2 = time.time()
-
-    acceptance_rate = accepted_count / draft_count
-    avg_tokens = accepted_count / draft_count * gamma
+    st = run.stats(time2 - time1)
+    n, acceptance_rate, avg_tokens = st["n"], st["acceptance_rate"], st["avg_tokens"]
     if verbose:
         print(f"Use {time2 - time1} sec to generate {n} tokens (now {eng.kv_cache.seq_len} tokens), "
               f"Tokens/s: {n / (time2 - time1)}", flush=True)
@@ -218,15 +257,12 @@ def TriForce(tokenizer, graph_engine, input_ids, gamma=4, max_len=256, top_k=-1,
     if file_path is not None:
         header = "target,acceptance_rate,token/s,avg_tokens,prefill,gen_len,dataset,acc_rate_middle,latency\n"
         entry = (f"{eng.model.config._name_or_path},{acceptance_rate},{n / (time2 - time1)},{avg_tokens},"
-                 f"{input_ids.shape[1]},{n},{dataset},{np.array(acc_rate_middle_list).mean()},{(time2 - time1) / n}\n")
+                 f"{input_ids.shape[1]},{n},{dataset},{st['acc_rate_middle']},{(time2 - time1) / n}\n")
         if spec_args is not None:
             for k, v in spec_args.items():
                 header = header.replace("\n", f",{k}\n")
                 entry = entry.replace("\n", f",{v}\n")
         log_csv(file_path, header, entry)
     if return_details:
-        return dict(acceptance_rate=acceptance_rate, tokens_per_s=n / (time2 - time1), tokens=emitted, n=n,
-                    counts=counts, accepted=accepted_count, drafted=draft_count, avg_tokens=avg_tokens,
-                    resampled=resample_count, bonus=target_sample_count, seconds=time2 - time1,
-                    outer_steps=len(counts), acc_rate_middle=float(np.mean(acc_rate_middle_list)))
+        return st
     return acceptance_rate, n / (time2 - time1)
