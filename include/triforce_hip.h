@@ -146,6 +146,18 @@ int tf_accept_chain(const float* p, const float* q, const int64_t* tokens, const
 int tf_middle_accept(const float* p, const float* q_d, int64_t* tokens, const float* uniforms,
                      int n, int gamma, int V, int64_t* out, void* stream);
 
+/* -------------------------------------------------------------------------------------------
+ * Offloading tier (models/cache.py:345-351 copy_back_from_buffer, :372-376 copy_kv, :573-575):
+ * asynchronous pinned-host <-> device copies of a head-major KV block = H rows of width_elems
+ * contiguous fp16 (n tokens x D) at the given pitches (in elements).  Enqueued on `copy_stream`
+ * (hipMemcpy2DAsync); the caller orders them against compute with events — no device-wide syncs.
+ * *_host pointers are HOST pointers to pinned memory.
+ * ------------------------------------------------------------------------------------------- */
+int tf_kv_h2d_async(void* dst_dev, int64_t dst_pitch_elems, const void* src_host, int64_t src_pitch_elems,
+                    int64_t width_elems, int H, void* copy_stream);
+int tf_kv_d2h_async(void* dst_host, int64_t dst_pitch_elems, const void* src_dev, int64_t src_pitch_elems,
+                    int64_t width_elems, int H, void* copy_stream);
+
 #ifdef __cplusplus
 }
 #endif

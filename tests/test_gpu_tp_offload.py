@@ -1,0 +1,85 @@
+"""TP engine + offloading tier on one MI355X (RCCL world_size 1): the pinned-host KV streaming path
+(hipMemcpy2DAsync on the copy stream, event-ordered double buffering, D2H write-back of new tokens) must
+give bit-identical logits to the same engine with every layer resident in HBM, and both must match the oracle."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from oracle import specs
+from tests import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _pg():
+    if not dist.is_initialized():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{port}")
+
+
+def _build(g, on_chip):
+    from triforce_amd.models.cache import StreamingLLMEvictionCache
+    from triforce_amd.models.config_yarn import LlamaConfig
+    from triforce_amd.models.modeling_llama_68m import LlamaForCausalLM as Draft
+    from triforce_amd.models.TP_llama import DistributedLlama
+    tsd = specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g["head_std"])
+    dsd = specs.random_state_dict(g["dcfg"], g["dseed"], head_std=g["head_std"])
+    gamma = g["gamma"]
+    draft = Draft.from_state_dict(LlamaConfig.from_dict(g["dcfg"]), dsd, DEV)
+    dcache = StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - gamma, gamma=gamma)
+    llm = DistributedLlama("unused", config=LlamaConfig.from_dict(g["tcfg"]), device=DEV, local_rank=0, world_size=1,
+                           prefill=g["prefill"], gen_len=g["gen_len"], temperature=g["temperature"], top_p=g["top_p"],
+                           retrieval_budget=g["budget"], kv_offload=True, on_chip_layers=on_chip, draft=draft,
+                           draft_cache=dcache, gamma=gamma)
+    llm.init_parameters(tsd)
+    return llm
+
+
+def _run(llm, g):
+    from triforce_amd.utils.decoding import TriForce_Dist
+    prompt = Hh.prompt_of(g).to(DEV)
+    llm.reset()
+    llm.prefill(prompt[:, :-1])
+    logits = llm.build_retrieval_cache(prompt[:, -1:])
+    S = llm.kv_cache.seq_len
+    gamma = g["gamma"]
+    vt = torch.tensor([[11, 12, 13] + [100] * (gamma - 2)], device=DEV)
+    spec = llm.retrieval_inference(vt, torch.arange(S, S + gamma + 1, device=DEV).unsqueeze(0))
+    step = llm.inference(vt)                                   # a verify-sized target forward (streams offloaded layers)
+    res = TriForce_Dist(Hh.FakeTokenizer(), llm, prompt, gamma=gamma, max_len=20, top_k=-1, top_p=g["top_p"],
+                        temperature=g["temperature"], return_details=True)
+    torch.cuda.synchronize()
+    return logits.cpu(), spec.cpu(), step.cpu(), res
+
+
+def test_offloaded_layers_equal_resident_layers_and_oracle():
+    _pg()
+    g = Hh.load_golden("small_gamma6")
+    L = g["tcfg"]["num_hidden_layers"]
+    resident = _run(_build(g, on_chip=L), g)
+    for on_chip in (0, 1, L - 1):
+        off = _run(_build(g, on_chip=on_chip), g)
+        assert torch.equal(off[0], resident[0]), f"on_chip={on_chip}: prefill logits differ from the resident run"
+        assert torch.equal(off[1], resident[1]), f"on_chip={on_chip}: retrieval-verify logits differ"
+        assert torch.equal(off[2], resident[2]), f"on_chip={on_chip}: target-verify logits differ"
+        assert off[3]["tokens"] == resident[3]["tokens"] and off[3]["counts"] == resident[3]["counts"]
+    gaps = Hh.teacher_forced_gaps(g, resident[3]["tokens"])
+    assert max(gaps) < 8e-3
+    assert Hh.common_prefix(resident[3]["tokens"], g["ar_tokens"]) >= 12
+    # host copy of an offloaded layer holds exactly what the device computed (write-back path)
+    llm0, llmL = _build(g, on_chip=0), _build(g, on_chip=L)
+    p = Hh.prompt_of(g).to(DEV)
+    for m in (llm0, llmL):
+        m.reset()
+        m.prefill(p[:, :300])
+    torch.cuda.synchronize()
+    assert torch.equal(llm0.kv_cache.cpu_k[:, :, :300], llmL.kv_cache.k[:, :, :300].cpu())
+    assert torch.equal(llm0.kv_cache.cpu_v[:, :, :300], llmL.kv_cache.v[:, :, :300].cpu())

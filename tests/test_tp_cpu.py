@@ -1,0 +1,108 @@
+"""Tensor-parallel host logic on CPU: world_size 2 over gloo, HIP ops swapped for the oracle restatements.
+Checks head/column sharding + fp16 all-reduce reproduce the single-process oracle, that both ranks stay in
+lock-step, and that TriForce_Dist emits the target's greedy stream.  (No kernel is validated here.)"""
+import os
+import socket
+import sys
+import traceback
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.set_num_threads(2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from tests import cpu_backend, helpers as Hh
+        import triforce_amd.ops as ops
+        for n in cpu_backend.PATCHED:
+            setattr(ops, n, getattr(cpu_backend, n))
+        from oracle import specs
+        from triforce_amd.models.cache import StreamingLLMEvictionCache
+        from triforce_amd.models.config_yarn import LlamaConfig
+        from triforce_amd.models.modeling_llama_68m import LlamaForCausalLM as Draft
+        from triforce_amd.models.TP_llama import DistributedLlama
+        from triforce_amd.utils.decoding import TriForce_Dist
+        g = Hh.load_golden("small_gamma6")
+        tsd = specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g["head_std"])
+        dsd = specs.random_state_dict(g["dcfg"], g["dseed"], head_std=g["head_std"])
+        gamma = g["gamma"]
+        draft = Draft.from_state_dict(LlamaConfig.from_dict(g["dcfg"]), dsd, "cpu")
+        dcache = StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - gamma, gamma=gamma)
+        tcfg = LlamaConfig.from_dict(g["tcfg"])
+        llm = DistributedLlama("unused", config=tcfg, device="cpu", local_rank=rank, world_size=world,
+                               prefill=g["prefill"], gen_len=g["gen_len"], temperature=g["temperature"], top_p=g["top_p"],
+                               retrieval_budget=g["budget"], kv_offload=True, on_chip_layers=tcfg.num_hidden_layers,
+                               draft=draft, draft_cache=dcache, gamma=gamma)
+        llm.init_parameters(tsd)
+        prompt = Hh.prompt_of(g)
+        # 1) sharded forward == oracle forward (fp16 all-reduce changes the summation order only)
+        llm.reset()
+        llm.prefill(prompt[:, :-1])
+        logits = llm.build_retrieval_cache(prompt[:, -1:])
+        S = llm.kv_cache.seq_len
+        vt = torch.tensor([[11, 12, 13] + [100] * (gamma - 2)])
+        pos = torch.arange(S, S + gamma + 1).unsqueeze(0)
+        spec_logits = llm.retrieval_inference(vt, pos)
+        # 2) decode
+        res = TriForce_Dist(Hh.FakeTokenizer(), llm, prompt, gamma=gamma, max_len=24, top_k=-1, top_p=g["top_p"],
+                            temperature=g["temperature"], return_details=True)
+        q.put((rank, "ok", logits, spec_logits, res["tokens"], res["counts"], llm.kv_cache.seq_len))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_tp2_gloo_matches_oracle():
+    from oracle import ref_model as M
+    from tests import helpers as Hh
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {}
+    for _ in range(world):
+        item = q.get(timeout=600)
+        assert item[1] == "ok", item[2]
+        outs[item[0]] = item
+    for p in procs:
+        p.join(timeout=60)
+    g = Hh.load_golden("small_gamma6")
+    oeng, _, _ = Hh.build_oracle(g)
+    prompt = Hh.prompt_of(g)
+    oeng.inference(prompt[:, :-1])
+    lo = oeng.inference(prompt[:, -1:])
+    gamma = g["gamma"]
+    S = oeng.kv_cache.seq_len
+    so = oeng.model.forward(torch.tensor([[11, 12, 13] + [100] * (gamma - 2)]), oeng.kv_cache, oeng.graph_cache,
+                            position_ids=torch.arange(S, S + gamma + 1).unsqueeze(0), spec=True)
+    for r in range(world):
+        _, _, logits, spec_logits, tokens, counts, seq_len = outs[r]
+        assert (logits - lo).abs().max() < 4e-3, f"rank {r} prefill logits off by {(logits - lo).abs().max():.2e}"
+        assert (spec_logits - so).abs().max() < 4e-3, f"rank {r} spec logits off by {(spec_logits - so).abs().max():.2e}"
+    # ranks are in lock-step: identical logits (all-reduce gives every rank the same bits), tokens, rollbacks
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+    assert outs[0][4] == outs[1][4] and outs[0][5] == outs[1][5] and outs[0][6] == outs[1][6]
+    # lossless: the TP stream is the target's greedy stream (teacher-forced against the oracle)
+    gaps = Hh.teacher_forced_gaps(g, outs[0][4])
+    assert max(gaps) < 8e-3, f"TP stream leaves the oracle's greedy path: gap {max(gaps):.4f}"
+    assert Hh.common_prefix(outs[0][4], g["ar_tokens"]) >= 12

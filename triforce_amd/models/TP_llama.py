@@ -1,0 +1,249 @@
+"""Tensor-parallel + KV-offloading engine — host-side mirror of the reference's models/TP_llama.py
+(DistributedLlama :27-389, distributed_init :19-25) with the same constructor keywords and methods
+(reset / prefill / build_retrieval_cache / draft_run / inference / retrieval_verify / init_parameters).
+
+Parallelism: one process per GPU; attention heads and MLP columns are sharded
+Megatron-style (TP_layers.py:126-147), the KV caches, retrieval cache and offloaded KV follow the head
+shard; embed, norms, lm_head and the 68M draft are replicated.  The only exchange step is an fp16
+all-reduce(SUM) after wo and after down_proj (tensor_op.py:179,326,359) — RCCL over xGMI through
+torch.distributed ("nccl" is RCCL on ROCm).
+
+Offloading tier: layers >= on_chip_layers keep their KV in pinned host memory; a target forward streams
+them through two device buffers with hipMemcpy2DAsync on a copy stream (tf_kv_h2d_async), the new
+tokens' rows go back with tf_kv_d2h_async, and compute/copy are ordered with events — not with the
+reference's two device-wide synchronize() per layer (TP_llama.py:222,228).
+"""
+import math
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .. import ops
+from ..utils.sampling import norm_logits
+from .cache import DistributedKVCacheBuffer, DistributedRetrievalCache, DistributedSimpleCache
+from .config_yarn import LlamaConfig
+from .llama_core import LlamaWeights, parse_random_spec, rope_tables_for, softmax_scale_for
+from .TP_layers import DistributedOffloadingConfig
+
+
+def distributed_init(backend=None):
+    """torchrun entry: RCCL process group, one device per local rank (reference TP_llama.py:19-25)."""
+    backend = backend or os.environ.get("TRIFORCE_DIST_BACKEND", "nccl")
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend)
+    local_rank = dist.get_rank()
+    world_size = dist.get_world_size()
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", local_rank)))
+    return local_rank, world_size
+
+
+class DistributedLlama:
+    def __init__(self, model_name_or_path: str, dtype=torch.float16, kv_offload=False, on_chip_layers=32, local_rank=0,
+                 world_size=1, prefill=32768, bsz=1, gen_len=256, retrieval_budget=4096, retrieval_chunk_size=8, gamma=6,
+                 temperature=0.6, top_p=0.9, ssl=0, draft=None, draft_cache=None, flash_attn=True, config=None,
+                 device=None) -> None:
+        assert dtype == torch.float16
+        self.device = torch.device(device) if device is not None else torch.device("cuda", local_rank)
+        self.dtype = dtype
+        self.local_rank, self.world_size = local_rank, world_size
+        self.kv_offload = kv_offload
+        self.ssl, self.flash_attn = ssl, flash_attn
+        model_config = config if config is not None else LlamaConfig.from_pretrained(model_name_or_path)
+        self.model_name_or_path = model_name_or_path
+        self.config = DistributedOffloadingConfig(model_config, local_rank, world_size)
+        self.on_chip_layers = min(on_chip_layers, model_config.num_hidden_layers)
+        self.vocab_size = model_config.vocab_size
+        self.prefill_len = prefill
+        self.retrieval_budget = retrieval_budget
+        self.temperature, self.top_p, self.gamma, self.bsz = temperature, top_p, gamma, bsz
+        self.draft, self.draft_cache = draft, draft_cache
+        on_gpu = self.device.type == "cuda"
+        self.load_stream = torch.cuda.Stream(device=self.device) if on_gpu else None
+
+        if not kv_offload:
+            raise NotImplementedError
+        assert bsz == 1
+        budget = prefill + gen_len + 32
+        self.kv_cache = DistributedSimpleCache(self.config, max_budget=budget, device=self.device,
+                                               on_chip_layers=self.on_chip_layers, ssl=ssl)
+        n_off = model_config.num_hidden_layers - self.on_chip_layers
+        self.kv_buffer = [DistributedKVCacheBuffer(self.config, max_budget=budget, device=self.device)
+                          for _ in range(2 if n_off > 0 else 0)]
+        if retrieval_budget > 0:
+            self.retrieval_cache = DistributedRetrievalCache(self.config, max_budget=retrieval_budget, device=self.device,
+                                                             prefill=prefill, chunk_size=retrieval_chunk_size, gamma=gamma)
+            self.retrieval_cache.ensure_tail(gen_len + 32)
+        else:                                         # autoregressive baseline (offloading_TP.py:75)
+            self.retrieval_cache = None
+
+        self.hidden_size = model_config.hidden_size
+        self.num_heads = model_config.num_attention_heads
+        self.head_dim = self.hidden_size // self.num_heads
+        self.num_key_value_heads = model_config.num_key_value_heads
+        self.num_key_value_groups = self.num_heads // self.num_key_value_heads
+        self.max_position_embeddings = model_config.max_position_embeddings
+        self.rope_theta = model_config.rope_theta
+        self.local_num_heads = self.num_heads // world_size
+        self.local_num_key_value_heads = self.num_key_value_heads // world_size
+        self.scale = softmax_scale_for(self.head_dim)
+        self.weights = None
+        self.num_layers = model_config.num_hidden_layers
+        self._ev_ready = self._ev_done = None
+
+    # ---------------------------------------------------------------------------------------
+    def init_parameters(self, hf_model=None):
+        """Shard this rank's slice of the weights (TP_layers.py:126-147).  Accepts an HF-keyed state dict, an
+        object with .state_dict(), or None / 'random:<seed>' (random init; every rank draws its own shard)."""
+        cfg = self.config.model_config
+        W = LlamaWeights(cfg, self.device, rank=self.local_rank, world_size=self.world_size)
+        seed = parse_random_spec(hf_model if isinstance(hf_model, str) else self.model_name_or_path) \
+            if (hf_model is None or isinstance(hf_model, str)) else None
+        if hf_model is None or isinstance(hf_model, str):
+            W.init_random(seed if seed is not None else 0)
+        else:
+            sd = hf_model if isinstance(hf_model, dict) else hf_model.state_dict()
+            W.load_state_dict(sd)
+        self.weights = W
+        cos, sin = rope_tables_for(cfg)
+        self.cos_cache, self.sin_cache = cos.to(self.device), sin.to(self.device)
+        self.embed_tokens, self.lm_head, self.norm_weight = W.embed, W.lm_head, W.norm
+        self.norm_variance_epsilon = W.eps
+
+    def reset(self):
+        self.kv_cache.reset()
+        if self.retrieval_cache is not None:
+            self.retrieval_cache.reset()
+        if self.draft_cache is not None:
+            self.draft_cache.reset()
+
+    # ---------------------------------------------------------------------------------------
+    def _all_reduce(self, t):
+        if self.world_size > 1:
+            dist.all_reduce(t, dist.ReduceOp.SUM)
+        return t
+
+    def _layer(self, i, x, d, pos, kl, vl, slot, sk, q_len, retrieval_build=False):
+        """One decoder layer on this rank's shard.  x: residual stream (updated in place), d: pending MLP output
+        of the previous layer (None for layer 0).  Returns the (all-reduced) MLP output of this layer."""
+        W = self.weights
+        Hl, D = W.H_local, W.D
+        if d is None:
+            h = ops.rmsnorm(x, W.ln1[i], W.eps)
+        else:
+            h = ops.rmsnorm(d, W.ln1[i], W.eps, residual=x, sum_out=x)
+        qkv = ops.linear(h, W.wqkv[i])
+        q = ops.rope_append(qkv, self.cos_cache, self.sin_cache, pos, kl, vl, slot, Hl, D)
+        if retrieval_build:                               # tensor_op.py:161-162
+            self.retrieval_cache.init_graph_cache((kl, vl), q, i)
+        a = ops.attn_prefill(q, kl, vl, sk, self.scale)
+        o = self._all_reduce(ops.linear(a, W.wo[i]))                        # tensor_op.py:176-179
+        h = ops.rmsnorm(o, W.ln2[i], W.eps, residual=x, sum_out=x)
+        act = ops.silu_mul(ops.linear(h, W.wgu[i]))
+        return self._all_reduce(ops.linear(act, W.wd[i]))                   # tensor_op.py:353-359
+
+    def _finish(self, x, d):
+        W = self.weights
+        h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)
+        return ops.linear(h, W.lm_head).float().unsqueeze(0)
+
+    @torch.inference_mode()
+    def inference(self, input_ids, position_ids=None, attention_mask=None, retrieval_cache=None):
+        """Target forward over the full KV cache (TP_llama.py:200-243)."""
+        assert attention_mask is None, "tree attention (Sequoia) is out of scope"
+        W, kvc = self.weights, self.kv_cache
+        q_len = input_ids.shape[1]
+        S = kvc.seq_len
+        if S + q_len > kvc.max_budget:
+            raise IndexError(f"KV cache overflow: {S}+{q_len} > {kvc.max_budget}")
+        if position_ids is None:
+            position_ids = (S + torch.arange(q_len, dtype=torch.long, device=self.device)).unsqueeze(0)
+        pos = position_ids.reshape(-1).contiguous()
+        x = self.embed_tokens[input_ids.reshape(-1)]
+        build = retrieval_cache is not None
+        n_on, L = self.on_chip_layers, self.num_layers
+        tail = self.retrieval_cache if (self.retrieval_cache is not None and S >= self.prefill_len) else None
+
+        if n_on < L:                                      # prime the double buffer (copy stream)
+            cs = self.load_stream
+            cs.wait_stream(torch.cuda.current_stream(self.device))
+            ready = {}
+            for idx in (n_on, n_on + 1):
+                if idx < L:
+                    self.kv_buffer[idx % 2].copy_kv(kvc, idx, cs)
+                    ready[idx] = torch.cuda.Event()
+                    ready[idx].record(cs)
+        d = None
+        for idx in range(L):
+            if idx < n_on:
+                kl, vl = kvc.layer_kv(idx)
+            else:
+                buf = self.kv_buffer[idx % 2]
+                torch.cuda.current_stream(self.device).wait_event(ready[idx])      # H2D of this layer landed
+                kl, vl = buf.k, buf.v
+            d = self._layer(idx, x, d, pos, kl, vl, S, S + q_len, q_len, retrieval_build=build)
+            if tail is not None:                          # keep the generated rows on the device for the retrieval tail
+                ops.kv_copy_rows(kl.unsqueeze(0), tail.tail_k[idx:idx + 1], S, S - self.prefill_len, q_len)
+                ops.kv_copy_rows(vl.unsqueeze(0), tail.tail_v[idx:idx + 1], S, S - self.prefill_len, q_len)
+            if idx >= n_on:
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(self.device))
+                cs.wait_event(done)                       # buffer free + new rows written
+                buf.copy_back(kvc, idx, S, q_len, cs)     # D2H of the q_len new rows
+                if idx + 2 < L:
+                    buf.copy_kv(kvc, idx + 2, cs)          # prefetch into the buffer just released
+                    ready[idx + 2] = torch.cuda.Event()
+                    ready[idx + 2].record(cs)
+        if n_on < L:
+            torch.cuda.current_stream(self.device).wait_stream(cs)              # write-backs visible before reuse
+        kvc.seq_len = S + q_len
+        return self._finish(x, d)
+
+    @torch.inference_mode()
+    def prefill(self, input_ids):
+        for i in range(math.ceil(input_ids.shape[1] / 128)):                   # TP_llama.py:246-250
+            logits = self.inference(input_ids=input_ids[:, i * 128:(i + 1) * 128])
+        return logits
+
+    @torch.inference_mode()
+    def build_retrieval_cache(self, input_ids):
+        assert input_ids.shape[-1] == 1
+        return self.inference(input_ids=input_ids, retrieval_cache=self.retrieval_cache)
+
+    # ---------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def draft_run(self, input_ids, gamma_offset: int = 0, probs=True, temperature=0.6, top_p=0.9):
+        """Replicated 68M draft (TP_llama.py:117-132).  NB the reference's call sites never pass temperature /
+        top_p, so the draft always samples at 0.6 / 0.9 — kept."""
+        if input_ids.shape[-1] > 64:
+            for i in range(math.ceil(input_ids.shape[1] / 128)):
+                self.draft_cache.evict_prefill(128)
+                logits = self.draft(input_ids=input_ids[:, i * 128:(i + 1) * 128], kv_cache=self.draft_cache,
+                                    graph_cache=None).logits
+        else:
+            logits = self.draft(input_ids=input_ids, kv_cache=self.draft_cache, graph_cache=self.draft_cache,
+                                gamma_offset=gamma_offset).logits
+        if probs:
+            return norm_logits(logits[0], temperature=temperature, top_k=-1, top_p=top_p)[-1]
+        return logits
+
+    @torch.inference_mode()
+    def retrieval_inference(self, input_ids, position_ids):
+        """Retrieval-cache (spec) forward: gamma+1 tokens against the B+gamma+1 retrieval slots (TP_llama.py:371-385)."""
+        W, rc = self.weights, self.retrieval_cache
+        q_len = input_ids.shape[1]
+        assert q_len == rc.gamma + 1
+        pos = position_ids.reshape(-1).contiguous()
+        x = self.embed_tokens[input_ids.reshape(-1)]
+        d = None
+        for idx in range(self.num_layers):
+            kl, vl = rc.layer_kv(idx)
+            d = self._layer(idx, x, d, pos, kl, vl, rc.spec_slot, rc.real_budget, q_len)
+        return self._finish(x, d)
+
+    @torch.inference_mode()
+    def retrieval_verify(self, input_ids, position_ids, temperature=0.6, top_p=0.9):
+        logits = self.retrieval_inference(input_ids, position_ids)
+        return norm_logits(logits[0], temperature=temperature, top_k=-1, top_p=top_p)

@@ -233,3 +233,174 @@ class StreamingLLMEvictionCache(Cache):
     def evict_for_spec(self, current_seq_len):
         ops.kv_shift_rows(self.k, current_seq_len - self.recent_size, self.start_size, self.recent_size)
         ops.kv_shift_rows(self.v, current_seq_len - self.recent_size, self.start_size, self.recent_size)
+
+
+# =============================================================================================
+# Tensor-parallel / offloading caches (reference cache.py:268-383, :485-584)
+# =============================================================================================
+def _pin(t):
+    return t.pin_memory() if torch.cuda.is_available() else t
+
+
+class DistributedSimpleCache(Cache):
+    """This rank's heads of the full KV cache: layers < on_chip_layers live in HBM, the rest in pinned host
+    memory and are streamed through two DistributedKVCacheBuffer's (reference cache.py:268-351).
+    Unlike the reference, on_chip_layers == num_layers (nothing offloaded — the natural setting with
+    288 GB of HBM) is allowed."""
+
+    def __init__(self, config, max_budget=1024, device=None, on_chip_layers=0, ssl=0):
+        self.config = config
+        self.world_size, self.local_rank = config.world_size, config.local_rank
+        self.device = torch.device(device)
+        self.max_budget = max_budget
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_key_value_heads // self.world_size
+        self.head_dim = config.hidden_size // config.num_attention_heads
+        self.layers = config.num_hidden_layers
+        self.on_chip_layers = min(on_chip_layers, self.layers)
+        self.seq_len = 0
+        n_on, n_off = self.on_chip_layers, self.layers - self.on_chip_layers
+        self.k, self.v = _alloc(n_on, self.num_heads, max_budget, self.head_dim, self.device)
+        self.cpu_k = _pin(torch.zeros(n_off, self.num_heads, max_budget, self.head_dim, dtype=torch.float16))
+        self.cpu_v = _pin(torch.zeros(n_off, self.num_heads, max_budget, self.head_dim, dtype=torch.float16))
+        self.key_cache, self.value_cache = _ref_view(self.k), _ref_view(self.v)
+        self.cpu_key_cache, self.cpu_value_cache = _ref_view(self.cpu_k), _ref_view(self.cpu_v)
+
+    def print_status(self):
+        print("Cached Size:", self.seq_len, "| Max Budget:", self.max_budget)
+
+    def reset(self):
+        self.seq_len = 0
+        self.cpu_k.zero_()
+        self.cpu_v.zero_()
+        self.k.zero_()
+        self.v.zero_()
+
+    def normal_(self, seq_len=1024 * 127):
+        """The reference's own synthetic filler (cache.py:303-308)."""
+        self.seq_len = seq_len
+        for t in (self.cpu_k, self.cpu_v, self.k, self.v):
+            t.normal_()
+
+    def layer_kv(self, layer_idx):
+        assert layer_idx < self.on_chip_layers, (layer_idx, self.on_chip_layers)
+        return self.k[layer_idx], self.v[layer_idx]
+
+    def host_layer_kv(self, layer_idx):
+        i = layer_idx - self.on_chip_layers
+        assert 0 <= i, (layer_idx, self.on_chip_layers)
+        return self.cpu_k[i], self.cpu_v[i]
+
+
+class DistributedKVCacheBuffer:
+    """Device staging buffer for one offloaded layer (reference cache.py:353-383)."""
+
+    def __init__(self, config, max_budget=1024, device=None) -> None:
+        self.config = config
+        self.max_budget = max_budget
+        self.device = torch.device(device)
+        self.num_heads = config.num_key_value_heads // config.world_size
+        self.head_dim = config.hidden_size // config.num_attention_heads
+        self.k = torch.zeros(self.num_heads, max_budget, self.head_dim, dtype=torch.float16, device=self.device)
+        self.v = torch.zeros(self.num_heads, max_budget, self.head_dim, dtype=torch.float16, device=self.device)
+        self.key_cache, self.value_cache = self.k.permute(1, 0, 2).unsqueeze(0), self.v.permute(1, 0, 2).unsqueeze(0)
+        self.seq_len = 0
+
+    def copy_kv(self, kv_cache, layer_idx, stream):
+        """Stream the live tokens of one offloaded layer host -> device on `stream` (cache.py:372-376)."""
+        hk, hv = kv_cache.host_layer_kv(layer_idx)
+        ops.kv_h2d_async(self.k, hk, kv_cache.seq_len, stream)
+        ops.kv_h2d_async(self.v, hv, kv_cache.seq_len, stream)
+        self.seq_len = kv_cache.seq_len
+
+    def copy_back(self, kv_cache, layer_idx, t0, n, stream):
+        """Write the n new tokens back to the pinned host cache (cache.py:345-351)."""
+        hk, hv = kv_cache.host_layer_kv(layer_idx)
+        ops.kv_d2h_async(hk, self.k, t0, n, stream)
+        ops.kv_d2h_async(hv, self.v, t0, n, stream)
+
+
+class DistributedRetrievalCache:
+    """Per-rank retrieval cache, always in HBM (reference cache.py:485-584).  Differences from the
+    single-GPU class that the reference has and we keep: reset() clears init_graph, and building twice
+    without a reset raises (cache.py:519-520,577-580)."""
+
+    def __init__(self, config, max_budget=1024, device=None, prefill=1024, chunk_size=8, gamma=6) -> None:
+        self.config = config
+        self.world_size, self.local_rank = config.world_size, config.local_rank
+        self.device = torch.device(device)
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_key_value_heads // self.world_size
+        self.head_dim = config.hidden_size // config.num_attention_heads
+        self.layers = config.num_hidden_layers
+        self.chunk_size, self.prefill, self.gamma, self.max_budget = chunk_size, prefill, gamma, max_budget
+        self.chunks = prefill // chunk_size
+        self.select_sets = max_budget // chunk_size
+        assert prefill % self.chunk_size == 0, f"prefill should be multiple of chunk_size, got {prefill} % {self.chunk_size}"
+        assert max_budget % self.chunk_size == 0, f"max_budget should be multiple of chunk_size, got {max_budget} % {self.chunk_size}"
+        self.real_budget = max_budget + gamma + 1
+        self.init_graph = False
+        self.k, self.v = _alloc(self.layers, self.num_heads, self.real_budget, self.head_dim, self.device)
+        self.key_cache, self.value_cache = _ref_view(self.k), _ref_view(self.v)
+        # device-side copy of the generated-token KV of EVERY layer ([prefill, seq_len) rows), filled as the
+        # target forward produces them, so refreshing the retrieval tail never has to touch host memory
+        self.tail_k = self.tail_v = None
+        self.last_scores = [None] * self.layers
+        self.last_idx = [None] * self.layers
+
+    def print_status(self):
+        print("Budget:", self.max_budget, " | Real Budget:", self.real_budget, " | PreFill:", self.prefill, " | Chunk Size:",
+              self.chunk_size, " | Chunks:", self.chunks, " | Select Sets:", self.select_sets)
+
+    def layer_kv(self, layer_idx):
+        return self.k[layer_idx], self.v[layer_idx]
+
+    @property
+    def spec_slot(self):
+        return self.real_budget - self.gamma - 1
+
+    def init_graph_cache(self, kv_view, query_states, layer_idx):
+        """kv_view: (k_layer, v_layer) head-major views holding this layer's prefix (HBM cache or staging buffer)."""
+        if self.init_graph:
+            raise ValueError("Graph is already initialized")
+        q = query_states.reshape(-1, self.num_heads, self.head_dim)
+        assert 1 == q.shape[0], "query_states should be 1 for init"
+        src_k, src_v = kv_view
+        scores = ops.retrieval_score(src_k, q[0].contiguous(), self.chunks, self.chunk_size)
+        idx = ops.retrieval_topk(scores, self.select_sets)
+        ops.retrieval_gather(src_k, src_v, idx, self.k[layer_idx], self.v[layer_idx], self.chunk_size)
+        self.last_scores[layer_idx], self.last_idx[layer_idx] = scores, idx
+        if layer_idx == self.layers - 1:
+            self.init_graph = True
+
+    def update(self, key_states, value_states, layer_idx):
+        k, v = _rows(key_states), _rows(value_states)
+        s = self.spec_slot
+        self.k[layer_idx, :, s:] = k.permute(1, 0, 2)
+        self.v[layer_idx, :, s:] = v.permute(1, 0, 2)
+        return self.key_cache[layer_idx][:, :self.real_budget], self.value_cache[layer_idx][:, :self.real_budget]
+
+    def ensure_tail(self, capacity):
+        if self.tail_k is None or self.tail_k.shape[2] < capacity:
+            self.tail_k, self.tail_v = _alloc(self.layers, self.num_heads, capacity, self.head_dim, self.device)
+
+    def update_graph_cache(self, kv_cache=None):
+        """Copy the generated tokens' KV [prefill, seq_len) of all layers into slots [B-g, B)
+        (cache.py:566-575).  The reference reads the offloaded layers back from pinned host memory here;
+        we keep those rows in `tail_k/v` on the device (written during the target forward)."""
+        g = kv_cache.seq_len - self.prefill
+        if g <= 0:
+            return
+        if g > self.max_budget:
+            raise IndexError(f"generated tail ({g}) exceeds the retrieval budget ({self.max_budget})")
+        ops.kv_copy_rows(self.tail_k, self.k, 0, self.max_budget - g, g)
+        ops.kv_copy_rows(self.tail_v, self.v, 0, self.max_budget - g, g)
+
+    def reset(self):
+        self.k.zero_()
+        self.v.zero_()
+        self.init_graph = False
+
+    def normal_(self):
+        self.k.normal_()
+        self.v.normal_()

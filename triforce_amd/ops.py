@@ -236,3 +236,23 @@ def middle_accept(p, q_d, tokens, uniforms, n, gamma, out):
     assert tokens.dtype == torch.int64 and tokens.numel() >= gamma + 1 and uniforms.numel() >= 2
     hip.check(hip.lib().tf_middle_accept(_ptr(p), _ptr(q_d), _ptr(tokens), _ptr(uniforms), int(n), int(gamma), V,
                                          _ptr(out), _stream()), "tf_middle_accept")
+
+
+def kv_h2d_async(dst_dev, src_host, n_tokens, stream):
+    """Pinned host (H,T,D) -> device (H,T',D): tokens [0, n_tokens) of every head, on `stream` (a torch Stream)."""
+    _dev(dst_dev)
+    H, _, D = dst_dev.shape
+    assert src_host.shape[0] == H and src_host.shape[2] == D and src_host.dtype == _HALF and not src_host.is_cuda
+    hip.check(hip.lib().tf_kv_h2d_async(_ptr(dst_dev), dst_dev.stride(0), _ptr(src_host), src_host.stride(0),
+                                        int(n_tokens) * D, H, ctypes.c_void_p(stream.cuda_stream)), "tf_kv_h2d_async")
+
+
+def kv_d2h_async(dst_host, src_dev, t0, n_tokens, stream):
+    """Device (H,T',D) tokens [t0, t0+n) -> pinned host (H,T,D) same token range, on `stream`."""
+    _dev(src_dev)
+    H, _, D = src_dev.shape
+    assert dst_host.shape[0] == H and dst_host.shape[2] == D and dst_host.dtype == _HALF and not dst_host.is_cuda
+    dst = ctypes.c_void_p(dst_host.data_ptr() + int(t0) * D * 2)
+    src = ctypes.c_void_p(src_dev.data_ptr() + int(t0) * D * 2)
+    hip.check(hip.lib().tf_kv_d2h_async(dst, dst_host.stride(0), src, src_dev.stride(0), int(n_tokens) * D, H,
+                                        ctypes.c_void_p(stream.cuda_stream)), "tf_kv_d2h_async")

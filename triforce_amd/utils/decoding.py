@@ -81,7 +81,7 @@ def _buffers(graph_engine, gamma, vocab, device):
 
 
 @torch.inference_mode()
-def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, buffers=None):
+def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, buffers=None, sync_record=None):
     """Inner loop: the 68M drafts one token at a time for the retrieval-cache model (decoding.py:163-223).
     Returns (ids [next, t1..t_g2], rows = device (g2, V) view of the retrieval-model prob rows, acceptance)."""
     eng = graph_engine.engine
@@ -103,6 +103,10 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
         ops.sample_inverse_cdf(q_d, u[0:1], flat[n + 1:n + 2])               # d ~ q_d, written into verify_tokens
         p = graph_engine.graph_verify(input_ids=vt, position_ids=position_ids)
         ops.middle_accept(p, q_d, flat, u[1:3], n, gamma, buffers.mid_out)   # accept test + follow-up sample
+        if sync_record is not None:                                           # TP: rank 0's decision wins
+            sync_record(buffers.mid_out)
+            if n + 1 < flat.numel():
+                flat[n + 1:n + 3].copy_(_mid_tokens(buffers.mid_out, n, gamma, flat))
         acc, b, d = buffers.mid_out[:3].tolist()                              # the one host sync of this step
         rng.advance(3)
         drafted += 1
@@ -125,11 +129,27 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
     return ids, buffers.spec_rows[:len(ids) - 1], accepted / drafted
 
 
+def _mid_tokens(rec, n, gamma, flat):
+    """verify_tokens[n+1 : n+3] implied by a (possibly broadcast) middle_accept record (acc, b, d)."""
+    acc, b, d = rec[0], rec[1], rec[2]
+    cur = flat[n + 1:n + 3].clone()
+    first = torch.where(acc > 0, d, b)                 # accepted: d stays at n+1, b goes to n+2; rejected: b at n+1
+    cur[0] = first
+    if cur.numel() > 1:
+        cur[1] = torch.where(acc > 0, b, cur[1])
+    return cur
+
+
 class TriForceRunner:
     """The TriForce outer loop (decoding.py:41-160) as prefill() + step(): ``TriForce`` below drives it to
     ``max_len`` tokens, bench.py drives it for an exact number of steps."""
 
-    def __init__(self, tokenizer, graph_engine, gamma, top_k=-1, top_p=0.9, temperature=0.6, verbose=False, rng=None):
+    def __init__(self, tokenizer, graph_engine, gamma, top_k=-1, top_p=0.9, temperature=0.6, verbose=False, rng=None,
+                 inclusive_accept=False, sync_record=None):
+        # inclusive_accept: the TP outer loop tests ``r <=`` (decoding.py:347) where on-chip tests ``r <`` (:99)
+        # sync_record: optional callable applied to each device decision record before it is read (TP: broadcast
+        #              from rank 0, the role of sample_dist / the r broadcast, decoding.py:230-239,345-346)
+        self.inclusive_accept, self.sync_record = inclusive_accept, sync_record
         self.tokenizer, self.ge, self.eng = tokenizer, graph_engine, graph_engine.engine
         self.gamma, self.top_k, self.top_p, self.temperature, self.verbose = gamma, top_k, top_p, temperature, verbose
         self.device = self.eng.model.device
@@ -173,7 +193,8 @@ class TriForceRunner:
         tokenizer, verbose = self.tokenizer, self.verbose
         next_token = self.next_token
         n0 = self.n
-        ids, spec_rows, acc_mid = Middle_Spec(next_token, ge, gamma, False, tokenizer, rng=rng, buffers=bufs)
+        ids, spec_rows, acc_mid = Middle_Spec(next_token, ge, gamma, False, tokenizer, rng=rng, buffers=bufs,
+                                              sync_record=self.sync_record)
         self.acc_rate_middle_list.append(acc_mid)
         generated = ids[1:]
         g2 = len(generated)
@@ -184,8 +205,10 @@ class TriForceRunner:
         verify_tokens = torch.tensor([ids], dtype=torch.long, device=device)
         logits = ge.inference(input_ids=verify_tokens)
         probs = norm_logits(logits[0], temperature=self.temperature, top_k=self.top_k, top_p=self.top_p)
-        ops.accept_chain(probs, spec_rows, verify_tokens.view(-1)[1:], rng.take(g2 + 1), g2, False, self.eos,
-                         bufs.chain_out)
+        ops.accept_chain(probs, spec_rows, verify_tokens.view(-1)[1:], rng.take(g2 + 1), g2, self.inclusive_accept,
+                         self.eos, bufs.chain_out)
+        if self.sync_record is not None:
+            self.sync_record(bufs.chain_out)
         count, pred, reason, consumed = bufs.chain_out.tolist()          # the one host sync of the outer step
         rng.advance(consumed)
 
@@ -266,3 +289,102 @@ def TriForce(tokenizer, graph_engine, input_ids, gamma=4, max_len=256, top_k=-1,
     if return_details:
         return st
     return acceptance_rate, n / (time2 - time1)
+
+
+################### Dist Spec (TP + offloading) ####################
+import types
+
+import torch.distributed as dist
+
+
+def _bcast_record(t):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src=0)
+
+
+def sample_dist(probs, rng=None):
+    """Rank 0 samples, everyone gets the token (reference decoding.py:230-239) — one 8-byte broadcast, no barrier."""
+    tok = sample(probs, rng=rng)
+    _bcast_record(tok)
+    return tok
+
+
+class _DistEngine:
+    """Presents a DistributedLlama through the GraphInferenceEngine surface the decode loops drive."""
+
+    def __init__(self, llm):
+        self.llm = llm
+        self.engine = types.SimpleNamespace(
+            model=types.SimpleNamespace(device=llm.device, config=llm.config.model_config),
+            kv_cache=llm.kv_cache, graph_cache=llm.retrieval_cache, draft_cache=llm.draft_cache)
+
+    def graph_draft_inference(self, input_ids, gamma_offset=0):
+        return self.llm.draft_run(input_ids=input_ids, gamma_offset=gamma_offset)       # 0.6/0.9 hard-wired (SURVEY §7)
+
+    def graph_verify(self, input_ids, position_ids):
+        return self.llm.retrieval_verify(input_ids=input_ids, position_ids=position_ids,
+                                         temperature=self.llm.temperature, top_p=self.llm.top_p)
+
+    def inference(self, input_ids):
+        return self.llm.inference(input_ids=input_ids)
+
+    def update_graph_cache(self):
+        self.llm.retrieval_cache.update_graph_cache(self.llm.kv_cache)
+
+
+@torch.inference_mode()
+def Baseline_Dist(tokenizer, graph_engine, input_ids, max_len=256, top_k=-1, top_p=0.9, temperature=0.6, verbose=False,
+                  local_rank=0, rng=None):
+    """Autoregressive TP baseline (reference decoding.py:243-287): returns (ms per token, generated ids)."""
+    llm = graph_engine
+    rng = rng or UniformSource(llm.device, seed=1)
+    llm.reset()
+    logits = llm.prefill(input_ids=input_ids)
+    next_token = sample_dist(norm_logits(logits[:, -1, :], temperature=temperature, top_k=top_k, top_p=top_p), rng)
+    gen_tokens = torch.zeros((input_ids.size(0), max_len), dtype=torch.long, device=input_ids.device)
+    n = 0
+    _sync(llm.device)
+    time1 = time.time()
+    while n < max_len:
+        logits = llm.inference(input_ids=next_token)
+        next_token = sample_dist(norm_logits(logits[:, -1, :], temperature=temperature, top_k=top_k, top_p=top_p), rng)
+        gen_tokens[:, n] = next_token.squeeze()
+        n += 1
+    _sync(llm.device)
+    time2 = time.time()
+    return 1000 * (time2 - time1) / n, gen_tokens
+
+
+@torch.inference_mode()
+def Middle_Spec_Dist(next_token, llm, gamma, verbose, tokenizer, rng=None):
+    """Reference decoding.py:432-495."""
+    ge = llm if isinstance(llm, _DistEngine) else _DistEngine(llm)
+    return Middle_Spec(next_token, ge, gamma, verbose, tokenizer, rng=rng, sync_record=_bcast_record)
+
+
+@torch.inference_mode()
+def TriForce_Dist(tokenizer, llm, input_ids, gamma=4, max_len=256, top_k=-1, top_p=0.9, temperature=0.6, verbose=False,
+                  file_path=None, dataset=None, spec_args=None, rng=None, return_details=False):
+    """Reference decoding.py:291-428: returns (avg accepted tokens, seconds per token)."""
+    ge = _DistEngine(llm)
+    rng = rng or UniformSource(llm.device, seed=1)          # same seed on every rank: identical uniform streams
+    run = TriForceRunner(tokenizer, ge, gamma, top_k, top_p, temperature, verbose, rng, inclusive_accept=True,
+                         sync_record=_bcast_record)
+    llm.reset()
+    llm.prefill(input_ids=input_ids[:, :-1])
+    logits = llm.build_retrieval_cache(input_ids=input_ids[:, -1:])
+    run.start(logits)
+    llm.draft_run(input_ids=input_ids)
+    eos = run.eos
+    _sync(llm.device)
+    time1 = time.time()
+    while run.n < max_len:
+        run.step()
+        if run.next_token == eos:                            # the TP loop stops at eos (decoding.py:382-383)
+            break
+    _sync(llm.device)
+    time2 = time.time()
+    st = run.stats(time2 - time1)
+    if return_details:
+        return st
+    return st["avg_tokens"], (time2 - time1) / max(run.n, 1)
