@@ -202,7 +202,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or os.environ.get("TRIFORCE_BENCH_FORCE_TP") == "1":
         from bench_tp import run_tp                  # tensor-parallel decode (heads sharded, RCCL all-reduce)
         return run_tp(args, rank, world, local)
 

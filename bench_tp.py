@@ -1,0 +1,84 @@
+"""bench.py --gpus N (N>1): tensor-parallel TriForce decode, one process per GPU over RCCL/xGMI.
+
+Same model, prompt length and decode loop as the 1-GPU workload; attention heads, MLP columns, the KV cache
+and the retrieval cache are sharded N ways, with the two fp16 all-reduces per layer as the only
+exchange step.  Total work is fixed, so scaling is "strong".  All layers stay resident in HBM (on_chip = L):
+with 288 GB per MI355X the offloading tier is never needed for these shapes (it is exercised by the tests and
+by test/offloading_TP.py --on_chip)."""
+import json
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def run_tp(args, rank, world, local):
+    from bench import _Tok, target_config
+    from triforce_amd.models.cache import StreamingLLMEvictionCache
+    from triforce_amd.models.modeling_llama_68m import LlamaForCausalLM as Draft68M
+    from triforce_amd.models.TP_llama import DistributedLlama, distributed_init
+    from triforce_amd.utils.decoding import TriForceRunner, _DistEngine, _bcast_record
+    from triforce_amd.utils.sampling import UniformSource
+
+    distributed_init("nccl")
+    device = torch.device("cuda", local)
+    tcfg, dcfg = target_config(args.target)
+    draft = Draft68M(dcfg, device).init_random(args.seed + 2)
+    dcache = StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - args.gamma, gamma=args.gamma)
+    llm = DistributedLlama(f"random:{args.seed + 1}", config=tcfg, local_rank=rank, world_size=world, device=device,
+                           prefill=args.prefill, gen_len=args.gen_cap, temperature=args.temp, top_p=args.top_p,
+                           retrieval_budget=args.budget, retrieval_chunk_size=args.chunk_size, kv_offload=True,
+                           on_chip_layers=tcfg.num_hidden_layers, draft=draft, draft_cache=dcache, gamma=args.gamma)
+    llm.init_parameters(f"random:{args.seed + 1}")
+    gen = torch.Generator().manual_seed(args.seed)
+    input_ids = torch.randint(3, tcfg.vocab_size, (1, args.prefill), generator=gen).to(device)
+
+    ge = _DistEngine(llm)
+    run = TriForceRunner(_Tok(), ge, args.gamma, top_k=-1, top_p=args.top_p, temperature=args.temp,
+                         rng=UniformSource(device, seed=args.seed), inclusive_accept=True, sync_record=_bcast_record)
+    t0 = time.time()
+    llm.reset()
+    if args.prefill_mode == "real":
+        llm.prefill(input_ids=input_ids[:, :-1])
+    else:
+        llm.kv_cache.normal_(seq_len=args.prefill - 1)
+    logits = llm.build_retrieval_cache(input_ids=input_ids[:, -1:])
+    run.start(logits)
+    llm.draft_run(input_ids=input_ids)
+    torch.cuda.synchronize()
+    t_prefill = time.time() - t0
+
+    for _ in range(args.warmup):
+        run.step()
+    n0, acc0, dr0 = run.n, run.accepted_count, run.draft_count
+    dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.time()
+    for _ in range(args.steps):
+        run.step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t2 = time.time()
+    elapsed = torch.tensor([t2 - t1], dtype=torch.float64, device=device)
+    dist.all_reduce(elapsed, dist.ReduceOp.MAX)                 # slowest rank defines the job time
+    seconds = float(elapsed.item())
+    tokens = run.n - n0
+    accepted, drafted = run.accepted_count - acc0, run.draft_count - dr0
+    if rank == 0:
+        print(json.dumps({
+            "metric": "decode tokens/sec + avg accepted len, Llama-7B-128K @124K ctx",
+            "value": round(tokens / seconds, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(seconds / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1] shapes, tensor-parallel: {tcfg._name_or_path} TriForce decode, "
+                                   f"prefill {args.prefill}, budget {args.budget}, chunk {args.chunk_size}, gamma "
+                                   f"{args.gamma}, T={args.temp}, top_p={args.top_p}, TP={world} over RCCL/xGMI, "
+                                   f"KV resident in HBM",
+                       "parallelism": f"tp{world}", "prefill_mode": args.prefill_mode,
+                       "weights": "random-init N(0,0.02) fp16"},
+            "avg_accepted_len": round(accepted / max(drafted, 1) * args.gamma, 4),
+            "acceptance_rate": round(accepted / max(drafted, 1), 4), "tokens": tokens,
+            "tokens_per_step": round(tokens / args.steps, 3), "prefill_seconds": round(t_prefill, 2),
+            "kv_seq_len": llm.kv_cache.seq_len}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
