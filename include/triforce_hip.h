@@ -124,6 +124,19 @@ int tf_rope_append(const void* qkv, int64_t qkv_row_stride, const void* cos, con
 int tf_silu_mul(const void* gate_up, void* out, int rows, int I, void* stream);
 
 /* -------------------------------------------------------------------------------------------
+ * Skinny (decode) GEMMs — nn.Linear / F.linear with M <= 32 activation rows (models/modeling_llama.py:
+ * 156-159,212-214,243,408; models/tensor_op.py:140-142,175,353-357): y = x . W^T, fp16 in, fp32 MFMA accumulate.
+ * W is passed PRE-PACKED in MFMA-operand order: [N/16 panels][K/32 chunks][64 pieces][8 fp16], piece (g*16+i)
+ * of a tile = W[n0+i][k0+8g .. +7]  (triforce_amd.ops.pack_weight); N % 16 == 0, K % 32 == 0.
+ * tf_skinny_gemm        : y [M][ldy] fp16, or fp32 when out_f32 != 0 (the fp16 result cast to float — `logits.float()`).
+ * tf_skinny_gemm_swiglu : act [M][I] = fp16(silu(fp16(x.Wg^T))) * fp16(x.Wu^T)  — gate/up GEMMs + SwiGLU fused.
+ * ------------------------------------------------------------------------------------------- */
+int tf_skinny_gemm(const void* w_packed, const void* x, int64_t ldx, void* y, int64_t ldy, int M, int N, int K,
+                   int out_f32, void* stream);
+int tf_skinny_gemm_swiglu(const void* gate_packed, const void* up_packed, const void* x, int64_t ldx, void* act,
+                          int64_t ldy, int M, int I, int K, void* stream);
+
+/* -------------------------------------------------------------------------------------------
  * Sampling / accept-rollback (utils/sampling.py:63-75, utils/decoding.py:97-134,190-220).
  * tf_sample_inverse_cdf: token = first index whose inclusive cumulative sum of probs exceeds
  *                        u * sum(probs)  (stand-in for torch.multinomial with an explicit uniform).
@@ -140,6 +153,10 @@ int tf_silu_mul(const void* gate_up, void* out, int rows, int I, void* stream);
  *                        out[0]=accepted(0/1), out[1]=follow-up token.  Also writes the follow-up
  *                        token into tokens[n+1+acc] when that index is <= gamma.
  * ------------------------------------------------------------------------------------------- */
+/* tf_topp_probs: probs = softmax(top_p_filter(logits / temperature)) for `rows` rows of V <= 32768 fp32 logits —
+ * utils/sampling.py:43-60 (norm_logits with top_k = -1) without the vocabulary sort: threshold search on the
+ * fp32 bit pattern + index-ordered tie scan (== a stable descending sort; ties -> lowest token id). */
+int tf_topp_probs(const float* logits, float* probs, int rows, int V, float temperature, float top_p, void* stream);
 int tf_sample_inverse_cdf(const float* probs, const float* u, int64_t* token_out, int V, void* stream);
 int tf_accept_chain(const float* p, const float* q, const int64_t* tokens, const float* uniforms,
                     int g2, int V, int inclusive, int64_t eos_token_id, int64_t* out, void* stream);

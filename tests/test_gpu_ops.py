@@ -378,3 +378,80 @@ def test_accept_chain_and_middle_accept_match_oracle():
         assert out[:3].tolist() == [acc, b, d]
         if n + 1 + acc <= gamma:
             assert int(td[n + 1 + acc]) == b
+
+
+@pytest.mark.parametrize("V", [512, 1024, 32000])
+@pytest.mark.parametrize("T,P", [(0.6, 0.9), (1.0, 1e-9), (0.3, 0.5), (1.0, 0.999), (2.0, 0.95)])
+def test_topp_probs_matches_oracle(V, T, P):
+    """Fused temperature/top-p/softmax kernel vs the oracle's sort-based norm_logits (stable order)."""
+    ops = _ops()
+    lg = rnd(9, V, seed=90 + V, dtype=torch.float32) * 2.5
+    lg[1] = lg[1].half().float()                       # fp16-valued logits (what the lm_head produces): exact ties
+    lg[2, :5] = lg[2].max()                            # ties at the very top
+    lg[3] = 0.0                                        # everything tied
+    lg[4, 7] = 30.0                                    # one dominant token
+    want = R.norm_logits(lg.clone(), T, -1, P)
+    got = ops.topp_probs(lg.to(DEV), T, P).cpu()
+    assert torch.isfinite(got).all() and (got.sum(-1) - 1).abs().max() < 1e-5
+    for r in range(lg.shape[0]):
+        sg, sw = got[r] > 0, want[r] > 0
+        if torch.equal(sg, sw):
+            torch.testing.assert_close(got[r], want[r], rtol=2e-4, atol=1e-8)
+        else:
+            # the kept set may differ only at the top-p boundary, where the cumulative mass (summed in a
+            # different fp32 order) is within rounding of top_p; ties must still resolve to the lower token id
+            diff = torch.nonzero(sg != sw).flatten()
+            assert diff.numel() <= 2, f"row {r}: kept sets differ in {diff.numel()} entries"
+            p_full = torch.softmax(lg[r] / T, -1)
+            order = torch.sort(p_full, descending=True, stable=True)
+            cum = torch.cumsum(order.values.double(), 0)
+            ranks = {int(t): i for i, t in enumerate(order.indices.tolist())}
+            for t in diff.tolist():
+                rk = ranks[t]
+                before = float(cum[rk - 1]) if rk > 0 else 0.0
+                assert abs(before - P) < 2e-5, f"row {r}: token {t} (rank {rk}) flipped far from the boundary ({before} vs {P})"
+    if P < 1e-6:                                        # greedy emulation: one-hot on the LOWEST index among the maxima
+        assert torch.equal(got, want)
+
+
+def test_norm_logits_routes_to_fused_kernel_and_draft_row_shortcut():
+    from triforce_amd.utils.sampling import norm_logits
+    lg = rnd(7, 32000, seed=5, dtype=torch.float32).to(DEV) * 3
+    full = norm_logits(lg, 0.6, -1, 0.9)
+    last = norm_logits(lg[-1:], 0.6, -1, 0.9)[0]
+    assert torch.equal(full[-1], last)                  # rows are independent
+    want = R.norm_logits(lg.cpu(), 0.6, -1, 0.9)
+    assert ((full.cpu() > 0) == (want > 0)).float().mean() > 0.9999
+
+
+@pytest.mark.parametrize("M", [1, 7, 8, 16, 17, 32])
+@pytest.mark.parametrize("N,K", [(768, 768), (2304, 768), (4096, 4096), (12288, 4096), (4096, 11008), (32000, 768)])
+def test_skinny_gemm_matches_linear(M, N, K):
+    """Hand-written weight-streaming GEMM (pre-packed weights) vs the oracle's F.linear."""
+    ops = _ops()
+    x, w = rnd(M, K, seed=110 + M), rnd(N, K, seed=111, scale=0.05)
+    want = R.linear(x, w)
+    pl = ops.PackedLinear(w.to(DEV))
+    assert pl.wp is not None
+    got = ops.linear(x.to(DEV), pl)
+    # fp32 accumulation in a different order than the CPU GEMM: <=1 fp16 ulp on a small fraction of outputs
+    ulp_report("skinny_gemm", got, want, max_ulp_frac=3e-2, atol=1e-4)
+    got32 = ops.linear(x.to(DEV), pl, out_f32=True)
+    assert got32.dtype == torch.float32 and torch.equal(got32.cpu(), got.float().cpu())   # fp16 GEMM, then the cast
+    # pack/unpack is a pure permutation
+    back = pl.wp.view(N // 16, K // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(N, K)
+    assert torch.equal(back.cpu(), w)
+
+
+@pytest.mark.parametrize("M,I,K", [(1, 3072, 768), (7, 11008, 4096), (18, 1728, 5120), (32, 768, 256)])
+def test_skinny_gemm_swiglu_matches_oracle(M, I, K):
+    ops = _ops()
+    x, wgu = rnd(M, K, seed=120 + M), rnd(2 * I, K, seed=121, scale=0.05)
+    gu = R.linear(x, wgu)
+    want = R.silu_mul(gu[:, :I], gu[:, I:])
+    pl = ops.PackedLinear(wgu.to(DEV), split=2)
+    got = ops.mlp_act(x.to(DEV), pl)
+    # two GEMM roundings + silu + product: a 1-ulp difference in gate or up can become 2 ulp of the product
+    ulp_report("skinny_swiglu", got, want, max_ulp_frac=6e-2, atol=1e-4, ulps=2)
+    big = ops.mlp_act(rnd(40, K, seed=5).to(DEV), pl)                 # >32 rows: hipBLASLt + silu_mul path
+    assert big.shape == (40, I)

@@ -105,6 +105,30 @@ def _gemm():
     print("gemm", json.dumps(res), flush=True)
 
 
+@section("skinny_gemm")
+def _sg():
+    res = {}
+    for (name, N, K) in [("qkv", 12288, 4096), ("o", 4096, 4096), ("down", 4096, 11008), ("lm_head", 32000, 4096),
+                         ("draft_qkv", 2304, 768), ("draft_head", 32000, 768)]:
+        w = torch.randn(N, K, device=DEV, dtype=torch.float16) * 0.02
+        pl = ops.PackedLinear(w)
+        for M in [1, 8, 18]:
+            x = torch.randn(M, K, device=DEV, dtype=torch.float16)
+            us = timeit(lambda: ops.linear(x, pl))
+            ref = timeit(lambda: torch.nn.functional.linear(x, w))
+            res[f"{name}_M{M}"] = {"us": round(us, 1), "GBps": round(N * K * 2 / us / 1e3, 1), "hipblaslt_us": round(ref, 1)}
+        del w, pl
+    wgu = torch.randn(22016, 4096, device=DEV, dtype=torch.float16) * 0.02
+    pl = ops.PackedLinear(wgu, split=2)
+    for M in [1, 8, 18]:
+        x = torch.randn(M, 4096, device=DEV, dtype=torch.float16)
+        us = timeit(lambda: ops.mlp_act(x, pl))
+        ref = timeit(lambda: ops.silu_mul(torch.nn.functional.linear(x, wgu)))
+        res[f"gate_up_swiglu_M{M}"] = {"us": round(us, 1), "GBps": round(22016 * 4096 * 2 / us / 1e3, 1), "hipblaslt_plus_silu_us": round(ref, 1)}
+    OUT["skinny_gemm"] = res
+    print("skinny_gemm", json.dumps(res), flush=True)
+
+
 @section("glue")
 def _glue():
     res = {}
@@ -124,6 +148,9 @@ def _glue():
     logits = torch.randn(8, 32000, device=DEV)
     from triforce_amd.utils.sampling import norm_logits
     res["norm_logits_8x32000_us"] = round(timeit(lambda: norm_logits(logits, 0.6, -1, 0.9)), 1)
+    res["norm_logits_1x32000_us"] = round(timeit(lambda: norm_logits(logits[:1], 0.6, -1, 0.9)), 1)
+    from triforce_amd.utils.sampling import top_k_top_p_filter
+    res["norm_logits_torch_sort_8x32000_us"] = round(timeit(lambda: torch.softmax(top_k_top_p_filter(logits / 0.6, -1, 0.9), -1)), 1)
     p = torch.softmax(logits, -1)
     out = torch.zeros(4, dtype=torch.int64, device=DEV)
     toks = torch.randint(0, 32000, (7,), device=DEV)

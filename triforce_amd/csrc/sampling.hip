@@ -167,3 +167,130 @@ extern "C" int tf_middle_accept(const float* p, const float* q_d, int64_t* token
     TF_LAUNCH_CHECK();
     return TF_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Fused temperature + top-p + softmax  (utils/sampling.py:5-27,43-60 `norm_logits`, top_k = -1).
+//
+// The reference sorts the whole vocabulary (torch.sort + softmax + cumsum + scatter + softmax: ~10 kernels,
+// ~350 us for 8 x 32000 on MI355X).  The kept set is a threshold set, so no sort is needed:
+//   e_i = exp(l_i/T - max), Z = sum e.  With G(u) = mass of the entries strictly greater than u, an entry of
+//   value w is kept iff G(w) + (mass of equal entries with a lower index) <= top_p * Z  — exactly the
+//   "drop rank r when the inclusive cumulative mass of rank r-1 exceeds top_p" rule with a stable descending
+//   sort.  The smallest u with G(u) <= top_p*Z is found by a 31-step search over the fp32 bit pattern (G is
+//   monotone), each step one block-wide deterministic reduction; ties at u are resolved by one index-ordered
+//   block scan.  One workgroup per row, the row lives in registers (V <= 32768).
+// ------------------------------------------------------------------------------------------------
+#define TOPP_THREADS 1024
+#define TOPP_EPT 32
+
+__device__ __forceinline__ float block_sum_1024(float v, float* sm, int tid) {
+    v = wave_sum(v);
+    __syncthreads();                       // sm reuse across consecutive calls
+    if ((tid & 63) == 0) sm[tid >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < TOPP_THREADS / 64; ++w) t += sm[w];
+    return t;
+}
+__device__ __forceinline__ float block_max_1024(float v, float* sm, int tid) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((tid & 63) == 0) sm[tid >> 6] = v;
+    __syncthreads();
+    float t = sm[0];
+#pragma unroll
+    for (int w = 1; w < TOPP_THREADS / 64; ++w) t = fmaxf(t, sm[w]);
+    return t;
+}
+
+__global__ __launch_bounds__(TOPP_THREADS) void topp_probs_kernel(const float* __restrict__ logits,
+                                                                  float* __restrict__ probs, int V,
+                                                                  float inv_temperature_is_div, float temperature,
+                                                                  float top_p) {
+    __shared__ float sm[TOPP_THREADS / 64];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* lr = logits + (int64_t)row * V;
+    float* pr = probs + (int64_t)row * V;
+    // thread t owns the CONTIGUOUS indices [t*EPT, (t+1)*EPT): index order == (thread, slot) order
+    const int i0 = tid * TOPP_EPT;
+    float e[TOPP_EPT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < TOPP_EPT; ++s) {
+        const int i = i0 + s;
+        const float x = (i < V) ? lr[i] / temperature : -INFINITY;       // logits / temperature (sampling.py:56)
+        e[s] = x;
+        mx = fmaxf(mx, x);
+    }
+    mx = block_max_1024(mx, sm, tid);
+    float zl = 0.f;
+#pragma unroll
+    for (int s = 0; s < TOPP_EPT; ++s) {
+        e[s] = (i0 + s < V) ? expf(e[s] - mx) : 0.f;
+        zl += e[s];
+    }
+    const float Z = block_sum_1024(zl, sm, tid);
+    const float tau = top_p * Z;
+    // v = largest bit pattern with G(v) > tau  (G(0) = Z > tau for top_p < 1; e >= 0 so patterns order like values)
+    unsigned v = 0u;
+    for (int bit = 30; bit >= 0; --bit) {
+        const unsigned cand = v | (1u << bit);
+        float g = 0.f;
+#pragma unroll
+        for (int s = 0; s < TOPP_EPT; ++s) g += (__float_as_uint(e[s]) > cand) ? e[s] : 0.f;
+        g = block_sum_1024(g, sm, tid);
+        if (g > tau) v = cand;
+    }
+    const unsigned u = v + 1u;                       // smallest pattern with G(u) <= tau
+    float gl = 0.f, tl = 0.f;
+#pragma unroll
+    for (int s = 0; s < TOPP_EPT; ++s) {
+        const unsigned b = __float_as_uint(e[s]);
+        gl += (b > u) ? e[s] : 0.f;
+        tl += (b == u) ? e[s] : 0.f;
+    }
+    const float G = block_sum_1024(gl, sm, tid);
+    // exclusive prefix (index order) of the tie mass held by earlier threads
+    float inc = tl;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float n = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += n;
+    }
+    __syncthreads();
+    if (lane == 63) sm[wave] = inc;
+    __syncthreads();
+    float before = inc - tl;
+    for (int w = 0; w < wave; ++w) before += sm[w];
+    // keep: > u always; == u while G + (ties before) <= tau.  Always keep rank 0 (filter[...,0] = 0).
+    float kept_sum = 0.f;
+    unsigned keepmask = 0u;
+    float run = before;
+#pragma unroll
+    for (int s = 0; s < TOPP_EPT; ++s) {
+        const unsigned b = __float_as_uint(e[s]);
+        bool keep = b > u;
+        if (b == u) {
+            keep = (G + run <= tau) || (G == 0.f && run == 0.f);
+            run += e[s];
+        }
+        if (keep && e[s] > 0.f) { keepmask |= (1u << s); kept_sum += e[s]; }
+    }
+    const float Zk = block_sum_1024(kept_sum, sm, tid);
+#pragma unroll
+    for (int s = 0; s < TOPP_EPT; ++s) {
+        const int i = i0 + s;
+        if (i < V) pr[i] = ((keepmask >> s) & 1u) ? e[s] / Zk : 0.f;
+    }
+}
+
+extern "C" int tf_topp_probs(const float* logits, float* probs, int rows, int V, float temperature, float top_p,
+                             void* stream) {
+    if (!logits || !probs || rows < 1 || V < 1 || !(temperature > 0.f) || !(top_p > 0.f)) return TF_EINVAL;
+    if (V > TOPP_THREADS * TOPP_EPT) return TF_ERANGE;
+    hipLaunchKernelGGL(topp_probs_kernel, dim3(rows), dim3(TOPP_THREADS), 0, (hipStream_t)stream, logits, probs, V,
+                       0.f, temperature, top_p);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}

@@ -26,6 +26,9 @@ SIGNATURES = {
     "tf_rmsnorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "tf_rope_append": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "tf_silu_mul": (_i32, [_vp, _vp, _i32, _i32, _vp]),
+    "tf_skinny_gemm": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "tf_skinny_gemm_swiglu": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "tf_topp_probs": (_i32, [_vp, _vp, _i32, _i32, _f32, _f32, _vp]),
     "tf_sample_inverse_cdf": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "tf_accept_chain": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
     "tf_middle_accept": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),

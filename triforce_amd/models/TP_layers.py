@@ -33,12 +33,14 @@ class DistributedLlamaLayer:
     """Read-only view of one layer's local shard (names of reference TP_layers.py:100-163)."""
 
     def __init__(self, layer_idx, weights) -> None:
+        from .. import ops
         W, hd, I = weights, weights.H_local * weights.D, weights.I_local
         self.layer_idx = layer_idx
-        self.wq, self.wk, self.wv = W.wqkv[layer_idx][:hd], W.wqkv[layer_idx][hd:2 * hd], W.wqkv[layer_idx][2 * hd:]
-        self.wo = W.wo[layer_idx]
-        self.gate_proj, self.up_proj = W.wgu[layer_idx][:I], W.wgu[layer_idx][I:]
-        self.down_proj = W.wd[layer_idx]
+        qkv, gu = ops._w(W.wqkv[layer_idx]), ops._w(W.wgu[layer_idx])
+        self.wq, self.wk, self.wv = qkv[:hd], qkv[hd:2 * hd], qkv[2 * hd:]
+        self.wo = ops._w(W.wo[layer_idx])
+        self.gate_proj, self.up_proj = gu[:I], gu[I:]
+        self.down_proj = ops._w(W.wd[layer_idx])
         self.input_layernorm_weight = W.ln1[layer_idx]
         self.post_attention_layernorm_weight = W.ln2[layer_idx]
         self.input_layernorm_variance_epsilon = self.post_attention_layernorm_variance_epsilon = W.eps

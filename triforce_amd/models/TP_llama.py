@@ -141,13 +141,13 @@ class DistributedLlama:
         a = ops.attn_prefill(q, kl, vl, sk, self.scale)
         o = self._all_reduce(ops.linear(a, W.wo[i]))                        # tensor_op.py:176-179
         h = ops.rmsnorm(o, W.ln2[i], W.eps, residual=x, sum_out=x)
-        act = ops.silu_mul(ops.linear(h, W.wgu[i]))
+        act = ops.mlp_act(h, W.wgu[i])
         return self._all_reduce(ops.linear(act, W.wd[i]))                   # tensor_op.py:353-359
 
     def _finish(self, x, d):
         W = self.weights
         h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)
-        return ops.linear(h, W.lm_head).float().unsqueeze(0)
+        return ops.linear(h, W.lm_head, out_f32=True).unsqueeze(0)
 
     @torch.inference_mode()
     def inference(self, input_ids, position_ids=None, attention_mask=None, retrieval_cache=None):
@@ -226,7 +226,7 @@ class DistributedLlama:
             logits = self.draft(input_ids=input_ids, kv_cache=self.draft_cache, graph_cache=self.draft_cache,
                                 gamma_offset=gamma_offset).logits
         if probs:
-            return norm_logits(logits[0], temperature=temperature, top_k=-1, top_p=top_p)[-1]
+            return norm_logits(logits[0, -1:], temperature=temperature, top_k=-1, top_p=top_p)[0]
         return logits
 
     @torch.inference_mode()

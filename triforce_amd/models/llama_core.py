@@ -12,6 +12,7 @@ import zlib
 
 import torch
 
+from .. import ops
 from .config_yarn import LlamaConfig
 
 
@@ -113,7 +114,7 @@ class LlamaWeights:
             self.wd.append(self._shard_cols(get(p + "mlp.down_proj.weight"), self.I_local).contiguous().to(dev))
             self.ln1.append(get(p + "input_layernorm.weight").to(dev))
             self.ln2.append(get(p + "post_attention_layernorm.weight").to(dev))
-        return self
+        return self.finalize()
 
     def init_random(self, seed, std=0.02):
         """Random-init directly on the device (no checkpoints offline): N(0,std) like
@@ -138,10 +139,26 @@ class LlamaWeights:
             self.wd.append(draw(("d", i, self.rank), hid, self.I_local))
             self.ln1.append(torch.ones(hid, dtype=torch.float16, device=dev))
             self.ln2.append(torch.ones(hid, dtype=torch.float16, device=dev))
+        return self.finalize()
+
+    def finalize(self):
+        """Wrap the GEMM weights: on a HIP device each gets its MFMA-packed copy for the decode kernel."""
+        PL = ops.PackedLinear
+        if isinstance(self.lm_head, PL):
+            return self
+        tied = self.lm_head is self.embed
+        self.lm_head = PL(self.lm_head)
+        if tied:
+            self.embed = self.lm_head.w
+        self.wqkv = [PL(w) for w in self.wqkv]
+        self.wo = [PL(w) for w in self.wo]
+        self.wgu = [PL(w, split=2) for w in self.wgu]
+        self.wd = [PL(w) for w in self.wd]
         return self
 
     def nbytes(self):
         ts = [self.embed, self.lm_head, self.norm] + self.wqkv + self.wo + self.wgu + self.wd + self.ln1 + self.ln2
+        ts = [ops._w(t) for t in ts]
         return sum(t.numel() * t.element_size() for t in ts)
 
 

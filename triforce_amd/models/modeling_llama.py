@@ -95,8 +95,8 @@ class LlamaForCausalLM:
                 a = ops.attn_prefill(q, kl, vl, slot + q_len, self.scale)
             o = ops.linear(a, W.wo[i])
             h = ops.rmsnorm(o, W.ln2[i], W.eps, residual=x, sum_out=x)       # x += attn_out
-            act = ops.silu_mul(ops.linear(h, W.wgu[i]))
+            act = ops.mlp_act(h, W.wgu[i])
             d = ops.linear(act, W.wd[i])
         h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)
-        logits = ops.linear(h, W.lm_head).float().unsqueeze(0)               # (1, q, V) fp32  (:408-409)
+        logits = ops.linear(h, W.lm_head, out_f32=True).unsqueeze(0)               # (1, q, V) fp32  (:408-409)
         return CausalLMOutput(logits)

@@ -84,8 +84,8 @@ class LlamaForCausalLM:
             a = ops.attn_rope_on_read(q, kl, vl, self.cos, self.sin, kv_len, self.scale)
             o = ops.linear(a, W.wo[i])
             h = ops.rmsnorm(o, W.ln2[i], W.eps, residual=x, sum_out=x)
-            act = ops.silu_mul(ops.linear(h, W.wgu[i]))
+            act = ops.mlp_act(h, W.wgu[i])
             d = ops.linear(act, W.wd[i])
         h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)
-        logits = ops.linear(h, W.lm_head).float().unsqueeze(0)
+        logits = ops.linear(h, W.lm_head, out_f32=True).unsqueeze(0)
         return CausalLMOutput(logits)

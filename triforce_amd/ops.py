@@ -39,9 +39,59 @@ def _kv(t):
 
 
 # ------------------------------------------------------------------------------------------
-def linear(x, w):
-    """fp16 GEMM with fp32 accumulation (hipBLASLt through torch) — the reference's nn.Linear/F.linear."""
-    return F.linear(x, w)
+SKINNY_MAX_ROWS = 32
+
+
+def pack_weight(w):
+    """[N, K] fp16 -> MFMA-operand order [N/16][K/32][4 (g)][16 (i)][8]: one 16x32 tile = one contiguous KiB."""
+    N, K = w.shape
+    assert N % 16 == 0 and K % 32 == 0 and w.dtype == _HALF
+    return w.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+class PackedLinear:
+    """A weight matrix with (on a HIP device) its pre-packed copy for the skinny decode GEMM.  ``w`` stays
+    available for the >32-row prefill GEMMs (hipBLASLt).  ``split`` = number of equal row blocks that were
+    fused (2 for gate|up) — each block is packed on its own so the SwiGLU kernel can pair them."""
+
+    def __init__(self, w, split=1, pack=None):
+        self.w = w
+        self.N, self.K = w.shape
+        self.split = split
+        pack = w.is_cuda if pack is None else pack
+        ok = pack and (self.N // split) % 16 == 0 and self.K % 32 == 0
+        self.parts = [pack_weight(b) for b in w.chunk(split, dim=0)] if ok else None
+        self.wp = self.parts[0] if (ok and split == 1) else None
+
+
+def _w(w):
+    return w.w if isinstance(w, PackedLinear) else w
+
+
+def linear(x, w, out_f32=False):
+    """y = x . W^T, fp16 with fp32 accumulation — the reference's nn.Linear / F.linear.  <=32 rows against a
+    PackedLinear run the hand-written weight-streaming kernel; larger blocks (prefill) go to hipBLASLt."""
+    if isinstance(w, PackedLinear) and w.wp is not None and x.shape[0] <= SKINNY_MAX_ROWS and x.is_cuda:
+        assert x.dtype == _HALF and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == w.K
+        y = torch.empty(x.shape[0], w.N, dtype=torch.float32 if out_f32 else _HALF, device=x.device)
+        hip.check(hip.lib().tf_skinny_gemm(_ptr(w.wp), _ptr(x), x.stride(0), _ptr(y), w.N, x.shape[0], w.N, w.K,
+                                           1 if out_f32 else 0, _stream()), "tf_skinny_gemm")
+        return y
+    y = F.linear(x, _w(w))
+    return y.float() if out_f32 else y
+
+
+def mlp_act(h, wgu):
+    """fp16(silu(gate(h))) * up(h) for a fused gate|up weight: one kernel for <=32 rows, GEMM + silu_mul otherwise."""
+    if isinstance(wgu, PackedLinear) and wgu.parts is not None and wgu.split == 2 and h.shape[0] <= SKINNY_MAX_ROWS \
+            and h.is_cuda:
+        I = wgu.N // 2
+        act = torch.empty(h.shape[0], I, dtype=_HALF, device=h.device)
+        hip.check(hip.lib().tf_skinny_gemm_swiglu(_ptr(wgu.parts[0]), _ptr(wgu.parts[1]), _ptr(h), h.stride(0),
+                                                  _ptr(act), I, h.shape[0], I, wgu.K, _stream()),
+                  "tf_skinny_gemm_swiglu")
+        return act
+    return silu_mul(F.linear(h, _w(wgu)))
 
 
 def rmsnorm(x, w, eps, residual=None, sum_out=None):
@@ -204,6 +254,19 @@ def kv_shift_rows(cache, src_t0, dst_t0, n):
     sl, st, sh = _lhtd(cache)
     hip.check(hip.lib().tf_kv_shift_rows(_ptr(cache), sl, st, sh, int(src_t0), int(dst_t0), int(n), L, H, D,
                                          _stream()), "tf_kv_shift_rows")
+
+
+TOPP_MAX_VOCAB = 32768
+
+
+def topp_probs(logits, temperature, top_p):
+    """softmax(top_p_filter(logits / temperature)) for (rows, V) fp32 logits, V <= 32768 — one fused kernel."""
+    _dev(logits)
+    assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.is_contiguous()
+    probs = torch.empty_like(logits)
+    hip.check(hip.lib().tf_topp_probs(_ptr(logits), _ptr(probs), logits.shape[0], logits.shape[1], float(temperature),
+                                      float(top_p), _stream()), "tf_topp_probs")
+    return probs
 
 
 def sample_inverse_cdf(probs, u, token_out):

@@ -44,8 +44,8 @@ class InferenceEngine:
         else:
             logits = self.draft(input_ids=input_ids, kv_cache=self.draft_cache, graph_cache=self.draft_cache,
                                 gamma_offset=gamma_offset).logits
-        if probs:
-            return norm_logits(logits[0], temperature=temperature, top_k=-1, top_p=top_p)[-1]
+        if probs:     # only the last row is used (graph_infer.py:57); rows are independent, so normalise just that one
+            return norm_logits(logits[0, -1:], temperature=temperature, top_k=-1, top_p=top_p)[0]
         return logits
 
     @torch.inference_mode()

@@ -31,6 +31,9 @@ def top_k_top_p_filter(logits: torch.Tensor, top_k: int = 0, top_p: float = 0.0)
 def norm_logits(logits: torch.Tensor, temperature=0.6, top_k=-1, top_p=0.9) -> torch.Tensor:
     """(rows, vocab) fp32 logits -> probabilities after temperature / top-k / top-p."""
     assert logits.dim() == 2
+    if logits.is_cuda and top_k <= 0 and 0.0 < top_p and logits.shape[-1] <= ops.TOPP_MAX_VOCAB \
+            and logits.dtype == torch.float32:
+        return ops.topp_probs(logits.contiguous(), temperature, top_p)      # fused HIP kernel, no vocabulary sort
     logits = logits / temperature
     logits = top_k_top_p_filter(logits, top_k=top_k, top_p=top_p)
     return F.softmax(logits, dim=-1)
