@@ -194,6 +194,28 @@ def cpu_baseline(args, tokens_per_step, inner_per_step):
             "step_seconds_est": round(step, 2)}
 
 
+def pmc_traffic(alg_bytes, H, D):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, KiB units, FETCH_SIZE doubled for gfx950 — MI355X_MICROARCH.md §HBM).
+    PMC counters cannot be read from inside this process; the latest profiles/*pmc_attn*.json is used when it
+    was measured on the same shape (H, D, key count within 0.1%), else traffic stays null."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_attn*.json"))):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        sh = j.get("shape", {})
+        if sh.get("H") == H and sh.get("D") == D and abs(j["algorithmic_bytes_per_launch"] / alg_bytes - 1) < 1e-3:
+            best = (f, j)
+    if best is None:
+        return {"traffic": None}
+    f, j = best
+    return {"traffic": j["traffic_bytes_per_launch"], "traffic_unit": "bytes/launch",
+            "traffic_source": os.path.relpath(f, ROOT), "traffic_over_algorithmic": j["traffic_over_algorithmic"]}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -252,6 +274,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                 "launches": len(full), "avg_launch_us": round(dur * 1e6, 1),
                 "algorithmic_bytes_per_launch": int(byts)}
+        roof.update(pmc_traffic(byts, H, D))
     else:
         roof = None
 
