@@ -30,6 +30,8 @@ def run_tp(args, rank, world, local):
                            retrieval_budget=args.budget, retrieval_chunk_size=args.chunk_size, kv_offload=True,
                            on_chip_layers=tcfg.num_hidden_layers, draft=draft, draft_cache=dcache, gamma=args.gamma)
     llm.init_parameters(f"random:{args.seed + 1}")
+    if not args.no_graphs:
+        llm.initialize_graphs(args.gamma)
     gen = torch.Generator().manual_seed(args.seed)
     input_ids = torch.randint(3, tcfg.vocab_size, (1, args.prefill), generator=gen).to(device)
 

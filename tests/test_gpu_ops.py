@@ -451,7 +451,8 @@ def test_skinny_gemm_swiglu_matches_oracle(M, I, K):
     want = R.silu_mul(gu[:, :I], gu[:, I:])
     pl = ops.PackedLinear(wgu.to(DEV), split=2)
     got = ops.mlp_act(x.to(DEV), pl)
-    # two GEMM roundings + silu + product: a 1-ulp difference in gate or up can become 2 ulp of the product
-    ulp_report("skinny_swiglu", got, want, max_ulp_frac=6e-2, atol=1e-4, ulps=2)
+    # gate and up may each round to the neighbouring fp16 (fp32 sums in another order): relative error up to
+    # 2^-10 each, so the product may be off by 2^-9 relative = "3 x |want| x 2^-10" in this helper's units
+    ulp_report("skinny_swiglu", got, want, max_ulp_frac=6e-2, atol=1e-4, ulps=3)
     big = ops.mlp_act(rnd(40, K, seed=5).to(DEV), pl)                 # >32 rows: hipBLASLt + silu_mul path
     assert big.shape == (40, I)

@@ -25,14 +25,14 @@ def _pg():
         dist.init_process_group("nccl", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{port}")
 
 
-def _build(g, on_chip):
+def _build(g, on_chip, gamma=None, graphs=False):
     from triforce_amd.models.cache import StreamingLLMEvictionCache
     from triforce_amd.models.config_yarn import LlamaConfig
     from triforce_amd.models.modeling_llama_68m import LlamaForCausalLM as Draft
     from triforce_amd.models.TP_llama import DistributedLlama
     tsd = specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g["head_std"])
     dsd = specs.random_state_dict(g["dcfg"], g["dseed"], head_std=g["head_std"])
-    gamma = g["gamma"]
+    gamma = gamma or g["gamma"]
     draft = Draft.from_state_dict(LlamaConfig.from_dict(g["dcfg"]), dsd, DEV)
     dcache = StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - gamma, gamma=gamma)
     llm = DistributedLlama("unused", config=LlamaConfig.from_dict(g["tcfg"]), device=DEV, local_rank=0, world_size=1,
@@ -40,6 +40,8 @@ def _build(g, on_chip):
                            retrieval_budget=g["budget"], kv_offload=True, on_chip_layers=on_chip, draft=draft,
                            draft_cache=dcache, gamma=gamma)
     llm.init_parameters(tsd)
+    if graphs:
+        llm.initialize_graphs()
     return llm
 
 
@@ -83,3 +85,32 @@ def test_offloaded_layers_equal_resident_layers_and_oracle():
     torch.cuda.synchronize()
     assert torch.equal(llm0.kv_cache.cpu_k[:, :, :300], llmL.kv_cache.k[:, :, :300].cpu())
     assert torch.equal(llm0.kv_cache.cpu_v[:, :, :300], llmL.kv_cache.v[:, :, :300].cpu())
+
+
+def test_gamma16_two_query_tiles():
+    """cfg4/cfg5 use gamma=16: retrieval verify has 17 query rows and the target verify 17-18, i.e. the two-tile
+    (32-row) instantiation of the attention kernel and the MT=2 skinny GEMM, inside the engine."""
+    from triforce_amd.utils.decoding import TriForce_Dist
+    _pg()
+    g = Hh.load_golden("small_gamma6")
+    L = g["tcfg"]["num_hidden_layers"]
+    llm = _build(g, on_chip=L, gamma=16)
+    prompt = Hh.prompt_of(g).to(DEV)
+    res = TriForce_Dist(Hh.FakeTokenizer(), llm, prompt, gamma=16, max_len=24, top_k=-1, top_p=g["top_p"],
+                        temperature=g["temperature"], return_details=True)
+    gaps = Hh.teacher_forced_gaps(g, res["tokens"])
+    assert max(gaps) < 8e-3, f"gamma=16 stream leaves the oracle's greedy path (gap {max(gaps):.4f})"
+    assert Hh.common_prefix(res["tokens"], g["ar_tokens"]) >= 12
+
+
+def test_tp_graphs_equal_eager():
+    """Captured draft steps + captured retrieval verify (world 1: RCCL calls are no-ops) == the eager engine."""
+    _pg()
+    g = Hh.load_golden("small_gamma6")
+    L = g["tcfg"]["num_hidden_layers"]
+    eager = _run(_build(g, on_chip=L), g)
+    graphed_llm = _build(g, on_chip=L, graphs=True)
+    assert graphed_llm._verify_graph is not None and len(graphed_llm._draft_graphs) == g["gamma"] + 3
+    graphed = _run(graphed_llm, g)
+    assert torch.equal(eager[0], graphed[0]) and torch.equal(eager[2], graphed[2])
+    assert eager[3]["tokens"] == graphed[3]["tokens"] and eager[3]["counts"] == graphed[3]["counts"]

@@ -214,9 +214,47 @@ class DistributedLlama:
 
     # ---------------------------------------------------------------------------------------
     @torch.inference_mode()
+    def initialize_graphs(self, gamma=None, capture_verify=None, verbose=False):
+        """hipGraph capture for the TP engine.  The replicated 68M draft steps (one graph per gamma_offset, like
+        utils/graph_infer.py:143-152; the reference runs them eagerly in the TP path, TP_llama.py:117-132) are
+        always captured — they contain no collective.  The retrieval verify can be captured INCLUDING its RCCL
+        all-reduces (the reference could not, README.md:58); that is on by default only for world_size == 1 and
+        opt-in (TRIFORCE_TP_GRAPHS=1) for more ranks until it has been validated on a multi-GPU node."""
+        from ..utils.graph_infer import _capture
+        gamma = self.gamma if gamma is None else gamma
+        if capture_verify is None:
+            capture_verify = self.world_size == 1 or os.environ.get("TRIFORCE_TP_GRAPHS") == "1"
+        self._mempool = torch.cuda.graphs.graph_pool_handle()
+        self._draft_graphs = {}
+        for off in range(gamma + 3):
+            ids = torch.zeros((1, off + 1), dtype=torch.long, device=self.device)
+            graph, out = _capture(lambda t, off=off: self._draft_run_eager(t, off, True, 0.6, 0.9), (ids,),
+                                  self._mempool, 3)
+            self._draft_graphs[off] = (graph, ids, out)
+        self._verify_graph = None
+        if capture_verify and self.retrieval_cache is not None:
+            ids = torch.zeros((1, gamma + 1), dtype=torch.long, device=self.device)
+            pos = torch.arange(gamma + 1, device=self.device).unsqueeze(0)
+            T, P = self.temperature, self.top_p
+            graph, out = _capture(lambda a, b: norm_logits(self.retrieval_inference(a, b)[0], temperature=T, top_k=-1,
+                                                           top_p=P), (ids, pos), self._mempool, 3)
+            self._verify_graph = (graph, ids, pos, out, T, P)
+        self.reset()
+
+    @torch.inference_mode()
     def draft_run(self, input_ids, gamma_offset: int = 0, probs=True, temperature=0.6, top_p=0.9):
         """Replicated 68M draft (TP_llama.py:117-132).  NB the reference's call sites never pass temperature /
         top_p, so the draft always samples at 0.6 / 0.9 — kept."""
+        g = getattr(self, "_draft_graphs", None)
+        if g and probs and input_ids.shape[-1] <= 64 and gamma_offset in g and (temperature, top_p) == (0.6, 0.9) \
+                and input_ids.shape[-1] == gamma_offset + 1:
+            graph, ids, out = g[gamma_offset]
+            ids.copy_(input_ids)
+            graph.replay()
+            return out.clone()
+        return self._draft_run_eager(input_ids, gamma_offset, probs, temperature, top_p)
+
+    def _draft_run_eager(self, input_ids, gamma_offset, probs, temperature, top_p):
         if input_ids.shape[-1] > 64:
             for i in range(math.ceil(input_ids.shape[1] / 128)):
                 self.draft_cache.evict_prefill(128)
@@ -245,5 +283,12 @@ class DistributedLlama:
 
     @torch.inference_mode()
     def retrieval_verify(self, input_ids, position_ids, temperature=0.6, top_p=0.9):
+        vg = getattr(self, "_verify_graph", None)
+        if vg is not None and (temperature, top_p) == (vg[4], vg[5]):
+            graph, ids, pos, out, _, _ = vg
+            ids.copy_(input_ids)
+            pos.copy_(position_ids)
+            graph.replay()
+            return out.clone()
         logits = self.retrieval_inference(input_ids, position_ids)
         return norm_logits(logits[0], temperature=temperature, top_k=-1, top_p=top_p)
