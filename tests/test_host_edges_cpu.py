@@ -1,0 +1,107 @@
+"""Edge cases of the host logic on CPU (oracle-backed ops): EOS inside the accepted chain, capacity limits the
+reference enforces by crashing, config validation, the uniform stream, synthetic data."""
+import pytest
+import torch
+
+from oracle import ref_model as M
+from tests import helpers as Hh
+
+
+@pytest.mark.parametrize("eos_pick", [3, 6, 9, 14])
+def test_eos_paths_match_oracle(cpu_ops, eos_pick):
+    """Whatever token is declared EOS, product and oracle take the same branch (decoding.py:108-110,120-121)."""
+    from triforce_amd.utils.decoding import TriForce
+    from triforce_amd.utils.sampling import UniformSource
+    g = Hh.load_golden("small_gamma6")
+    us = Hh.fixed_uniforms(seed=7)
+    oeng, tsd, dsd = Hh.build_oracle(g, temperature=0.6, top_p=0.9)
+    prompt = Hh.prompt_of(g)
+    base = M.triforce(oeng, prompt, g["gamma"], 20, 0.6, 0.9, rng=M.InjectedRng(us), eos_token_id=-1)
+    eos = base["tokens"][eos_pick]                      # a token that really occurs in the stream
+    oeng, _, _ = Hh.build_oracle(g, temperature=0.6, top_p=0.9)       # fresh engine: a 2nd prompt carries state over
+    want = M.triforce(oeng, prompt, g["gamma"], 20, 0.6, 0.9, rng=M.InjectedRng(us), eos_token_id=eos)
+    tok = Hh.FakeTokenizer()
+    tok.eos_token_id = eos
+    ge = Hh.build_product(g, "cpu", tsd, dsd, temperature=0.6, top_p=0.9)
+    got = TriForce(tok, ge, prompt, gamma=g["gamma"], max_len=20, top_k=-1, top_p=0.9, temperature=0.6,
+                   rng=UniformSource("cpu", values=us), return_details=True)
+    assert got["tokens"] == want["tokens"] and got["counts"] == want["counts"]
+    assert got["drafted"] == want["drafted"] and got["accepted"] == want["accepted"]
+
+
+def test_retrieval_tail_overflow_raises_like_the_reference(cpu_ops):
+    """gen_len + gamma + 1 > budget makes the reference crash in cache.py:181; here it is an
+    explicit IndexError instead of a shape-mismatch RuntimeError."""
+    from triforce_amd.models.cache import FlashSimpleCache, RetrievalCache
+    from triforce_amd.models.config_yarn import LlamaConfig
+    from triforce_amd.models.modeling_llama import LlamaForCausalLM
+    from oracle import specs
+    cfg = specs.tiny_target_config(vocab_size=128, layers=1, hidden=128, heads=1, max_pos=512)
+    m = LlamaForCausalLM.from_state_dict(LlamaConfig.from_dict(cfg), specs.random_state_dict(cfg, 1), "cpu")
+    kv = FlashSimpleCache(m, 64 + 40)
+    rc = RetrievalCache(m, max_budget=16, prefill=64, gamma=2, chunk_size=8)
+    kv.seq_len = 64 + 17                                 # 17 generated tokens > budget 16
+    with pytest.raises(IndexError):
+        rc.update_graph_cache(kv)
+    kv.seq_len = 64 + 16
+    rc.update_graph_cache(kv)                            # exactly full is fine
+    with pytest.raises(IndexError):
+        kv.seq_len = 64 + 40
+        kv.append_slot(0, 1)                             # full-cache overflow (on_chip.py:78 slack exhausted)
+    with pytest.raises(AssertionError):
+        RetrievalCache(m, max_budget=16, prefill=60, gamma=2, chunk_size=8)     # prefill % chunk != 0 (cache.py:126)
+
+
+def test_config_validation():
+    from triforce_amd.models.config_yarn import LlamaConfig
+    from triforce_amd.models import zoo
+    c = zoo.config("llama-7B-128K")
+    assert (c.hidden_size, c.num_hidden_layers, c.head_dim, c.rope_scaling["factor"]) == (4096, 32, 128, 32.0)
+    assert zoo.config("llama-13B-128K").intermediate_size == 13824 and zoo.config("lwm-128K").rope_theta == 1e7
+    with pytest.raises(ValueError):
+        LlamaConfig(num_attention_heads=8, num_key_value_heads=2)        # GQA unsupported
+    with pytest.raises(ValueError):
+        LlamaConfig(rope_scaling={"type": "linear", "factor": 2.0})
+    with pytest.raises(ValueError):
+        LlamaConfig(rope_scaling={"type": "yarn", "factor": 0.5, "original_max_position_embeddings": 4096})
+    with pytest.raises(NotImplementedError):
+        zoo.config("gpt-17")
+
+
+def test_uniform_source_matches_injected_rng_across_wraparound():
+    from triforce_amd.utils.sampling import UniformSource
+    vals = [i / 97.0 for i in range(97)]
+    src = UniformSource("cpu", values=vals, block=128)
+    ref = M.InjectedRng(vals)
+    for k in [3, 1, 7, 60, 64, 2, 33, 64, 64, 5]:
+        got = src.take(k).tolist()
+        want = [ref._next() for _ in range(k)]
+        assert got == pytest.approx(want)
+        src.advance(k)
+
+
+def test_synthetic_dataset_and_null_tokenizer():
+    from triforce_amd.data.dataset import NullTokenizer, get_dataset, load_tokenizer
+    a = get_dataset("synthetic", datalen=100, vocab_size=500, num_prompts=2, seed=3)
+    b = get_dataset("synthetic", datalen=100, vocab_size=500, num_prompts=2, seed=3)
+    assert len(a) == 2 and a[0].shape == (1, 100) and torch.equal(a[1], b[1]) and int(a[0].min()) >= 3
+    tok = load_tokenizer("none", 500)
+    assert isinstance(tok, NullTokenizer) and tok.decode([1, 2]) == ""
+    with pytest.raises(Exception):
+        get_dataset("no-such-dataset")
+
+
+def test_middle_spec_standalone_signature(cpu_ops):
+    """Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer) is callable exactly like the reference's."""
+    from triforce_amd.utils.decoding import Middle_Spec
+    g = Hh.load_golden("small_gamma6")
+    ge = Hh.build_product(g, "cpu")
+    prompt = Hh.prompt_of(g)
+    ge.engine.kv_cache.reset()
+    ge.inference(prompt[:, :-1])
+    ge.inference(prompt[:, -1:])
+    ge.graph_draft_prefill(prompt)
+    ids, rows, acc = Middle_Spec(torch.tensor([[5]]), ge, g["gamma"], False, Hh.FakeTokenizer())
+    assert ids[0] == 5 and g["gamma"] <= len(ids) - 1 <= g["gamma"] + 1
+    assert rows.shape == (len(ids) - 1, g["tcfg"]["vocab_size"]) and 0.0 <= acc <= 1.0
+    assert torch.allclose(rows.sum(-1), torch.ones(len(ids) - 1), atol=1e-5)
