@@ -114,3 +114,33 @@ def test_tp_graphs_equal_eager():
     graphed = _run(graphed_llm, g)
     assert torch.equal(eager[0], graphed[0]) and torch.equal(eager[2], graphed[2])
     assert eager[3]["tokens"] == graphed[3]["tokens"] and eager[3]["counts"] == graphed[3]["counts"]
+
+
+def test_single_gpu_offloading_cache_equals_resident_cache():
+    """test/offloading.py path: OffloadingFlashSimpleCache (all KV in pinned host memory, streamed per forward)
+    must reproduce the on-chip FlashSimpleCache run bit for bit — same kernels, the data only travels."""
+    from triforce_amd.models.cache import OffloadingFlashSimpleCache
+    from triforce_amd.utils.decoding import Autoregressive, TriForce
+    g = Hh.load_golden("small_gamma6")
+    prompt = Hh.prompt_of(g).to(DEV)
+    tok = Hh.FakeTokenizer()
+    ge_res = Hh.build_product(g, DEV, graphs=True)
+    want = TriForce(tok, ge_res, prompt, gamma=g["gamma"], max_len=24, top_k=-1, top_p=g["top_p"],
+                    temperature=g["temperature"], return_details=True)
+    ge_off = Hh.build_product(g, DEV, graphs=True)
+    off = OffloadingFlashSimpleCache(ge_off.engine.model, g["prefill"] + g["gen_len"] + 32)
+    off.set_tail(g["prefill"], g["gen_len"] + 32)
+    ge_off.engine.kv_cache = off
+    got = TriForce(tok, ge_off, prompt, gamma=g["gamma"], max_len=24, top_k=-1, top_p=g["top_p"],
+                   temperature=g["temperature"], return_details=True)
+    assert got["tokens"] == want["tokens"] and got["counts"] == want["counts"]
+    torch.cuda.synchronize()
+    S = ge_res.engine.kv_cache.seq_len
+    assert off.seq_len == S
+    assert torch.equal(off.cpu_k[:, :, :S], ge_res.engine.kv_cache.k[:, :, :S].cpu())      # host copy == device cache
+    assert torch.equal(off.cpu_v[:, :, :S], ge_res.engine.kv_cache.v[:, :, :S].cpu())
+    _, ar_off = Autoregressive(tok, ge_off, prompt, max_len=12, top_k=-1, top_p=g["top_p"], temperature=g["temperature"],
+                               return_tokens=True)
+    _, ar_res = Autoregressive(tok, ge_res, prompt, max_len=12, top_k=-1, top_p=g["top_p"], temperature=g["temperature"],
+                               return_tokens=True)
+    assert ar_off == ar_res

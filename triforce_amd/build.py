@@ -31,6 +31,16 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def build_variant(name, defines, verbose=True):
+    """Tuning builds (A/B of compile-time knobs): lib/libtriforce_hip_<name>.so, selected with TRIFORCE_HIP_LIB."""
+    out = os.path.join(LIB_DIR, f"libtriforce_hip_{name}.so")
+    cmd = [hipcc_path()] + FLAGS + [f"-D{d}" for d in defines] + sources() + ["-o", out]
+    if verbose:
+        print("[triforce_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return out
+
+
 def build_library(force=False, verbose=True):
     if not force and not needs_build():
         return LIB_PATH

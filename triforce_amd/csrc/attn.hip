@@ -42,8 +42,8 @@ __device__ __forceinline__ void load_kv_tile(const h16* __restrict__ kbase, cons
     const int64_t off = (int64_t)key * stride_t + 8 * g;
 #pragma unroll
     for (int c = 0; c < D / 32; ++c) {
-        kf[c] = load_half8(kbase + off + 32 * c);
-        vf[c] = load_half8(vbase + off + 32 * c);
+        kf[c] = load_half8_stream(kbase + off + 32 * c);
+        vf[c] = load_half8_stream(vbase + off + 32 * c);
     }
 }
 

@@ -33,4 +33,13 @@ __device__ __forceinline__ h16 hmul_rn(h16 a, h16 b) { return (h16)((float)a * (
 __device__ __forceinline__ h16 hadd_rn(h16 a, h16 b) { return (h16)((float)a + (float)b); }
 
 __device__ __forceinline__ half8 load_half8(const h16* p) { return *reinterpret_cast<const half8*>(p); }
+// Streamed-once data (KV pages, weights in a decode forward): non-temporal 16-B load (global_load_dwordx4 ... nt)
+// — shorter issue->landed latency for data no other CU will re-read (MI355X_MICROARCH.md, row nt-weights).
+__device__ __forceinline__ half8 load_half8_stream(const h16* p) {
+#ifdef TF_NO_NT
+    return *reinterpret_cast<const half8*>(p);
+#else
+    return __builtin_nontemporal_load(reinterpret_cast<const half8*>(p));
+#endif
+}
 __device__ __forceinline__ void store_half8(h16* p, half8 v) { *reinterpret_cast<half8*>(p) = v; }

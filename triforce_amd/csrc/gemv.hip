@@ -14,7 +14,18 @@
 //     (act = fp16(silu(fp16 gate)) * fp16 up — the reference's rounding points), saving a kernel and a round trip.
 #include "common.h"
 
-#define SG_WAVES 4
+#ifdef TF_NO_NT
+#define SG_LOAD(p) (*(p))
+#else
+#define SG_LOAD(p) __builtin_nontemporal_load(p)   // weights are read once per forward: non-temporal
+#endif
+
+#ifndef SG_WAVES
+#define SG_WAVES 4          // waves per workgroup = K-splits of one 16-row panel
+#endif
+#ifndef SG_U
+#define SG_U 4              // k-chunks (KiB of weights) in flight per wave
+#endif
 
 template <int MT, bool GATEUP, bool OUT_F32>
 __global__ __launch_bounds__(SG_WAVES * 64) void skinny_gemm_kernel(const half8* __restrict__ wp,
@@ -47,14 +58,14 @@ __global__ __launch_bounds__(SG_WAVES * 64) void skinny_gemm_kernel(const half8*
     }
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    constexpr int U = 4;                               // k-chunks in flight per wave (4 KiB of weights)
+    constexpr int U = SG_U;
     int c = c0;
     for (; c + U <= c1; c += U) {
         half8 a[U], a2[U], b[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            a[u] = wa[(int64_t)(c + u) * 64];
-            if (GATEUP) a2[u] = wu[(int64_t)(c + u) * 64];
+            a[u] = SG_LOAD(wa + (int64_t)(c + u) * 64);
+            if (GATEUP) a2[u] = SG_LOAD(wu + (int64_t)(c + u) * 64);
 #pragma unroll
             for (int t = 0; t < MT; ++t) b[u][t] = xok[t] ? load_half8(xr[t] + 32 * (c + u)) : zero8;
         }
@@ -67,9 +78,9 @@ __global__ __launch_bounds__(SG_WAVES * 64) void skinny_gemm_kernel(const half8*
             }
     }
     for (; c < c1; ++c) {
-        const half8 a = wa[(int64_t)c * 64];
+        const half8 a = SG_LOAD(wa + (int64_t)c * 64);
         half8 a2 = zero8;
-        if (GATEUP) a2 = wu[(int64_t)c * 64];
+        if (GATEUP) a2 = SG_LOAD(wu + (int64_t)c * 64);
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const half8 b = xok[t] ? load_half8(xr[t] + 32 * c) : zero8;
@@ -95,10 +106,14 @@ __global__ __launch_bounds__(SG_WAVES * 64) void skinny_gemm_kernel(const half8*
             if (m >= M) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float s = sm[0][0][t][lane][r] + sm[1][0][t][lane][r] + sm[2][0][t][lane][r] + sm[3][0][t][lane][r];
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < SG_WAVES; ++w) s += sm[w][0][t][lane][r];
                 const int n = panel * 16 + 4 * g + r;
                 if (GATEUP) {
-                    const float s2 = sm[0][1][t][lane][r] + sm[1][1][t][lane][r] + sm[2][1][t][lane][r] + sm[3][1][t][lane][r];
+                    float s2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < SG_WAVES; ++w) s2 += sm[w][GATEUP ? 1 : 0][t][lane][r];
                     const h16 gt = (h16)s, up = (h16)s2;
                     const float gf = (float)gt;
                     const h16 act = (h16)(gf / (1.0f + expf(-gf)));

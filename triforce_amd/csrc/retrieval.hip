@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void retrieval_score_kernel(const h16* __restr
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const h16* kp = kb + (int64_t)c * chunk * stride_t;
         for (int r = 0; r < chunk; ++r) {          // sequential fp32 accumulation over the chunk rows
-            const half8 kv = load_half8(kp + (int64_t)r * stride_t);
+            const half8 kv = load_half8_stream(kp + (int64_t)r * stride_t);
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += (float)kv[e];
         }

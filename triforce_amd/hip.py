@@ -60,16 +60,17 @@ def lib():
     global _lib
     if _lib is None:
         _preload_torch_hip_runtime()
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("TRIFORCE_HIP_LIB", LIB_PATH)        # tuning builds (triforce_amd.build.build_variant)
+        if not os.path.exists(path):
             raise TriforceHipError(
-                f"{LIB_PATH} not found: the HIP extension is required (python -m triforce_amd.build); "
+                f"{path} not found: the HIP extension is required (python -m triforce_amd.build); "
                 "there is no CPU fallback")
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             try:
                 fn = getattr(L, name)
             except AttributeError as e:
-                raise TriforceHipError(f"{LIB_PATH} does not export {name}") from e
+                raise TriforceHipError(f"{path} does not export {name}") from e
             fn.restype, fn.argtypes = res, args
         if L.tf_abi_version() != ABI_VERSION:
             raise TriforceHipError(f"ABI mismatch: library {L.tf_abi_version()} != binding {ABI_VERSION}")

@@ -71,6 +71,10 @@ class FlashSimpleCache(Cache):
     def layer_kv(self, layer_idx):
         return self.k[layer_idx], self.v[layer_idx]
 
+    def tail_source(self, layers, prefill):
+        """(k, v, first_row) holding the generated-token rows [prefill, seq_len) of `layers` on the device."""
+        return self.k[layers], self.v[layers], prefill
+
     def append_slot(self, layer_idx, n):
         """Slot where the fused RoPE+append kernel writes this layer's n new rows; seq_len advances
         after the last layer exactly like update() (cache.py:58-59)."""
@@ -92,6 +96,97 @@ class FlashSimpleCache(Cache):
         if layer_idx == self.layers - 1:
             self.seq_len += n
         return key, value
+
+
+class OffloadingFlashSimpleCache(Cache):
+    """Single-GPU offloading cache (reference cache.py:63-115, entry point test/offloading.py): the whole KV
+    lives in pinned host memory and every target forward streams it layer by layer through two device buffers.
+
+    The reference does this synchronously (`.cpu()` of the new rows, then a full-layer H2D on the compute stream,
+    :98-104).  Here the live tokens of layer i+1 are prefetched on a copy stream (tf_kv_h2d_async) while layer i
+    computes, the new rows go back with tf_kv_d2h_async, and a small device mirror of the generated-token rows
+    serves RetrievalCache.update_graph_cache without touching host memory."""
+
+    def __init__(self, model, max_budget=1024, tail_capacity=None) -> None:
+        self.seq_len = 0
+        self.max_budget = max_budget
+        self.layers, self.num_heads, self.head_dim = _geom(model)
+        self.hidden_size = model.config.hidden_size
+        self.device = model.device
+        L, H, T, D = self.layers, self.num_heads, max_budget, self.head_dim
+        self.cpu_k = _pin(torch.zeros(L, H, T, D, dtype=torch.float16))
+        self.cpu_v = _pin(torch.zeros(L, H, T, D, dtype=torch.float16))
+        self.key_cache, self.value_cache = _ref_view(self.cpu_k), _ref_view(self.cpu_v)
+        self.buf_k = [torch.zeros(H, T, D, dtype=torch.float16, device=self.device) for _ in range(2)]
+        self.buf_v = [torch.zeros(H, T, D, dtype=torch.float16, device=self.device) for _ in range(2)]
+        self.key_cache_buffer, self.value_cache_buffer = self.buf_k[0], self.buf_v[0]
+        self.load_stream = torch.cuda.Stream(device=self.device)
+        self.tail_base = None                       # first token row mirrored in tail_k/v (= prefill length)
+        self.tail_capacity = tail_capacity
+        self.tail_k = self.tail_v = None
+        self._ready = {}
+
+    def print_status(self):
+        print("[Offloading Flash Simple Cache] Cached Size:", self.seq_len, "| Budget:", self.max_budget)
+
+    def reset(self):
+        self.seq_len = 0
+        self.cpu_k.zero_()
+        self.cpu_v.zero_()
+
+    def set_tail(self, base, capacity):
+        """Mirror rows [base, base+capacity) (the generated tokens) on the device as they are produced."""
+        self.tail_base = base
+        if self.tail_k is None or self.tail_k.shape[2] < capacity:
+            self.tail_k, self.tail_v = _alloc(self.layers, self.num_heads, capacity, self.head_dim, self.device)
+
+    def tail_source(self, layers, prefill):
+        assert self.tail_base == prefill, "OffloadingFlashSimpleCache.set_tail(prefill, capacity) must be called first"
+        return self.tail_k[layers], self.tail_v[layers], 0
+
+    # -- streaming protocol driven by the model forward ---------------------------------------
+    def _fetch(self, layer_idx):
+        b = layer_idx % 2
+        ops.kv_h2d_async(self.buf_k[b], self.cpu_k[layer_idx], self.seq_len, self.load_stream)
+        ops.kv_h2d_async(self.buf_v[b], self.cpu_v[layer_idx], self.seq_len, self.load_stream)
+        ev = torch.cuda.Event()
+        ev.record(self.load_stream)
+        self._ready[layer_idx] = ev
+
+    def begin_forward(self):
+        self.load_stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._ready = {}
+        for i in range(min(2, self.layers)):
+            self._fetch(i)
+
+    def layer_kv(self, layer_idx):
+        torch.cuda.current_stream(self.device).wait_event(self._ready[layer_idx])
+        b = layer_idx % 2
+        return self.buf_k[b], self.buf_v[b]
+
+    def append_slot(self, layer_idx, n):
+        if self.seq_len + n > self.max_budget:
+            raise IndexError(f"OffloadingFlashSimpleCache overflow: {self.seq_len}+{n} > {self.max_budget}")
+        return self.seq_len                          # seq_len advances in end_forward (every layer sees the same slot)
+
+    def layer_done(self, layer_idx, slot, n):
+        b = layer_idx % 2
+        if self.tail_base is not None and slot >= self.tail_base:
+            ops.kv_copy_rows(self.buf_k[b].unsqueeze(0), self.tail_k[layer_idx:layer_idx + 1], slot, slot - self.tail_base, n)
+            ops.kv_copy_rows(self.buf_v[b].unsqueeze(0), self.tail_v[layer_idx:layer_idx + 1], slot, slot - self.tail_base, n)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        self.load_stream.wait_event(done)
+        ops.kv_d2h_async(self.cpu_k[layer_idx], self.buf_k[b], slot, n, self.load_stream)
+        ops.kv_d2h_async(self.cpu_v[layer_idx], self.buf_v[b], slot, n, self.load_stream)
+        if layer_idx + 2 < self.layers:
+            self._fetch(layer_idx + 2)
+        self._pending = n
+
+    def end_forward(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.load_stream)
+        self.seq_len += getattr(self, "_pending", 0)
+        self._pending = 0
 
 
 class RetrievalCache(Cache):
@@ -142,8 +237,9 @@ class RetrievalCache(Cache):
         g = kv_cache.seq_len - self.prefill
         if g > self.max_budget:
             raise IndexError(f"generated tail ({g}) exceeds the retrieval budget ({self.max_budget})")
-        ops.kv_copy_rows(kv_cache.k[layers], self.k[layers], self.prefill, self.max_budget - g, g)
-        ops.kv_copy_rows(kv_cache.v[layers], self.v[layers], self.prefill, self.max_budget - g, g)
+        src_k, src_v, t0 = kv_cache.tail_source(layers, self.prefill)
+        ops.kv_copy_rows(src_k, self.k[layers], t0, self.max_budget - g, g)
+        ops.kv_copy_rows(src_v, self.v[layers], t0, self.max_budget - g, g)
 
     def update_graph_cache(self, kv_cache=None):
         self._copy_tail(kv_cache, slice(0, self.layers))

@@ -71,6 +71,9 @@ class LlamaForCausalLM:
         pos = position_ids.reshape(-1).contiguous()
         x = W.embed[input_ids.reshape(-1)]              # (q, hidden) fp16 gather
         build = (not spec) and q_len == 1 and isinstance(graph_cache, RetrievalCache)
+        streaming = (not spec) and hasattr(kv_cache, "begin_forward")     # host-offloaded KV (test/offloading.py)
+        if streaming:
+            kv_cache.begin_forward()
         d = None
         for i in range(W.L):
             if d is None:
@@ -93,10 +96,14 @@ class LlamaForCausalLM:
                     else:
                         graph_cache.update_graph_cache_retrieval(kv_cache, q, i)
                 a = ops.attn_prefill(q, kl, vl, slot + q_len, self.scale)
+                if streaming:
+                    kv_cache.layer_done(i, slot, q_len)
             o = ops.linear(a, W.wo[i])
             h = ops.rmsnorm(o, W.ln2[i], W.eps, residual=x, sum_out=x)       # x += attn_out
             act = ops.mlp_act(h, W.wgu[i])
             d = ops.linear(act, W.wd[i])
+        if streaming:
+            kv_cache.end_forward()
         h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)
         logits = ops.linear(h, W.lm_head, out_f32=True).unsqueeze(0)               # (1, q, V) fp32  (:408-409)
         return CausalLMOutput(logits)
