@@ -61,6 +61,19 @@ int tf_attn_decode(const void* q, const void* k, const void* v, void* out,
                    int nsplit, float* ws, int64_t ws_floats, void* stream);
 
 /* -------------------------------------------------------------------------------------------
+ * Block (prefill-chunk) attention  (flash_attn_with_kvcache with q_len = 128 in the chunked prefill,
+ * utils/graph_infer.py:30-37 -> models/modeling_llama.py:240; models/TP_llama.py:246-250 ->
+ * models/tensor_op.py:168).  Same contract as tf_attn_decode for 1 <= sq <= 128 query rows: the KV
+ * cache is streamed from HBM ONCE per chunk (each of the 4 waves of a workgroup owns 32 query rows and
+ * all waves walk the same key tiles).  ws: at least tf_attn_block_ws_floats(H, D, nsplit) floats.
+ * ------------------------------------------------------------------------------------------- */
+int64_t tf_attn_block_ws_floats(int H, int D, int nsplit);
+int tf_attn_block_pick_nsplit(int H, int sk);
+int tf_attn_block(const void* q, const void* k, const void* v, void* out,
+                  int64_t stride_t, int64_t stride_h, int sq, int sk, int H, int D, float scale,
+                  int nsplit, float* ws, int64_t ws_floats, void* stream);
+
+/* -------------------------------------------------------------------------------------------
  * Draft (Llama-68M) attention with RoPE applied to the cached keys on read
  * (models/modeling_llama_68m.py:151-190): keys are cached UN-rotated and rotated with
  * cache-relative positions 0..kv_len-1 at every call; q arrives already rotated.

@@ -174,14 +174,29 @@ def test_attn_decode_online_softmax_rescale_is_exercised():
         torch.testing.assert_close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
 
 
-def test_attn_prefill_block_equals_oracle():
+@pytest.mark.parametrize("sq,sk,H,D", [(128, 640, 2, 128), (128, 128, 2, 128), (64, 64, 3, 64), (100, 1000, 2, 128),
+                                        (33, 5000, 4, 128), (128, 9000, 4, 64), (300, 700, 2, 128)])
+def test_attn_prefill_block_equals_oracle(sq, sk, H, D):
+    """Chunked-prefill attention (tf_attn_block: <=128 rows per pass; 300 rows = three bottom-right-aligned slabs)."""
     ops = _ops()
-    sq, sk, H, D = 128, 640, 2, 128
     scale = R.softmax_scale_for(D)
-    q, k, v, kd, vd = _attn_inputs(sq, sk, H, D, seed=3)
+    q, k, v, kd, vd = _attn_inputs(sq, sk, H, D, seed=3 + sq)
     want = R.attn_kvcache(q, k, v, scale).reshape(sq, H * D)
     got = ops.attn_prefill(q.to(DEV), kd, vd, sk, scale)
     torch.testing.assert_close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+
+
+def test_attn_block_splits_agree_and_match_decode_kernel():
+    """Same block through 1 / 3 / 16 KV splits and, row slab by row slab, through the <=32-row decode kernel."""
+    ops = _ops()
+    sq, sk, H, D = 96, 3000, 2, 128
+    scale = R.softmax_scale_for(D)
+    q, k, v, kd, vd = _attn_inputs(sq, sk, H, D, seed=77)
+    qd = q.to(DEV)
+    ref = torch.cat([ops.attn_decode(qd[r:r + 32].contiguous(), kd, vd, sk - (sq - r - 32), scale) for r in (0, 32, 64)])
+    for ns in (1, 3, 16):
+        got = ops.attn_block(qd, kd, vd, sk, scale, nsplit=ns)
+        torch.testing.assert_close(got.float(), ref.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
 
 
 def test_attn_decode_full_size_cfg2_layer():
@@ -201,7 +216,8 @@ def test_attn_decode_full_size_cfg2_layer():
     torch.testing.assert_close(got2.float(), got.float() * 2, atol=2 * ATTN_ATOL, rtol=ATTN_RTOL)
 
 
-@pytest.mark.parametrize("sq,kv_len,H", [(1, 5, 2), (3, 64, 12), (9, 259, 12), (64, 200, 12), (7, 130, 3)])
+@pytest.mark.parametrize("sq,kv_len,H", [(1, 5, 2), (3, 64, 12), (9, 259, 12), (64, 200, 12), (7, 130, 3), (64, 314, 12), (128, 378, 12), (17, 384, 4),
+                                          (5, 400, 2)])
 def test_attn_rope_on_read(sq, kv_len, H):
     ops = _ops()
     D = 64
@@ -455,7 +471,11 @@ def test_skinny_gemm_swiglu_matches_oracle(M, I, K):
     #     wave split => identical accumulation), must equal the oracle's silu*up up to expf's last bit
     gate16 = ops.linear(x.to(DEV), ops.PackedLinear(wgu[:I].to(DEV)))
     up16 = ops.linear(x.to(DEV), ops.PackedLinear(wgu[I:].to(DEV)))
-    ulp_report("swiglu epilogue", got, R.silu_mul(gate16.cpu(), up16.cpu()), max_ulp_frac=2e-2, ulps=1)
+    #     (few-panel shapes run the un-fused GEMM with more K-splits per panel than the fused one — SG_WAVES_WIDE,
+    #     csrc/gemv.hip — so their gate/up may differ by an fp16 rounding; the strict check covers the other shapes)
+    same_split = (I // 16) > 512 or (K // 32) < 16
+    if same_split:
+        ulp_report("swiglu epilogue", got, R.silu_mul(gate16.cpu(), up16.cpu()), max_ulp_frac=2e-2, ulps=1)
     # (2) against the pure CPU pipeline: gate/up may each land on the neighbouring fp16 (different fp32 summation
     #     order) and silu amplifies a relative gate error by |1 + g(1-sigmoid(g))| (up to ~4x for g ~ -4), so the
     #     bound is absolute in terms of the inputs' spacing rather than a few ulp of the product

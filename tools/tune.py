@@ -13,6 +13,7 @@ from triforce_amd import ops  # noqa: E402
 
 DEV = "cuda:0"
 tag = sys.argv[1] if len(sys.argv) > 1 else "default"
+only_gemm = len(sys.argv) > 2 and sys.argv[2] == "gemm"
 
 
 def timeit(fns, iters=40):
@@ -51,7 +52,7 @@ us = timeit([(lambda p=p: ops.mlp_act(x, p)) for p in pls])
 res["gate_up_swiglu"] = {"us": round(us, 2), "GBps": round(22016 * 4096 * 2 / us / 1e3, 1)}
 del pls
 g = torch.Generator(device=DEV).manual_seed(0)
-for (sq, sk, H, tagk) in [(8, 124936, 32, "attn_target"), (7, 4103, 32, "attn_retrieval")]:
+for (sq, sk, H, tagk) in ([] if only_gemm else [(8, 124936, 32, "attn_target"), (7, 4103, 32, "attn_retrieval")]):
     kvs = [(torch.randn(H, sk, 128, generator=g, device=DEV, dtype=torch.float16),
             torch.randn(H, sk, 128, generator=g, device=DEV, dtype=torch.float16)) for _ in range(2 if sk > 10000 else 12)]
     q = torch.randn(sq, H, 128, generator=g, device=DEV, dtype=torch.float16)

@@ -50,7 +50,7 @@ __device__ __forceinline__ void load_kv_tile(const h16* __restrict__ kbase, cons
 template <int D, int QT>
 __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf)[D / 32],
                                           const half8 (&vf)[D / 32], half8 sel0, half8 sel1, int tile,
-                                          int sk, int sq, float scale, int li, int g) {
+                                          int sk, int sq, float scale, int li, int g, int qbase = 0) {
     constexpr int NC = D / 32, NT = D / 16;
     // V tile -> key-contiguous fragments through the matrix core (exact: multiplies by 0/1)
     half4 va[NT];
@@ -66,7 +66,7 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
 #pragma unroll
         for (int c = 0; c < NC; ++c) s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[c], st.qf[qt][c], s, 0, 0, 0);
         // lane holds S^T[key = tile*16 + 4g + r][q = qt*16 + li]
-        const int qrow = qt * 16 + li;
+        const int qrow = qbase + qt * 16 + li;
         const int kmax = (qrow < sq) ? (sk - sq + qrow) : (sk - 1);   // bottom-right causal
         float x[4];
         bool ok[4];
@@ -197,6 +197,85 @@ __global__ __launch_bounds__(256) void attn_split_kernel(
     }
 }
 
+// Block (prefill) variant: up to 128 query rows in one pass over the keys.  Wave w owns query rows 32w..32w+31
+// (two MFMA q-tiles) and ALL four waves walk every key tile of the split, so a 128-token prefill chunk streams the
+// KV cache from HBM once (the 4 waves' identical tile loads meet in L1/L2) instead of once per 32-row slab — 4x less
+// HBM traffic for the chunked prefill of graph_infer.py:30-37 / TP_llama.py:246-250.  Each wave's partial
+// (m, l, O) goes straight to the workspace (QR = 128 rows); the same combine kernel folds the splits.
+template <int D>
+__global__ __launch_bounds__(256) void attn_block_kernel(
+    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
+    int64_t stride_h, int sq, int sk, int H, float scale, int nsplit, float* __restrict__ ws) {
+    constexpr int NC = D / 32, NT = D / 16, QT = 2, QR = 128;
+    const int split = blockIdx.x, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int qbase = wave * 32;
+    const int ntiles = (sk + 15) >> 4;
+    const int tps = (ntiles + nsplit - 1) / nsplit;
+    const int t_begin = split * tps;
+    int t_end = min(ntiles, t_begin + tps);
+    // causal: rows of this wave see keys <= sk - sq + qbase + 31
+    const int last_key = sk - sq + min(sq - 1, qbase + 31);
+    t_end = min(t_end, (last_key >> 4) + 1);
+    const bool wave_active = qbase < sq;
+
+    AttnState<D, QT> st;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int row = qbase + qt * 16 + li;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            st.qf[qt][c] = (row < sq) ? load_half8(q + ((int64_t)row * H + h) * D + 32 * c + 8 * g) : z;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) st.acc[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        st.m[qt] = NEG_BIG;
+        st.l[qt] = 0.f;
+    }
+    half8 sel0, sel1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sel0[e] = (8 * g + e == li) ? (h16)1.0f : (h16)0.0f;
+        sel1[e] = (8 * g + e == 16 + li) ? (h16)1.0f : (h16)0.0f;
+    }
+    const h16* kbase = k + (int64_t)h * stride_h;
+    const h16* vbase = v + (int64_t)h * stride_h;
+    if (wave_active) {
+        half8 ka[NC], va_[NC], kb[NC], vb[NC];
+        int t = t_begin;
+        if (t < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t, sk, li, g, ka, va_);
+        while (t < t_end) {
+            const int t1 = t + 1;
+            if (t1 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t1, sk, li, g, kb, vb);
+            attn_tile<D, QT>(st, ka, va_, sel0, sel1, t, sk, sq, scale, li, g, qbase);
+            if (t1 >= t_end) break;
+            const int t2 = t1 + 1;
+            if (t2 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t2, sk, li, g, ka, va_);
+            attn_tile<D, QT>(st, kb, vb, sel0, sel1, t1, sk, sq, scale, li, g, qbase);
+            t = t2;
+        }
+    }
+    float* ws_o = ws;
+    float* ws_m = ws + (int64_t)H * nsplit * QR * D;
+    float* ws_l = ws_m + (int64_t)H * nsplit * QR;
+    const int64_t pbase = ((int64_t)h * nsplit + split) * QR;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float lsum = st.l[qt];
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        const int64_t row = pbase + qbase + qt * 16 + li;      // lane holds O[q = li][d = 16t + 4g + r]
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) *reinterpret_cast<f32x4*>(ws_o + row * D + 16 * tt + 4 * g) = st.acc[qt][tt];
+        if (g == 0) {
+            ws_m[row] = st.m[qt];
+            ws_l[row] = lsum;
+        }
+    }
+}
+
 // Merge of the per-split partials.  grid (H, sq), block (D, CG): thread (d, g) folds the splits s == g (mod CG)
 // with independent loads (the first version walked all splits serially per thread: 29 us at nsplit=32 — a
 // dependent-latency chain, 8% on top of the 331 us split kernel); the CG partial sums meet in LDS.
@@ -315,6 +394,127 @@ __global__ __launch_bounds__(256) void attn_rope_on_read_kernel(
     }
 }
 
+// Fast path of the draft attention (kv_len <= DRAFT_LDS_MAX_KEYS): one workgroup per (head, 16-query block).
+//   phase 1  all 4 waves rotate the head's cached keys ONCE into LDS (fp16, the reference's rounding points)
+//            and stage V transposed (Vt[d][key]) so that both MFMA B operands are 16-byte LDS reads;
+//   phase 2  S = Q K^T on the matrix core (v_mfma_f32_16x16x32_f16, wave w takes key tiles w, w+4, ...);
+//   phase 3  fp32 softmax, wave w owns query rows 4w..4w+3, P rounded to fp16 like flash-attn;
+//   phase 4  O = P V on the matrix core, wave w owns the 16 output columns 16w..16w+15.
+// The first version (kept below as the large-kv fallback) re-rotated every key for every query row and walked
+// the PV sum serially per lane: 68 us per call in the 125K-token draft prefill, 39 us in a decode step.
+#define DRAFT_LDS_MAX_KEYS 384
+#define DRAFT_KPAD 8                       // halfs of row padding: 144-B K rows / (kv+8)-half P,Vt rows
+template <int D>
+__global__ __launch_bounds__(256) void attn_rope_on_read_mfma_kernel(
+    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, const h16* __restrict__ cosb,
+    const h16* __restrict__ sinb, h16* __restrict__ out, int64_t stride_t, int64_t stride_h, int sq, int kv_len,
+    int H, float scale) {
+    static_assert(D == 64, "draft head_dim");
+    constexpr int KS = D + DRAFT_KPAD;                // K row stride (halfs)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int kvp = (kv_len + 31) & ~31;              // keys padded to the MFMA k-step
+    const int PS = kvp + DRAFT_KPAD;                  // P / Vt row stride (halfs)
+    h16* sK = reinterpret_cast<h16*>(smem_raw);       // [kvp][KS]
+    h16* sVt = sK + (size_t)kvp * KS;                 // [D][PS]
+    h16* sP = sVt + (size_t)D * PS;                   // [16][PS]
+    float* sS = reinterpret_cast<float*>(sP + (size_t)16 * PS);   // [16][kvp]
+    float* sL = sS + (size_t)16 * kvp;                // [16]
+
+    const int h = blockIdx.x, q0 = blockIdx.y * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const h16* kb = k + (int64_t)h * stride_h;
+    const h16* vb = v + (int64_t)h * stride_h;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // ---- phase 1: rotate K -> sK, transpose V -> sVt ----
+    for (int e = tid; e < kvp * 4; e += 256) {
+        const int j = e >> 2, i = e & 3;              // key j, 8-wide vector i of the low half (d = 8i..8i+7)
+        half8 lo = zero8, hi = zero8;
+        if (j < kv_len) {
+            const h16* kp = kb + (int64_t)j * stride_t;
+            const half8 x1 = load_half8(kp + 8 * i), x2 = load_half8(kp + 8 * i + 32);
+            const half8 c1 = load_half8(cosb + (int64_t)j * D + 8 * i), c2 = load_half8(cosb + (int64_t)j * D + 8 * i + 32);
+            const half8 s1 = load_half8(sinb + (int64_t)j * D + 8 * i), s2 = load_half8(sinb + (int64_t)j * D + 8 * i + 32);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                // (x*cos) + (rotate_half(x)*sin), every op rounded to fp16 like the reference
+                lo[t] = hadd_rn(hmul_rn(x1[t], c1[t]), hmul_rn((h16)(-(float)x2[t]), s1[t]));
+                hi[t] = hadd_rn(hmul_rn(x2[t], c2[t]), hmul_rn(x1[t], s2[t]));
+            }
+        }
+        store_half8(sK + (size_t)j * KS + 8 * i, lo);
+        store_half8(sK + (size_t)j * KS + 8 * i + 32, hi);
+    }
+    for (int e = tid; e < kvp * 8; e += 256) {
+        const int j = e >> 3, i = e & 7;
+        const half8 x = (j < kv_len) ? load_half8(vb + (int64_t)j * stride_t + 8 * i) : zero8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) sVt[(size_t)(8 * i + t) * PS + j] = x[t];
+    }
+    half8 qf[D / 32];
+    {
+        const int row = q0 + li;
+#pragma unroll
+        for (int c = 0; c < D / 32; ++c)
+            qf[c] = (row < sq) ? load_half8(q + ((int64_t)row * H + h) * D + 32 * c + 8 * g) : zero8;
+    }
+    __syncthreads();
+
+    // ---- phase 2: S[q][key] = scale * Q K^T ----
+    for (int t = wave; t < kvp / 16; t += 4) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < D / 32; ++c) {
+            const half8 bk = load_half8(sK + (size_t)(t * 16 + li) * KS + 32 * c + 8 * g);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[c], bk, s, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sS[(size_t)(4 * g + r) * kvp + t * 16 + li] = s[r] * scale;   // C: row 4g+r, col li
+    }
+    __syncthreads();
+
+    // ---- phase 3: softmax, wave owns rows 4w..4w+3 ----
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = wave * 4 + rr, qrow = q0 + row;
+        const int kmax = (qrow < sq) ? (kv_len - sq + qrow) : -1;       // bottom-right causal
+        float mloc = NEG_BIG;
+        for (int j = lane; j <= kmax; j += 64) mloc = fmaxf(mloc, sS[(size_t)row * kvp + j]);
+        const float mx = wave_max(mloc);
+        float lsum = 0.f;
+        for (int j = lane; j < kvp; j += 64) {
+            float p = 0.f;
+            if (j <= kmax) {
+                p = __expf(sS[(size_t)row * kvp + j] - mx);
+                lsum += p;
+            }
+            sP[(size_t)row * PS + j] = (h16)p;
+        }
+        lsum = wave_sum(lsum);
+        if (lane == 0) sL[row] = lsum;
+    }
+    __syncthreads();
+
+    // ---- phase 4: O[:, 16w..16w+15] = P V ----
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < kvp / 32; ++c) {
+        const half8 ap = load_half8(sP + (size_t)li * PS + 32 * c + 8 * g);
+        const half8 bv = load_half8(sVt + (size_t)(16 * wave + li) * PS + 32 * c + 8 * g);
+        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ap, bv, o, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r, qrow = q0 + row;
+        if (qrow < sq) out[((int64_t)qrow * H + h) * D + 16 * wave + li] = (h16)(o[r] / sL[row]);
+    }
+}
+
+static size_t draft_mfma_lds_bytes(int kv_len) {
+    const size_t kvp = (size_t)((kv_len + 31) & ~31), PS = kvp + DRAFT_KPAD;
+    return kvp * (64 + DRAFT_KPAD) * 2 + 64 * PS * 2 + 16 * PS * 2 + 16 * kvp * 4 + 16 * 4;
+}
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
@@ -363,11 +563,69 @@ extern "C" int tf_attn_decode(const void* q, const void* k, const void* v, void*
     return TF_EINVAL;
 }
 
+extern "C" int64_t tf_attn_block_ws_floats(int H, int D, int nsplit) { return (int64_t)H * nsplit * 128 * (D + 2); }
+
+extern "C" int tf_attn_block_pick_nsplit(int H, int sk) {
+    const int tiles = (sk + 15) / 16;
+    int by_work = tiles / 16;                        // >= 16 key tiles per workgroup
+    int by_grid = 1024 / (H > 0 ? H : 1);
+    int n = by_work < by_grid ? by_work : by_grid;
+    if (n < 1) n = 1;
+    if (n > COMBINE_MAX_SPLITS) n = COMBINE_MAX_SPLITS;
+    return n;
+}
+
+// Causal attention of a block of 33..128 query rows against the cache (bottom-right aligned), D = 128 or 64.
+extern "C" int tf_attn_block(const void* q, const void* k, const void* v, void* out, int64_t stride_t,
+                             int64_t stride_h, int sq, int sk, int H, int D, float scale, int nsplit, float* ws,
+                             int64_t ws_floats, void* stream) {
+    if (!q || !k || !v || !out || !ws) return TF_EINVAL;
+    if (sq < 1 || sq > 128 || sk < sq || H < 1 || nsplit < 1 || nsplit > COMBINE_MAX_SPLITS) return TF_EINVAL;
+    if ((stride_t % 8) || (stride_h % 8)) return TF_EINVAL;
+    if (ws_floats < tf_attn_block_ws_floats(H, D, nsplit)) return TF_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(nsplit, H), block(256);
+    if (D == 128)
+        hipLaunchKernelGGL((attn_block_kernel<128>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
+                           stride_t, stride_h, sq, sk, H, scale, nsplit, ws);
+    else if (D == 64)
+        hipLaunchKernelGGL((attn_block_kernel<64>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
+                           stride_t, stride_h, sq, sk, H, scale, nsplit, ws);
+    else
+        return TF_EINVAL;
+    TF_LAUNCH_CHECK();
+    if (D == 128)
+        hipLaunchKernelGGL((attn_combine_kernel<128>), dim3(H, sq), dim3(128, COMBINE_GROUPS), 0, st, (const float*)ws,
+                           (h16*)out, sq, H, nsplit, 128);
+    else
+        hipLaunchKernelGGL((attn_combine_kernel<64>), dim3(H, sq), dim3(64, COMBINE_GROUPS), 0, st, (const float*)ws,
+                           (h16*)out, sq, H, nsplit, 128);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}
+
 extern "C" int tf_attn_rope_on_read(const void* q, const void* k, const void* v, const void* cosb, const void* sinb,
                                     void* out, int64_t stride_t, int64_t stride_h, int sq, int kv_len, int H, int D,
                                     float scale, void* stream) {
     if (!q || !k || !v || !cosb || !sinb || !out) return TF_EINVAL;
     if (D != 64 || sq < 1 || kv_len < sq || H < 1) return TF_EINVAL;
+    if (kv_len <= DRAFT_LDS_MAX_KEYS) {
+        static bool attr_set = false;                     // > 64 KiB of dynamic LDS needs the opt-in once
+        const size_t lds = draft_mfma_lds_bytes(kv_len);
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn_rope_on_read_mfma_kernel<64>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)draft_mfma_lds_bytes(DRAFT_LDS_MAX_KEYS));
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        dim3 grid(H, (sq + 15) / 16), block(256);
+        hipLaunchKernelGGL((attn_rope_on_read_mfma_kernel<64>), grid, block, lds, (hipStream_t)stream, (const h16*)q,
+                           (const h16*)k, (const h16*)v, (const h16*)cosb, (const h16*)sinb, (h16*)out, stride_t,
+                           stride_h, sq, kv_len, H, scale);
+        TF_LAUNCH_CHECK();
+        return TF_OK;
+    }
     const size_t lds = (size_t)4 * kv_len * sizeof(float);
     if (lds > 64 * 1024) return TF_ERANGE;
     dim3 grid(H, (sq + 3) / 4), block(256);

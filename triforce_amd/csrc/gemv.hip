@@ -20,15 +20,25 @@
 #define SG_LOAD(p) __builtin_nontemporal_load(p)   // weights are read once per forward: non-temporal
 #endif
 
+// Waves per workgroup = K-splits of one 16-row panel.  A wave keeps SG_U KiB of weights in flight, so a grid of
+// few panels (o_proj / down_proj: N = 4096 -> 256 workgroups, one per CU) needs more waves per panel to cover the
+// HBM latency-bandwidth product (cold-cache graph replay, tools/tune.py): o_proj 9.0 -> 7.6 us, down_proj 20.8 ->
+// 18.3 us with 8 waves per panel; 16 waves measured the same as 8.
 #ifndef SG_WAVES
-#define SG_WAVES 4          // waves per workgroup = K-splits of one 16-row panel
+#define SG_WAVES 4
+#endif
+#ifndef SG_WAVES_WIDE
+#define SG_WAVES_WIDE 8
+#endif
+#ifndef SG_WIDE_MAX_PANELS
+#define SG_WIDE_MAX_PANELS 512   // <= 2 workgroups per CU -> use the wide (more K-splits) variant
 #endif
 #ifndef SG_U
 #define SG_U 4              // k-chunks (KiB of weights) in flight per wave
 #endif
 
-template <int MT, bool GATEUP, bool OUT_F32>
-__global__ __launch_bounds__(SG_WAVES * 64) void skinny_gemm_kernel(const half8* __restrict__ wp,
+template <int MT, bool GATEUP, bool OUT_F32, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __restrict__ wp,
                                                                     const half8* __restrict__ wp_up,
                                                                     const h16* __restrict__ x, int64_t ldx,
                                                                     void* __restrict__ yv, int64_t ldy, int M, int N,
@@ -37,7 +47,7 @@ __global__ __launch_bounds__(SG_WAVES * 64) void skinny_gemm_kernel(const half8*
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     const int nchunks = K >> 5;
-    const int cpw = (nchunks + SG_WAVES - 1) / SG_WAVES;
+    const int cpw = (nchunks + WAVES - 1) / WAVES;
     const int c0 = wave * cpw, c1 = min(nchunks, c0 + cpw);
 
     f32x4 acc[MT], acc2[MT];
@@ -90,7 +100,7 @@ __global__ __launch_bounds__(SG_WAVES * 64) void skinny_gemm_kernel(const half8*
     }
 
     // split-K merge across the 4 waves; C layout: lane holds D[n = 4g + r][m = li]
-    __shared__ float sm[SG_WAVES][GATEUP ? 2 : 1][MT][64][4];
+    __shared__ float sm[WAVES][GATEUP ? 2 : 1][MT][64][4];
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -108,12 +118,12 @@ __global__ __launch_bounds__(SG_WAVES * 64) void skinny_gemm_kernel(const half8*
             for (int r = 0; r < 4; ++r) {
                 float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < SG_WAVES; ++w) s += sm[w][0][t][lane][r];
+                for (int w = 0; w < WAVES; ++w) s += sm[w][0][t][lane][r];
                 const int n = panel * 16 + 4 * g + r;
                 if (GATEUP) {
                     float s2 = 0.f;
 #pragma unroll
-                    for (int w = 0; w < SG_WAVES; ++w) s2 += sm[w][GATEUP ? 1 : 0][t][lane][r];
+                    for (int w = 0; w < WAVES; ++w) s2 += sm[w][GATEUP ? 1 : 0][t][lane][r];
                     const h16 gt = (h16)s, up = (h16)s2;
                     const float gf = (float)gt;
                     const h16 act = (h16)(gf / (1.0f + expf(-gf)));
@@ -128,16 +138,25 @@ __global__ __launch_bounds__(SG_WAVES * 64) void skinny_gemm_kernel(const half8*
     }
 }
 
+template <int MT, bool GATEUP, bool OUT_F32, int WAVES>
+static void launch_sg_w(const void* wp, const void* wp_up, const void* x, int64_t ldx, void* y, int64_t ldy, int M,
+                        int N, int K, hipStream_t st) {
+    hipLaunchKernelGGL((skinny_gemm_kernel<MT, GATEUP, OUT_F32, WAVES>), dim3(N / 16), dim3(WAVES * 64), 0, st,
+                       (const half8*)wp, (const half8*)wp_up, (const h16*)x, ldx, y, ldy, M, N, K);
+}
+
 template <bool GATEUP, bool OUT_F32>
 static int launch_sg(const void* wp, const void* wp_up, const void* x, int64_t ldx, void* y, int64_t ldy, int M, int N,
                      int K, hipStream_t st) {
-    dim3 grid(N / 16), block(SG_WAVES * 64);
-    if (M <= 16)
-        hipLaunchKernelGGL((skinny_gemm_kernel<1, GATEUP, OUT_F32>), grid, block, 0, st, (const half8*)wp,
-                           (const half8*)wp_up, (const h16*)x, ldx, y, ldy, M, N, K);
-    else
-        hipLaunchKernelGGL((skinny_gemm_kernel<2, GATEUP, OUT_F32>), grid, block, 0, st, (const half8*)wp,
-                           (const half8*)wp_up, (const h16*)x, ldx, y, ldy, M, N, K);
+    // wide variant: few panels and enough k-chunks that every wave still gets >= 2 of them
+    const bool wide = !GATEUP && (N / 16) <= SG_WIDE_MAX_PANELS && (K >> 5) >= 2 * SG_WAVES_WIDE;
+    if (M <= 16) {
+        if (wide) launch_sg_w<1, GATEUP, OUT_F32, GATEUP ? SG_WAVES : SG_WAVES_WIDE>(wp, wp_up, x, ldx, y, ldy, M, N, K, st);
+        else launch_sg_w<1, GATEUP, OUT_F32, SG_WAVES>(wp, wp_up, x, ldx, y, ldy, M, N, K, st);
+    } else {
+        if (wide) launch_sg_w<2, GATEUP, OUT_F32, GATEUP ? SG_WAVES : SG_WAVES_WIDE>(wp, wp_up, x, ldx, y, ldy, M, N, K, st);
+        else launch_sg_w<2, GATEUP, OUT_F32, SG_WAVES>(wp, wp_up, x, ldx, y, ldy, M, N, K, st);
+    }
     TF_LAUNCH_CHECK();
     return TF_OK;
 }

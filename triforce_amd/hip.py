@@ -17,6 +17,9 @@ SIGNATURES = {
     "tf_attn_decode_ws_floats": (_i64, [_i32, _i32, _i32, _i32]),
     "tf_attn_decode_pick_nsplit": (_i32, [_i32, _i32]),
     "tf_attn_decode": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _i32, _f32, _i32, _vp, _i64, _vp]),
+    "tf_attn_block_ws_floats": (_i64, [_i32, _i32, _i32]),
+    "tf_attn_block_pick_nsplit": (_i32, [_i32, _i32]),
+    "tf_attn_block": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _i64, _vp]),
     "tf_attn_rope_on_read": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp]),
     "tf_retrieval_score": (_i32, [_vp, _i64, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "tf_retrieval_topk": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),

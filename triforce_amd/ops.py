@@ -166,16 +166,36 @@ def attn_decode(q, k_layer, v_layer, sk, scale, sk_dev=None, nsplit=None):
     return out
 
 
+def attn_block(q, k_layer, v_layer, sk, scale, nsplit=None):
+    """Causal attention of a block of <=128 query rows (a prefill chunk): one pass over the keys."""
+    _dev(q, k_layer, v_layer)
+    sq, H, D = q.shape
+    assert q.dtype == _HALF and q.is_contiguous() and sq <= 128
+    st, sh = _kv(k_layer)
+    assert _kv(v_layer) == (st, sh)
+    L = hip.lib()
+    if nsplit is None:
+        nsplit = L.tf_attn_block_pick_nsplit(H, int(sk))
+    ws = _workspace(q.device, L.tf_attn_block_ws_floats(H, D, nsplit))
+    out = torch.empty(sq, H * D, dtype=_HALF, device=q.device)
+    hip.check(L.tf_attn_block(_ptr(q), _ptr(k_layer), _ptr(v_layer), _ptr(out), st, sh, sq, int(sk), H, D, float(scale),
+                              nsplit, _ptr(ws), ws.numel(), _stream()), "tf_attn_block")
+    return out
+
+
 def attn_prefill(q, k_layer, v_layer, sk, scale):
-    """Causal attention for a prefill block of any length: the block is cut into <=32-row slabs, slab j
-    seeing keys [0, sk - sq + end_j) — each slab is one bottom-right-aligned tf_attn_decode call."""
+    """Causal attention for a prefill block of any length: <=32 rows use the decode kernel, longer blocks are cut
+    into <=128-row slabs, slab j seeing keys [0, sk - sq + end_j) — each slab is one bottom-right-aligned
+    tf_attn_block call (one pass over the KV cache per 128 rows)."""
     sq = q.shape[0]
     if sq <= 32:
         return attn_decode(q, k_layer, v_layer, sk, scale)
+    if sq <= 128:
+        return attn_block(q, k_layer, v_layer, sk, scale)
     outs = []
-    for r0 in range(0, sq, 32):
-        r1 = min(sq, r0 + 32)
-        outs.append(attn_decode(q[r0:r1].contiguous(), k_layer, v_layer, sk - (sq - r1), scale))
+    for r0 in range(0, sq, 128):
+        r1 = min(sq, r0 + 128)
+        outs.append(attn_block(q[r0:r1].contiguous(), k_layer, v_layer, sk - (sq - r1), scale))
     return torch.cat(outs, dim=0)
 
 
