@@ -61,17 +61,24 @@ int tf_attn_decode(const void* q, const void* k, const void* v, void* out,
                    int nsplit, float* ws, int64_t ws_floats, void* stream);
 
 /* -------------------------------------------------------------------------------------------
- * Block (prefill-chunk) attention  (flash_attn_with_kvcache with q_len = 128 in the chunked prefill,
- * utils/graph_infer.py:30-37 -> models/modeling_llama.py:240; models/TP_llama.py:246-250 ->
- * models/tensor_op.py:168).  Same contract as tf_attn_decode for 1 <= sq <= 128 query rows: the KV
- * cache is streamed from HBM ONCE per chunk (each of the 4 waves of a workgroup owns 32 query rows and
- * all waves walk the same key tiles).  ws: at least tf_attn_block_ws_floats(H, D, nsplit) floats.
+ * Block attention: 1 <= sq <= 128 query rows in ONE pass over the keys.
+ *   mask == NULL  bottom-right causal — flash_attn_with_kvcache with q_len = 128 in the chunked prefill
+ *                 (utils/graph_infer.py:30-37 -> models/modeling_llama.py:240; models/TP_llama.py:246-250 ->
+ *                 models/tensor_op.py:168).
+ *   mask != NULL  tree attention — F.scaled_dot_product_attention with the dense additive [prefix | tree] mask
+ *                 of the Sequoia path (models/tensor_op.py:171,265; masks built at utils/SpecTree_TP.py:65-67,
+ *                 83-87,170): keys [0, tree_start) are visible to every row, key tree_start + j is visible to
+ *                 query row i iff bit (j % 32) of mask[(mask_row0 + i) * mask_words + j / 32] is set; keys
+ *                 [tree_start, sk) must fit 32 * mask_words bits.
+ * Each workgroup's waves own 32 query rows apiece and walk the same key tiles, so the KV cache is streamed
+ * from HBM once per call.  ws: at least tf_attn_block_ws_floats(H, D, nsplit) floats.
  * ------------------------------------------------------------------------------------------- */
 int64_t tf_attn_block_ws_floats(int H, int D, int nsplit);
-int tf_attn_block_pick_nsplit(int H, int sk);
+int tf_attn_block_pick_nsplit(int H, int sq, int sk);
 int tf_attn_block(const void* q, const void* k, const void* v, void* out,
                   int64_t stride_t, int64_t stride_h, int sq, int sk, int H, int D, float scale,
-                  int nsplit, float* ws, int64_t ws_floats, void* stream);
+                  int nsplit, float* ws, int64_t ws_floats,
+                  const uint32_t* mask, int mask_words, int mask_row0, int tree_start, void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Draft (Llama-68M) attention with RoPE applied to the cached keys on read
@@ -116,6 +123,12 @@ int tf_kv_copy_rows(const void* src, int64_t src_stride_l, int64_t src_stride_t,
                     int src_t0, int dst_t0, int n, int L, int H, int D, void* stream);
 int tf_kv_shift_rows(void* cache, int64_t stride_l, int64_t stride_t, int64_t stride_h,
                      int src_t0, int dst_t0, int n, int L, int H, int D, void* stream);
+
+/* tf_kv_gather_rows: rows offset+idx[j] -> offset+j (j < n) of K and V for L layers x H heads — the compaction of
+ *                   the accepted tree nodes, DistributedSimpleCache.gather_kv_incremental (cache.py:333-343).
+ *                   idx (device int32) must be strictly increasing (a root-to-leaf path of the tree). */
+int tf_kv_gather_rows(void* k_cache, void* v_cache, int64_t stride_l, int64_t stride_t, int64_t stride_h,
+                      int offset, const int32_t* idx, int n, int L, int H, int D, void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Dense-block glue (models/modeling_llama.py:132-159,221-238; models/tensor_op.py:25-64).
@@ -175,6 +188,21 @@ int tf_accept_chain(const float* p, const float* q, const int64_t* tokens, const
                     int g2, int V, int inclusive, int64_t eos_token_id, int64_t* out, void* stream);
 int tf_middle_accept(const float* p, const float* q_d, int64_t* tokens, const float* uniforms,
                      int n, int gamma, int V, int64_t* out, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Sequoia tree verification (utils/SpecTree_TP.py:147-199: accept_step + the walk in verify()).
+ *   p_rows        [N][V] fp32 target probabilities of every tree node (top-p filtered softmax)
+ *   draft_logits  [N][V] fp32 draft logits of every node (q = softmax(draft_logits / temperature), with the
+ *                 rejected sibling tokens removed, as :159-166)
+ *   tokens        [N] int64 token of every node;  succ_off [N+1], succ: CSR of grow_map["Successors"]
+ *   uniforms      fp32 stream: one per examined child, then one for the residual sample
+ *   out int64 [4 + 60]: out[0] = len(accept_list) incl. the root, out[1] = next token, out[2] = terminal
+ *                 (accepted token 0 / 2, or a NaN residual), out[3] = uniforms consumed, out[4+j] = accept_list[j]
+ * One single-workgroup launch replaces the reference's host loop (one device sync per examined child).  V <= 32768.
+ * ------------------------------------------------------------------------------------------- */
+int tf_tree_accept(const float* p_rows, const float* draft_logits, const int64_t* tokens,
+                   const int32_t* succ_off, const int32_t* succ, const float* uniforms, int V,
+                   float temperature, int64_t* out, void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Offloading tier (models/cache.py:345-351 copy_back_from_buffer, :372-376 copy_kv, :573-575):

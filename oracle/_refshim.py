@@ -129,3 +129,80 @@ class FakeTokenizer:
 
     def decode(self, ids, **kw):
         return ""
+
+
+# ----------------------------------------------------------------------------------------------
+# Sequoia tree path: models/TP_llama_tree.py + utils/SpecTree_TP.py on a CPU-only box
+# ----------------------------------------------------------------------------------------------
+class _CudaProxy:
+    """Stands in for ``torch.cuda`` inside the reference's TP modules: streams / synchronize become no-ops."""
+
+    class Stream:
+        def __init__(self, *a, **k):
+            pass
+
+    @staticmethod
+    def stream(_s):
+        import contextlib
+        return contextlib.nullcontext()
+
+    @staticmethod
+    def synchronize(*a, **k):
+        return None
+
+    @staticmethod
+    def set_device(*a, **k):
+        return None
+
+    def __getattr__(self, name):
+        return getattr(torch.cuda, name)
+
+
+class _TorchProxy:
+    """Module-level ``torch`` replacement for ONE reference module: ``torch.device("cuda", r)`` -> cpu,
+    ``torch.cuda`` -> _CudaProxy, ``pin_memory=True`` dropped from factory calls; everything else forwards."""
+
+    def __init__(self):
+        self.cuda = _CudaProxy()
+
+    def device(self, *a, **k):
+        return torch.device("cpu")
+
+    def zeros(self, *a, **k):
+        k.pop("pin_memory", None)
+        if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+            k["device"] = "cpu"
+        return torch.zeros(*a, **k)
+
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+
+def load_reference_tree():
+    """Reference modules of the Sequoia path, importable on CPU: a 1-rank gloo group (the reference calls
+    dist.all_reduce / broadcast / barrier unconditionally), Tensor.pin_memory -> identity, and a torch proxy in
+    the globals of models.cache / models.TP_layers / models.TP_llama_tree.  No reference source is edited."""
+    ref = load_reference()
+    if "tree" in _loaded:
+        return types.SimpleNamespace(**_loaded)
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        import os
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(port))
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    torch.Tensor.pin_memory = lambda self, *a, **k: self
+    proxy = _TorchProxy()
+    ref.cache.torch = proxy
+    tp_layers = importlib.import_module("models.TP_layers")
+    tp_layers.torch = proxy
+    tree = importlib.import_module("models.TP_llama_tree")
+    tree.torch = proxy
+    spectree = importlib.import_module("utils.SpecTree_TP")
+    _loaded.update(tree=tree, spectree=spectree, tp_layers=tp_layers)
+    return types.SimpleNamespace(**_loaded)

@@ -237,6 +237,96 @@ def rope_case(name="rope_tables"):
     print(f"[{name}] ok (mscale {y.mscale:.5f})")
 
 
+def sequoia_case(name, tcfg, tseed, pseed, prefill, budget, chunk, gen_len, temperature, top_p, rng_seed,
+                 branches=None, head_std=0.05):
+    """Sequoia tree path: the UNMODIFIED reference SpecTree + TP_llama_tree.DistributedLlama + tensor_op run on
+    CPU (1-rank gloo, torch proxies for the CUDA-only calls) vs the restatement in oracle/ref_tree.py."""
+    import tempfile
+    from oracle import ref_tree as RT
+    ref = _refshim.load_reference_tree()
+    tsd = specs.random_state_dict(tcfg, tseed, head_std=head_std)
+    prompt = specs.random_prompt(tcfg["vocab_size"], prefill, pseed)[0]
+    V = tcfg["vocab_size"]
+    if branches is None:
+        grow_map = torch.load(os.path.join(_refshim.REFERENCE_ROOT, "tree", "512.pt"))
+        branches = grow_map["branches"]
+        rebuilt = RT.grow_map_from_branches(branches)
+        for k in ("roots", "branches", "Successors", "size"):
+            assert rebuilt[k] == grow_map[k], f"grow_map_from_branches: {k} differs from tree/512.pt"
+        assert torch.equal(rebuilt["mask"], grow_map["mask"]) and torch.equal(rebuilt["depth"], grow_map["depth"])
+    else:
+        grow_map = RT.grow_map_from_branches(branches)
+    tree_size = grow_map["size"]
+    L = tcfg["num_hidden_layers"]
+
+    # ---------------- reference ----------------
+    hf = build_reference_model(ref, tcfg, tsd)
+    tmp = tempfile.mkdtemp()
+    hf.config.save_pretrained(tmp)
+    llm = ref.tree.DistributedLlama(model_name_or_path=tmp, local_rank=0, world_size=1, prefill=prefill, gen_len=gen_len,
+                                    temperature=temperature, top_p=top_p, flash_attn=True, retrieval_budget=budget,
+                                    retrieval_chunk_size=chunk, kv_offload=True, on_chip_layers=L - 1,
+                                    tree_size=tree_size)
+    llm.init_parameters(hf_model=hf)
+
+    def get_residual(p, q):                               # test/offloading_seqouia.py:24-27
+        r = (p - q).relu_()
+        return r / (r.sum(dim=-1).unsqueeze(-1))
+
+    def make_sampler(k):                                  # test/offloading_seqouia.py:29-39 (rank-0 branch)
+        return lambda lg, rnd: (rnd.log() / torch.softmax(lg / temperature, dim=-1)).topk(k=k).indices.flatten()
+
+    draft_step = len(grow_map["roots"])
+    samplers = {i: make_sampler(max(grow_map["branches"][i])) for i in range(draft_step - 1)}
+    gathers = {}
+    for i in range(draft_step - 1):                       # :124-134
+        mx = max(grow_map["branches"][i])
+        gathers[i] = torch.cat([torch.arange(b) + j * mx for j, b in enumerate(grow_map["branches"][i])])
+    torch.manual_seed(rng_seed)
+    t0 = time.time()
+    st = ref.spectree.SpecTree(engine=llm, temperature=temperature, top_p=top_p, max_length=prefill + gen_len,
+                               grow_map=grow_map, residual_graph=get_residual, sampling_callables=samplers,
+                               sample_gather_indices=gathers, tokenizer=_refshim.FakeTokenizer(), vocab_size=V)
+    steps = []
+    with torch.inference_mode():
+        next_token = st.prefill(prefix=prompt)
+        first = int(next_token)
+        generated, n = [first], 0
+        rand_table = st.rand.clone()
+        while n < gen_len:                                # test/offloading_seqouia.py:155-185
+            st.construct_grow_map(next_token=next_token)
+            tree_tokens = st.verify_tokens.clone()
+            draft0 = st.draft_logits[:8].clone()
+            next_token, acc, toks = st.verify()
+            if next_token is None:
+                steps.append(dict(tree_tokens=tree_tokens, acc_count=acc, terminal=True))
+                break
+            generated.extend(toks[1:].tolist())
+            steps.append(dict(tree_tokens=tree_tokens, acc_count=acc, accept_tokens=toks.tolist(), terminal=False,
+                              draft_logits_head=draft0, seq_len=llm.kv_cache.seq_len))
+            next_token = next_token.unsqueeze(0)
+            n += acc
+    t_ref = time.time() - t0
+
+    # ---------------- oracle restatement ----------------
+    eng = RT.TreeEngine(tcfg, tsd, prefill, gen_len, budget, chunk, tree_size)
+    torch.manual_seed(rng_seed)
+    so = RT.SpecTreeO(eng, grow_map, temperature, top_p, V, M.TorchRng(), rand=None)
+    o_gen, o_counts = RT.run_sequoia(so, prompt, gen_len)
+    assert o_gen == generated, f"[{name}] Sequoia stream mismatch\n{o_gen}\n{generated}"
+    assert o_counts == [s["acc_count"] for s in steps if not s["terminal"]], f"[{name}] accept counts differ"
+    for tr, s in zip(so.trace, steps):
+        assert torch.equal(tr["tokens"], s["tree_tokens"]), f"[{name}] tree tokens differ"
+    assert eng.kv_cache.seq_len == llm.kv_cache.seq_len
+    torch.save(dict(name=name, tcfg=tcfg, tseed=tseed, pseed=pseed, head_std=head_std, prefill=prefill, budget=budget,
+                    chunk=chunk, gen_len=gen_len, temperature=temperature, top_p=top_p, rng_seed=rng_seed,
+                    branches=grow_map["branches"], tree_size=tree_size, mask_rowsum=grow_map["mask"].sum(dim=1),
+                    depth=grow_map["depth"], generated=generated, steps=steps, rand_table_digest=rand_table.float().sum(dim=1),
+                    final_seq_len=llm.kv_cache.seq_len), os.path.join(GOLDEN, f"{name}.pt"))
+    print(f"[{name}] ok: reference {t_ref:.1f}s, {len(generated)} tokens in {len(steps)} steps, "
+          f"accepts {[s['acc_count'] for s in steps]}")
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
@@ -258,5 +348,27 @@ def main():
                   temperature=1.0, top_p=1e-9, repeats=1)
 
 
+def main_sequoia():
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.set_num_threads(8)
+    small = specs.llama_config(256, 512, 2, 2, vocab_size=1024, max_position_embeddings=4096,
+                               rope_scaling=dict(type="yarn", factor=8.0, original_max_position_embeddings=512),
+                               name="tiny-d128-tree")
+    # the reference's own 512-node tree (tree/512.pt) on a tiny D=128 target
+    sequoia_case("sequoia_tree512", small, 301, 302, prefill=1024, budget=128, chunk=8, gen_len=24,
+                 temperature=0.6, top_p=0.9, rng_seed=5)
+    # a small hand-made tree (ragged fan-out, a leaf on level 1) and D=64 heads
+    d64 = specs.llama_config(256, 512, 3, 4, vocab_size=1024, max_position_embeddings=4096,
+                             rope_scaling=dict(type="yarn", factor=8.0, original_max_position_embeddings=512),
+                             name="tiny-d64-tree")
+    sequoia_case("sequoia_small", d64, 311, 312, prefill=600 - 600 % 8, budget=64, chunk=8, gen_len=20,
+                 temperature=0.8, top_p=0.95, rng_seed=9,
+                 branches=[[4], [3, 2, 0, 1], [2, 1, 1, 1, 0, 1], [1, 1, 0, 1, 0, 0], [1, 0, 0]])
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "sequoia":
+        main_sequoia()
+    else:
+        main()
+        main_sequoia()

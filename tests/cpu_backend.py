@@ -6,7 +6,7 @@ from oracle import ref_ops as R
 
 PATCHED = ["rmsnorm", "rope_append", "silu_mul", "attn_decode", "attn_prefill", "attn_rope_on_read", "retrieval_score",
            "retrieval_topk", "retrieval_gather", "kv_copy_rows", "kv_shift_rows", "sample_inverse_cdf",
-           "accept_chain", "middle_accept"]
+           "accept_chain", "middle_accept", "attn_block", "attn_tree", "kv_gather_rows", "tree_accept"]
 
 
 def rmsnorm(x, w, eps, residual=None, sum_out=None):
@@ -94,3 +94,46 @@ def middle_accept(p, q_d, tokens, uniforms, n, gamma, out):
     out[:3] = torch.tensor([acc, b, d])
     if n + 1 + acc <= gamma:
         tokens[n + 1 + acc] = b
+
+
+# ---- Sequoia tree path ----------------------------------------------------------------------
+def _unpack_bits(bits, T):
+    w = bits.to(torch.int64) & 0xFFFFFFFF
+    cols = torch.arange(T)
+    return ((w[:, cols // 32] >> (cols % 32)) & 1).bool()
+
+
+def attn_block(q, k_layer, v_layer, sk, scale, nsplit=None, tree_mask=None, mask_row0=0, tree_start=0):
+    if tree_mask is None:
+        return attn_decode(q, k_layer, v_layer, sk, scale)
+    from oracle import ref_tree as RT
+    sq, H, D = q.shape
+    assert abs(scale - D ** -0.5) < 1e-9, "tree attention uses SDPA's default 1/sqrt(D) scale"
+    vis = _unpack_bits(tree_mask[mask_row0:mask_row0 + sq], sk - tree_start)
+    add = torch.zeros(sq, sk, dtype=torch.float16)
+    add[:, tree_start:] = torch.where(vis, 0.0, torch.finfo(torch.float16).min).to(torch.float16)
+    k = k_layer[:, :sk].permute(1, 0, 2)
+    v = v_layer[:, :sk].permute(1, 0, 2)
+    return RT.attn_sdpa(q, k, v, add).reshape(sq, H * D)
+
+
+def attn_tree(q, k_layer, v_layer, sk, scale, tree_mask, tree_start, mask_row0=0):
+    return attn_block(q, k_layer, v_layer, sk, scale, tree_mask=tree_mask, mask_row0=mask_row0, tree_start=tree_start)
+
+
+def kv_gather_rows(k_cache, v_cache, offset, idx):
+    src = [offset + int(i) for i in idx.tolist()]
+    for t in (k_cache, v_cache):
+        t[:, :, offset:offset + len(src)] = t[:, :, src].clone()
+
+
+def tree_accept(p_rows, draft_logits, tokens, succ_off, succ, uniforms, temperature, out):
+    from oracle import ref_model as M
+    from oracle import ref_tree as RT
+    so, sc = succ_off.tolist(), succ.tolist()
+    successors = [sc[so[i]:so[i + 1]] for i in range(len(so) - 1)]
+    rng = M.InjectedRng(uniforms.tolist())
+    acc_list, nxt, terminal, _ = RT.accept_walk(p_rows, draft_logits, tokens, successors, temperature, rng)
+    out.zero_()
+    out[0], out[1], out[2], out[3] = len(acc_list), (0 if nxt is None else nxt), int(terminal), rng.i
+    out[4:4 + len(acc_list)] = torch.tensor(acc_list)

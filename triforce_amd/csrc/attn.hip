@@ -47,10 +47,16 @@ __device__ __forceinline__ void load_kv_tile(const h16* __restrict__ kbase, cons
     }
 }
 
-template <int D, int QT>
+struct TreeMask {                      // tree-attention visibility bits (block kernel, TREE = true)
+    const uint32_t* rows;              // [n_rows][words] uint32, bit j of a row = tree key j visible
+    int words, row0, start;            // words per row, first row of this launch, key index of tree key 0
+};
+
+template <int D, int QT, bool TREE = false>
 __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf)[D / 32],
                                           const half8 (&vf)[D / 32], half8 sel0, half8 sel1, int tile,
-                                          int sk, int sq, float scale, int li, int g, int qbase = 0) {
+                                          int sk, int sq, float scale, int li, int g, int qbase = 0,
+                                          TreeMask tm = TreeMask{nullptr, 0, 0, 0}) {
     constexpr int NC = D / 32, NT = D / 16;
     // V tile -> key-contiguous fragments through the matrix core (exact: multiplies by 0/1)
     half4 va[NT];
@@ -74,7 +80,16 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int kidx = tile * 16 + 4 * g + r;
-            ok[r] = kidx <= kmax;
+            if (TREE) {
+                const int j = kidx - tm.start;
+                ok[r] = kidx < sk;
+                if (j >= 0 && ok[r]) {
+                    const int mrow = tm.row0 + min(qrow, sq - 1);
+                    ok[r] = (tm.rows[(int64_t)mrow * tm.words + (j >> 5)] >> (j & 31)) & 1u;
+                }
+            } else {
+                ok[r] = kidx <= kmax;
+            }
             x[r] = s[r] * scale;
             tmax = ok[r] ? fmaxf(tmax, x[r]) : tmax;
         }
@@ -197,27 +212,38 @@ __global__ __launch_bounds__(256) void attn_split_kernel(
     }
 }
 
-// Block (prefill) variant: up to 128 query rows in one pass over the keys.  Wave w owns query rows 32w..32w+31
-// (two MFMA q-tiles) and ALL four waves walk every key tile of the split, so a 128-token prefill chunk streams the
-// KV cache from HBM once (the 4 waves' identical tile loads meet in L1/L2) instead of once per 32-row slab — 4x less
-// HBM traffic for the chunked prefill of graph_infer.py:30-37 / TP_llama.py:246-250.  Each wave's partial
-// (m, l, O) goes straight to the workspace (QR = 128 rows); the same combine kernel folds the splits.
-template <int D>
+// Block variant: up to 128 query rows in one pass over the keys — the chunked prefill (graph_infer.py:30-37,
+// TP_llama.py:246-250: q_len = 128) and the Sequoia tree passes (tensor_op.py:171,265: SDPA with a dense
+// additive mask over [prefix | tree]).  The 128 rows are cut into `rg` row groups of 32 (two MFMA q-tiles per
+// wave); wave w owns row group w % rg and walks the key tiles ti, ti + TI, ... of the split (ti = w / rg,
+// TI = 4 / rg).  With rg = 4 every wave walks every tile, so a 128-token chunk streams the KV cache from HBM once
+// (the waves' identical tile loads meet in L1/L2) instead of once per 32-row slab; with rg = 1 the 4 waves
+// interleave tiles like the decode kernel.  Each wave writes its own partial (m, l, O) — the workspace holds
+// nsplit * TI partials of QR = 32 * rg rows per head — and the same combine kernel folds them.
+//
+// TREE = false: bottom-right causal mask.  TREE = true: keys [0, tree_start) are visible to every row, key
+// tree_start + j is visible to row i iff bit j of mask row (mask_row0 + i) is set (the reference's additive mask
+// is 0 / fp16-min over the tree columns: SpecTree_TP.py:65-67,83-87,170; a 0/1 bit loses nothing).
+template <int D, bool TREE>
 __global__ __launch_bounds__(256) void attn_block_kernel(
     const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
-    int64_t stride_h, int sq, int sk, int H, float scale, int nsplit, float* __restrict__ ws) {
-    constexpr int NC = D / 32, NT = D / 16, QT = 2, QR = 128;
+    int64_t stride_h, int sq, int sk, int H, float scale, int nsplit, int rg, float* __restrict__ ws,
+    const uint32_t* __restrict__ mask, int mask_words, int mask_row0, int tree_start) {
+    constexpr int NC = D / 32, NT = D / 16, QT = 2;
     const int split = blockIdx.x, h = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
-    const int qbase = wave * 32;
+    const int TI = 4 / rg, rgi = wave % rg, ti = wave / rg;
+    const int QR = 32 * rg;
+    const int qbase = rgi * 32;
     const int ntiles = (sk + 15) >> 4;
     const int tps = (ntiles + nsplit - 1) / nsplit;
     const int t_begin = split * tps;
     int t_end = min(ntiles, t_begin + tps);
-    // causal: rows of this wave see keys <= sk - sq + qbase + 31
-    const int last_key = sk - sq + min(sq - 1, qbase + 31);
-    t_end = min(t_end, (last_key >> 4) + 1);
+    if (!TREE) {                                   // causal: rows of this wave see keys <= sk - sq + qbase + 31
+        const int last_key = sk - sq + min(sq - 1, qbase + 31);
+        t_end = min(t_end, (last_key >> 4) + 1);
+    }
     const bool wave_active = qbase < sq;
 
     AttnState<D, QT> st;
@@ -242,25 +268,31 @@ __global__ __launch_bounds__(256) void attn_block_kernel(
     }
     const h16* kbase = k + (int64_t)h * stride_h;
     const h16* vbase = v + (int64_t)h * stride_h;
+    TreeMask tm;
+    tm.rows = mask;
+    tm.words = mask_words;
+    tm.row0 = mask_row0;
+    tm.start = tree_start;
     if (wave_active) {
         half8 ka[NC], va_[NC], kb[NC], vb[NC];
-        int t = t_begin;
+        int t = t_begin + ti;
         if (t < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t, sk, li, g, ka, va_);
         while (t < t_end) {
-            const int t1 = t + 1;
+            const int t1 = t + TI;
             if (t1 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t1, sk, li, g, kb, vb);
-            attn_tile<D, QT>(st, ka, va_, sel0, sel1, t, sk, sq, scale, li, g, qbase);
+            attn_tile<D, QT, TREE>(st, ka, va_, sel0, sel1, t, sk, sq, scale, li, g, qbase, tm);
             if (t1 >= t_end) break;
-            const int t2 = t1 + 1;
+            const int t2 = t1 + TI;
             if (t2 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t2, sk, li, g, ka, va_);
-            attn_tile<D, QT>(st, kb, vb, sel0, sel1, t1, sk, sq, scale, li, g, qbase);
+            attn_tile<D, QT, TREE>(st, kb, vb, sel0, sel1, t1, sk, sq, scale, li, g, qbase, tm);
             t = t2;
         }
     }
+    const int np = nsplit * TI;                               // partials per head
     float* ws_o = ws;
-    float* ws_m = ws + (int64_t)H * nsplit * QR * D;
-    float* ws_l = ws_m + (int64_t)H * nsplit * QR;
-    const int64_t pbase = ((int64_t)h * nsplit + split) * QR;
+    float* ws_m = ws + (int64_t)H * np * QR * D;
+    float* ws_l = ws_m + (int64_t)H * np * QR;
+    const int64_t pbase = ((int64_t)h * np + split * TI + ti) * QR;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         float lsum = st.l[qt];
@@ -565,43 +597,61 @@ extern "C" int tf_attn_decode(const void* q, const void* k, const void* v, void*
 
 extern "C" int64_t tf_attn_block_ws_floats(int H, int D, int nsplit) { return (int64_t)H * nsplit * 128 * (D + 2); }
 
-extern "C" int tf_attn_block_pick_nsplit(int H, int sk) {
+extern "C" int tf_attn_block_pick_nsplit(int H, int sq, int sk) {
     const int tiles = (sk + 15) / 16;
-    int by_work = tiles / 16;                        // >= 16 key tiles per workgroup
+    const int rg = sq <= 32 ? 1 : (sq <= 64 ? 2 : 4);
+    int by_work = tiles / (sq <= 32 ? 32 : 16);      // >= 8 key tiles per wave (rg = 1) / 16 per workgroup
     int by_grid = 1024 / (H > 0 ? H : 1);
     int n = by_work < by_grid ? by_work : by_grid;
+    const int cap = COMBINE_MAX_SPLITS / (4 / rg);   // partials per head = nsplit * (4 / rg)
+    if (n > cap) n = cap;
     if (n < 1) n = 1;
-    if (n > COMBINE_MAX_SPLITS) n = COMBINE_MAX_SPLITS;
     return n;
 }
 
-// Causal attention of a block of 33..128 query rows against the cache (bottom-right aligned), D = 128 or 64.
+template <int D, bool TREE>
+static int launch_block(const void* q, const void* k, const void* v, void* out, int64_t stride_t, int64_t stride_h,
+                        int sq, int sk, int H, float scale, int nsplit, float* ws, const uint32_t* mask,
+                        int mask_words, int mask_row0, int tree_start, hipStream_t st) {
+    const int rg = sq <= 32 ? 1 : (sq <= 64 ? 2 : 4);
+    hipLaunchKernelGGL((attn_block_kernel<D, TREE>), dim3(nsplit, H), dim3(256), 0, st, (const h16*)q, (const h16*)k,
+                       (const h16*)v, stride_t, stride_h, sq, sk, H, scale, nsplit, rg, ws, mask, mask_words,
+                       mask_row0, tree_start);
+    TF_LAUNCH_CHECK();
+    hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(H, sq), dim3(D, COMBINE_GROUPS), 0, st, (const float*)ws,
+                       (h16*)out, sq, H, nsplit * (4 / rg), 32 * rg);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}
+
+// Attention of a block of 1..128 query rows against the cache, D = 128 or 64.  mask == NULL: bottom-right causal
+// (a prefill chunk).  mask != NULL: tree attention — keys [0, tree_start) visible to all rows, key tree_start + j
+// visible to row i iff bit j of mask[(mask_row0 + i) * mask_words + j / 32] is set.
 extern "C" int tf_attn_block(const void* q, const void* k, const void* v, void* out, int64_t stride_t,
                              int64_t stride_h, int sq, int sk, int H, int D, float scale, int nsplit, float* ws,
-                             int64_t ws_floats, void* stream) {
+                             int64_t ws_floats, const uint32_t* mask, int mask_words, int mask_row0, int tree_start,
+                             void* stream) {
     if (!q || !k || !v || !out || !ws) return TF_EINVAL;
-    if (sq < 1 || sq > 128 || sk < sq || H < 1 || nsplit < 1 || nsplit > COMBINE_MAX_SPLITS) return TF_EINVAL;
+    if (sq < 1 || sq > 128 || sk < 1 || H < 1 || nsplit < 1) return TF_EINVAL;
+    if (!mask && sk < sq) return TF_EINVAL;
+    if (mask && (mask_words < 1 || mask_row0 < 0 || tree_start < 0 || tree_start > sk ||
+                 sk - tree_start > 32 * mask_words)) return TF_EINVAL;
+    const int rg = sq <= 32 ? 1 : (sq <= 64 ? 2 : 4);
+    if (nsplit * (4 / rg) > COMBINE_MAX_SPLITS) return TF_EINVAL;
     if ((stride_t % 8) || (stride_h % 8)) return TF_EINVAL;
     if (ws_floats < tf_attn_block_ws_floats(H, D, nsplit)) return TF_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(nsplit, H), block(256);
     if (D == 128)
-        hipLaunchKernelGGL((attn_block_kernel<128>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
-                           stride_t, stride_h, sq, sk, H, scale, nsplit, ws);
-    else if (D == 64)
-        hipLaunchKernelGGL((attn_block_kernel<64>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
-                           stride_t, stride_h, sq, sk, H, scale, nsplit, ws);
-    else
-        return TF_EINVAL;
-    TF_LAUNCH_CHECK();
-    if (D == 128)
-        hipLaunchKernelGGL((attn_combine_kernel<128>), dim3(H, sq), dim3(128, COMBINE_GROUPS), 0, st, (const float*)ws,
-                           (h16*)out, sq, H, nsplit, 128);
-    else
-        hipLaunchKernelGGL((attn_combine_kernel<64>), dim3(H, sq), dim3(64, COMBINE_GROUPS), 0, st, (const float*)ws,
-                           (h16*)out, sq, H, nsplit, 128);
-    TF_LAUNCH_CHECK();
-    return TF_OK;
+        return mask ? launch_block<128, true>(q, k, v, out, stride_t, stride_h, sq, sk, H, scale, nsplit, ws, mask,
+                                              mask_words, mask_row0, tree_start, st)
+                    : launch_block<128, false>(q, k, v, out, stride_t, stride_h, sq, sk, H, scale, nsplit, ws, nullptr,
+                                               0, 0, 0, st);
+    if (D == 64)
+        return mask ? launch_block<64, true>(q, k, v, out, stride_t, stride_h, sq, sk, H, scale, nsplit, ws, mask,
+                                             mask_words, mask_row0, tree_start, st)
+                    : launch_block<64, false>(q, k, v, out, stride_t, stride_h, sq, sk, H, scale, nsplit, ws, nullptr,
+                                              0, 0, 0, st);
+    return TF_EINVAL;
 }
 
 extern "C" int tf_attn_rope_on_read(const void* q, const void* k, const void* v, const void* cosb, const void* sinb,

@@ -200,6 +200,39 @@ extern "C" int tf_retrieval_gather(const void* k_src, const void* v_src, int64_t
     return TF_OK;
 }
 
+// Compaction of accepted tree nodes (DistributedSimpleCache.gather_kv_incremental, models/cache.py:333-343):
+// rows offset + idx[j] -> offset + j for j in [0, n), K and V, every layer and head.  idx must be strictly
+// increasing (a root-to-leaf path of the Sequoia tree: node ids grow with depth), so idx[j] >= j and walking the
+// rows in ascending batches with read-all / barrier / write-all is overlap-safe without the reference's clone().
+__global__ __launch_bounds__(256) void kv_gather_rows_kernel(h16* __restrict__ kc, h16* __restrict__ vc, int64_t sl,
+                                                             int64_t st, int64_t sh, int offset,
+                                                             const int32_t* __restrict__ idx, int n, int H, int D) {
+    const int l = blockIdx.x / H, h = blockIdx.x % H;
+    h16* base = (blockIdx.y ? vc : kc) + (int64_t)l * sl + (int64_t)h * sh;
+    const int vpr = D / 8;
+    const int rows_per_blk = 256 / vpr;
+    const int r_in = threadIdx.x / vpr, dv = threadIdx.x % vpr;
+    for (int r0 = 0; r0 < n; r0 += rows_per_blk) {
+        const int r = r0 + r_in;
+        half8 x;
+        const bool ok = (r < n) && (r_in < rows_per_blk);
+        if (ok) x = load_half8(base + (int64_t)(offset + idx[r]) * st + 8 * dv);
+        __syncthreads();
+        if (ok) store_half8(base + (int64_t)(offset + r) * st + 8 * dv, x);
+        __syncthreads();
+    }
+}
+
+extern "C" int tf_kv_gather_rows(void* k_cache, void* v_cache, int64_t stride_l, int64_t stride_t, int64_t stride_h,
+                                 int offset, const int32_t* idx, int n, int L, int H, int D, void* stream) {
+    if (!k_cache || !v_cache || !idx || n < 1 || offset < 0 || L < 1 || H < 1 || D < 8 || (D % 8) || D > 2048)
+        return TF_EINVAL;
+    hipLaunchKernelGGL(kv_gather_rows_kernel, dim3(L * H, 2), dim3(256), 0, (hipStream_t)stream, (h16*)k_cache,
+                       (h16*)v_cache, stride_l, stride_t, stride_h, offset, idx, n, H, D);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}
+
 extern "C" int tf_kv_copy_rows(const void* src, int64_t src_stride_l, int64_t src_stride_t, int64_t src_stride_h,
                                void* dst, int64_t dst_stride_l, int64_t dst_stride_t, int64_t dst_stride_h,
                                int src_t0, int dst_t0, int n, int L, int H, int D, void* stream) {

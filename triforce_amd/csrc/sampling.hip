@@ -143,6 +143,189 @@ __global__ __launch_bounds__(SAMP_THREADS) void middle_accept_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sequoia tree verification (utils/SpecTree_TP.py:147-199 `accept_step` + the loop of `verify`): walk the static
+// tree from the root; at a node, test its children in order — child token x is accepted iff p[x] > r * q[x]
+// (r a fresh uniform, q = softmax(draft_logits / T) with the already rejected sibling tokens forced to -inf);
+// a rejection replaces p by the normalised residual relu(p - q).  The walk stops at the first node with no
+// accepted child (or a leaf, or an accepted token 0 / 2), then the next token is drawn from the residual.
+// The reference syncs the host at every child test (`if p[token] > r * q[token]`); here the whole walk is ONE
+// single-workgroup kernel: the node's target row and draft row live in registers (thread t owns the contiguous
+// vocabulary slice [32t, 32t+32)), every test is two block reductions, and the host reads one record.
+//   out[0] = len(accept_list) (root included)   out[1] = next token   out[2] = terminal (0/1)
+//   out[3] = uniforms consumed                  out[4 + j] = accept_list[j]
+// ------------------------------------------------------------------------------------------------
+#define TREE_EPT 32
+#define TREE_MAX_PATH 60
+
+__device__ __forceinline__ float block_sum_s(float v, float* sm, int tid) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) sm[tid >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < SAMP_THREADS / 64; ++w) t += sm[w];
+    return t;
+}
+__device__ __forceinline__ float block_max_s(float v, float* sm, int tid) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((tid & 63) == 0) sm[tid >> 6] = v;
+    __syncthreads();
+    float t = sm[0];
+#pragma unroll
+    for (int w = 1; w < SAMP_THREADS / 64; ++w) t = fmaxf(t, sm[w]);
+    return t;
+}
+
+__global__ __launch_bounds__(SAMP_THREADS) void tree_accept_kernel(
+    const float* __restrict__ p_rows, const float* __restrict__ draft_logits, const int64_t* __restrict__ tokens,
+    const int32_t* __restrict__ succ_off, const int32_t* __restrict__ succ, const float* __restrict__ uniforms,
+    int V, float temperature, int64_t* __restrict__ out) {
+    __shared__ float sm[SAMP_THREADS / 64];
+    __shared__ int s_flag, s_nan, s_first, s_lastnz;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = tid * TREE_EPT;
+    float p[TREE_EPT], dl[TREE_EPT], qv[TREE_EPT];
+    int node = 0, nacc = 1, consumed = 0, terminal = 0;
+    if (tid == 0) out[4] = 0;
+    for (int depth = 0; depth < TREE_MAX_PATH; ++depth) {
+#pragma unroll
+        for (int s = 0; s < TREE_EPT; ++s) {
+            const int i = i0 + s;
+            p[s] = (i < V) ? p_rows[(int64_t)node * V + i] : 0.f;
+            dl[s] = (i < V) ? draft_logits[(int64_t)node * V + i] : -INFINITY;
+        }
+        const int c0 = succ_off[node], c1 = succ_off[node + 1];
+        int accepted = -1;
+        int64_t acc_tok = -1;
+        for (int c = c0; c < c1; ++c) {
+            const int pos = succ[c];
+            const int64_t tok = tokens[pos];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int s = 0; s < TREE_EPT; ++s) {
+                qv[s] = dl[s] / temperature;                       // softmax(draft_logits / T), SpecTree_TP.py:159
+                mx = fmaxf(mx, qv[s]);
+            }
+            mx = block_max_s(mx, sm, tid);
+            float zl = 0.f;
+#pragma unroll
+            for (int s = 0; s < TREE_EPT; ++s) {
+                qv[s] = (i0 + s < V) ? expf(qv[s] - mx) : 0.f;
+                zl += qv[s];
+            }
+            const float Z = block_sum_s(zl, sm, tid);
+            const float r = uniforms[consumed];
+            ++consumed;
+            if (tid == 0) s_flag = 0;
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < TREE_EPT; ++s) {
+                qv[s] = qv[s] / Z;
+                if ((int64_t)(i0 + s) == tok && p[s] > r * qv[s]) s_flag = 1;       // :162
+            }
+            __syncthreads();
+            if (s_flag) {
+                accepted = pos;
+                acc_tok = tok;
+                break;
+            }
+            float rl = 0.f;                                           // residual (offloading_seqouia.py:24-27)
+#pragma unroll
+            for (int s = 0; s < TREE_EPT; ++s) {
+                const float df = p[s] - qv[s];
+                p[s] = (df != df) ? df : fmaxf(df, 0.f);              // torch relu keeps NaN (fmaxf would drop it)
+                rl += p[s];
+                if ((int64_t)(i0 + s) == tok) dl[s] = -3.4028234663852886e38f;    // finfo(float32).min, :166
+            }
+            const float S = block_sum_s(rl, sm, tid);
+#pragma unroll
+            for (int s = 0; s < TREE_EPT; ++s) p[s] = p[s] / S;
+        }
+        if (accepted < 0) break;                                      // all children rejected, or a leaf
+        if (tid == 0 && nacc < TREE_MAX_PATH) out[4 + nacc] = accepted;
+        ++nacc;
+        if (acc_tok == 0 || acc_tok == 2) {                           // :188-190
+            terminal = 1;
+            break;
+        }
+        node = accepted;
+    }
+    int64_t next = 0;
+    if (!terminal) {
+        if (tid == 0) { s_nan = 0; s_first = V; s_lastnz = -1; }
+        __syncthreads();
+        bool has_nan = false;
+        float local = 0.f;
+        int my_last = -1;
+#pragma unroll
+        for (int s = 0; s < TREE_EPT; ++s) {
+            if (i0 + s < V) {
+                has_nan |= (p[s] != p[s]);
+                local += p[s];
+                if (p[s] > 0.f) my_last = i0 + s;
+            }
+        }
+        if (has_nan) s_nan = 1;
+        __syncthreads();
+        if (s_nan) {                                                  // :199-200
+            terminal = 1;
+        } else {                                                      // residual.multinomial -> inverse CDF
+            float inc = local;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float nb = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += nb;
+            }
+            __syncthreads();
+            if (lane == 63) sm[wave] = inc;
+            __syncthreads();
+            float prefix = 0.f, total = 0.f;
+#pragma unroll
+            for (int w = 0; w < SAMP_THREADS / 64; ++w) {
+                const float t = sm[w];
+                if (w < wave) prefix += t;
+                total += t;
+            }
+            const float target = uniforms[consumed] * total;
+            float cacc = prefix + (inc - local);
+#pragma unroll
+            for (int s = 0; s < TREE_EPT; ++s) {
+                if (i0 + s < V) {
+                    cacc += p[s];
+                    if (p[s] > 0.f && cacc > target) { atomicMin(&s_first, i0 + s); break; }
+                }
+            }
+            if (my_last >= 0) atomicMax(&s_lastnz, my_last);
+            __syncthreads();
+            int rtok = s_first;
+            if (rtok >= V) rtok = s_lastnz >= 0 ? s_lastnz : 0;
+            next = rtok;
+            ++consumed;
+        }
+    }
+    if (tid == 0) {
+        out[0] = nacc;
+        out[1] = next;
+        out[2] = terminal;
+        out[3] = consumed;
+    }
+}
+
+extern "C" int tf_tree_accept(const float* p_rows, const float* draft_logits, const int64_t* tokens,
+                              const int32_t* succ_off, const int32_t* succ, const float* uniforms, int V,
+                              float temperature, int64_t* out, void* stream) {
+    if (!p_rows || !draft_logits || !tokens || !succ_off || !succ || !uniforms || !out) return TF_EINVAL;
+    if (V < 1 || !(temperature > 0.f)) return TF_EINVAL;
+    if (V > SAMP_THREADS * TREE_EPT) return TF_ERANGE;
+    hipLaunchKernelGGL(tree_accept_kernel, dim3(1), dim3(SAMP_THREADS), 0, (hipStream_t)stream, p_rows, draft_logits,
+                       tokens, succ_off, succ, uniforms, V, temperature, out);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}
+
 extern "C" int tf_sample_inverse_cdf(const float* probs, const float* u, int64_t* token_out, int V, void* stream) {
     if (!probs || !u || !token_out || V < 1) return TF_EINVAL;
     hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(SAMP_THREADS), 0, (hipStream_t)stream, probs, u, token_out, V);

@@ -18,14 +18,17 @@ SIGNATURES = {
     "tf_attn_decode_pick_nsplit": (_i32, [_i32, _i32]),
     "tf_attn_decode": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _i32, _f32, _i32, _vp, _i64, _vp]),
     "tf_attn_block_ws_floats": (_i64, [_i32, _i32, _i32]),
-    "tf_attn_block_pick_nsplit": (_i32, [_i32, _i32]),
-    "tf_attn_block": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _i64, _vp]),
+    "tf_attn_block_pick_nsplit": (_i32, [_i32, _i32, _i32]),
+    "tf_attn_block": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _i64, _vp, _i32,
+                             _i32, _i32, _vp]),
     "tf_attn_rope_on_read": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp]),
     "tf_retrieval_score": (_i32, [_vp, _i64, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "tf_retrieval_topk": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "tf_retrieval_gather": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "tf_kv_copy_rows": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "tf_kv_shift_rows": (_i32, [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "tf_kv_gather_rows": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "tf_tree_accept": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp]),
     "tf_rmsnorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "tf_rope_append": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "tf_silu_mul": (_i32, [_vp, _vp, _i32, _i32, _vp]),

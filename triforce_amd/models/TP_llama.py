@@ -22,7 +22,8 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..utils.sampling import norm_logits
-from .cache import DistributedKVCacheBuffer, DistributedRetrievalCache, DistributedSimpleCache
+from .cache import (DistributedKVCacheBuffer, DistributedRetrievalCache, DistributedRetrievalCache_Seqouia,
+                    DistributedSimpleCache)
 from .config_yarn import LlamaConfig
 from .llama_core import LlamaWeights, parse_random_spec, rope_tables_for, softmax_scale_for
 from .TP_layers import DistributedOffloadingConfig
@@ -40,11 +41,18 @@ def distributed_init(backend=None):
     return local_rank, world_size
 
 
+class TreeMask:
+    """Packed tree-attention mask: bit j of ``bits[row0 + i]`` = tree node j visible to query row i."""
+
+    def __init__(self, bits, row0=0):
+        self.bits, self.row0 = bits, row0
+
+
 class DistributedLlama:
     def __init__(self, model_name_or_path: str, dtype=torch.float16, kv_offload=False, on_chip_layers=32, local_rank=0,
                  world_size=1, prefill=32768, bsz=1, gen_len=256, retrieval_budget=4096, retrieval_chunk_size=8, gamma=6,
                  temperature=0.6, top_p=0.9, ssl=0, draft=None, draft_cache=None, flash_attn=True, config=None,
-                 device=None) -> None:
+                 device=None, tree_size=0) -> None:
         assert dtype == torch.float16
         self.device = torch.device(device) if device is not None else torch.device("cuda", local_rank)
         self.dtype = dtype
@@ -66,13 +74,20 @@ class DistributedLlama:
         if not kv_offload:
             raise NotImplementedError
         assert bsz == 1
-        budget = prefill + gen_len + 32
+        self.tree_size = tree_size
+        budget = prefill + gen_len + 32 + tree_size           # TP_llama_tree.py:70 adds the tree rows
         self.kv_cache = DistributedSimpleCache(self.config, max_budget=budget, device=self.device,
                                                on_chip_layers=self.on_chip_layers, ssl=ssl)
         n_off = model_config.num_hidden_layers - self.on_chip_layers
         self.kv_buffer = [DistributedKVCacheBuffer(self.config, max_budget=budget, device=self.device)
                           for _ in range(2 if n_off > 0 else 0)]
-        if retrieval_budget > 0:
+        if retrieval_budget > 0 and tree_size > 0:            # Sequoia tree path (TP_llama_tree.py:72)
+            self.retrieval_cache = DistributedRetrievalCache_Seqouia(
+                self.config, max_budget=retrieval_budget, device=self.device, prefill=prefill,
+                chunk_size=retrieval_chunk_size, tree_size=tree_size)
+            self.retrieval_cache.ensure_tail(gen_len + 32 + tree_size)
+            self.kv_cache.tail_mirror = self.retrieval_cache
+        elif retrieval_budget > 0:
             self.retrieval_cache = DistributedRetrievalCache(self.config, max_budget=retrieval_budget, device=self.device,
                                                              prefill=prefill, chunk_size=retrieval_chunk_size, gamma=gamma)
             self.retrieval_cache.ensure_tail(gen_len + 32)
@@ -89,6 +104,7 @@ class DistributedLlama:
         self.local_num_heads = self.num_heads // world_size
         self.local_num_key_value_heads = self.num_key_value_heads // world_size
         self.scale = softmax_scale_for(self.head_dim)
+        self.tree_scale = 1.0 / math.sqrt(self.head_dim)
         self.weights = None
         self.num_layers = model_config.num_hidden_layers
         self._ev_ready = self._ev_done = None
@@ -125,7 +141,7 @@ class DistributedLlama:
             dist.all_reduce(t, dist.ReduceOp.SUM)
         return t
 
-    def _layer(self, i, x, d, pos, kl, vl, slot, sk, q_len, retrieval_build=False):
+    def _layer(self, i, x, d, pos, kl, vl, slot, sk, q_len, retrieval_build=False, tree=None):
         """One decoder layer on this rank's shard.  x: residual stream (updated in place), d: pending MLP output
         of the previous layer (None for layer 0).  Returns the (all-reduced) MLP output of this layer."""
         W = self.weights
@@ -138,7 +154,11 @@ class DistributedLlama:
         q = ops.rope_append(qkv, self.cos_cache, self.sin_cache, pos, kl, vl, slot, Hl, D)
         if retrieval_build:                               # tensor_op.py:161-162
             self.retrieval_cache.init_graph_cache((kl, vl), q, i)
-        a = ops.attn_prefill(q, kl, vl, sk, self.scale)
+        if tree is None:
+            a = ops.attn_prefill(q, kl, vl, sk, self.scale)
+        else:                                             # tensor_op.py:171,265: SDPA, scale 1/sqrt(D) in fp32
+            bits, row0, tree_start = tree
+            a = ops.attn_tree(q, kl, vl, sk, self.tree_scale, bits, tree_start, mask_row0=row0)
         o = self._all_reduce(ops.linear(a, W.wo[i]))                        # tensor_op.py:176-179
         h = ops.rmsnorm(o, W.ln2[i], W.eps, residual=x, sum_out=x)
         act = ops.mlp_act(h, W.wgu[i])
@@ -152,10 +172,10 @@ class DistributedLlama:
     @torch.inference_mode()
     def inference(self, input_ids, position_ids=None, attention_mask=None, retrieval_cache=None):
         """Target forward over the full KV cache (TP_llama.py:200-243)."""
-        assert attention_mask is None, "tree attention (Sequoia) is out of scope"
         W, kvc = self.weights, self.kv_cache
         q_len = input_ids.shape[1]
         S = kvc.seq_len
+        tree = None if attention_mask is None else self._tree_mask(attention_mask, S, q_len)
         if S + q_len > kvc.max_budget:
             raise IndexError(f"KV cache overflow: {S}+{q_len} > {kvc.max_budget}")
         if position_ids is None:
@@ -183,7 +203,7 @@ class DistributedLlama:
                 buf = self.kv_buffer[idx % 2]
                 torch.cuda.current_stream(self.device).wait_event(ready[idx])      # H2D of this layer landed
                 kl, vl = buf.k, buf.v
-            d = self._layer(idx, x, d, pos, kl, vl, S, S + q_len, q_len, retrieval_build=build)
+            d = self._layer(idx, x, d, pos, kl, vl, S, S + q_len, q_len, retrieval_build=build, tree=tree)
             if tail is not None:                          # keep the generated rows on the device for the retrieval tail
                 ops.kv_copy_rows(kl.unsqueeze(0), tail.tail_k[idx:idx + 1], S, S - self.prefill_len, q_len)
                 ops.kv_copy_rows(vl.unsqueeze(0), tail.tail_v[idx:idx + 1], S, S - self.prefill_len, q_len)
@@ -200,6 +220,16 @@ class DistributedLlama:
             torch.cuda.current_stream(self.device).wait_stream(cs)              # write-backs visible before reuse
         kvc.seq_len = S + q_len
         return self._finish(x, d)
+
+    def _tree_mask(self, attention_mask, tree_start, q_len):
+        """Tree visibility for the block-attention kernel: (bit rows int32, first row, key index of tree column 0).
+        Accepts a ``TreeMask`` (bits already packed on the device) or the reference's dense additive mask
+        ``(1, 1, q_len, tree_start + T)`` (0 = visible, fp16 min = hidden; SpecTree_TP.py:65-67,170)."""
+        if isinstance(attention_mask, TreeMask):
+            return attention_mask.bits, attention_mask.row0, tree_start
+        m = attention_mask.reshape(q_len, -1)
+        assert m.shape[1] >= tree_start, "dense tree mask must cover [prefix | tree]"
+        return ops.pack_tree_mask(m[:, tree_start:] == 0), 0, tree_start
 
     @torch.inference_mode()
     def prefill(self, input_ids):

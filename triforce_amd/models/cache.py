@@ -387,6 +387,27 @@ class DistributedSimpleCache(Cache):
         assert 0 <= i, (layer_idx, self.on_chip_layers)
         return self.cpu_k[i], self.cpu_v[i]
 
+    def gather_kv_incremental(self, indices, offset):
+        """Sequoia: keep only the accepted tree nodes — rows offset+indices[j] -> offset+j of every layer, then
+        seq_len = offset + len(indices) (reference cache.py:333-343).  On-chip layers: one tf_kv_gather_rows
+        launch; host-resident layers: pinned-memory row copies; the device mirror of the generated rows kept by
+        the retrieval cache (``tail_mirror``) is compacted the same way."""
+        idx = [int(i) for i in indices]
+        assert all(b > a for a, b in zip(idx, idx[1:])), "accept list must be strictly increasing"
+        n = len(idx)
+        if n and idx != list(range(n)):
+            dev_idx = torch.tensor(idx, dtype=torch.int32, device=self.device)
+            if self.on_chip_layers > 0:
+                ops.kv_gather_rows(self.k, self.v, offset, dev_idx)
+            if self.on_chip_layers < self.layers:
+                src = torch.tensor([offset + i for i in idx], dtype=torch.long)
+                for t in (self.cpu_k, self.cpu_v):
+                    t[:, :, offset:offset + n] = t[:, :, src]
+            tm = getattr(self, "tail_mirror", None)
+            if tm is not None and tm.tail_k is not None:
+                ops.kv_gather_rows(tm.tail_k, tm.tail_v, offset - tm.prefill, dev_idx)
+        self.seq_len = offset + n
+
 
 class DistributedKVCacheBuffer:
     """Device staging buffer for one offloaded layer (reference cache.py:353-383)."""
@@ -500,3 +521,25 @@ class DistributedRetrievalCache:
     def normal_(self):
         self.k.normal_()
         self.v.normal_()
+
+
+class DistributedRetrievalCache_Seqouia(DistributedRetrievalCache):
+    """Retrieval cache of the Sequoia tree path (reference cache.py:385-483; the reference's spelling of the
+    class name is kept).  Same chunk-scored build as DistributedRetrievalCache; the speculative region holds one
+    KV row per TREE NODE — slot max_budget + node id, written through ``storage_ids`` (:459-466) — instead of the
+    gamma+1 chain slots, so real_budget = max_budget + tree_size."""
+
+    def __init__(self, config, max_budget=1024, device=None, prefill=1024, chunk_size=8, tree_size=128) -> None:
+        super().__init__(config, max_budget=max_budget, device=device, prefill=prefill, chunk_size=chunk_size,
+                         gamma=tree_size - 1)
+        self.tree_size = tree_size
+        assert self.real_budget == max_budget + tree_size
+
+    def update(self, key_states, value_states, layer_idx, storage_ids):
+        k, v = _rows(key_states), _rows(value_states)
+        input_length = len(storage_ids)
+        assert input_length == k.shape[0] and input_length == v.shape[0]
+        ids = torch.as_tensor(storage_ids, device=self.k.device, dtype=torch.long)
+        self.k[layer_idx].index_copy_(1, ids, k.permute(1, 0, 2).contiguous())
+        self.v[layer_idx].index_copy_(1, ids, v.permute(1, 0, 2).contiguous())
+        return self.key_cache[layer_idx], self.value_cache[layer_idx]

@@ -166,21 +166,53 @@ def attn_decode(q, k_layer, v_layer, sk, scale, sk_dev=None, nsplit=None):
     return out
 
 
-def attn_block(q, k_layer, v_layer, sk, scale, nsplit=None):
-    """Causal attention of a block of <=128 query rows (a prefill chunk): one pass over the keys."""
-    _dev(q, k_layer, v_layer)
+def attn_block(q, k_layer, v_layer, sk, scale, nsplit=None, tree_mask=None, mask_row0=0, tree_start=0):
+    """Attention of a block of <=128 query rows in one pass over the keys.  tree_mask None: bottom-right causal
+    (a prefill chunk).  tree_mask (n_rows, words) int32 bit rows: Sequoia tree attention — keys [0, tree_start)
+    visible to all rows, key tree_start+j visible to row i iff bit j of tree_mask[mask_row0+i] is set."""
+    _dev(q, k_layer, v_layer, tree_mask)
     sq, H, D = q.shape
     assert q.dtype == _HALF and q.is_contiguous() and sq <= 128
     st, sh = _kv(k_layer)
     assert _kv(v_layer) == (st, sh)
     L = hip.lib()
     if nsplit is None:
-        nsplit = L.tf_attn_block_pick_nsplit(H, int(sk))
+        nsplit = L.tf_attn_block_pick_nsplit(H, sq, int(sk))
     ws = _workspace(q.device, L.tf_attn_block_ws_floats(H, D, nsplit))
     out = torch.empty(sq, H * D, dtype=_HALF, device=q.device)
+    words = 0
+    if tree_mask is not None:
+        assert tree_mask.dtype == torch.int32 and tree_mask.dim() == 2 and tree_mask.is_contiguous()
+        assert mask_row0 + sq <= tree_mask.shape[0]
+        words = tree_mask.shape[1]
     hip.check(L.tf_attn_block(_ptr(q), _ptr(k_layer), _ptr(v_layer), _ptr(out), st, sh, sq, int(sk), H, D, float(scale),
-                              nsplit, _ptr(ws), ws.numel(), _stream()), "tf_attn_block")
+                              nsplit, _ptr(ws), ws.numel(), _ptr(tree_mask), words, int(mask_row0), int(tree_start),
+                              _stream()), "tf_attn_block")
     return out
+
+
+def attn_tree(q, k_layer, v_layer, sk, scale, tree_mask, tree_start, mask_row0=0):
+    """Tree attention for any number of query rows (<=128 per pass)."""
+    sq = q.shape[0]
+    if sq <= 128:
+        return attn_block(q, k_layer, v_layer, sk, scale, tree_mask=tree_mask, mask_row0=mask_row0, tree_start=tree_start)
+    outs = []
+    for r0 in range(0, sq, 128):
+        r1 = min(sq, r0 + 128)
+        outs.append(attn_block(q[r0:r1].contiguous(), k_layer, v_layer, sk, scale, tree_mask=tree_mask,
+                               mask_row0=mask_row0 + r0, tree_start=tree_start))
+    return torch.cat(outs, dim=0)
+
+
+def pack_tree_mask(visible):
+    """(rows, T) bool/0-1 tensor -> (rows, ceil(T/32)) int32 bit rows (bit j%32 of word j//32 = column j)."""
+    rows, T = visible.shape
+    words = (T + 31) // 32
+    v = torch.zeros(rows, words * 32, dtype=torch.int64, device=visible.device)
+    v[:, :T] = (visible != 0).to(torch.int64)
+    w = (v.view(rows, words, 32) << torch.arange(32, device=visible.device, dtype=torch.int64)).sum(dim=-1)
+    w = torch.where(w >= 2 ** 31, w - 2 ** 32, w)            # two's-complement into int32
+    return w.to(torch.int32).contiguous()
 
 
 def attn_prefill(q, k_layer, v_layer, sk, scale):
@@ -274,6 +306,34 @@ def kv_shift_rows(cache, src_t0, dst_t0, n):
     sl, st, sh = _lhtd(cache)
     hip.check(hip.lib().tf_kv_shift_rows(_ptr(cache), sl, st, sh, int(src_t0), int(dst_t0), int(n), L, H, D,
                                          _stream()), "tf_kv_shift_rows")
+
+
+def kv_gather_rows(k_cache, v_cache, offset, idx):
+    """Rows offset+idx[j] -> offset+j of every layer/head of the (L,H,T,D) K and V views (idx: device int32,
+    strictly increasing) — gather_kv_incremental (reference cache.py:333-343)."""
+    _dev(k_cache, v_cache, idx)
+    L, H, _, D = k_cache.shape
+    sl, st, sh = _lhtd(k_cache)
+    assert _lhtd(v_cache) == (sl, st, sh) and idx.dtype == torch.int32 and idx.is_contiguous()
+    hip.check(hip.lib().tf_kv_gather_rows(_ptr(k_cache), _ptr(v_cache), sl, st, sh, int(offset), _ptr(idx),
+                                          idx.numel(), L, H, D, _stream()), "tf_kv_gather_rows")
+
+
+TREE_ACCEPT_OUT = 64
+
+
+def tree_accept(p_rows, draft_logits, tokens, succ_off, succ, uniforms, temperature, out):
+    """Sequoia tree walk on the device: out[64] int64 <- (len(accept_list), next_token, terminal,
+    uniforms_consumed, accept_list...); see include/triforce_hip.h."""
+    _dev(p_rows, draft_logits, tokens, succ_off, succ, uniforms, out)
+    N, V = p_rows.shape
+    assert p_rows.dtype == torch.float32 and p_rows.is_contiguous() and draft_logits.shape == p_rows.shape
+    assert draft_logits.dtype == torch.float32 and draft_logits.is_contiguous()
+    assert tokens.dtype == torch.int64 and tokens.numel() == N and succ_off.dtype == torch.int32
+    assert succ_off.numel() == N + 1 and succ.dtype == torch.int32 and uniforms.dtype == torch.float32
+    assert out.dtype == torch.int64 and out.numel() >= TREE_ACCEPT_OUT
+    hip.check(hip.lib().tf_tree_accept(_ptr(p_rows), _ptr(draft_logits), _ptr(tokens), _ptr(succ_off), _ptr(succ),
+                                       _ptr(uniforms), V, float(temperature), _ptr(out), _stream()), "tf_tree_accept")
 
 
 TOPP_MAX_VOCAB = 32768

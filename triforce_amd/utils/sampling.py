@@ -54,6 +54,8 @@ class UniformSource:
     syncs.  ``values`` injects a fixed sequence (cycled) for parity tests.
     """
 
+    MAX_TAKE = 256        # most numbers one kernel may look at (the Sequoia tree walk: one per examined child)
+
     def __init__(self, device, seed=None, values=None, block=1 << 16):
         self.device = torch.device(device)
         self.block = block
@@ -61,7 +63,7 @@ class UniformSource:
         self._fixed = values is not None
         if self._fixed:
             v = torch.as_tensor(values, dtype=torch.float32).flatten()
-            reps = (block + 64 + v.numel() - 1) // v.numel() + 1
+            reps = (block + self.MAX_TAKE + v.numel() - 1) // v.numel() + 1
             self._period = v.numel()
             self.buf = v.repeat(reps).to(self.device)
         else:
@@ -70,15 +72,15 @@ class UniformSource:
                 self.gen.manual_seed(seed)
             else:
                 self.gen.seed()
-            self.buf = torch.rand(block + 64, generator=self.gen, device=self.device)
+            self.buf = torch.rand(block + self.MAX_TAKE, generator=self.gen, device=self.device)
 
     def take(self, n):
-        assert n <= 64
+        assert n <= self.MAX_TAKE
         if self.pos + n > self.block:
             if self._fixed:
                 self.pos %= self._period
             else:
-                self.buf = torch.rand(self.block + 64, generator=self.gen, device=self.device)
+                self.buf = torch.rand(self.block + self.MAX_TAKE, generator=self.gen, device=self.device)
                 self.pos = 0
         return self.buf[self.pos:self.pos + n]
 
