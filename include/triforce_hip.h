@@ -162,6 +162,27 @@ int tf_skinny_gemm(const void* w_packed, const void* x, int64_t ldx, void* y, in
 int tf_skinny_gemm_swiglu(const void* gate_packed, const void* up_packed, const void* x, int64_t ldx, void* act,
                           int64_t ldy, int M, int I, int K, void* stream);
 
+/* Fused forms of the same kernel — what sits between the GEMMs of a decoder layer folded into the GEMM that consumes
+ * or produces it, with the reference's rounding points (each was a 4-5 us launch of its own at <= 18 rows):
+ *   ln_w != NULL : RMSNorm prologue on the input rows, h = ln_w * fp16(x * rsqrt(mean(x^2) + eps))
+ *                  (models/modeling_llama.py:138-143, tensor_op.py:52-64); x is then the residual stream.
+ *   resid != NULL: y = fp16(resid + fp16(x . W^T))  (hidden_states = residual + ..., modeling_llama.py:278,284);
+ *                  y may alias resid (every element is read and written by the same lane).
+ * tf_skinny_qkv_rope: fused q|k|v projection + RoPE + KV append (modeling_llama.py:212-238 / tensor_op.py:140-160,
+ *                  the work of tf_rope_append in the GEMM epilogue).  The weight must be packed in ROTARY-PAIR row
+ *                  order: within the q and k sections every 16-row panel = rows d0..d0+7 and d0+D/2..d0+D/2+7 of one
+ *                  head (triforce_amd.ops.rope_row_order); v rows keep their order.  q -> q_out [M][H][D]; k (rotated
+ *                  unless rotate_k == 0) and v rows -> cache slot slot0 + m (slot0 read from slot0_dev if non-NULL). */
+int tf_skinny_gemm_ex(const void* w_packed, const void* x, int64_t ldx, const void* ln_w, float eps,
+                      const void* resid, int64_t ldr, void* y, int64_t ldy, int M, int N, int K, int out_f32,
+                      void* stream);
+int tf_skinny_gemm_swiglu_ex(const void* gate_packed, const void* up_packed, const void* x, int64_t ldx,
+                             const void* ln_w, float eps, void* act, int64_t ldy, int M, int I, int K, void* stream);
+int tf_skinny_qkv_rope(const void* wqkv_packed, const void* x, int64_t ldx, const void* ln_w, float eps,
+                       const void* cos, const void* sin, const int64_t* positions, void* q_out,
+                       void* k_cache, void* v_cache, int64_t stride_t, int64_t stride_h, int slot0,
+                       const int32_t* slot0_dev, int M, int H, int D, int K, int rotate_k, void* stream);
+
 /* -------------------------------------------------------------------------------------------
  * Sampling / accept-rollback (utils/sampling.py:63-75, utils/decoding.py:97-134,190-220).
  * tf_sample_inverse_cdf: token = first index whose inclusive cumulative sum of probs exceeds

@@ -485,3 +485,94 @@ def test_skinny_gemm_swiglu_matches_oracle(M, I, K):
     assert (d > 0).float().mean() < 6e-2
     big = ops.mlp_act(rnd(40, K, seed=5).to(DEV), pl)                 # >32 rows: hipBLASLt + silu_mul path
     assert big.shape == (40, I)
+
+
+# ------------------------------------------------------------------------------------------
+# fused forms of the skinny GEMM (csrc/gemv.hip): norm prologue, residual / RoPE+append epilogues
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,H,D,K", [(1, 2, 128, 256), (7, 32, 128, 4096), (18, 4, 64, 768), (32, 3, 128, 512),
+                                     (9, 12, 64, 768)])
+@pytest.mark.parametrize("rotate_k", [True, False])
+def test_qkv_rope_fused(M, H, D, K, rotate_k):
+    ops = _ops()
+    eps, slot0, T = 1e-5, 5, 64
+    w = rnd(3 * H * D, K, seed=200 + M, scale=0.05)
+    x = rnd(M, K, seed=201)
+    ln = (1 + 0.1 * rnd(K, seed=202).float()).half()
+    cos, sin = R.rope_tables_yarn(D, 4096, 16.0, 256) if D == 128 else R.rope_tables_plain(D, 4096)
+    pos = torch.randint(0, 4096, (M,), generator=torch.Generator().manual_seed(M))
+    pl = ops.PackedLinear(w.to(DEV), rope=(H, D))
+    assert pl.wp_rope is not None
+    cd, sd, pd = cos.to(DEV), sin.to(DEV), pos.to(DEV)
+
+    def caches():
+        return (torch.zeros(H, T, D, dtype=torch.float16, device=DEV), torch.zeros(H, T, D, dtype=torch.float16, device=DEV))
+    # (1) RoPE + append epilogue alone (input already normalised): bit-exact vs GEMM kernel + tf_rope_append —
+    #     the packed row order changes which panel a row sits in, not how its dot product is accumulated
+    h = ops.rmsnorm(x.to(DEV), ln.to(DEV), eps)
+    k1, v1 = caches()
+    k2, v2 = caches()
+    q1 = ops.qkv_rope(h, pl, None, 0.0, cd, sd, pd, k1, v1, slot0, H, D, rotate_k=rotate_k)
+    q2 = ops.rope_append(ops.linear(h, pl), cd, sd, pd, k2, v2, slot0, H, D, rotate_k=rotate_k)
+    assert torch.equal(q1, q2) and torch.equal(k1, k2) and torch.equal(v1, v2)
+    # (2) with the RMSNorm prologue, against the oracle pipeline (norm -> linear -> rope)
+    k3, v3 = caches()
+    sdev = torch.tensor([slot0], dtype=torch.int32, device=DEV)
+    q3 = ops.qkv_rope(x.to(DEV), pl, ln.to(DEV), eps, cd, sd, pd, k3, v3, 0, H, D, rotate_k=rotate_k, slot0_dev=sdev)
+    qkv = R.linear(R.rms_norm(x, ln, eps), w)
+    wq = R.apply_rope(qkv[:, :H * D].view(M, H, D), cos, sin, pos)
+    wk = qkv[:, H * D:2 * H * D].view(M, H, D)
+    wk = R.apply_rope(wk, cos, sin, pos) if rotate_k else wk
+    wv = qkv[:, 2 * H * D:].view(M, H, D)
+    # fp32 sums in a different order (norm and GEMM) -> neighbouring fp16 on a few elements, then two more fp16
+    # roundings in the rotation: <= 2 ulp (+1e-3 abs near zero crossings of x*cos + rot*sin)
+    ulp_report("qkv_rope q", q3, wq, max_ulp_frac=8e-2, ulps=2, atol=1e-3)
+    ulp_report("qkv_rope k", k3[:, slot0:slot0 + M].permute(1, 0, 2), wk, max_ulp_frac=8e-2, ulps=2, atol=1e-3)
+    ulp_report("qkv_rope v", v3[:, slot0:slot0 + M].permute(1, 0, 2), wv, max_ulp_frac=5e-2, ulps=1, atol=1e-4)
+    assert k3[:, :slot0].abs().sum() == 0 and k3[:, slot0 + M:].abs().sum() == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 4096, 11008), (18, 768, 3072), (32, 512, 256), (7, 32000, 4096)])
+def test_skinny_gemm_norm_prologue_and_residual_epilogue(M, N, K):
+    ops = _ops()
+    eps = 1e-5
+    w = rnd(N, K, seed=210 + M, scale=0.05)
+    x, res = rnd(M, K, seed=211), rnd(M, N, seed=212)
+    ln = (1 + 0.1 * rnd(K, seed=213).float()).half()
+    pl = ops.PackedLinear(w.to(DEV))
+    xd, resd, lnd = x.to(DEV), res.to(DEV), ln.to(DEV)
+    # residual epilogue: bit-exact vs the plain kernel followed by an fp16 add; in place on the residual buffer
+    y = ops.linear(xd, pl)
+    buf = resd.clone()
+    out = ops.linear(xd, pl, resid=buf, out=buf)
+    assert out.data_ptr() == buf.data_ptr() and torch.equal(buf, resd + y)
+    # norm prologue vs the stand-alone RMSNorm kernel + GEMM (same device, different fp32 summation order of the
+    # sum of squares) and vs the oracle
+    yn = ops.linear(xd, pl, ln=lnd, eps=eps)
+    ulp_report("norm prologue vs kernels", yn, ops.linear(ops.rmsnorm(xd, lnd, eps), pl), max_ulp_frac=3e-2, ulps=1, atol=1e-4)
+    ulp_report("norm prologue vs oracle", yn, R.linear(R.rms_norm(x, ln, eps), w), max_ulp_frac=5e-2, ulps=1, atol=1e-4)
+    if N <= 4096:
+        y32 = ops.linear(xd, pl, out_f32=True, ln=lnd, eps=eps)
+        assert torch.equal(y32, yn.float())
+    # both at once
+    buf = resd.clone()
+    ops.linear(xd, pl, ln=lnd, eps=eps, resid=buf, out=buf)
+    assert torch.equal(buf, resd + yn)
+
+
+@pytest.mark.parametrize("M,I,K", [(1, 3072, 768), (7, 11008, 4096), (18, 1728, 5120)])
+def test_swiglu_norm_prologue(M, I, K):
+    ops = _ops()
+    eps = 1e-5
+    x, wgu = rnd(M, K, seed=220 + M), rnd(2 * I, K, seed=221, scale=0.05)
+    ln = (1 + 0.1 * rnd(K, seed=222).float()).half()
+    pl = ops.PackedLinear(wgu.to(DEV), split=2)
+    got = ops.mlp_act(x.to(DEV), pl, ln=ln.to(DEV), eps=eps)
+    ref = ops.mlp_act(ops.rmsnorm(x.to(DEV), ln.to(DEV), eps), pl)
+    d = (got.float() - ref.float()).abs()
+    assert (d > 0).float().mean() < 5e-2 and d.max() < 2e-2, (float((d > 0).float().mean()), float(d.max()))
+    h = R.rms_norm(x, ln, eps)
+    gu = R.linear(h, wgu)
+    want = R.silu_mul(gu[:, :I], gu[:, I:])
+    dd = (got.float().cpu() - want.float()).abs()
+    assert dd.max() < 3e-2 and dd.mean() < 2e-4, (float(dd.max()), float(dd.mean()))

@@ -142,12 +142,12 @@ def test_tree_accept_edge_cases():
     rec = run(gm, p, draft, tokens, u)
     acc, nxt, terminal, _ = RT.accept_walk(p, draft, tokens, gm["Successors"], 0.6, M.InjectedRng(u.tolist()))
     assert terminal and rec[2] == 1 and rec[0] == len(acc) == 2 and rec[3] == 1
-    # (c) p == q: a rejection gives relu(p-q) = 0 -> 0/0 residual -> NaN -> terminal (:199-200)
-    gm, p, draft, tokens, u = _walk_case(5, identical=True)
-    u[:] = 1.0                                             # p[tok] > r*q[tok] holds for every r < 1 when p == q: force r = 1
+    # (c) a NaN target row: every test `p[tok] > r*q[tok]` is False, the residual stays NaN -> terminal (:199-200)
+    gm, p, draft, tokens, u = _walk_case(5)
+    p[0, :] = float("nan")
     rec = run(gm, p, draft, tokens, u)
     acc, nxt, terminal, _ = RT.accept_walk(p, draft, tokens, gm["Successors"], 0.6, M.InjectedRng(u.tolist()))
-    assert terminal and rec[2] == 1 and rec[0] == len(acc)
+    assert terminal and acc == [0] and rec[2] == 1 and rec[0] == 1 and rec[3] == len(gm["Successors"][0])
 
 
 def test_kv_gather_rows_bit_exact():

@@ -96,7 +96,6 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mnew = fmaxf(st.m[qt], tmax);
-        const float alpha = __expf(st.m[qt] - mnew);
         float psum = 0.f;
         half4 pb;
 #pragma unroll
@@ -105,14 +104,22 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
             psum += p;
             pb[r] = (h16)p;
         }
-        st.l[qt] = st.l[qt] * alpha + psum;
-        st.m[qt] = mnew;
+        // The running maximum settles after the first tiles of a stream; rescaling the 32 accumulator registers
+        // (alpha == 1 exactly when no query column of the wave raised its maximum) is skipped wave-uniformly then.
+        if (__builtin_amdgcn_ballot_w64(mnew != st.m[qt])) {
+            const float alpha = __expf(st.m[qt] - mnew);
+            st.l[qt] *= alpha;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            f32x4 a = st.acc[qt][t];
-            a[0] *= alpha; a[1] *= alpha; a[2] *= alpha; a[3] *= alpha;
-            st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(va[t], pb, a, 0, 0, 0);
+            for (int t = 0; t < NT; ++t) {
+                st.acc[qt][t][0] *= alpha; st.acc[qt][t][1] *= alpha;
+                st.acc[qt][t][2] *= alpha; st.acc[qt][t][3] *= alpha;
+            }
+            st.m[qt] = mnew;
         }
+        st.l[qt] += psum;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(va[t], pb, st.acc[qt][t], 0, 0, 0);
     }
 }
 
@@ -601,7 +608,9 @@ extern "C" int tf_attn_block_pick_nsplit(int H, int sq, int sk) {
     const int tiles = (sk + 15) / 16;
     const int rg = sq <= 32 ? 1 : (sq <= 64 ? 2 : 4);
     int by_work = tiles / (sq <= 32 ? 32 : 16);      // >= 8 key tiles per wave (rg = 1) / 16 per workgroup
-    int by_grid = 1024 / (H > 0 ? H : 1);
+    // rg = 4 is matrix-core bound with ~2 resident workgroups per CU: 512 workgroups fill the chip, and every
+    // extra split costs 128 rows x (D+2) floats of partials per head for the combine kernel to re-read
+    int by_grid = (rg == 4 ? 512 : 1024) / (H > 0 ? H : 1);
     int n = by_work < by_grid ? by_work : by_grid;
     const int cap = COMBINE_MAX_SPLITS / (4 / rg);   // partials per head = nsplit * (4 / rg)
     if (n > cap) n = cap;

@@ -8,10 +8,20 @@
 //     every 32-wide k-chunk, the 16x32 tile is stored as 64 consecutive 16-byte pieces, piece (g*16 + i) holding
 //     W[n0+i][k0+8g .. k0+8g+7].  A wavefront's A-operand load is then ONE fully contiguous 1 KiB read and a
 //     panel is a single sequential stream of K*32 bytes — no 64-byte row fragments, no LDS staging.
-//   * grid = N/16 panels, 4 waves per workgroup split the panel's K range; partial 16x16 accumulators meet in
+//   * grid = N/16 panels, the waves of a workgroup split the panel's K range; partial 16x16 accumulators meet in
 //     LDS.  x (<= 32 x K fp16, L2-resident) is read straight into the B operand.
-//   * Variant GATEUP computes the gate and the up panel of the same columns and applies SwiGLU in the epilogue
-//     (act = fp16(silu(fp16 gate)) * fp16 up — the reference's rounding points), saving a kernel and a round trip.
+//
+// Everything that used to sit BETWEEN the GEMMs of a decoder layer as its own launch (4-5 us each at <= 18 rows:
+// pure launch latency) is folded into the GEMM that consumes or produces it, with the reference's rounding
+// points kept:
+//   * NORM prologue — RMSNorm of the input rows (modeling_llama.py:138-143): every workgroup reduces the rows'
+//     sum of squares itself (x is <= 64 KiB and L2-resident; the first weight chunks are already in flight) and
+//     normalises its B operand on the fly: h = w_ln * fp16(x * rsqrt(mean(x^2) + eps)).
+//   * residual epilogue — y = fp16(res + fp16(acc))  (hidden_states = residual + o_proj(...), :278, :284).
+//   * SwiGLU epilogue (gate|up pair, :156-159) — act = fp16(silu(fp16 gate)) * fp16 up.
+//   * RoPE + KV-append epilogue (fused q|k|v, :212-238): the packed row order pairs rotary partners d and d + D/2
+//     inside one 16-row panel, so the epilogue rotates q / k in registers (one cross-lane exchange) and writes q
+//     to [M][H][D] and the k / v rows straight into the cache slots.
 #include "common.h"
 
 #ifdef TF_NO_NT
@@ -37,18 +47,46 @@
 #define SG_U 4              // k-chunks (KiB of weights) in flight per wave
 #endif
 
-template <int MT, bool GATEUP, bool OUT_F32, int WAVES>
+enum { SG_PLAIN = 0, SG_GATEUP = 1, SG_F32 = 2, SG_QKV = 3 };
+
+struct SgRope {                       // arguments of the RoPE + KV-append epilogue (SG_QKV)
+    const h16* cosb;                  // [max_pos][D] fp16
+    const h16* sinb;
+    const int64_t* positions;         // [M]
+    h16* q_out;                       // [M][H][D]
+    h16* k_cache;                     // layer base, element strides below
+    h16* v_cache;
+    int64_t stride_t, stride_h;
+    const int32_t* slot0_dev;
+    int slot0, H, D, rotate_k;
+};
+
+// h = w_ln * fp16(x * inv): the cast precedes the weight multiply (modeling_llama.py:141-143); the fp16 product of
+// two fp16 values rounded once is the native half multiply.
+__device__ __forceinline__ half8 sg_normalise(half8 xv, half8 wv, float inv) {
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = hmul_rn(wv[e], (h16)((float)xv[e] * inv));
+    return o;
+}
+
+template <int MT, int MODE, bool NORM, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __restrict__ wp,
-                                                                    const half8* __restrict__ wp_up,
-                                                                    const h16* __restrict__ x, int64_t ldx,
-                                                                    void* __restrict__ yv, int64_t ldy, int M, int N,
-                                                                    int K) {
+                                                                 const half8* __restrict__ wp_up,
+                                                                 const h16* __restrict__ x, int64_t ldx,
+                                                                 const h16* __restrict__ ln_w, float eps,
+                                                                 const h16* resid, int64_t ldr, void* yv, int64_t ldy,
+                                                                 int M, int N, int K, SgRope rp) {
+    constexpr bool GATEUP = MODE == SG_GATEUP;
     const int panel = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     const int nchunks = K >> 5;
     const int cpw = (nchunks + WAVES - 1) / WAVES;
     const int c0 = wave * cpw, c1 = min(nchunks, c0 + cpw);
+
+    __shared__ float sm[WAVES][GATEUP ? 2 : 1][MT][64][4];
+    __shared__ float sm_ss[NORM ? WAVES : 1][MT][16];
 
     f32x4 acc[MT], acc2[MT];
 #pragma unroll
@@ -67,17 +105,70 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
         xr[t] = x + (int64_t)(xok[t] ? m : 0) * ldx + 8 * g;
     }
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-
     constexpr int U = SG_U;
+
+    // first weight chunks of this wave: issued before the norm prologue so HBM is already streaming under it
+    half8 a_pre[U], a2_pre[U];
+    const bool pre = NORM && (c0 + U <= c1);
+    if (pre) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a_pre[u] = SG_LOAD(wa + (int64_t)(c0 + u) * 64);
+            if (GATEUP) a2_pre[u] = SG_LOAD(wu + (int64_t)(c0 + u) * 64);
+        }
+    }
+
+    float inv[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) inv[t] = 1.f;
+    if (NORM) {
+        float ss[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) ss[t] = 0.f;
+        for (int c = c0; c < c1; ++c) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const half8 v = xok[t] ? load_half8(xr[t] + 32 * c) : zero8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[e];
+                    ss[t] = fmaf(f, f, ss[t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            ss[t] += __shfl_xor(ss[t], 16, 64);
+            ss[t] += __shfl_xor(ss[t], 32, 64);
+            if (g == 0) sm_ss[wave][t][li] = ss[t];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) tot += sm_ss[w][t][li];
+            inv[t] = 1.0f / sqrtf(tot / (float)K + eps);
+        }
+    }
+
     int c = c0;
     for (; c + U <= c1; c += U) {
         half8 a[U], a2[U], b[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            a[u] = SG_LOAD(wa + (int64_t)(c + u) * 64);
-            if (GATEUP) a2[u] = SG_LOAD(wu + (int64_t)(c + u) * 64);
+            if (NORM && c == c0 && pre) {
+                a[u] = a_pre[u];
+                if (GATEUP) a2[u] = a2_pre[u];
+            } else {
+                a[u] = SG_LOAD(wa + (int64_t)(c + u) * 64);
+                if (GATEUP) a2[u] = SG_LOAD(wu + (int64_t)(c + u) * 64);
+            }
 #pragma unroll
-            for (int t = 0; t < MT; ++t) b[u][t] = xok[t] ? load_half8(xr[t] + 32 * (c + u)) : zero8;
+            for (int t = 0; t < MT; ++t) {
+                b[u][t] = xok[t] ? load_half8(xr[t] + 32 * (c + u)) : zero8;
+                if (NORM) b[u][t] = sg_normalise(b[u][t], load_half8(ln_w + 32 * (c + u) + 8 * g), inv[t]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -93,14 +184,14 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
         if (GATEUP) a2 = SG_LOAD(wu + (int64_t)c * 64);
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            const half8 b = xok[t] ? load_half8(xr[t] + 32 * c) : zero8;
+            half8 b = xok[t] ? load_half8(xr[t] + 32 * c) : zero8;
+            if (NORM) b = sg_normalise(b, load_half8(ln_w + 32 * c + 8 * g), inv[t]);
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[t], 0, 0, 0);
             if (GATEUP) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b, acc2[t], 0, 0, 0);
         }
     }
 
-    // split-K merge across the 4 waves; C layout: lane holds D[n = 4g + r][m = li]
-    __shared__ float sm[WAVES][GATEUP ? 2 : 1][MT][64][4];
+    // split-K merge across the waves; C layout: lane holds D[n = 4g + r][m = li]
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -109,71 +200,172 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
             if (GATEUP) sm[wave][GATEUP ? 1 : 0][t][lane][r] = acc2[t][r];
         }
     __syncthreads();
-    if (wave == 0) {
+    if (wave != 0) return;
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const int m = t * 16 + li;
-            if (m >= M) continue;
+    for (int t = 0; t < MT; ++t) {
+        const int m = t * 16 + li;
+        float s[4], s2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[r] = 0.f;
+            s2[r] = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                s[r] += sm[w][0][t][lane][r];
+                if (GATEUP) s2[r] += sm[w][GATEUP ? 1 : 0][t][lane][r];
+            }
+        }
+        if (MODE == SG_QKV) {
+            // panel -> (section, head, 8-wide rotary block): q and k panels hold rows d0..d0+7 | d0+D/2..d0+D/2+7
+            const int H = rp.H, D = rp.D, half = D >> 1, pph = D >> 4;
+            const int sec = panel / (H * pph), hd = (panel / pph) % H, pp = panel % pph;
+            h16 val[4], oth[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float s = 0.f;
+                val[r] = (h16)s[r];
+                oth[r] = (h16)__shfl_xor((float)val[r], 32, 64);         // rotary partner: lane g <-> g ^ 2 (exact)
+            }
+            if (m >= M) continue;
+            const int slot = (rp.slot0_dev ? *rp.slot0_dev : rp.slot0) + m;
+            half4 out;
+            if (sec == 2) {                                              // v: natural row order, plain copy
 #pragma unroll
-                for (int w = 0; w < WAVES; ++w) s += sm[w][0][t][lane][r];
-                const int n = panel * 16 + 4 * g + r;
-                if (GATEUP) {
-                    float s2 = 0.f;
+                for (int r = 0; r < 4; ++r) out[r] = val[r];
+                h16* dst = rp.v_cache + (int64_t)slot * rp.stride_t + (int64_t)hd * rp.stride_h + 16 * pp + 4 * g;
+                *reinterpret_cast<half4*>(dst) = out;
+                continue;
+            }
+            const bool hi = g >= 2;
+            const int d = 8 * pp + 4 * (g & 1) + (hi ? half : 0);
+            if (sec == 0 || rp.rotate_k) {
+                const int64_t pos = rp.positions[m];
 #pragma unroll
-                    for (int w = 0; w < WAVES; ++w) s2 += sm[w][GATEUP ? 1 : 0][t][lane][r];
-                    const h16 gt = (h16)s, up = (h16)s2;
-                    const float gf = (float)gt;
-                    const h16 act = (h16)(gf / (1.0f + expf(-gf)));
-                    ((h16*)yv)[(int64_t)m * ldy + n] = hmul_rn(act, up);
-                } else if (OUT_F32) {
-                    ((float*)yv)[(int64_t)m * ldy + n] = (float)(h16)s;          // logits.float(): fp16 GEMM, then cast
-                } else {
-                    ((h16*)yv)[(int64_t)m * ldy + n] = (h16)s;
+                for (int r = 0; r < 4; ++r) {
+                    const h16 cs = rp.cosb[pos * D + d + r], sn = rp.sinb[pos * D + d + r];
+                    // (x*cos) + (rotate_half(x)*sin) in fp16: rotate_half = -x2 for the low half, x1 for the high half
+                    const h16 rh = hi ? oth[r] : (h16)(-(float)oth[r]);
+                    out[r] = hadd_rn(hmul_rn(val[r], cs), hmul_rn(rh, sn));
                 }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[r] = val[r];
+            }
+            h16* dst = (sec == 0) ? rp.q_out + ((int64_t)m * H + hd) * D + d
+                                  : rp.k_cache + (int64_t)slot * rp.stride_t + (int64_t)hd * rp.stride_h + d;
+            *reinterpret_cast<half4*>(dst) = out;
+            continue;
+        }
+        if (m >= M) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = panel * 16 + 4 * g + r;
+            if (GATEUP) {
+                const h16 gt = (h16)s[r], up = (h16)s2[r];
+                const float gf = (float)gt;
+                const h16 act = (h16)(gf / (1.0f + expf(-gf)));
+                ((h16*)yv)[(int64_t)m * ldy + n] = hmul_rn(act, up);
+            } else if (MODE == SG_F32) {
+                ((float*)yv)[(int64_t)m * ldy + n] = (float)(h16)s[r];          // logits.float(): fp16 GEMM, then cast
+            } else {
+                h16 o = (h16)s[r];
+                if (resid) o = hadd_rn(resid[(int64_t)m * ldr + n], o);           // residual + hidden, fp16 add
+                ((h16*)yv)[(int64_t)m * ldy + n] = o;
             }
         }
     }
 }
 
-template <int MT, bool GATEUP, bool OUT_F32, int WAVES>
-static void launch_sg_w(const void* wp, const void* wp_up, const void* x, int64_t ldx, void* y, int64_t ldy, int M,
-                        int N, int K, hipStream_t st) {
-    hipLaunchKernelGGL((skinny_gemm_kernel<MT, GATEUP, OUT_F32, WAVES>), dim3(N / 16), dim3(WAVES * 64), 0, st,
-                       (const half8*)wp, (const half8*)wp_up, (const h16*)x, ldx, y, ldy, M, N, K);
+template <int MT, int MODE, bool NORM, int WAVES>
+static void launch_sg_w(const void* wp, const void* wp_up, const void* x, int64_t ldx, const void* ln_w, float eps,
+                        const void* resid, int64_t ldr, void* y, int64_t ldy, int M, int N, int K, const SgRope& rp,
+                        hipStream_t st) {
+    hipLaunchKernelGGL((skinny_gemm_kernel<MT, MODE, NORM, WAVES>), dim3(N / 16), dim3(WAVES * 64), 0, st,
+                       (const half8*)wp, (const half8*)wp_up, (const h16*)x, ldx, (const h16*)ln_w, eps,
+                       (const h16*)resid, ldr, y, ldy, M, N, K, rp);
 }
 
-template <bool GATEUP, bool OUT_F32>
-static int launch_sg(const void* wp, const void* wp_up, const void* x, int64_t ldx, void* y, int64_t ldy, int M, int N,
-                     int K, hipStream_t st) {
+template <int MODE, bool NORM>
+static int launch_sg(const void* wp, const void* wp_up, const void* x, int64_t ldx, const void* ln_w, float eps,
+                     const void* resid, int64_t ldr, void* y, int64_t ldy, int M, int N, int K, const SgRope& rp,
+                     hipStream_t st) {
     // wide variant: few panels and enough k-chunks that every wave still gets >= 2 of them
-    const bool wide = !GATEUP && (N / 16) <= SG_WIDE_MAX_PANELS && (K >> 5) >= 2 * SG_WAVES_WIDE;
+    constexpr bool CAN_WIDE = MODE != SG_GATEUP;
+    const bool wide = CAN_WIDE && (N / 16) <= SG_WIDE_MAX_PANELS && (K >> 5) >= 2 * SG_WAVES_WIDE;
+    constexpr int WW = CAN_WIDE ? SG_WAVES_WIDE : SG_WAVES;
     if (M <= 16) {
-        if (wide) launch_sg_w<1, GATEUP, OUT_F32, GATEUP ? SG_WAVES : SG_WAVES_WIDE>(wp, wp_up, x, ldx, y, ldy, M, N, K, st);
-        else launch_sg_w<1, GATEUP, OUT_F32, SG_WAVES>(wp, wp_up, x, ldx, y, ldy, M, N, K, st);
+        if (wide) launch_sg_w<1, MODE, NORM, WW>(wp, wp_up, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, st);
+        else launch_sg_w<1, MODE, NORM, SG_WAVES>(wp, wp_up, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, st);
     } else {
-        if (wide) launch_sg_w<2, GATEUP, OUT_F32, GATEUP ? SG_WAVES : SG_WAVES_WIDE>(wp, wp_up, x, ldx, y, ldy, M, N, K, st);
-        else launch_sg_w<2, GATEUP, OUT_F32, SG_WAVES>(wp, wp_up, x, ldx, y, ldy, M, N, K, st);
+        if (wide) launch_sg_w<2, MODE, NORM, WW>(wp, wp_up, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, st);
+        else launch_sg_w<2, MODE, NORM, SG_WAVES>(wp, wp_up, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, st);
     }
     TF_LAUNCH_CHECK();
     return TF_OK;
 }
 
+static bool sg_shape_ok(int M, int N, int K, int64_t ldx) {
+    return M >= 1 && M <= 32 && N >= 16 && (N % 16) == 0 && K >= 32 && (K % 32) == 0 && (ldx % 8) == 0;
+}
+
+extern "C" int tf_skinny_gemm_ex(const void* w_packed, const void* x, int64_t ldx, const void* ln_w, float eps,
+                                 const void* resid, int64_t ldr, void* y, int64_t ldy, int M, int N, int K, int out_f32,
+                                 void* stream) {
+    if (!w_packed || !x || !y || !sg_shape_ok(M, N, K, ldx)) return TF_EINVAL;
+    if (out_f32 && resid) return TF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const SgRope rp = {};
+    if (out_f32)
+        return ln_w ? launch_sg<SG_F32, true>(w_packed, nullptr, x, ldx, ln_w, eps, nullptr, 0, y, ldy, M, N, K, rp, st)
+                    : launch_sg<SG_F32, false>(w_packed, nullptr, x, ldx, nullptr, 0.f, nullptr, 0, y, ldy, M, N, K, rp, st);
+    return ln_w ? launch_sg<SG_PLAIN, true>(w_packed, nullptr, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, st)
+                : launch_sg<SG_PLAIN, false>(w_packed, nullptr, x, ldx, nullptr, 0.f, resid, ldr, y, ldy, M, N, K, rp, st);
+}
+
 extern "C" int tf_skinny_gemm(const void* w_packed, const void* x, int64_t ldx, void* y, int64_t ldy, int M, int N,
                               int K, int out_f32, void* stream) {
-    if (!w_packed || !x || !y || M < 1 || M > 32 || N < 16 || (N % 16) || K < 32 || (K % 32)) return TF_EINVAL;
-    if (ldx % 8) return TF_EINVAL;
+    return tf_skinny_gemm_ex(w_packed, x, ldx, nullptr, 0.f, nullptr, 0, y, ldy, M, N, K, out_f32, stream);
+}
+
+extern "C" int tf_skinny_gemm_swiglu_ex(const void* gate_packed, const void* up_packed, const void* x, int64_t ldx,
+                                        const void* ln_w, float eps, void* act, int64_t ldy, int M, int I, int K,
+                                        void* stream) {
+    if (!gate_packed || !up_packed || !x || !act || !sg_shape_ok(M, I, K, ldx)) return TF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    return out_f32 ? launch_sg<false, true>(w_packed, nullptr, x, ldx, y, ldy, M, N, K, st)
-                   : launch_sg<false, false>(w_packed, nullptr, x, ldx, y, ldy, M, N, K, st);
+    const SgRope rp = {};
+    return ln_w ? launch_sg<SG_GATEUP, true>(gate_packed, up_packed, x, ldx, ln_w, eps, nullptr, 0, act, ldy, M, I, K, rp, st)
+                : launch_sg<SG_GATEUP, false>(gate_packed, up_packed, x, ldx, nullptr, 0.f, nullptr, 0, act, ldy, M, I, K,
+                                              rp, st);
 }
 
 extern "C" int tf_skinny_gemm_swiglu(const void* gate_packed, const void* up_packed, const void* x, int64_t ldx,
                                      void* act, int64_t ldy, int M, int I, int K, void* stream) {
-    if (!gate_packed || !up_packed || !x || !act || M < 1 || M > 32 || I < 16 || (I % 16) || K < 32 || (K % 32))
-        return TF_EINVAL;
-    if (ldx % 8) return TF_EINVAL;
-    return launch_sg<true, false>(gate_packed, up_packed, x, ldx, act, ldy, M, I, K, (hipStream_t)stream);
+    return tf_skinny_gemm_swiglu_ex(gate_packed, up_packed, x, ldx, nullptr, 0.f, act, ldy, M, I, K, stream);
+}
+
+extern "C" int tf_skinny_qkv_rope(const void* wqkv_packed, const void* x, int64_t ldx, const void* ln_w, float eps,
+                                  const void* cosb, const void* sinb, const int64_t* positions, void* q_out,
+                                  void* k_cache, void* v_cache, int64_t stride_t, int64_t stride_h, int slot0,
+                                  const int32_t* slot0_dev, int M, int H, int D, int K, int rotate_k, void* stream) {
+    if (!wqkv_packed || !x || !cosb || !sinb || !positions || !q_out || !k_cache || !v_cache) return TF_EINVAL;
+    if (H < 1 || D < 32 || (D % 32) || !sg_shape_ok(M, 3 * H * D, K, ldx)) return TF_EINVAL;
+    if ((stride_t % 4) || (stride_h % 4)) return TF_EINVAL;                          // 8-byte epilogue stores
+    hipStream_t st = (hipStream_t)stream;
+    SgRope rp;
+    rp.cosb = (const h16*)cosb;
+    rp.sinb = (const h16*)sinb;
+    rp.positions = positions;
+    rp.q_out = (h16*)q_out;
+    rp.k_cache = (h16*)k_cache;
+    rp.v_cache = (h16*)v_cache;
+    rp.stride_t = stride_t;
+    rp.stride_h = stride_h;
+    rp.slot0_dev = slot0_dev;
+    rp.slot0 = slot0;
+    rp.H = H;
+    rp.D = D;
+    rp.rotate_k = rotate_k;
+    const int N = 3 * H * D;
+    return ln_w ? launch_sg<SG_QKV, true>(wqkv_packed, nullptr, x, ldx, ln_w, eps, nullptr, 0, nullptr, 0, M, N, K, rp, st)
+                : launch_sg<SG_QKV, false>(wqkv_packed, nullptr, x, ldx, nullptr, 0.f, nullptr, 0, nullptr, 0, M, N, K, rp,
+                                           st);
 }

@@ -150,7 +150,7 @@ class LlamaWeights:
         self.lm_head = PL(self.lm_head)
         if tied:
             self.embed = self.lm_head.w
-        self.wqkv = [PL(w) for w in self.wqkv]
+        self.wqkv = [PL(w, rope=(self.H_local, self.D)) for w in self.wqkv]
         self.wo = [PL(w) for w in self.wo]
         self.wgu = [PL(w, split=2) for w in self.wgu]
         self.wd = [PL(w) for w in self.wd]

@@ -4,9 +4,10 @@ the reference's models/modeling_llama.py: same call signature
 dispatch between full-cache forward, retrieval-cache (spec) forward and the q_len==1 retrieval
 build (:226-238), same numerics.
 
-Per layer the forward is 4 skinny GEMMs (fused qkv, o, fused gate-up, down — hipBLASLt through
-torch) and 5 hand-written kernels: RMSNorm(+residual), RoPE+KV-append, split-KV MFMA attention
-(+merge), SwiGLU.
+A decode-sized forward (<= 32 rows) is 6 launches per layer, all hand-written: qkv GEMM (RMSNorm prologue,
+RoPE + KV-append epilogue), split-KV MFMA attention + merge, o GEMM (+residual), gate|up GEMM (RMSNorm prologue,
+SwiGLU epilogue), down GEMM (+residual).  Prefill chunks (128 rows) run hipBLASLt GEMMs with the stand-alone
+RMSNorm / RoPE-append / SwiGLU kernels and the 128-row block attention.
 """
 import torch
 
@@ -74,36 +75,52 @@ class LlamaForCausalLM:
         streaming = (not spec) and hasattr(kv_cache, "begin_forward")     # host-offloaded KV (test/offloading.py)
         if streaming:
             kv_cache.begin_forward()
+        # decode-sized blocks run the fused kernels: [norm ->] qkv GEMM -> RoPE -> KV append in one launch, the
+        # residual adds in the o / down GEMM epilogues, the post-attention norm in the gate|up GEMM prologue
+        fused = ops.can_fuse(x, W.wqkv[0], W.wo[0], W.wgu[0], W.wd[0], W.lm_head) and W.wqkv[0].wp_rope is not None
         d = None
         for i in range(W.L):
-            if d is None:
-                h = ops.rmsnorm(x, W.ln1[i], W.eps)
-            else:                                       # x += mlp_out of the previous layer, fused into the norm
-                h = ops.rmsnorm(d, W.ln1[i], W.eps, residual=x, sum_out=x)
-            qkv = ops.linear(h, W.wqkv[i])
             if spec:                                    # :226-227  retrieval-cache forward
                 kl, vl = graph_cache.layer_kv(i)
                 assert q_len == graph_cache.gamma + 1, "spec forward takes exactly gamma+1 tokens (cache.py:184-189)"
-                q = ops.rope_append(qkv, self.cos, self.sin, pos, kl, vl, graph_cache.spec_slot, H, D)
-                a = ops.attn_decode(q, kl, vl, graph_cache.real_budget, self.scale)
+                slot, sk = graph_cache.spec_slot, graph_cache.real_budget
             else:                                       # :228-238  full-cache forward
                 kl, vl = kv_cache.layer_kv(i)
                 slot = kv_cache.append_slot(i, q_len)
-                q = ops.rope_append(qkv, self.cos, self.sin, pos, kl, vl, slot, H, D)
+                sk = slot + q_len
+            if fused:
+                q = ops.qkv_rope(x, W.wqkv[i], W.ln1[i], W.eps, self.cos, self.sin, pos, kl, vl, slot, H, D)
+            else:
+                if d is None:
+                    h = ops.rmsnorm(x, W.ln1[i], W.eps)
+                else:                                   # x += mlp_out of the previous layer, fused into the norm
+                    h = ops.rmsnorm(d, W.ln1[i], W.eps, residual=x, sum_out=x)
+                q = ops.rope_append(ops.linear(h, W.wqkv[i]), self.cos, self.sin, pos, kl, vl, slot, H, D)
+            if spec:
+                a = ops.attn_decode(q, kl, vl, sk, self.scale)
+            else:
                 if build:
                     if not graph_cache.init_graph:
                         graph_cache.init_graph_cache(kv_cache, q, i)
                     else:
                         graph_cache.update_graph_cache_retrieval(kv_cache, q, i)
-                a = ops.attn_prefill(q, kl, vl, slot + q_len, self.scale)
+                a = ops.attn_prefill(q, kl, vl, sk, self.scale)
                 if streaming:
                     kv_cache.layer_done(i, slot, q_len)
-            o = ops.linear(a, W.wo[i])
-            h = ops.rmsnorm(o, W.ln2[i], W.eps, residual=x, sum_out=x)       # x += attn_out
-            act = ops.mlp_act(h, W.wgu[i])
-            d = ops.linear(act, W.wd[i])
+            if fused:
+                ops.linear(a, W.wo[i], resid=x, out=x)                               # x += attn_out
+                act = ops.mlp_act(x, W.wgu[i], ln=W.ln2[i], eps=W.eps)
+                ops.linear(act, W.wd[i], resid=x, out=x)                             # x += mlp_out
+            else:
+                o = ops.linear(a, W.wo[i])
+                h = ops.rmsnorm(o, W.ln2[i], W.eps, residual=x, sum_out=x)           # x += attn_out
+                act = ops.mlp_act(h, W.wgu[i])
+                d = ops.linear(act, W.wd[i])
         if streaming:
             kv_cache.end_forward()
-        h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)
-        logits = ops.linear(h, W.lm_head, out_f32=True).unsqueeze(0)               # (1, q, V) fp32  (:408-409)
+        if fused:
+            logits = ops.linear(x, W.lm_head, out_f32=True, ln=W.norm, eps=W.eps).unsqueeze(0)
+        else:
+            h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)
+            logits = ops.linear(h, W.lm_head, out_f32=True).unsqueeze(0)           # (1, q, V) fp32  (:408-409)
         return CausalLMOutput(logits)

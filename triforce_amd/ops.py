@@ -49,12 +49,24 @@ def pack_weight(w):
     return w.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
 
 
+def rope_row_order(H, D, device=None):
+    """Row permutation of a fused [q | k | v] weight for the RoPE epilogue of tf_skinny_qkv_rope: every 16-row panel
+    of the q and k sections holds rows d0..d0+7 and their rotary partners d0+D/2..d0+D/2+7 of one head; v rows keep
+    their order."""
+    assert D % 32 == 0
+    d = torch.arange(D // 2, device=device).view(D // 16, 8)
+    per_head = torch.cat([d, d + D // 2], dim=1).reshape(-1)                     # (D,)
+    qk = (torch.arange(2 * H, device=device).view(-1, 1) * D + per_head.view(1, -1)).reshape(-1)
+    return torch.cat([qk, torch.arange(2 * H * D, 3 * H * D, device=device)])
+
+
 class PackedLinear:
     """A weight matrix with (on a HIP device) its pre-packed copy for the skinny decode GEMM.  ``w`` stays
     available for the >32-row prefill GEMMs (hipBLASLt).  ``split`` = number of equal row blocks that were
-    fused (2 for gate|up) — each block is packed on its own so the SwiGLU kernel can pair them."""
+    fused (2 for gate|up) — each block is packed on its own so the SwiGLU kernel can pair them.  ``rope=(H, D)``
+    marks a fused q|k|v weight: a second packed copy in rotary-pair row order feeds tf_skinny_qkv_rope."""
 
-    def __init__(self, w, split=1, pack=None):
+    def __init__(self, w, split=1, pack=None, rope=None):
         self.w = w
         self.N, self.K = w.shape
         self.split = split
@@ -62,36 +74,77 @@ class PackedLinear:
         ok = pack and (self.N // split) % 16 == 0 and self.K % 32 == 0
         self.parts = [pack_weight(b) for b in w.chunk(split, dim=0)] if ok else None
         self.wp = self.parts[0] if (ok and split == 1) else None
+        self.rope = rope
+        self.wp_rope = None
+        if ok and rope is not None and rope[1] % 32 == 0 and self.N == 3 * rope[0] * rope[1]:
+            self.wp_rope = pack_weight(w[rope_row_order(rope[0], rope[1], w.device)])
 
 
 def _w(w):
     return w.w if isinstance(w, PackedLinear) else w
 
 
-def linear(x, w, out_f32=False):
+def can_fuse(x, *ws):
+    """True when the fused decode kernels apply: HIP tensors, <= 32 rows, every weight packed."""
+    return (x.is_cuda and x.dim() == 2 and x.shape[0] <= SKINNY_MAX_ROWS and x.dtype == _HALF and x.stride(1) == 1
+            and all(isinstance(w, PackedLinear) and w.parts is not None for w in ws))
+
+
+def linear(x, w, out_f32=False, ln=None, eps=0.0, resid=None, out=None):
     """y = x . W^T, fp16 with fp32 accumulation — the reference's nn.Linear / F.linear.  <=32 rows against a
-    PackedLinear run the hand-written weight-streaming kernel; larger blocks (prefill) go to hipBLASLt."""
+    PackedLinear run the hand-written weight-streaming kernel; larger blocks (prefill) go to hipBLASLt.
+    Fused forms of the skinny kernel (only valid when ``can_fuse``): ``ln`` = RMSNorm weight applied to x first
+    (h = ln * fp16(x * rsqrt(mean(x^2)+eps))), ``resid`` = fp16 residual added to the fp16 result, ``out`` = where
+    to write (may be ``resid`` itself)."""
     if isinstance(w, PackedLinear) and w.wp is not None and x.shape[0] <= SKINNY_MAX_ROWS and x.is_cuda:
         assert x.dtype == _HALF and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == w.K
-        y = torch.empty(x.shape[0], w.N, dtype=torch.float32 if out_f32 else _HALF, device=x.device)
-        hip.check(hip.lib().tf_skinny_gemm(_ptr(w.wp), _ptr(x), x.stride(0), _ptr(y), w.N, x.shape[0], w.N, w.K,
-                                           1 if out_f32 else 0, _stream()), "tf_skinny_gemm")
-        return y
+        if out is None:
+            out = torch.empty(x.shape[0], w.N, dtype=torch.float32 if out_f32 else _HALF, device=x.device)
+        assert out.shape == (x.shape[0], w.N) and out.stride(1) == 1
+        if resid is not None:
+            assert resid.shape == out.shape and resid.dtype == _HALF and resid.stride(1) == 1 and not out_f32
+        hip.check(hip.lib().tf_skinny_gemm_ex(_ptr(w.wp), _ptr(x), x.stride(0), _ptr(ln), float(eps), _ptr(resid),
+                                              resid.stride(0) if resid is not None else 0, _ptr(out), out.stride(0),
+                                              x.shape[0], w.N, w.K, 1 if out_f32 else 0, _stream()), "tf_skinny_gemm_ex")
+        return out
+    assert ln is None and resid is None and out is None, "fused linear needs the skinny kernel (ops.can_fuse)"
     y = F.linear(x, _w(w))
     return y.float() if out_f32 else y
 
 
-def mlp_act(h, wgu):
-    """fp16(silu(gate(h))) * up(h) for a fused gate|up weight: one kernel for <=32 rows, GEMM + silu_mul otherwise."""
+def mlp_act(h, wgu, ln=None, eps=0.0):
+    """fp16(silu(gate(h))) * up(h) for a fused gate|up weight: one kernel for <=32 rows (optionally with the
+    RMSNorm of h folded in, ``ln``), GEMM + silu_mul otherwise."""
     if isinstance(wgu, PackedLinear) and wgu.parts is not None and wgu.split == 2 and h.shape[0] <= SKINNY_MAX_ROWS \
             and h.is_cuda:
         I = wgu.N // 2
         act = torch.empty(h.shape[0], I, dtype=_HALF, device=h.device)
-        hip.check(hip.lib().tf_skinny_gemm_swiglu(_ptr(wgu.parts[0]), _ptr(wgu.parts[1]), _ptr(h), h.stride(0),
-                                                  _ptr(act), I, h.shape[0], I, wgu.K, _stream()),
-                  "tf_skinny_gemm_swiglu")
+        hip.check(hip.lib().tf_skinny_gemm_swiglu_ex(_ptr(wgu.parts[0]), _ptr(wgu.parts[1]), _ptr(h), h.stride(0),
+                                                     _ptr(ln), float(eps), _ptr(act), I, h.shape[0], I, wgu.K,
+                                                     _stream()), "tf_skinny_gemm_swiglu_ex")
         return act
+    assert ln is None, "fused mlp_act needs the skinny kernel (ops.can_fuse)"
     return silu_mul(F.linear(h, _w(wgu)))
+
+
+def qkv_rope(x, wqkv, ln, eps, cos, sin, positions, k_layer, v_layer, slot0, H, D, rotate_k=True, slot0_dev=None):
+    """One kernel for [RMSNorm ->] fused q|k|v GEMM -> RoPE -> KV append: x (rows, hidden) is the residual stream
+    (ln = input_layernorm weight, or None when x is already normalised); q (rows,H,D) is returned rotated, the k
+    (rotated unless rotate_k is False) and v rows land in the cache at slot0+i."""
+    _dev(x, ln, cos, sin, positions, k_layer, v_layer, slot0_dev)
+    assert isinstance(wqkv, PackedLinear) and wqkv.wp_rope is not None and wqkv.rope == (H, D)
+    rows = x.shape[0]
+    assert x.dtype == _HALF and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == wqkv.K and rows <= SKINNY_MAX_ROWS
+    assert positions.dtype == torch.int64 and positions.numel() == rows and positions.is_contiguous()
+    assert cos.dtype == _HALF and cos.is_contiguous() and cos.shape[1] == D
+    st, sh = _kv(k_layer)
+    assert _kv(v_layer) == (st, sh)
+    q = torch.empty(rows, H, D, dtype=_HALF, device=x.device)
+    hip.check(hip.lib().tf_skinny_qkv_rope(_ptr(wqkv.wp_rope), _ptr(x), x.stride(0), _ptr(ln), float(eps), _ptr(cos),
+                                           _ptr(sin), _ptr(positions), _ptr(q), _ptr(k_layer), _ptr(v_layer), st, sh,
+                                           int(slot0), _ptr(slot0_dev), rows, H, D, wqkv.K, 1 if rotate_k else 0,
+                                           _stream()), "tf_skinny_qkv_rope")
+    return q
 
 
 def rmsnorm(x, w, eps, residual=None, sum_out=None):
