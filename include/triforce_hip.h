@@ -168,18 +168,23 @@ int tf_skinny_gemm_swiglu(const void* gate_packed, const void* up_packed, const 
  *                  (models/modeling_llama.py:138-143, tensor_op.py:52-64); x is then the residual stream.
  *   resid != NULL: y = fp16(resid + fp16(x . W^T))  (hidden_states = residual + ..., modeling_llama.py:278,284);
  *                  y may alias resid (every element is read and written by the same lane).
+ *   ss_out != NULL (with a fp16 output): every panel also writes sum(y[m][n]^2) over its 16 columns to
+ *                  ss_out[panel * 32 + m]; ss_in != NULL (with ln_w): the norm prologue folds those N/16 partials
+ *                  (of the GEMM that produced x, so K/16 of them) instead of re-reading x — the sum of squares of the
+ *                  residual stream is handed from GEMM to GEMM and x is read exactly once per GEMM.
  * tf_skinny_qkv_rope: fused q|k|v projection + RoPE + KV append (modeling_llama.py:212-238 / tensor_op.py:140-160,
  *                  the work of tf_rope_append in the GEMM epilogue).  The weight must be packed in ROTARY-PAIR row
  *                  order: within the q and k sections every 16-row panel = rows d0..d0+7 and d0+D/2..d0+D/2+7 of one
  *                  head (triforce_amd.ops.rope_row_order); v rows keep their order.  q -> q_out [M][H][D]; k (rotated
  *                  unless rotate_k == 0) and v rows -> cache slot slot0 + m (slot0 read from slot0_dev if non-NULL). */
 int tf_skinny_gemm_ex(const void* w_packed, const void* x, int64_t ldx, const void* ln_w, float eps,
-                      const void* resid, int64_t ldr, void* y, int64_t ldy, int M, int N, int K, int out_f32,
-                      void* stream);
+                      const float* ss_in, const void* resid, int64_t ldr, float* ss_out, void* y, int64_t ldy,
+                      int M, int N, int K, int out_f32, void* stream);
 int tf_skinny_gemm_swiglu_ex(const void* gate_packed, const void* up_packed, const void* x, int64_t ldx,
-                             const void* ln_w, float eps, void* act, int64_t ldy, int M, int I, int K, void* stream);
+                             const void* ln_w, float eps, const float* ss_in, void* act, int64_t ldy,
+                             int M, int I, int K, void* stream);
 int tf_skinny_qkv_rope(const void* wqkv_packed, const void* x, int64_t ldx, const void* ln_w, float eps,
-                       const void* cos, const void* sin, const int64_t* positions, void* q_out,
+                       const float* ss_in, const void* cos, const void* sin, const int64_t* positions, void* q_out,
                        void* k_cache, void* v_cache, int64_t stride_t, int64_t stride_h, int slot0,
                        const int32_t* slot0_dev, int M, int H, int D, int K, int rotate_k, void* stream);
 

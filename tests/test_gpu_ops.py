@@ -550,14 +550,26 @@ def test_skinny_gemm_norm_prologue_and_residual_epilogue(M, N, K):
     # sum of squares) and vs the oracle
     yn = ops.linear(xd, pl, ln=lnd, eps=eps)
     ulp_report("norm prologue vs kernels", yn, ops.linear(ops.rmsnorm(xd, lnd, eps), pl), max_ulp_frac=3e-2, ulps=1, atol=1e-4)
-    ulp_report("norm prologue vs oracle", yn, R.linear(R.rms_norm(x, ln, eps), w), max_ulp_frac=5e-2, ulps=1, atol=1e-4)
+    # (a different fp16 neighbour of a normalised input moves a dot product by up to ~1 ulp on top of the GEMM's own)
+    ulp_report("norm prologue vs oracle", yn, R.linear(R.rms_norm(x, ln, eps), w), max_ulp_frac=5e-2, ulps=2, atol=1e-4)
     if N <= 4096:
         y32 = ops.linear(xd, pl, out_f32=True, ln=lnd, eps=eps)
         assert torch.equal(y32, yn.float())
-    # both at once
+    # both at once, plus the sum-of-squares hand-off: the residual GEMM leaves per-panel sum(y^2), a following norm
+    # prologue that folds those partials must agree with one that re-reads its input
     buf = resd.clone()
-    ops.linear(xd, pl, ln=lnd, eps=eps, resid=buf, out=buf)
+    ss = ops.ss_buffer(N, DEV)
+    ops.linear(xd, pl, ln=lnd, eps=eps, resid=buf, out=buf, ss_out=ss)
     assert torch.equal(buf, resd + yn)
+    rows_ss = ss[:, :M].sum(dim=0)
+    torch.testing.assert_close(rows_ss, (buf.float() ** 2).sum(dim=1), rtol=1e-5, atol=1e-3)
+    if N % 32 == 0 and N <= 11008:
+        w2 = rnd(256, N, seed=214, scale=0.05)
+        ln2 = (1 + 0.1 * rnd(N, seed=215).float()).half().to(DEV)
+        pl2 = ops.PackedLinear(w2.to(DEV))
+        ya = ops.linear(buf, pl2, ln=ln2, eps=eps, ss_in=ss)
+        yb = ops.linear(buf, pl2, ln=ln2, eps=eps)
+        ulp_report("ss hand-off vs two-pass prologue", ya, yb, max_ulp_frac=3e-2, ulps=2, atol=1e-4)
 
 
 @pytest.mark.parametrize("M,I,K", [(1, 3072, 768), (7, 11008, 4096), (18, 1728, 5120)])
@@ -569,10 +581,14 @@ def test_swiglu_norm_prologue(M, I, K):
     pl = ops.PackedLinear(wgu.to(DEV), split=2)
     got = ops.mlp_act(x.to(DEV), pl, ln=ln.to(DEV), eps=eps)
     ref = ops.mlp_act(ops.rmsnorm(x.to(DEV), ln.to(DEV), eps), pl)
+    # vs the stand-alone RMSNorm kernel + fused SwiGLU GEMM: a normalised input landing on the neighbouring fp16 moves
+    # gate / up by ~1 ulp, silu amplifies the gate's share -> a few ulp of the product on a few % of the elements
     d = (got.float() - ref.float()).abs()
-    assert (d > 0).float().mean() < 5e-2 and d.max() < 2e-2, (float((d > 0).float().mean()), float(d.max()))
+    tol = 4 * ref.float().abs() * 2 ** -10 + 2e-3
+    assert (d > 0).float().mean() < 8e-2 and bool((d <= tol).all()), (float((d > 0).float().mean()), float(d.max()))
     h = R.rms_norm(x, ln, eps)
     gu = R.linear(h, wgu)
     want = R.silu_mul(gu[:, :I], gu[:, I:])
     dd = (got.float().cpu() - want.float()).abs()
-    assert dd.max() < 3e-2 and dd.mean() < 2e-4, (float(dd.max()), float(dd.mean()))
+    tolw = 6 * want.float().abs() * 2 ** -10 + 4e-3
+    assert bool((dd <= tolw).all()) and dd.mean() < 5e-4, (float(dd.max()), float(dd.mean()))

@@ -76,7 +76,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
                                                                  const h16* __restrict__ x, int64_t ldx,
                                                                  const h16* __restrict__ ln_w, float eps,
                                                                  const h16* resid, int64_t ldr, void* yv, int64_t ldy,
-                                                                 int M, int N, int K, SgRope rp) {
+                                                                 int M, int N, int K, SgRope rp,
+                                                                 const float* __restrict__ ss_in,
+                                                                 float* __restrict__ ss_out) {
     constexpr bool GATEUP = MODE == SG_GATEUP;
     const int panel = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -122,34 +124,85 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
 #pragma unroll
     for (int t = 0; t < MT; ++t) inv[t] = 1.f;
     if (NORM) {
-        float ss[MT];
-#pragma unroll
-        for (int t = 0; t < MT; ++t) ss[t] = 0.f;
-        for (int c = c0; c < c1; ++c) {
+        float tot[MT];
+        if (ss_in) {
+            // The producer of x (a residual-epilogue GEMM over K/16 panels) left the per-panel sums of squares of
+            // every row: ss_in[panel][32 rows].  Fold them in a fixed order — one round trip instead of a second
+            // pass over x.  Thread (pg, m): partials of panels pg, pg + G, ... of row m; G = threads / 16.
+            constexpr int G = WAVES * 4;
+            const int nparts = K >> 4;
+            const int pg = tid >> 4, m16 = tid & 15;
+            float* red = &sm[0][0][0][0][0];                            // reuse the merge buffer: [MT][G][16] floats
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                const half8 v = xok[t] ? load_half8(xr[t] + 32 * c) : zero8;
+                float part = 0.f;
+                for (int p0 = pg; p0 < nparts; p0 += 8 * G) {
+                    float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float f = (float)v[e];
-                    ss[t] = fmaf(f, f, ss[t]);
+                    for (int j = 0; j < 8; ++j) {
+                        const int p = p0 + j * G;
+                        v[j] = (p < nparts) ? ss_in[(int64_t)p * 32 + t * 16 + m16] : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) part += v[j];
                 }
+                red[(t * G + pg) * 16 + m16] = part;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                tot[t] = 0.f;
+                for (int j = 0; j < G; ++j) tot[t] += red[(t * G + j) * 16 + li];
+            }
+            __syncthreads();                                             // red aliases the split-K merge buffer
+        } else {
+            float ss[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) ss[t] = 0.f;
+            int cc = c0;
+            for (; cc + 8 <= c1; cc += 8) {                             // 8 independent loads per row tile in flight
+                half8 v[8][MT];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) v[j][t] = xok[t] ? load_half8(xr[t] + 32 * (cc + j)) : zero8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float f = (float)v[j][t][e];
+                            ss[t] = fmaf(f, f, ss[t]);
+                        }
+            }
+            for (; cc < c1; ++cc) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const half8 v = xok[t] ? load_half8(xr[t] + 32 * cc) : zero8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = (float)v[e];
+                        ss[t] = fmaf(f, f, ss[t]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                ss[t] += __shfl_xor(ss[t], 16, 64);
+                ss[t] += __shfl_xor(ss[t], 32, 64);
+                if (g == 0) sm_ss[wave][t][li] = ss[t];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                tot[t] = 0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) tot[t] += sm_ss[w][t][li];
             }
         }
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            ss[t] += __shfl_xor(ss[t], 16, 64);
-            ss[t] += __shfl_xor(ss[t], 32, 64);
-            if (g == 0) sm_ss[wave][t][li] = ss[t];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            float tot = 0.f;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) tot += sm_ss[w][t][li];
-            inv[t] = 1.0f / sqrtf(tot / (float)K + eps);
-        }
+        for (int t = 0; t < MT; ++t) inv[t] = 1.0f / sqrtf(tot[t] / (float)K + eps);
     }
 
     int c = c0;
@@ -255,9 +308,14 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
             *reinterpret_cast<half4*>(dst) = out;
             continue;
         }
-        if (m >= M) continue;
+        const bool row_ok = m < M;
+        if (!row_ok && !(MODE == SG_PLAIN && ss_out)) continue;
+        if (!row_ok) {                               // keep the wave converged for the shuffles below
+            s2[0] = s2[1] = s2[2] = s2[3] = 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            if (!row_ok) break;
             const int n = panel * 16 + 4 * g + r;
             if (GATEUP) {
                 const h16 gt = (h16)s[r], up = (h16)s2[r];
@@ -270,7 +328,14 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
                 h16 o = (h16)s[r];
                 if (resid) o = hadd_rn(resid[(int64_t)m * ldr + n], o);           // residual + hidden, fp16 add
                 ((h16*)yv)[(int64_t)m * ldy + n] = o;
+                s2[r] = (float)o;
             }
+        }
+        if (MODE == SG_PLAIN && ss_out) {            // this panel's share of sum(y^2) per row, for the next norm prologue
+            float q = s2[0] * s2[0] + s2[1] * s2[1] + s2[2] * s2[2] + s2[3] * s2[3];
+            q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (g == 0) ss_out[(int64_t)panel * 32 + m] = q;
         }
     }
 }
@@ -278,26 +343,26 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
 template <int MT, int MODE, bool NORM, int WAVES>
 static void launch_sg_w(const void* wp, const void* wp_up, const void* x, int64_t ldx, const void* ln_w, float eps,
                         const void* resid, int64_t ldr, void* y, int64_t ldy, int M, int N, int K, const SgRope& rp,
-                        hipStream_t st) {
+                        const float* ss_in, float* ss_out, hipStream_t st) {
     hipLaunchKernelGGL((skinny_gemm_kernel<MT, MODE, NORM, WAVES>), dim3(N / 16), dim3(WAVES * 64), 0, st,
                        (const half8*)wp, (const half8*)wp_up, (const h16*)x, ldx, (const h16*)ln_w, eps,
-                       (const h16*)resid, ldr, y, ldy, M, N, K, rp);
+                       (const h16*)resid, ldr, y, ldy, M, N, K, rp, ss_in, ss_out);
 }
 
 template <int MODE, bool NORM>
 static int launch_sg(const void* wp, const void* wp_up, const void* x, int64_t ldx, const void* ln_w, float eps,
                      const void* resid, int64_t ldr, void* y, int64_t ldy, int M, int N, int K, const SgRope& rp,
-                     hipStream_t st) {
+                     hipStream_t st, const float* ss_in = nullptr, float* ss_out = nullptr) {
     // wide variant: few panels and enough k-chunks that every wave still gets >= 2 of them
     constexpr bool CAN_WIDE = MODE != SG_GATEUP;
     const bool wide = CAN_WIDE && (N / 16) <= SG_WIDE_MAX_PANELS && (K >> 5) >= 2 * SG_WAVES_WIDE;
     constexpr int WW = CAN_WIDE ? SG_WAVES_WIDE : SG_WAVES;
     if (M <= 16) {
-        if (wide) launch_sg_w<1, MODE, NORM, WW>(wp, wp_up, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, st);
-        else launch_sg_w<1, MODE, NORM, SG_WAVES>(wp, wp_up, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, st);
+        if (wide) launch_sg_w<1, MODE, NORM, WW>(wp, wp_up, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, ss_in, ss_out, st);
+        else launch_sg_w<1, MODE, NORM, SG_WAVES>(wp, wp_up, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, ss_in, ss_out, st);
     } else {
-        if (wide) launch_sg_w<2, MODE, NORM, WW>(wp, wp_up, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, st);
-        else launch_sg_w<2, MODE, NORM, SG_WAVES>(wp, wp_up, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, st);
+        if (wide) launch_sg_w<2, MODE, NORM, WW>(wp, wp_up, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, ss_in, ss_out, st);
+        else launch_sg_w<2, MODE, NORM, SG_WAVES>(wp, wp_up, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, ss_in, ss_out, st);
     }
     TF_LAUNCH_CHECK();
     return TF_OK;
@@ -308,46 +373,50 @@ static bool sg_shape_ok(int M, int N, int K, int64_t ldx) {
 }
 
 extern "C" int tf_skinny_gemm_ex(const void* w_packed, const void* x, int64_t ldx, const void* ln_w, float eps,
-                                 const void* resid, int64_t ldr, void* y, int64_t ldy, int M, int N, int K, int out_f32,
-                                 void* stream) {
+                                 const float* ss_in, const void* resid, int64_t ldr, float* ss_out, void* y,
+                                 int64_t ldy, int M, int N, int K, int out_f32, void* stream) {
     if (!w_packed || !x || !y || !sg_shape_ok(M, N, K, ldx)) return TF_EINVAL;
-    if (out_f32 && resid) return TF_EINVAL;
+    if ((out_f32 && (resid || ss_out)) || (ss_in && !ln_w)) return TF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const SgRope rp = {};
     if (out_f32)
-        return ln_w ? launch_sg<SG_F32, true>(w_packed, nullptr, x, ldx, ln_w, eps, nullptr, 0, y, ldy, M, N, K, rp, st)
+        return ln_w ? launch_sg<SG_F32, true>(w_packed, nullptr, x, ldx, ln_w, eps, nullptr, 0, y, ldy, M, N, K, rp, st, ss_in)
                     : launch_sg<SG_F32, false>(w_packed, nullptr, x, ldx, nullptr, 0.f, nullptr, 0, y, ldy, M, N, K, rp, st);
-    return ln_w ? launch_sg<SG_PLAIN, true>(w_packed, nullptr, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, st)
-                : launch_sg<SG_PLAIN, false>(w_packed, nullptr, x, ldx, nullptr, 0.f, resid, ldr, y, ldy, M, N, K, rp, st);
+    return ln_w ? launch_sg<SG_PLAIN, true>(w_packed, nullptr, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, st, ss_in,
+                                            ss_out)
+                : launch_sg<SG_PLAIN, false>(w_packed, nullptr, x, ldx, nullptr, 0.f, resid, ldr, y, ldy, M, N, K, rp, st,
+                                             nullptr, ss_out);
 }
 
 extern "C" int tf_skinny_gemm(const void* w_packed, const void* x, int64_t ldx, void* y, int64_t ldy, int M, int N,
                               int K, int out_f32, void* stream) {
-    return tf_skinny_gemm_ex(w_packed, x, ldx, nullptr, 0.f, nullptr, 0, y, ldy, M, N, K, out_f32, stream);
+    return tf_skinny_gemm_ex(w_packed, x, ldx, nullptr, 0.f, nullptr, nullptr, 0, nullptr, y, ldy, M, N, K, out_f32, stream);
 }
 
 extern "C" int tf_skinny_gemm_swiglu_ex(const void* gate_packed, const void* up_packed, const void* x, int64_t ldx,
-                                        const void* ln_w, float eps, void* act, int64_t ldy, int M, int I, int K,
-                                        void* stream) {
-    if (!gate_packed || !up_packed || !x || !act || !sg_shape_ok(M, I, K, ldx)) return TF_EINVAL;
+                                        const void* ln_w, float eps, const float* ss_in, void* act, int64_t ldy, int M,
+                                        int I, int K, void* stream) {
+    if (!gate_packed || !up_packed || !x || !act || !sg_shape_ok(M, I, K, ldx) || (ss_in && !ln_w)) return TF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const SgRope rp = {};
-    return ln_w ? launch_sg<SG_GATEUP, true>(gate_packed, up_packed, x, ldx, ln_w, eps, nullptr, 0, act, ldy, M, I, K, rp, st)
+    return ln_w ? launch_sg<SG_GATEUP, true>(gate_packed, up_packed, x, ldx, ln_w, eps, nullptr, 0, act, ldy, M, I, K, rp, st,
+                                             ss_in)
                 : launch_sg<SG_GATEUP, false>(gate_packed, up_packed, x, ldx, nullptr, 0.f, nullptr, 0, act, ldy, M, I, K,
                                               rp, st);
 }
 
 extern "C" int tf_skinny_gemm_swiglu(const void* gate_packed, const void* up_packed, const void* x, int64_t ldx,
                                      void* act, int64_t ldy, int M, int I, int K, void* stream) {
-    return tf_skinny_gemm_swiglu_ex(gate_packed, up_packed, x, ldx, nullptr, 0.f, act, ldy, M, I, K, stream);
+    return tf_skinny_gemm_swiglu_ex(gate_packed, up_packed, x, ldx, nullptr, 0.f, nullptr, act, ldy, M, I, K, stream);
 }
 
 extern "C" int tf_skinny_qkv_rope(const void* wqkv_packed, const void* x, int64_t ldx, const void* ln_w, float eps,
-                                  const void* cosb, const void* sinb, const int64_t* positions, void* q_out,
-                                  void* k_cache, void* v_cache, int64_t stride_t, int64_t stride_h, int slot0,
-                                  const int32_t* slot0_dev, int M, int H, int D, int K, int rotate_k, void* stream) {
+                                  const float* ss_in, const void* cosb, const void* sinb, const int64_t* positions,
+                                  void* q_out, void* k_cache, void* v_cache, int64_t stride_t, int64_t stride_h,
+                                  int slot0, const int32_t* slot0_dev, int M, int H, int D, int K, int rotate_k,
+                                  void* stream) {
     if (!wqkv_packed || !x || !cosb || !sinb || !positions || !q_out || !k_cache || !v_cache) return TF_EINVAL;
-    if (H < 1 || D < 32 || (D % 32) || !sg_shape_ok(M, 3 * H * D, K, ldx)) return TF_EINVAL;
+    if (H < 1 || D < 32 || (D % 32) || !sg_shape_ok(M, 3 * H * D, K, ldx) || (ss_in && !ln_w)) return TF_EINVAL;
     if ((stride_t % 4) || (stride_h % 4)) return TF_EINVAL;                          // 8-byte epilogue stores
     hipStream_t st = (hipStream_t)stream;
     SgRope rp;
@@ -365,7 +434,8 @@ extern "C" int tf_skinny_qkv_rope(const void* wqkv_packed, const void* x, int64_
     rp.D = D;
     rp.rotate_k = rotate_k;
     const int N = 3 * H * D;
-    return ln_w ? launch_sg<SG_QKV, true>(wqkv_packed, nullptr, x, ldx, ln_w, eps, nullptr, 0, nullptr, 0, M, N, K, rp, st)
+    return ln_w ? launch_sg<SG_QKV, true>(wqkv_packed, nullptr, x, ldx, ln_w, eps, nullptr, 0, nullptr, 0, M, N, K, rp, st,
+                                          ss_in)
                 : launch_sg<SG_QKV, false>(wqkv_packed, nullptr, x, ldx, nullptr, 0.f, nullptr, 0, nullptr, 0, M, N, K, rp,
                                            st);
 }

@@ -33,10 +33,10 @@ SIGNATURES = {
     "tf_rope_append": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "tf_silu_mul": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "tf_skinny_gemm": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
-    "tf_skinny_gemm_ex": (_i32, [_vp, _vp, _i64, _vp, _f32, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
-    "tf_skinny_gemm_swiglu_ex": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _vp, _i64, _i32, _i32, _i32, _vp]),
-    "tf_skinny_qkv_rope": (_i32, [_vp, _vp, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i32,
-                                  _i32, _i32, _i32, _i32, _vp]),
+    "tf_skinny_gemm_ex": (_i32, [_vp, _vp, _i64, _vp, _f32, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "tf_skinny_gemm_swiglu_ex": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "tf_skinny_qkv_rope": (_i32, [_vp, _vp, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp,
+                                  _i32, _i32, _i32, _i32, _i32, _vp]),
     "tf_skinny_gemm_swiglu": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
     "tf_topp_probs": (_i32, [_vp, _vp, _i32, _i32, _f32, _f32, _vp]),
     "tf_sample_inverse_cdf": (_i32, [_vp, _vp, _vp, _i32, _vp]),

@@ -77,7 +77,10 @@ class LlamaForCausalLM:
             kv_cache.begin_forward()
         # decode-sized blocks run the fused kernels: [norm ->] qkv GEMM -> RoPE -> KV append in one launch, the
         # residual adds in the o / down GEMM epilogues, the post-attention norm in the gate|up GEMM prologue
-        fused = ops.can_fuse(x, W.wqkv[0], W.wo[0], W.wgu[0], W.wd[0], W.lm_head) and W.wqkv[0].wp_rope is not None
+        mode = ops.FUSE_MODE if (ops.can_fuse(x, W.wqkv[0], W.wo[0], W.wgu[0], W.wd[0], W.lm_head)
+                                 and W.wqkv[0].wp_rope is not None) else "none"
+        fused = mode in ("all", "all2")
+        ss = ops.ss_buffer(x.shape[1], x.device) if mode == "all" else None     # sum(x^2) hand-off between GEMMs
         d = None
         for i in range(W.L):
             if spec:                                    # :226-227  retrieval-cache forward
@@ -89,13 +92,17 @@ class LlamaForCausalLM:
                 slot = kv_cache.append_slot(i, q_len)
                 sk = slot + q_len
             if fused:
-                q = ops.qkv_rope(x, W.wqkv[i], W.ln1[i], W.eps, self.cos, self.sin, pos, kl, vl, slot, H, D)
+                q = ops.qkv_rope(x, W.wqkv[i], W.ln1[i], W.eps, self.cos, self.sin, pos, kl, vl, slot, H, D,
+                                 ss_in=ss if i > 0 else None)
             else:
                 if d is None:
                     h = ops.rmsnorm(x, W.ln1[i], W.eps)
                 else:                                   # x += mlp_out of the previous layer, fused into the norm
                     h = ops.rmsnorm(d, W.ln1[i], W.eps, residual=x, sum_out=x)
-                q = ops.rope_append(ops.linear(h, W.wqkv[i]), self.cos, self.sin, pos, kl, vl, slot, H, D)
+                if mode == "rope":
+                    q = ops.qkv_rope(h, W.wqkv[i], None, 0.0, self.cos, self.sin, pos, kl, vl, slot, H, D)
+                else:
+                    q = ops.rope_append(ops.linear(h, W.wqkv[i]), self.cos, self.sin, pos, kl, vl, slot, H, D)
             if spec:
                 a = ops.attn_decode(q, kl, vl, sk, self.scale)
             else:
@@ -108,9 +115,9 @@ class LlamaForCausalLM:
                 if streaming:
                     kv_cache.layer_done(i, slot, q_len)
             if fused:
-                ops.linear(a, W.wo[i], resid=x, out=x)                               # x += attn_out
-                act = ops.mlp_act(x, W.wgu[i], ln=W.ln2[i], eps=W.eps)
-                ops.linear(act, W.wd[i], resid=x, out=x)                             # x += mlp_out
+                ops.linear(a, W.wo[i], resid=x, out=x, ss_out=ss)                               # x += attn_out
+                act = ops.mlp_act(x, W.wgu[i], ln=W.ln2[i], eps=W.eps, ss_in=ss)
+                ops.linear(act, W.wd[i], resid=x, out=x, ss_out=ss)                             # x += mlp_out
             else:
                 o = ops.linear(a, W.wo[i])
                 h = ops.rmsnorm(o, W.ln2[i], W.eps, residual=x, sum_out=x)           # x += attn_out
@@ -119,7 +126,7 @@ class LlamaForCausalLM:
         if streaming:
             kv_cache.end_forward()
         if fused:
-            logits = ops.linear(x, W.lm_head, out_f32=True, ln=W.norm, eps=W.eps).unsqueeze(0)
+            logits = ops.linear(x, W.lm_head, out_f32=True, ln=W.norm, eps=W.eps, ss_in=ss).unsqueeze(0)
         else:
             h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)
             logits = ops.linear(h, W.lm_head, out_f32=True).unsqueeze(0)           # (1, q, V) fp32  (:408-409)

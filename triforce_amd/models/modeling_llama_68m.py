@@ -70,7 +70,10 @@ class LlamaForCausalLM:
             slot0 = c.seq_len
             kv_len = slot0 + q_len
             pos = torch.arange(slot0, slot0 + q_len, dtype=torch.long, device=self.device)
-        fused = ops.can_fuse(x, W.wqkv[0], W.wo[0], W.wgu[0], W.wd[0], W.lm_head) and W.wqkv[0].wp_rope is not None
+        mode = ops.FUSE_MODE if (ops.can_fuse(x, W.wqkv[0], W.wo[0], W.wgu[0], W.wd[0], W.lm_head)
+                                 and W.wqkv[0].wp_rope is not None) else "none"
+        fused = mode in ("all", "all2")
+        ss = ops.ss_buffer(x.shape[1], x.device) if mode == "all" else None     # sum(x^2) hand-off between GEMMs
         d = None
         for i in range(W.L):
             kl, vl = c.layer_kv(i)
@@ -78,26 +81,30 @@ class LlamaForCausalLM:
                 c.append_slot(i, q_len)
             if fused:
                 q = ops.qkv_rope(x, W.wqkv[i], W.ln1[i], W.eps, self.cos, self.sin, pos, kl, vl, slot0, H, D,
-                                 rotate_k=False)
+                                 rotate_k=False, ss_in=ss if i > 0 else None)
             else:
                 if d is None:
                     h = ops.rmsnorm(x, W.ln1[i], W.eps)
                 else:
                     h = ops.rmsnorm(d, W.ln1[i], W.eps, residual=x, sum_out=x)
-                q = ops.rope_append(ops.linear(h, W.wqkv[i]), self.cos, self.sin, pos, kl, vl, slot0, H, D,
-                                    rotate_k=False)
+                if mode == "rope":
+                    q = ops.qkv_rope(h, W.wqkv[i], None, 0.0, self.cos, self.sin, pos, kl, vl, slot0, H, D,
+                                     rotate_k=False)
+                else:
+                    q = ops.rope_append(ops.linear(h, W.wqkv[i]), self.cos, self.sin, pos, kl, vl, slot0, H, D,
+                                        rotate_k=False)
             a = ops.attn_rope_on_read(q, kl, vl, self.cos, self.sin, kv_len, self.scale)
             if fused:
-                ops.linear(a, W.wo[i], resid=x, out=x)
-                act = ops.mlp_act(x, W.wgu[i], ln=W.ln2[i], eps=W.eps)
-                ops.linear(act, W.wd[i], resid=x, out=x)
+                ops.linear(a, W.wo[i], resid=x, out=x, ss_out=ss)
+                act = ops.mlp_act(x, W.wgu[i], ln=W.ln2[i], eps=W.eps, ss_in=ss)
+                ops.linear(act, W.wd[i], resid=x, out=x, ss_out=ss)
             else:
                 o = ops.linear(a, W.wo[i])
                 h = ops.rmsnorm(o, W.ln2[i], W.eps, residual=x, sum_out=x)
                 act = ops.mlp_act(h, W.wgu[i])
                 d = ops.linear(act, W.wd[i])
         if fused:
-            logits = ops.linear(x, W.lm_head, out_f32=True, ln=W.norm, eps=W.eps).unsqueeze(0)
+            logits = ops.linear(x, W.lm_head, out_f32=True, ln=W.norm, eps=W.eps, ss_in=ss).unsqueeze(0)
         else:
             h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)
             logits = ops.linear(h, W.lm_head, out_f32=True).unsqueeze(0)

@@ -40,6 +40,11 @@ def _kv(t):
 
 # ------------------------------------------------------------------------------------------
 SKINNY_MAX_ROWS = 32
+# Decode-layer fusion level (A/B switch, env TRIFORCE_FUSE): "all" = norm prologues fed by the GEMM-to-GEMM
+# sum-of-squares hand-off + residual / RoPE epilogues (6 launches per layer); "all2" = same but every norm prologue
+# re-reads x; "rope" = only the RoPE + KV-append epilogue; "none" = one launch per op (9 per layer).
+import os as _os
+FUSE_MODE = _os.environ.get("TRIFORCE_FUSE", "all")
 
 
 def pack_weight(w):
@@ -90,12 +95,13 @@ def can_fuse(x, *ws):
             and all(isinstance(w, PackedLinear) and w.parts is not None for w in ws))
 
 
-def linear(x, w, out_f32=False, ln=None, eps=0.0, resid=None, out=None):
+def linear(x, w, out_f32=False, ln=None, eps=0.0, resid=None, out=None, ss_in=None, ss_out=None):
     """y = x . W^T, fp16 with fp32 accumulation — the reference's nn.Linear / F.linear.  <=32 rows against a
     PackedLinear run the hand-written weight-streaming kernel; larger blocks (prefill) go to hipBLASLt.
     Fused forms of the skinny kernel (only valid when ``can_fuse``): ``ln`` = RMSNorm weight applied to x first
     (h = ln * fp16(x * rsqrt(mean(x^2)+eps))), ``resid`` = fp16 residual added to the fp16 result, ``out`` = where
-    to write (may be ``resid`` itself)."""
+    to write (may be ``resid`` itself); ``ss_out`` (N/16, 32) fp32 receives the per-panel sums of squares of the
+    output rows and ``ss_in`` feeds such partials of x to the norm prologue (see ``ss_buffer``)."""
     if isinstance(w, PackedLinear) and w.wp is not None and x.shape[0] <= SKINNY_MAX_ROWS and x.is_cuda:
         assert x.dtype == _HALF and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == w.K
         if out is None:
@@ -103,16 +109,22 @@ def linear(x, w, out_f32=False, ln=None, eps=0.0, resid=None, out=None):
         assert out.shape == (x.shape[0], w.N) and out.stride(1) == 1
         if resid is not None:
             assert resid.shape == out.shape and resid.dtype == _HALF and resid.stride(1) == 1 and not out_f32
-        hip.check(hip.lib().tf_skinny_gemm_ex(_ptr(w.wp), _ptr(x), x.stride(0), _ptr(ln), float(eps), _ptr(resid),
-                                              resid.stride(0) if resid is not None else 0, _ptr(out), out.stride(0),
-                                              x.shape[0], w.N, w.K, 1 if out_f32 else 0, _stream()), "tf_skinny_gemm_ex")
+        if ss_in is not None:
+            assert ss_in.dtype == torch.float32 and ss_in.shape == (w.K // 16, 32) and ss_in.is_contiguous()
+        if ss_out is not None:
+            assert ss_out.dtype == torch.float32 and ss_out.shape == (w.N // 16, 32) and ss_out.is_contiguous()
+        hip.check(hip.lib().tf_skinny_gemm_ex(_ptr(w.wp), _ptr(x), x.stride(0), _ptr(ln), float(eps), _ptr(ss_in),
+                                              _ptr(resid), resid.stride(0) if resid is not None else 0, _ptr(ss_out),
+                                              _ptr(out), out.stride(0), x.shape[0], w.N, w.K, 1 if out_f32 else 0,
+                                              _stream()), "tf_skinny_gemm_ex")
         return out
-    assert ln is None and resid is None and out is None, "fused linear needs the skinny kernel (ops.can_fuse)"
+    assert ln is None and resid is None and out is None and ss_in is None and ss_out is None, \
+        "fused linear needs the skinny kernel (ops.can_fuse)"
     y = F.linear(x, _w(w))
     return y.float() if out_f32 else y
 
 
-def mlp_act(h, wgu, ln=None, eps=0.0):
+def mlp_act(h, wgu, ln=None, eps=0.0, ss_in=None):
     """fp16(silu(gate(h))) * up(h) for a fused gate|up weight: one kernel for <=32 rows (optionally with the
     RMSNorm of h folded in, ``ln``), GEMM + silu_mul otherwise."""
     if isinstance(wgu, PackedLinear) and wgu.parts is not None and wgu.split == 2 and h.shape[0] <= SKINNY_MAX_ROWS \
@@ -120,14 +132,20 @@ def mlp_act(h, wgu, ln=None, eps=0.0):
         I = wgu.N // 2
         act = torch.empty(h.shape[0], I, dtype=_HALF, device=h.device)
         hip.check(hip.lib().tf_skinny_gemm_swiglu_ex(_ptr(wgu.parts[0]), _ptr(wgu.parts[1]), _ptr(h), h.stride(0),
-                                                     _ptr(ln), float(eps), _ptr(act), I, h.shape[0], I, wgu.K,
-                                                     _stream()), "tf_skinny_gemm_swiglu_ex")
+                                                     _ptr(ln), float(eps), _ptr(ss_in), _ptr(act), I, h.shape[0], I,
+                                                     wgu.K, _stream()), "tf_skinny_gemm_swiglu_ex")
         return act
     assert ln is None, "fused mlp_act needs the skinny kernel (ops.can_fuse)"
     return silu_mul(F.linear(h, _w(wgu)))
 
 
-def qkv_rope(x, wqkv, ln, eps, cos, sin, positions, k_layer, v_layer, slot0, H, D, rotate_k=True, slot0_dev=None):
+def ss_buffer(hidden, device):
+    """Hand-off buffer for the residual stream's per-panel sums of squares (hidden/16 panels x 32 rows, fp32)."""
+    return torch.empty(hidden // 16, 32, dtype=torch.float32, device=device)
+
+
+def qkv_rope(x, wqkv, ln, eps, cos, sin, positions, k_layer, v_layer, slot0, H, D, rotate_k=True, slot0_dev=None,
+             ss_in=None):
     """One kernel for [RMSNorm ->] fused q|k|v GEMM -> RoPE -> KV append: x (rows, hidden) is the residual stream
     (ln = input_layernorm weight, or None when x is already normalised); q (rows,H,D) is returned rotated, the k
     (rotated unless rotate_k is False) and v rows land in the cache at slot0+i."""
@@ -140,8 +158,9 @@ def qkv_rope(x, wqkv, ln, eps, cos, sin, positions, k_layer, v_layer, slot0, H, 
     st, sh = _kv(k_layer)
     assert _kv(v_layer) == (st, sh)
     q = torch.empty(rows, H, D, dtype=_HALF, device=x.device)
-    hip.check(hip.lib().tf_skinny_qkv_rope(_ptr(wqkv.wp_rope), _ptr(x), x.stride(0), _ptr(ln), float(eps), _ptr(cos),
-                                           _ptr(sin), _ptr(positions), _ptr(q), _ptr(k_layer), _ptr(v_layer), st, sh,
+    hip.check(hip.lib().tf_skinny_qkv_rope(_ptr(wqkv.wp_rope), _ptr(x), x.stride(0), _ptr(ln), float(eps), _ptr(ss_in),
+                                           _ptr(cos), _ptr(sin), _ptr(positions), _ptr(q), _ptr(k_layer), _ptr(v_layer),
+                                           st, sh,
                                            int(slot0), _ptr(slot0_dev), rows, H, D, wqkv.K, 1 if rotate_k else 0,
                                            _stream()), "tf_skinny_qkv_rope")
     return q
