@@ -551,7 +551,9 @@ def test_skinny_gemm_norm_prologue_and_residual_epilogue(M, N, K):
     yn = ops.linear(xd, pl, ln=lnd, eps=eps)
     ulp_report("norm prologue vs kernels", yn, ops.linear(ops.rmsnorm(xd, lnd, eps), pl), max_ulp_frac=3e-2, ulps=1, atol=1e-4)
     # (a different fp16 neighbour of a normalised input moves a dot product by up to ~1 ulp on top of the GEMM's own)
-    ulp_report("norm prologue vs oracle", yn, R.linear(R.rms_norm(x, ln, eps), w), max_ulp_frac=5e-2, ulps=2, atol=1e-4)
+    #  — and the absolute error of a K-term fp16 dot product does not shrink with a small result (cancellation):
+    #  atol = one fp16 spacing at the typical |y| ~ 2..4
+    ulp_report("norm prologue vs oracle", yn, R.linear(R.rms_norm(x, ln, eps), w), max_ulp_frac=5e-2, ulps=2, atol=2e-3)
     if N <= 4096:
         y32 = ops.linear(xd, pl, out_f32=True, ln=lnd, eps=eps)
         assert torch.equal(y32, yn.float())
