@@ -194,6 +194,33 @@ def cpu_baseline(args, tokens_per_step, inner_per_step):
             "step_seconds_est": round(step, 2)}
 
 
+def projection(stages, gamma, overhead_us, pairs=((0.5, 0.9), (0.7, 0.9), (0.9, 0.95))):
+    """NOT a measurement: tokens/s the measured stage latencies would give if the models agreed like trained ones do.
+    Random-init weights make the 68M draft and the target disagree (acceptance ~1 %), which pins every step at the
+    worst case (gamma inner iterations, ~1 token).  For a (draft->retrieval, retrieval->target) per-token acceptance
+    pair the loop of utils/decoding.py:70-141,163-223 is simulated 20 000 times and priced with
+    step = target_verify + k * (retrieval_verify + draft) + draft + measured per-step overhead."""
+    import random
+    rnd = random.Random(0)
+    out = {}
+    for a1, a2 in pairs:
+        tok = t_us = 0.0
+        for _ in range(20000):
+            n = k = 0
+            while n < gamma:                                  # Middle_Spec: +2 tokens on accept, +1 on reject
+                k += 1
+                n += 2 if rnd.random() < a1 else 1
+            count = 0
+            while count < n and rnd.random() < a2:            # accepted prefix, then the resample / bonus token
+                count += 1
+            tok += count + 1
+            t_us += stages["target_verify_us"] + k * (stages["retrieval_verify_us"] + stages["draft_step_us"]) \
+                + stages["draft_step_us"] + overhead_us
+        out[f"draft_acc={a1},retrieval_acc={a2}"] = {"tokens_per_s": round(tok / t_us * 1e6, 1),
+                                                     "tokens_per_step": round(tok / 20000, 2)}
+    return out
+
+
 def pmc_traffic(alg_bytes, H, D):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, KiB units, FETCH_SIZE doubled for gfx950 — MI355X_MICROARCH.md §HBM).
@@ -301,6 +328,11 @@ def main():
         "kv_seq_len": ge.engine.kv_cache.seq_len,
         "roofline": roof,
     }
+    modelled = stages["target_verify_us"] + inner_per_step * (stages["retrieval_verify_us"] + stages["draft_step_us"]) \
+        + stages["draft_step_us"]
+    overhead_us = max(0.0, seconds / args.steps * 1e6 - modelled)
+    result["step_overhead_us"] = round(overhead_us, 1)          # accept kernels, cache fix-ups, host round trips
+    result["projection_not_measured"] = projection(stages, args.gamma, overhead_us)
     if not args.no_cpu_baseline:
         inner_iters = (run.inner_iters - inner0) / max(args.steps, 1)   # 68M drafts + retrieval verifies per step
         try:

@@ -408,6 +408,8 @@ extern "C" int tf_middle_accept(const float* p, const float* q_d, int64_t* token
 // ------------------------------------------------------------------------------------------------
 #define TOPP_THREADS 1024
 #define TOPP_EPT 32
+#define TOPP_BLOCK_BITS 12       // bits decided with block-wide reductions before the single-wave finish
+#define TOPP_CAND_CAP 2048       // undecided entries the finishing wave can hold (32 per lane)
 
 __device__ __forceinline__ float block_sum_1024(float v, float* sm, int tid) {
     v = wave_sum(v);
@@ -435,6 +437,9 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_probs_kernel(const float* _
                                                                   float inv_temperature_is_div, float temperature,
                                                                   float top_p) {
     __shared__ float sm[TOPP_THREADS / 64];
+    __shared__ int sm_i[TOPP_THREADS / 64];
+    __shared__ float sm_cand[TOPP_CAND_CAP];
+    __shared__ unsigned sm_v;
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* lr = logits + (int64_t)row * V;
     float* pr = probs + (int64_t)row * V;
@@ -458,15 +463,85 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_probs_kernel(const float* _
     }
     const float Z = block_sum_1024(zl, sm, tid);
     const float tau = top_p * Z;
-    // v = largest bit pattern with G(v) > tau  (G(0) = Z > tau for top_p < 1; e >= 0 so patterns order like values)
+    // v = largest bit pattern with G(v) > tau  (G(0) = Z > tau for top_p < 1; e >= 0 so patterns order like values).
+    // e <= 1.0f = 0x3F800000, so bit 30 is never part of the answer.  The first TOPP_BLOCK_BITS bits are decided with
+    // block-wide reductions (two barriers each, ~2 us per bit); by then the open interval (v, v + 2^(bit+1)) holds a few
+    // hundred of the 32000 entries, which are compacted into LDS and finished by ONE wave with shuffle reductions only
+    // (31 block-wide steps cost 67 us per call — a third of a 68M draft step).
     unsigned v = 0u;
-    for (int bit = 30; bit >= 0; --bit) {
+    int bit = 29;
+    for (; bit > 29 - TOPP_BLOCK_BITS; --bit) {
         const unsigned cand = v | (1u << bit);
         float g = 0.f;
 #pragma unroll
         for (int s = 0; s < TOPP_EPT; ++s) g += (__float_as_uint(e[s]) > cand) ? e[s] : 0.f;
         g = block_sum_1024(g, sm, tid);
         if (g > tau) v = cand;
+    }
+    {
+        const unsigned span = 1u << (bit + 1);               // remaining candidates: v | x, x < span
+        float gh = 0.f;
+        int cnt = 0;
+#pragma unroll
+        for (int s = 0; s < TOPP_EPT; ++s) {
+            const unsigned b = __float_as_uint(e[s]);
+            if (b - v >= span && b > v) gh += e[s];          // above every remaining candidate
+            else if (b > v) ++cnt;                           // undecided: v < b < v + span
+        }
+        const float Ghigh = block_sum_1024(gh, sm, tid);
+        // exclusive prefix of cnt over the block (wave scan + wave totals)
+        int inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int n = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += n;
+        }
+        __syncthreads();
+        if (lane == 63) sm_i[wave] = inc;
+        __syncthreads();
+        int before = inc - cnt, total = 0;
+#pragma unroll
+        for (int w = 0; w < TOPP_THREADS / 64; ++w) {
+            const int t = sm_i[w];
+            if (w < wave) before += t;
+            total += t;
+        }
+        if (total <= TOPP_CAND_CAP) {                        // block-uniform
+#pragma unroll
+            for (int s = 0; s < TOPP_EPT; ++s) {
+                const unsigned b = __float_as_uint(e[s]);
+                if (b > v && b - v < span) sm_cand[before++] = e[s];
+            }
+            __syncthreads();
+            if (wave == 0) {
+                float x[TOPP_CAND_CAP / 64];
+#pragma unroll
+                for (int j = 0; j < TOPP_CAND_CAP / 64; ++j) {
+                    const int i = lane + 64 * j;
+                    x[j] = (i < total) ? sm_cand[i] : 0.f;   // pattern 0 is never > cand
+                }
+                for (int b2 = bit; b2 >= 0; --b2) {
+                    const unsigned cand = v | (1u << b2);
+                    float g = 0.f;
+#pragma unroll
+                    for (int j = 0; j < TOPP_CAND_CAP / 64; ++j) g += (__float_as_uint(x[j]) > cand) ? x[j] : 0.f;
+                    g = Ghigh + wave_sum(g);
+                    if (g > tau) v = cand;
+                }
+                if (lane == 0) sm_v = v;
+            }
+            __syncthreads();
+            v = sm_v;
+        } else {                                             // degenerate rows (huge tie groups): stay block-wide
+            for (; bit >= 0; --bit) {
+                const unsigned cand = v | (1u << bit);
+                float g = 0.f;
+#pragma unroll
+                for (int s = 0; s < TOPP_EPT; ++s) g += (__float_as_uint(e[s]) > cand) ? e[s] : 0.f;
+                g = block_sum_1024(g, sm, tid);
+                if (g > tau) v = cand;
+            }
+        }
     }
     const unsigned u = v + 1u;                       // smallest pattern with G(u) <= tau
     float gl = 0.f, tl = 0.f;
