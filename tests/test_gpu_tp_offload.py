@@ -116,6 +116,23 @@ def test_tp_graphs_equal_eager():
     assert eager[3]["tokens"] == graphed[3]["tokens"] and eager[3]["counts"] == graphed[3]["counts"]
 
 
+def test_tp_segment_graphs_equal_eager(monkeypatch):
+    """The multi-rank default: the retrieval verify as 2L+1 collective-free hipGraph segments with the all-reduces
+    issued eagerly between them (forced here with one rank, where the all-reduce is the identity) == eager."""
+    _pg()
+    monkeypatch.setenv("TRIFORCE_TP_SEGMENTS", "1")
+    g = Hh.load_golden("small_gamma6")
+    L = g["tcfg"]["num_hidden_layers"]
+    seg_llm = _build(g, on_chip=L, graphs=True)
+    assert seg_llm._verify_graph is None and seg_llm._verify_segments is not None
+    assert len(seg_llm._verify_segments["graphs"]) == 2 * L
+    seg = _run(seg_llm, g)
+    monkeypatch.delenv("TRIFORCE_TP_SEGMENTS")
+    eager = _run(_build(g, on_chip=L), g)
+    assert torch.equal(eager[0], seg[0]) and torch.equal(eager[2], seg[2])
+    assert eager[3]["tokens"] == seg[3]["tokens"] and eager[3]["counts"] == seg[3]["counts"]
+
+
 def test_single_gpu_offloading_cache_equals_resident_cache():
     """test/offloading.py path: OffloadingFlashSimpleCache (all KV in pinned host memory, streamed per forward)
     must reproduce the on-chip FlashSimpleCache run bit for bit — same kernels, the data only travels."""

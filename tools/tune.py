@@ -56,7 +56,7 @@ for (sq, sk, H, tagk) in ([] if only_gemm else [(8, 124936, 32, "attn_target"), 
     kvs = [(torch.randn(H, sk, 128, generator=g, device=DEV, dtype=torch.float16),
             torch.randn(H, sk, 128, generator=g, device=DEV, dtype=torch.float16)) for _ in range(2 if sk > 10000 else 12)]
     q = torch.randn(sq, H, 128, generator=g, device=DEV, dtype=torch.float16)
-    for ns in ([None, 16, 32] if sk > 10000 else [None, 4, 8, 16]):
+    for ns in ([None, 16, 64, 128] if sk > 10000 else [None, 8, 16, 32]):
         us = timeit([(lambda kv=kv: ops.attn_decode(q, kv[0], kv[1], sk, 0.08837890625, nsplit=ns)) for kv in kvs], iters=24)
         res[f"{tagk}_ns{ns}"] = {"us": round(us, 2), "GBps": round(2 * sk * H * 128 * 2 / us / 1e3, 1)}
     del kvs

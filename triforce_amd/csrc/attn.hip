@@ -22,6 +22,9 @@
 #include "common.h"
 
 #define NEG_BIG (-1.0e30f)
+#ifndef TF_ATTN_DEPTH
+#define TF_ATTN_DEPTH 2        // KV tiles in flight per wave in the split-KV kernel (3 = 24 KiB; A/B in tools/tune.py)
+#endif
 
 template <int D, int QT>
 struct AttnState {
@@ -166,6 +169,24 @@ __global__ __launch_bounds__(256) void attn_split_kernel(
     const h16* kbase = k + (int64_t)h * stride_h;
     const h16* vbase = v + (int64_t)h * stride_h;
 
+#if TF_ATTN_DEPTH == 3
+    // three tiles deep (24 KiB in flight per wave): tile t+8 is requested before tile t goes to the matrix core
+    half8 ka[NC], va_[NC], kb[NC], vb[NC], kc[NC], vc[NC];
+    int t = t_begin + wave;
+    if (t < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t, sk, li, g, ka, va_);
+    if (t + 4 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t + 4, sk, li, g, kb, vb);
+    while (t < t_end) {
+        if (t + 8 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t + 8, sk, li, g, kc, vc);
+        attn_tile<D, QT>(st, ka, va_, sel0, sel1, t, sk, sq, scale, li, g);
+        if (t + 4 >= t_end) break;
+        if (t + 12 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t + 12, sk, li, g, ka, va_);
+        attn_tile<D, QT>(st, kb, vb, sel0, sel1, t + 4, sk, sq, scale, li, g);
+        if (t + 8 >= t_end) break;
+        if (t + 16 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t + 16, sk, li, g, kb, vb);
+        attn_tile<D, QT>(st, kc, vc, sel0, sel1, t + 8, sk, sq, scale, li, g);
+        t += 12;
+    }
+#else
     // two tiles deep: the loads of tile t+4 are in flight while tile t is on the matrix core
     half8 ka[NC], va_[NC], kb[NC], vb[NC];
     int t = t_begin + wave;
@@ -180,6 +201,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(
         attn_tile<D, QT>(st, kb, vb, sel0, sel1, t1, sk, sq, scale, li, g);
         t = t2;
     }
+#endif
 
     // ---- merge the 4 waves of this split through LDS, one q-tile at a time ----
     __shared__ float sm_o[4][16][D + 1];

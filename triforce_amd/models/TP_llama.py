@@ -141,9 +141,10 @@ class DistributedLlama:
             dist.all_reduce(t, dist.ReduceOp.SUM)
         return t
 
-    def _layer(self, i, x, d, pos, kl, vl, slot, sk, q_len, retrieval_build=False, tree=None):
-        """One decoder layer on this rank's shard.  x: residual stream (updated in place), d: pending MLP output
-        of the previous layer (None for layer 0).  Returns the (all-reduced) MLP output of this layer."""
+    def _attn_half(self, i, x, d, pos, kl, vl, slot, sk, retrieval_build=False, tree=None, out=None, slot_dev=None,
+                   sk_dev=None):
+        """Attention block of layer i on this rank's shard up to (not including) the all-reduce: returns the partial
+        o_proj output.  x: residual stream (updated in place with the pending MLP output d of the previous layer)."""
         W = self.weights
         Hl, D = W.H_local, W.D
         if d is None:
@@ -151,18 +152,31 @@ class DistributedLlama:
         else:
             h = ops.rmsnorm(d, W.ln1[i], W.eps, residual=x, sum_out=x)
         qkv = ops.linear(h, W.wqkv[i])
-        q = ops.rope_append(qkv, self.cos_cache, self.sin_cache, pos, kl, vl, slot, Hl, D)
+        q = ops.rope_append(qkv, self.cos_cache, self.sin_cache, pos, kl, vl, slot, Hl, D, slot0_dev=slot_dev)
         if retrieval_build:                               # tensor_op.py:161-162
             self.retrieval_cache.init_graph_cache((kl, vl), q, i)
-        if tree is None:
+        if sk_dev is not None:                            # captured form: slot / key count live in device memory
+            a = ops.attn_decode(q, kl, vl, sk, self.scale, sk_dev=sk_dev)
+        elif tree is None:
             a = ops.attn_prefill(q, kl, vl, sk, self.scale)
         else:                                             # tensor_op.py:171,265: SDPA, scale 1/sqrt(D) in fp32
             bits, row0, tree_start = tree
             a = ops.attn_tree(q, kl, vl, sk, self.tree_scale, bits, tree_start, mask_row0=row0)
-        o = self._all_reduce(ops.linear(a, W.wo[i]))                        # tensor_op.py:176-179
+        return ops.linear(a, W.wo[i]) if out is None else ops.linear(a, W.wo[i], out=out)
+
+    def _mlp_half(self, i, x, o, out=None):
+        """MLP block of layer i up to the all-reduce: x += o (all-reduced attention output), returns the partial
+        down_proj output."""
+        W = self.weights
         h = ops.rmsnorm(o, W.ln2[i], W.eps, residual=x, sum_out=x)
         act = ops.mlp_act(h, W.wgu[i])
-        return self._all_reduce(ops.linear(act, W.wd[i]))                   # tensor_op.py:353-359
+        return ops.linear(act, W.wd[i]) if out is None else ops.linear(act, W.wd[i], out=out)
+
+    def _layer(self, i, x, d, pos, kl, vl, slot, sk, q_len, retrieval_build=False, tree=None):
+        """One decoder layer on this rank's shard.  x: residual stream (updated in place), d: pending MLP output
+        of the previous layer (None for layer 0).  Returns the (all-reduced) MLP output of this layer."""
+        o = self._all_reduce(self._attn_half(i, x, d, pos, kl, vl, slot, sk, retrieval_build, tree))   # tensor_op.py:176-179
+        return self._all_reduce(self._mlp_half(i, x, o))                                               # tensor_op.py:353-359
 
     def _finish(self, x, d):
         W = self.weights
@@ -178,6 +192,9 @@ class DistributedLlama:
         tree = None if attention_mask is None else self._tree_mask(attention_mask, S, q_len)
         if S + q_len > kvc.max_budget:
             raise IndexError(f"KV cache overflow: {S}+{q_len} > {kvc.max_budget}")
+        seg = getattr(self, "_target_segments", {}).get(q_len)
+        if seg is not None and position_ids is None and attention_mask is None and retrieval_cache is None:
+            return self._inference_segments(seg, input_ids)
         if position_ids is None:
             position_ids = (S + torch.arange(q_len, dtype=torch.long, device=self.device)).unsqueeze(0)
         pos = position_ids.reshape(-1).contiguous()
@@ -249,11 +266,14 @@ class DistributedLlama:
         utils/graph_infer.py:143-152; the reference runs them eagerly in the TP path, TP_llama.py:117-132) are
         always captured — they contain no collective.  The retrieval verify can be captured INCLUDING its RCCL
         all-reduces (the reference could not, README.md:58); that is on by default only for world_size == 1 and
-        opt-in (TRIFORCE_TP_GRAPHS=1) for more ranks until it has been validated on a multi-GPU node."""
+        opt-in (TRIFORCE_TP_GRAPHS=1) for more ranks until it has been validated on a multi-GPU node.  With more
+        ranks the default is the collective-free segment form (`_capture_verify_segments`; TRIFORCE_TP_SEGMENTS=0
+        turns it off, =1 with one rank forces it for testing)."""
         from ..utils.graph_infer import _capture
         gamma = self.gamma if gamma is None else gamma
         if capture_verify is None:
-            capture_verify = self.world_size == 1 or os.environ.get("TRIFORCE_TP_GRAPHS") == "1"
+            capture_verify = (self.world_size == 1 and os.environ.get("TRIFORCE_TP_SEGMENTS") != "1") \
+                or os.environ.get("TRIFORCE_TP_GRAPHS") == "1"
         self._mempool = torch.cuda.graphs.graph_pool_handle()
         self._draft_graphs = {}
         for off in range(gamma + 3):
@@ -262,14 +282,121 @@ class DistributedLlama:
                                   self._mempool, 3)
             self._draft_graphs[off] = (graph, ids, out)
         self._verify_graph = None
-        if capture_verify and self.retrieval_cache is not None:
+        self._verify_segments = None
+        if self.retrieval_cache is not None and capture_verify:
             ids = torch.zeros((1, gamma + 1), dtype=torch.long, device=self.device)
             pos = torch.arange(gamma + 1, device=self.device).unsqueeze(0)
             T, P = self.temperature, self.top_p
             graph, out = _capture(lambda a, b: norm_logits(self.retrieval_inference(a, b)[0], temperature=T, top_k=-1,
                                                            top_p=P), (ids, pos), self._mempool, 3)
             self._verify_graph = (graph, ids, pos, out, T, P)
+        elif self.retrieval_cache is not None and os.environ.get("TRIFORCE_TP_SEGMENTS", "1") == "1":
+            self._verify_segments = self._capture_verify_segments(gamma)
+        self._target_segments = {}
+        if not capture_verify and os.environ.get("TRIFORCE_TP_SEGMENTS", "1") == "1" \
+                and self.on_chip_layers == self.num_layers and self.retrieval_cache is not None:
+            for q_len in (gamma + 1, gamma + 2):          # the target verifies [next, t1..t_g2], g2 in {gamma, gamma+1}
+                self._target_segments[q_len] = self._capture_target_segments(q_len)
         self.reset()
+
+    def _capture_verify_segments(self, gamma):
+        """world_size > 1: the retrieval verify as 2L+1 collective-free hipGraph segments with the two all-reduces of
+        every layer issued eagerly between them.  In eager mode a TP forward is host-launch-bound (~9 short kernels +
+        2 RCCL calls per layer); replaying segments leaves 2 graph launches + 2 RCCL calls per layer on the host and
+        does NOT depend on RCCL being capturable (the whole-forward graph, TRIFORCE_TP_GRAPHS=1, does)."""
+        from ..utils.graph_infer import _capture
+        W, rc, L = self.weights, self.retrieval_cache, self.num_layers
+        q_len = gamma + 1
+        dev, hid = self.device, self.hidden_size
+        st = dict(ids=torch.zeros((1, q_len), dtype=torch.long, device=dev),
+                  pos=torch.arange(q_len, device=dev, dtype=torch.long),
+                  x=torch.zeros(q_len, hid, dtype=torch.float16, device=dev),
+                  o=torch.zeros(q_len, hid, dtype=torch.float16, device=dev),
+                  d=torch.zeros(q_len, hid, dtype=torch.float16, device=dev))
+        T, P = self.temperature, self.top_p
+
+        def seg_attn(i):
+            def run():
+                if i == 0:
+                    st["x"].copy_(self.embed_tokens[st["ids"].reshape(-1)])
+                kl, vl = rc.layer_kv(i)
+                self._attn_half(i, st["x"], None if i == 0 else st["d"], st["pos"], kl, vl, rc.spec_slot, rc.real_budget,
+                                out=st["o"])
+                return st["o"]
+            return run
+
+        def seg_mlp(i):
+            def run():
+                self._mlp_half(i, st["x"], st["o"], out=st["d"])
+                return st["d"]
+            return run
+
+        def seg_finish():
+            return norm_logits(self._finish(st["x"], st["d"])[0], temperature=T, top_k=-1, top_p=P)
+
+        graphs = []
+        for i in range(L):
+            graphs.append((_capture(seg_attn(i), (), self._mempool, 2)[0], st["o"]))
+            graphs.append((_capture(seg_mlp(i), (), self._mempool, 2)[0], st["d"]))
+        gfin, out = _capture(seg_finish, (), self._mempool, 2)
+        return dict(graphs=graphs, finish=gfin, out=out, st=st, T=T, P=P)
+
+    def _capture_target_segments(self, q_len):
+        """The target verify over the full (HBM-resident) KV cache in the same collective-free segment form.  The
+        cache length changes every step, so the append slot and the key count are read from device memory
+        (tf_rope_append slot0_dev, tf_attn_decode sk_dev) and the launch is sized by the cache capacity."""
+        from ..utils.graph_infer import _capture
+        kvc, L = self.kv_cache, self.num_layers
+        dev, hid = self.device, self.hidden_size
+        st = dict(ids=torch.zeros((1, q_len), dtype=torch.long, device=dev),
+                  pos=torch.arange(q_len, device=dev, dtype=torch.long),
+                  base=torch.arange(q_len, device=dev, dtype=torch.long),
+                  slot=torch.zeros(1, dtype=torch.int32, device=dev),
+                  sk=torch.full((1,), q_len, dtype=torch.int32, device=dev),
+                  x=torch.zeros(q_len, hid, dtype=torch.float16, device=dev),
+                  o=torch.zeros(q_len, hid, dtype=torch.float16, device=dev),
+                  d=torch.zeros(q_len, hid, dtype=torch.float16, device=dev))
+
+        def seg_attn(i):
+            def run():
+                if i == 0:
+                    st["x"].copy_(self.embed_tokens[st["ids"].reshape(-1)])
+                kl, vl = kvc.layer_kv(i)
+                self._attn_half(i, st["x"], None if i == 0 else st["d"], st["pos"], kl, vl, 0, kvc.max_budget,
+                                out=st["o"], slot_dev=st["slot"], sk_dev=st["sk"])
+                return st["o"]
+            return run
+
+        def seg_mlp(i):
+            def run():
+                self._mlp_half(i, st["x"], st["o"], out=st["d"])
+                return st["d"]
+            return run
+
+        graphs = []
+        for i in range(L):
+            graphs.append((_capture(seg_attn(i), (), self._mempool, 2)[0], st["o"]))
+            graphs.append((_capture(seg_mlp(i), (), self._mempool, 2)[0], st["d"]))
+        gfin, out = _capture(lambda: self._finish(st["x"], st["d"]), (), self._mempool, 2)
+        return dict(graphs=graphs, finish=gfin, out=out, st=st)
+
+    def _inference_segments(self, seg, input_ids):
+        kvc, S, q_len = self.kv_cache, self.kv_cache.seq_len, input_ids.shape[1]
+        st = seg["st"]
+        st["ids"].copy_(input_ids)
+        torch.add(st["base"], S, out=st["pos"])
+        st["slot"].fill_(S)
+        st["sk"].fill_(S + q_len)
+        for graph, buf in seg["graphs"]:
+            graph.replay()
+            self._all_reduce(buf)
+        seg["finish"].replay()
+        tail = self.retrieval_cache
+        if tail is not None and S >= self.prefill_len:    # device mirror of the generated rows, all layers at once
+            ops.kv_copy_rows(kvc.k, tail.tail_k, S, S - self.prefill_len, q_len)
+            ops.kv_copy_rows(kvc.v, tail.tail_v, S, S - self.prefill_len, q_len)
+        kvc.seq_len = S + q_len
+        return seg["out"].clone()
 
     @torch.inference_mode()
     def draft_run(self, input_ids, gamma_offset: int = 0, probs=True, temperature=0.6, top_p=0.9):
@@ -320,5 +447,14 @@ class DistributedLlama:
             pos.copy_(position_ids)
             graph.replay()
             return out.clone()
+        vs = getattr(self, "_verify_segments", None)
+        if vs is not None and (temperature, top_p) == (vs["T"], vs["P"]):
+            vs["st"]["ids"].copy_(input_ids)
+            vs["st"]["pos"].copy_(position_ids.reshape(-1))
+            for graph, buf in vs["graphs"]:
+                graph.replay()
+                self._all_reduce(buf)
+            vs["finish"].replay()
+            return vs["out"].clone()
         logits = self.retrieval_inference(input_ids, position_ids)
         return norm_logits(logits[0], temperature=temperature, top_k=-1, top_p=top_p)
