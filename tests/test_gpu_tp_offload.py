@@ -103,34 +103,46 @@ def test_gamma16_two_query_tiles():
     assert Hh.common_prefix(res["tokens"], g["ar_tokens"]) >= 12
 
 
-def test_tp_graphs_equal_eager():
-    """Captured draft steps + captured retrieval verify (world 1: RCCL calls are no-ops) == the eager engine."""
+@pytest.mark.parametrize("form", ["whole", "segments"])
+def test_tp_graphs_equal_eager(form, monkeypatch):
+    """Captured draft steps + captured retrieval verify + captured target verify (device-side cache length), in the
+    whole-forward form and in the collective-free segment form (the multi-rank fallback; with one rank the RCCL
+    calls are no-ops) == the eager engine."""
+    from tests.test_gpu_e2e import _logit_check
     _pg()
+    monkeypatch.setenv("TRIFORCE_TP_GRAPHS", form)
     g = Hh.load_golden("small_gamma6")
     L = g["tcfg"]["num_hidden_layers"]
-    eager = _run(_build(g, on_chip=L), g)
     graphed_llm = _build(g, on_chip=L, graphs=True)
-    assert graphed_llm._verify_graph is not None and len(graphed_llm._draft_graphs) == g["gamma"] + 3
+    assert graphed_llm.graph_form == form and len(graphed_llm._draft_graphs) == g["gamma"] + 3
+    assert sorted(graphed_llm._target_caps) == [g["gamma"] + 1, g["gamma"] + 2]
+    if form == "segments":
+        assert len(graphed_llm._verify_cap["graphs"]) == 2 * L + 1
     graphed = _run(graphed_llm, g)
-    assert torch.equal(eager[0], graphed[0]) and torch.equal(eager[2], graphed[2])
-    assert eager[3]["tokens"] == graphed[3]["tokens"] and eager[3]["counts"] == graphed[3]["counts"]
+    monkeypatch.setenv("TRIFORCE_TP_GRAPHS", "0")
+    eager_llm = _build(g, on_chip=L, graphs=True)
+    assert eager_llm.graph_form == "eager" and not eager_llm._target_caps
+    eager = _run(eager_llm, g)
+    assert torch.equal(eager[0], graphed[0]) and torch.equal(eager[1], graphed[1])
+    # the captured target verify sizes its KV splits by the cache capacity, the eager one by the live length:
+    # same math, different fp32 summation order
+    _logit_check(f"{form}: captured target verify", graphed[2], eager[2])
+    assert Hh.common_prefix(eager[3]["tokens"], graphed[3]["tokens"]) >= 12
 
 
-def test_tp_segment_graphs_equal_eager(monkeypatch):
-    """The multi-rank default: the retrieval verify as 2L+1 collective-free hipGraph segments with the all-reduces
-    issued eagerly between them (forced here with one rank, where the all-reduce is the identity) == eager."""
+def test_tp_auto_mode_single_rank_is_whole_graph(monkeypatch):
     _pg()
-    monkeypatch.setenv("TRIFORCE_TP_SEGMENTS", "1")
+    monkeypatch.delenv("TRIFORCE_TP_GRAPHS", raising=False)
     g = Hh.load_golden("small_gamma6")
-    L = g["tcfg"]["num_hidden_layers"]
-    seg_llm = _build(g, on_chip=L, graphs=True)
-    assert seg_llm._verify_graph is None and seg_llm._verify_segments is not None
-    assert len(seg_llm._verify_segments["graphs"]) == 2 * L
-    seg = _run(seg_llm, g)
-    monkeypatch.delenv("TRIFORCE_TP_SEGMENTS")
-    eager = _run(_build(g, on_chip=L), g)
-    assert torch.equal(eager[0], seg[0]) and torch.equal(eager[2], seg[2])
-    assert eager[3]["tokens"] == seg[3]["tokens"] and eager[3]["counts"] == seg[3]["counts"]
+    llm = _build(g, on_chip=g["tcfg"]["num_hidden_layers"], graphs=True)
+    assert llm.graph_form == "whole"
+    # the probe used by the multi-rank auto mode: capture + one replay checked against the eager forward
+    llm.reset()
+    prompt = Hh.prompt_of(g).to(DEV)
+    llm.prefill(prompt[:, :-1])
+    llm.build_retrieval_cache(prompt[:, -1:])
+    assert llm._try_whole(g["gamma"] + 1, "retrieval", False) is not None
+    assert llm._try_whole(g["gamma"] + 1, "target", False) is not None
 
 
 def test_single_gpu_offloading_cache_equals_resident_cache():

@@ -192,9 +192,9 @@ class DistributedLlama:
         tree = None if attention_mask is None else self._tree_mask(attention_mask, S, q_len)
         if S + q_len > kvc.max_budget:
             raise IndexError(f"KV cache overflow: {S}+{q_len} > {kvc.max_budget}")
-        seg = getattr(self, "_target_segments", {}).get(q_len)
-        if seg is not None and position_ids is None and attention_mask is None and retrieval_cache is None:
-            return self._inference_segments(seg, input_ids)
+        cap = getattr(self, "_target_caps", {}).get(q_len)
+        if cap is not None and position_ids is None and attention_mask is None and retrieval_cache is None:
+            return self._inference_captured(cap, input_ids)
         if position_ids is None:
             position_ids = (S + torch.arange(q_len, dtype=torch.long, device=self.device)).unsqueeze(0)
         pos = position_ids.reshape(-1).contiguous()
@@ -260,143 +260,188 @@ class DistributedLlama:
         return self.inference(input_ids=input_ids, retrieval_cache=self.retrieval_cache)
 
     # ---------------------------------------------------------------------------------------
+    # hipGraph capture.  A decode-sized TP forward is ~9 short kernels + 2 RCCL calls per layer: launched eagerly it is
+    # host-bound (the reference runs it that way and notes that NCCL could not be captured on its hardware,
+    # README.md:58).  Three forms, selected by TRIFORCE_TP_GRAPHS:
+    #   "whole"    one graph per forward INCLUDING the RCCL all-reduces (PyTorch-ROCm captures RCCL >= 2.9.6)
+    #   "segments" 2L+1 collective-free graphs per forward, the all-reduces issued eagerly between them
+    #   "0"        eager
+    #   "auto"     (default) world_size == 1: whole.  More ranks: try whole, replay it once against the eager forward
+    #              on a probe input, agree across ranks (all-reduce MIN of the verdict) and fall back to segments when
+    #              capture raised or the replay disagreed.
+    # The target verify is captured too (all layers HBM-resident): its append slot and key count live in device
+    # memory (tf_rope_append slot0_dev, tf_attn_decode sk_dev), the launch is sized by the cache capacity.
+    # ---------------------------------------------------------------------------------------
+    def _stage_buffers(self, q_len):
+        dev, hid = self.device, self.hidden_size
+        return dict(ids=torch.zeros((1, q_len), dtype=torch.long, device=dev),
+                    pos=torch.arange(q_len, device=dev, dtype=torch.long),
+                    base=torch.arange(q_len, device=dev, dtype=torch.long),
+                    slot=torch.zeros(1, dtype=torch.int32, device=dev),
+                    sk=torch.full((1,), q_len, dtype=torch.int32, device=dev),
+                    x=torch.zeros(q_len, hid, dtype=torch.float16, device=dev),
+                    o=torch.zeros(q_len, hid, dtype=torch.float16, device=dev),
+                    d=torch.zeros(q_len, hid, dtype=torch.float16, device=dev))
+
+    def _stages(self, st, kind):
+        """The forward as a list of collective-free stages [(fn, buffer to all-reduce afterwards | None)] on static
+        buffers.  kind "retrieval": gamma+1 tokens over the retrieval cache -> probabilities;  kind "target": a verify
+        block over the full cache at the device-resident length -> logits."""
+        L = self.num_layers
+        rc, kvc = self.retrieval_cache, self.kv_cache
+
+        def attn(i):
+            def run():
+                if i == 0:
+                    st["x"].copy_(self.embed_tokens[st["ids"].reshape(-1)])
+                d = None if i == 0 else st["d"]
+                if kind == "retrieval":
+                    kl, vl = rc.layer_kv(i)
+                    self._attn_half(i, st["x"], d, st["pos"], kl, vl, rc.spec_slot, rc.real_budget, out=st["o"])
+                else:
+                    kl, vl = kvc.layer_kv(i)
+                    self._attn_half(i, st["x"], d, st["pos"], kl, vl, 0, kvc.max_budget, out=st["o"],
+                                    slot_dev=st["slot"], sk_dev=st["sk"])
+                return st["o"]
+            return run
+
+        def mlp(i):
+            def run():
+                return self._mlp_half(i, st["x"], st["o"], out=st["d"])
+            return run
+
+        def finish():
+            logits = self._finish(st["x"], st["d"])
+            if kind == "retrieval":
+                return norm_logits(logits[0], temperature=self.temperature, top_k=-1, top_p=self.top_p)
+            return logits
+
+        stages = []
+        for i in range(L):
+            stages.append((attn(i), st["o"]))
+            stages.append((mlp(i), st["d"]))
+        stages.append((finish, None))
+        return stages
+
+    def _capture_forward(self, q_len, kind, form):
+        from ..utils.graph_infer import _capture
+        st = self._stage_buffers(q_len)
+        stages = self._stages(st, kind)
+        if form == "whole":
+            def run_all():
+                out = None
+                for fn, buf in stages:
+                    out = fn()
+                    if buf is not None:
+                        self._all_reduce(buf)
+                return out
+            graph, out = _capture(run_all, (), self._mempool, 3)
+            return dict(form="whole", graph=graph, out=out, st=st, T=self.temperature, P=self.top_p)
+        graphs = []
+        out = None
+        for fn, buf in stages:
+            g, out = _capture(fn, (), self._mempool, 2)
+            graphs.append((g, buf))
+        return dict(form="segments", graphs=graphs, out=out, st=st, T=self.temperature, P=self.top_p)
+
+    def _replay(self, cap):
+        if cap["form"] == "whole":
+            cap["graph"].replay()
+        else:
+            for g, buf in cap["graphs"]:
+                g.replay()
+                if buf is not None:
+                    self._all_reduce(buf)
+        return cap["out"].clone()
+
+    def _agree(self, ok):
+        """Same verdict on every rank (a capture that failed on one rank must be dropped by all)."""
+        if self.world_size == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(t, dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def _try_whole(self, q_len, kind, verbose):
+        """Capture a whole-forward graph and check one replay against the eager forward on a probe input."""
+        cap, ok = None, True
+        try:
+            cap = self._capture_forward(q_len, kind, "whole")
+            ids = torch.full((1, q_len), 7, dtype=torch.long, device=self.device)
+            if kind == "retrieval":
+                S = self.kv_cache.seq_len
+                pos = torch.arange(S, S + q_len, device=self.device).unsqueeze(0)
+                want = norm_logits(self.retrieval_inference(ids, pos)[0], temperature=self.temperature, top_k=-1,
+                                   top_p=self.top_p)
+                cap["st"]["ids"].copy_(ids)
+                cap["st"]["pos"].copy_(pos.reshape(-1))
+                got = self._replay(cap)
+                ok = bool(torch.isfinite(got).all()) and float((got - want).abs().max()) < 5e-2
+            else:
+                got = self._inference_captured(cap, ids, advance=False)
+                ok = bool(torch.isfinite(got).all())
+            torch.cuda.synchronize(self.device)
+        except Exception as ex:                            # capture of a collective refused / failed: use segments
+            ok = False
+            if verbose or self.local_rank == 0:
+                print(f"[TP graphs] whole-forward capture ({kind}, q={q_len}) unavailable: {type(ex).__name__}: {ex}",
+                      flush=True)
+        return cap if self._agree(ok) else None
+
     @torch.inference_mode()
     def initialize_graphs(self, gamma=None, capture_verify=None, verbose=False):
-        """hipGraph capture for the TP engine.  The replicated 68M draft steps (one graph per gamma_offset, like
-        utils/graph_infer.py:143-152; the reference runs them eagerly in the TP path, TP_llama.py:117-132) are
-        always captured — they contain no collective.  The retrieval verify can be captured INCLUDING its RCCL
-        all-reduces (the reference could not, README.md:58); that is on by default only for world_size == 1 and
-        opt-in (TRIFORCE_TP_GRAPHS=1) for more ranks until it has been validated on a multi-GPU node.  With more
-        ranks the default is the collective-free segment form (`_capture_verify_segments`; TRIFORCE_TP_SEGMENTS=0
-        turns it off, =1 with one rank forces it for testing)."""
         from ..utils.graph_infer import _capture
         gamma = self.gamma if gamma is None else gamma
-        if capture_verify is None:
-            capture_verify = (self.world_size == 1 and os.environ.get("TRIFORCE_TP_SEGMENTS") != "1") \
-                or os.environ.get("TRIFORCE_TP_GRAPHS") == "1"
+        mode = os.environ.get("TRIFORCE_TP_GRAPHS", "auto")
+        mode = {"1": "whole", "": "auto"}.get(mode, mode)
+        if capture_verify is not None:
+            mode = "whole" if capture_verify else "0"
         self._mempool = torch.cuda.graphs.graph_pool_handle()
         self._draft_graphs = {}
-        for off in range(gamma + 3):
+        for off in range(gamma + 3):                       # replicated 68M draft steps: no collective inside
             ids = torch.zeros((1, off + 1), dtype=torch.long, device=self.device)
             graph, out = _capture(lambda t, off=off: self._draft_run_eager(t, off, True, 0.6, 0.9), (ids,),
                                   self._mempool, 3)
             self._draft_graphs[off] = (graph, ids, out)
-        self._verify_graph = None
-        self._verify_segments = None
-        if self.retrieval_cache is not None and capture_verify:
-            ids = torch.zeros((1, gamma + 1), dtype=torch.long, device=self.device)
-            pos = torch.arange(gamma + 1, device=self.device).unsqueeze(0)
-            T, P = self.temperature, self.top_p
-            graph, out = _capture(lambda a, b: norm_logits(self.retrieval_inference(a, b)[0], temperature=T, top_k=-1,
-                                                           top_p=P), (ids, pos), self._mempool, 3)
-            self._verify_graph = (graph, ids, pos, out, T, P)
-        elif self.retrieval_cache is not None and os.environ.get("TRIFORCE_TP_SEGMENTS", "1") == "1":
-            self._verify_segments = self._capture_verify_segments(gamma)
-        self._target_segments = {}
-        if not capture_verify and os.environ.get("TRIFORCE_TP_SEGMENTS", "1") == "1" \
-                and self.on_chip_layers == self.num_layers and self.retrieval_cache is not None:
-            for q_len in (gamma + 1, gamma + 2):          # the target verifies [next, t1..t_g2], g2 in {gamma, gamma+1}
-                self._target_segments[q_len] = self._capture_target_segments(q_len)
+        self._verify_cap, self._target_caps = None, {}
+        if self.retrieval_cache is None or mode == "0":
+            self.reset()
+            return
+        target_ok = self.on_chip_layers == self.num_layers
+        jobs = [(gamma + 1, "retrieval")] + ([(gamma + 1, "target"), (gamma + 2, "target")] if target_ok else [])
+        for q_len, kind in jobs:
+            cap = None
+            if mode == "whole" or (mode == "auto" and self.world_size == 1):
+                cap = self._capture_forward(q_len, kind, "whole")
+            elif mode == "auto":
+                cap = self._try_whole(q_len, kind, verbose)
+                if cap is None:
+                    mode = "segments"                      # do not retry the collective capture for the other shapes
+            if cap is None and mode == "segments":
+                cap = self._capture_forward(q_len, kind, "segments")
+            if kind == "retrieval":
+                self._verify_cap = cap
+            elif cap is not None:
+                self._target_caps[q_len] = cap
+        self.graph_form = self._verify_cap["form"] if self._verify_cap else "eager"
         self.reset()
 
-    def _capture_verify_segments(self, gamma):
-        """world_size > 1: the retrieval verify as 2L+1 collective-free hipGraph segments with the two all-reduces of
-        every layer issued eagerly between them.  In eager mode a TP forward is host-launch-bound (~9 short kernels +
-        2 RCCL calls per layer); replaying segments leaves 2 graph launches + 2 RCCL calls per layer on the host and
-        does NOT depend on RCCL being capturable (the whole-forward graph, TRIFORCE_TP_GRAPHS=1, does)."""
-        from ..utils.graph_infer import _capture
-        W, rc, L = self.weights, self.retrieval_cache, self.num_layers
-        q_len = gamma + 1
-        dev, hid = self.device, self.hidden_size
-        st = dict(ids=torch.zeros((1, q_len), dtype=torch.long, device=dev),
-                  pos=torch.arange(q_len, device=dev, dtype=torch.long),
-                  x=torch.zeros(q_len, hid, dtype=torch.float16, device=dev),
-                  o=torch.zeros(q_len, hid, dtype=torch.float16, device=dev),
-                  d=torch.zeros(q_len, hid, dtype=torch.float16, device=dev))
-        T, P = self.temperature, self.top_p
-
-        def seg_attn(i):
-            def run():
-                if i == 0:
-                    st["x"].copy_(self.embed_tokens[st["ids"].reshape(-1)])
-                kl, vl = rc.layer_kv(i)
-                self._attn_half(i, st["x"], None if i == 0 else st["d"], st["pos"], kl, vl, rc.spec_slot, rc.real_budget,
-                                out=st["o"])
-                return st["o"]
-            return run
-
-        def seg_mlp(i):
-            def run():
-                self._mlp_half(i, st["x"], st["o"], out=st["d"])
-                return st["d"]
-            return run
-
-        def seg_finish():
-            return norm_logits(self._finish(st["x"], st["d"])[0], temperature=T, top_k=-1, top_p=P)
-
-        graphs = []
-        for i in range(L):
-            graphs.append((_capture(seg_attn(i), (), self._mempool, 2)[0], st["o"]))
-            graphs.append((_capture(seg_mlp(i), (), self._mempool, 2)[0], st["d"]))
-        gfin, out = _capture(seg_finish, (), self._mempool, 2)
-        return dict(graphs=graphs, finish=gfin, out=out, st=st, T=T, P=P)
-
-    def _capture_target_segments(self, q_len):
-        """The target verify over the full (HBM-resident) KV cache in the same collective-free segment form.  The
-        cache length changes every step, so the append slot and the key count are read from device memory
-        (tf_rope_append slot0_dev, tf_attn_decode sk_dev) and the launch is sized by the cache capacity."""
-        from ..utils.graph_infer import _capture
-        kvc, L = self.kv_cache, self.num_layers
-        dev, hid = self.device, self.hidden_size
-        st = dict(ids=torch.zeros((1, q_len), dtype=torch.long, device=dev),
-                  pos=torch.arange(q_len, device=dev, dtype=torch.long),
-                  base=torch.arange(q_len, device=dev, dtype=torch.long),
-                  slot=torch.zeros(1, dtype=torch.int32, device=dev),
-                  sk=torch.full((1,), q_len, dtype=torch.int32, device=dev),
-                  x=torch.zeros(q_len, hid, dtype=torch.float16, device=dev),
-                  o=torch.zeros(q_len, hid, dtype=torch.float16, device=dev),
-                  d=torch.zeros(q_len, hid, dtype=torch.float16, device=dev))
-
-        def seg_attn(i):
-            def run():
-                if i == 0:
-                    st["x"].copy_(self.embed_tokens[st["ids"].reshape(-1)])
-                kl, vl = kvc.layer_kv(i)
-                self._attn_half(i, st["x"], None if i == 0 else st["d"], st["pos"], kl, vl, 0, kvc.max_budget,
-                                out=st["o"], slot_dev=st["slot"], sk_dev=st["sk"])
-                return st["o"]
-            return run
-
-        def seg_mlp(i):
-            def run():
-                self._mlp_half(i, st["x"], st["o"], out=st["d"])
-                return st["d"]
-            return run
-
-        graphs = []
-        for i in range(L):
-            graphs.append((_capture(seg_attn(i), (), self._mempool, 2)[0], st["o"]))
-            graphs.append((_capture(seg_mlp(i), (), self._mempool, 2)[0], st["d"]))
-        gfin, out = _capture(lambda: self._finish(st["x"], st["d"]), (), self._mempool, 2)
-        return dict(graphs=graphs, finish=gfin, out=out, st=st)
-
-    def _inference_segments(self, seg, input_ids):
+    def _inference_captured(self, cap, input_ids, advance=True):
         kvc, S, q_len = self.kv_cache, self.kv_cache.seq_len, input_ids.shape[1]
-        st = seg["st"]
+        st = cap["st"]
         st["ids"].copy_(input_ids)
         torch.add(st["base"], S, out=st["pos"])
         st["slot"].fill_(S)
         st["sk"].fill_(S + q_len)
-        for graph, buf in seg["graphs"]:
-            graph.replay()
-            self._all_reduce(buf)
-        seg["finish"].replay()
+        out = self._replay(cap)
+        if not advance:
+            return out
         tail = self.retrieval_cache
         if tail is not None and S >= self.prefill_len:    # device mirror of the generated rows, all layers at once
             ops.kv_copy_rows(kvc.k, tail.tail_k, S, S - self.prefill_len, q_len)
             ops.kv_copy_rows(kvc.v, tail.tail_v, S, S - self.prefill_len, q_len)
         kvc.seq_len = S + q_len
-        return seg["out"].clone()
+        return out
 
     @torch.inference_mode()
     def draft_run(self, input_ids, gamma_offset: int = 0, probs=True, temperature=0.6, top_p=0.9):
@@ -440,21 +485,10 @@ class DistributedLlama:
 
     @torch.inference_mode()
     def retrieval_verify(self, input_ids, position_ids, temperature=0.6, top_p=0.9):
-        vg = getattr(self, "_verify_graph", None)
-        if vg is not None and (temperature, top_p) == (vg[4], vg[5]):
-            graph, ids, pos, out, _, _ = vg
-            ids.copy_(input_ids)
-            pos.copy_(position_ids)
-            graph.replay()
-            return out.clone()
-        vs = getattr(self, "_verify_segments", None)
-        if vs is not None and (temperature, top_p) == (vs["T"], vs["P"]):
-            vs["st"]["ids"].copy_(input_ids)
-            vs["st"]["pos"].copy_(position_ids.reshape(-1))
-            for graph, buf in vs["graphs"]:
-                graph.replay()
-                self._all_reduce(buf)
-            vs["finish"].replay()
-            return vs["out"].clone()
+        cap = getattr(self, "_verify_cap", None)
+        if cap is not None and (temperature, top_p) == (cap["T"], cap["P"]):
+            cap["st"]["ids"].copy_(input_ids)
+            cap["st"]["pos"].copy_(position_ids.reshape(-1))
+            return self._replay(cap)
         logits = self.retrieval_inference(input_ids, position_ids)
         return norm_logits(logits[0], temperature=temperature, top_k=-1, top_p=top_p)
