@@ -46,6 +46,7 @@ def parse_arguments():
     parser.add_argument("--weights", type=str, default="random:1", help="random:<seed> or a local HF checkpoint dir")
     parser.add_argument("--draft-weights", type=str, default="random:2")
     parser.add_argument("--tokenizer", type=str, default="none")
+    parser.add_argument("--no_graphs", action="store_true", help="run every forward eagerly like the reference")
     return parser.parse_args()
 
 
@@ -92,6 +93,8 @@ else:
                            retrieval_budget=retrieval_budget, kv_offload=True, on_chip_layers=args.on_chip, draft=draft,
                            draft_cache=draft_cache, gamma=gamma, device=device)
     load_target_weights(llm)
+    if not args.no_graphs:                                # draft steps, retrieval verify and (HBM-resident) target verify
+        llm.initialize_graphs(gamma)
     all_avg_tokens, all_latency = [], []
     for prompt in tokenized_prompts:
         prompt = prompt[:, :prefill].to(llm.device)
