@@ -362,6 +362,7 @@ class DistributedLlama:
         dist.all_reduce(t, dist.ReduceOp.MIN)
         return bool(t.item())
 
+    @torch.inference_mode()
     def _try_whole(self, q_len, kind, verbose):
         """Capture a whole-forward graph and check one replay against the eager forward on a probe input."""
         cap, ok = None, True
@@ -404,6 +405,7 @@ class DistributedLlama:
                                   self._mempool, 3)
             self._draft_graphs[off] = (graph, ids, out)
         self._verify_cap, self._target_caps = None, {}
+        self.graph_form = "eager"
         if self.retrieval_cache is None or mode == "0":
             self.reset()
             return
