@@ -199,6 +199,25 @@ def test_attn_block_splits_agree_and_match_decode_kernel():
         torch.testing.assert_close(got.float(), ref.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
 
 
+def test_attn_block_full_size_prefill_chunk():
+    """A 128-token prefill chunk at the END of a BASELINE configs[1] prompt (124 928 keys, 32 heads): the one-pass block
+    kernel must agree with the <=32-row decode kernel run slab by slab (itself checked against the oracle at this
+    size below), and be causal — perturbing the last key changes only the last query row."""
+    ops = _ops()
+    sq, sk, H, D = 128, 124928, 32, 128
+    scale = R.softmax_scale_for(D)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    kd = torch.randn(H, sk, D, generator=g, device=DEV, dtype=torch.float16)
+    vd = torch.randn(H, sk, D, generator=g, device=DEV, dtype=torch.float16)
+    qd = torch.randn(sq, H, D, generator=g, device=DEV, dtype=torch.float16)
+    got = ops.attn_block(qd, kd, vd, sk, scale)
+    ref = torch.cat([ops.attn_decode(qd[r:r + 32].contiguous(), kd, vd, sk - (sq - r - 32), scale) for r in range(0, sq, 32)])
+    torch.testing.assert_close(got.float(), ref.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+    kd[:, sk - 1] += 4.0
+    got2 = ops.attn_block(qd, kd, vd, sk, scale)
+    assert torch.equal(got2[:sq - 1], got[:sq - 1]) and not torch.equal(got2[sq - 1], got[sq - 1])
+
+
 def test_attn_decode_full_size_cfg2_layer():
     """BASELINE configs[1] shape for one layer: 8 queries x 124 935 keys x 32 heads x 128 (2 GB of KV)."""
     ops = _ops()
