@@ -417,10 +417,23 @@ class DistributedLlama:
                 cap = self._capture_forward(q_len, kind, "whole")
             elif mode == "auto":
                 cap = self._try_whole(q_len, kind, verbose)
-                if cap is None:
-                    mode = "segments"                      # do not retry the collective capture for the other shapes
+                if cap is None:                            # do not retry the collective capture for the other shapes,
+                    mode = "segments-auto"                 # and start from a fresh graph memory pool
+                    self._mempool = torch.cuda.graphs.graph_pool_handle()
             if cap is None and mode == "segments":
                 cap = self._capture_forward(q_len, kind, "segments")
+            elif cap is None and mode == "segments-auto":  # fallback of the fallback: eager
+                ok = True
+                try:
+                    cap = self._capture_forward(q_len, kind, "segments")
+                except Exception as ex:
+                    ok = False
+                    if self.local_rank == 0:
+                        print(f"[TP graphs] segment capture ({kind}, q={q_len}) failed: {type(ex).__name__}: {ex}", flush=True)
+                if not self._agree(ok):
+                    cap, mode = None, "0"
+            if mode == "0":
+                break
             if kind == "retrieval":
                 self._verify_cap = cap
             elif cap is not None:
