@@ -15,7 +15,8 @@ like the reference's time1/time2 (decoding.py:69,143), with device syncs added o
 value = tokens emitted in the K timed steps / wall time (tokens/s, whole job).
 roofline = the dominant kernel (split-KV target-verify attention, tf_attn_decode): algorithmic bytes per
 launch 2*S*H*D*2 / mean launch duration from HIP events recorded on the launch stream
-inside the timed region.
+inside the timed region (every 8th launch is bracketed: an event record is a queue packet of its own, and
+bracketing all 32 per target verify would add ~0.4 ms of gaps to the step being measured).
 cpu_baseline = the CPU oracle (oracle/, kind "port") timed on this host for a bounded per-layer sample
 of the same step, extrapolated to the step.
 """
@@ -299,7 +300,8 @@ def main():
         roof = {"bound": "hbm", "kernel": "attn_split_kernel<128,1> (+merge) via tf_attn_decode",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                "launches": len(full), "avg_launch_us": round(dur * 1e6, 1),
+                "launches": len(full), "launches_sampled_every": ops.ATTN_TIMER_EVERY,
+                "avg_launch_us": round(dur * 1e6, 1),
                 "algorithmic_bytes_per_launch": int(byts)}
         roof.update(pmc_traffic(byts, H, D))
     else:

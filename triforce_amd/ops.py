@@ -10,6 +10,7 @@ the physical layout (head-major [L][H][T][D] in triforce_amd, token-major in the
 is the caller's choice.  Other modules must call these as ``ops.<name>(...)``.
 """
 import ctypes
+import functools
 
 import torch
 import torch.nn.functional as F
@@ -207,9 +208,23 @@ def _workspace(device, floats):
     return torch.empty(int(floats), dtype=torch.float32, device=device)
 
 
-# When set to a list, every eager attn_decode call appends (start_event, end_event, sk, H, D): HIP events on
-# the stream the kernel is launched on, used by bench.py for the live roofline figure.
+# When set to a list, eager attn_decode calls append (start_event, end_event, sk, H, D): HIP events on the stream
+# the kernel is launched on, used by bench.py for the live roofline figure.  Every ATTN_TIMER_EVERY-th call is
+# timed: an event record is a queue packet of its own (~3 us of gap on each side of the kernel), so bracketing all
+# 32 launches of a target verify would cost the step ~0.4 ms of the very time being measured.
 ATTN_TIMER = None
+ATTN_TIMER_EVERY = 8
+_attn_calls = 0
+
+
+@functools.lru_cache(maxsize=4096)
+def _pick_nsplit(H, sk):
+    return hip.lib().tf_attn_decode_pick_nsplit(H, sk)
+
+
+@functools.lru_cache(maxsize=4096)
+def _ws_floats(H, sq, D, nsplit):
+    return hip.lib().tf_attn_decode_ws_floats(H, sq, D, nsplit)
 
 
 def attn_decode(q, k_layer, v_layer, sk, scale, sk_dev=None, nsplit=None):
@@ -222,11 +237,14 @@ def attn_decode(q, k_layer, v_layer, sk, scale, sk_dev=None, nsplit=None):
     assert _kv(v_layer) == (st, sh)
     L = hip.lib()
     if nsplit is None:
-        nsplit = L.tf_attn_decode_pick_nsplit(H, int(sk))
-    need = L.tf_attn_decode_ws_floats(H, sq, D, nsplit)
-    ws = _workspace(q.device, need)
+        nsplit = _pick_nsplit(H, int(sk))
+    ws = _workspace(q.device, _ws_floats(H, sq, D, nsplit))
     out = torch.empty(sq, H * D, dtype=_HALF, device=q.device)
-    timed = ATTN_TIMER is not None and not torch.cuda.is_current_stream_capturing()
+    timed = False
+    if ATTN_TIMER is not None and not torch.cuda.is_current_stream_capturing():
+        global _attn_calls
+        _attn_calls += 1
+        timed = _attn_calls % ATTN_TIMER_EVERY == 0
     if timed:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
