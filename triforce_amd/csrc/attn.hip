@@ -55,7 +55,9 @@ struct TreeMask {                      // tree-attention visibility bits (block 
     int words, row0, start;            // words per row, first row of this launch, key index of tree key 0
 };
 
-template <int D, int QT, bool TREE = false>
+// MASKED = false: every key of the tile is visible to every query row of the wave (all tiles but the last one or
+// two of a causal stream; the unmasked prefix of a tree pass) — the per-key compare/select chain is dropped.
+template <int D, int QT, bool TREE = false, bool MASKED = true>
 __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf)[D / 32],
                                           const half8 (&vf)[D / 32], half8 sel0, half8 sel1, int tile,
                                           int sk, int sq, float scale, int li, int g, int qbase = 0,
@@ -83,7 +85,9 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int kidx = tile * 16 + 4 * g + r;
-            if (TREE) {
+            if (!MASKED) {
+                ok[r] = true;
+            } else if (TREE) {
                 const int j = kidx - tm.start;
                 ok[r] = kidx < sk;
                 if (j >= 0 && ok[r]) {
@@ -169,6 +173,12 @@ __global__ __launch_bounds__(256) void attn_split_kernel(
     const h16* kbase = k + (int64_t)h * stride_h;
     const h16* vbase = v + (int64_t)h * stride_h;
 
+    // tiles whose 16 keys are all <= sk - sq are visible to every row: no mask arithmetic
+#define ATTN_TILE_AUTO(KF, VF, T)                                                                     \
+    do {                                                                                                \
+        if ((T) * 16 + 15 <= sk - sq) attn_tile<D, QT, false, false>(st, KF, VF, sel0, sel1, (T), sk, sq, scale, li, g); \
+        else attn_tile<D, QT, false, true>(st, KF, VF, sel0, sel1, (T), sk, sq, scale, li, g);        \
+    } while (0)
 #if TF_ATTN_DEPTH == 3
     // three tiles deep (24 KiB in flight per wave): tile t+8 is requested before tile t goes to the matrix core
     half8 ka[NC], va_[NC], kb[NC], vb[NC], kc[NC], vc[NC];
@@ -177,13 +187,13 @@ __global__ __launch_bounds__(256) void attn_split_kernel(
     if (t + 4 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t + 4, sk, li, g, kb, vb);
     while (t < t_end) {
         if (t + 8 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t + 8, sk, li, g, kc, vc);
-        attn_tile<D, QT>(st, ka, va_, sel0, sel1, t, sk, sq, scale, li, g);
+        ATTN_TILE_AUTO(ka, va_, t);
         if (t + 4 >= t_end) break;
         if (t + 12 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t + 12, sk, li, g, ka, va_);
-        attn_tile<D, QT>(st, kb, vb, sel0, sel1, t + 4, sk, sq, scale, li, g);
+        ATTN_TILE_AUTO(kb, vb, t + 4);
         if (t + 8 >= t_end) break;
         if (t + 16 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t + 16, sk, li, g, kb, vb);
-        attn_tile<D, QT>(st, kc, vc, sel0, sel1, t + 8, sk, sq, scale, li, g);
+        ATTN_TILE_AUTO(kc, vc, t + 8);
         t += 12;
     }
 #else
@@ -194,15 +204,16 @@ __global__ __launch_bounds__(256) void attn_split_kernel(
     while (t < t_end) {
         const int t1 = t + 4;
         if (t1 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t1, sk, li, g, kb, vb);
-        attn_tile<D, QT>(st, ka, va_, sel0, sel1, t, sk, sq, scale, li, g);
+        ATTN_TILE_AUTO(ka, va_, t);
         if (t1 >= t_end) break;
         const int t2 = t1 + 4;
         if (t2 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t2, sk, li, g, ka, va_);
-        attn_tile<D, QT>(st, kb, vb, sel0, sel1, t1, sk, sq, scale, li, g);
+        ATTN_TILE_AUTO(kb, vb, t1);
         t = t2;
     }
 #endif
 
+#undef ATTN_TILE_AUTO
     // ---- merge the 4 waves of this split through LDS, one q-tile at a time ----
     __shared__ float sm_o[4][16][D + 1];
     __shared__ float sm_m[4][16];
@@ -241,6 +252,103 @@ __global__ __launch_bounds__(256) void attn_split_kernel(
     }
 }
 
+// ---- 32-key step of the block kernel: two 16-key tiles A, B per softmax update ----------------------------
+// The QK^T products of both tiles give a lane 8 keys of one query (A keys 4g..4g+3, B keys 4g..4g+3); the V tiles
+// transposed on the matrix core give a lane the SAME 8 keys of one d — so exp(S) and V^T are the B and A operands of
+// ONE v_mfma_f32_16x16x32_f16 per 16 output columns: half the PV MFMAs and half the running-max bookkeeping of the
+// 16-key step.  Scores are kept in the log2 domain (scale * log2 e folded into one multiply, v_exp_f32 is 2^x).
+template <int D, int QT>
+struct PairScores {
+    f32x4 sa[QT], sb[QT];
+    half8 va8[D / 16];
+};
+
+template <int D, int QT>
+__device__ __forceinline__ void pair_qk(const AttnState<D, QT>& st, const half8 (&kfa)[D / 32], const half8 (&vfa)[D / 32],
+                                        const half8 (&kfb)[D / 32], const half8 (&vfb)[D / 32], half8 sel0, half8 sel1,
+                                        PairScores<D, QT>& ps) {
+    constexpr int NC = D / 32, NT = D / 16;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 ra = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfa[t >> 1], (t & 1) ? sel1 : sel0, z, 0, 0, 0);
+        const f32x4 rb = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfb[t >> 1], (t & 1) ? sel1 : sel0, z, 0, 0, 0);
+        ps.va8[t] = half8{(h16)ra[0], (h16)ra[1], (h16)ra[2], (h16)ra[3], (h16)rb[0], (h16)rb[1], (h16)rb[2], (h16)rb[3]};
+    }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfa[c], st.qf[qt][c], a, 0, 0, 0);
+            b = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfb[c], st.qf[qt][c], b, 0, 0, 0);
+        }
+        ps.sa[qt] = a;
+        ps.sb[qt] = b;
+    }
+}
+
+// st.m is kept in the log2 domain by the callers of this function (converted back before the partials are stored)
+template <int D, int QT, bool TREE, bool MASKED = true>
+__device__ __forceinline__ void pair_softmax_pv(AttnState<D, QT>& st, const PairScores<D, QT>& ps, int tile_a, int tile_b,
+                                                bool b_valid, int sk, int sq, float scale_log2, int li, int g, int qbase,
+                                                TreeMask tm) {
+    constexpr int NT = D / 16;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int qrow = qbase + qt * 16 + li;
+        const int kmax = (qrow < sq) ? (sk - sq + qrow) : (sk - 1);   // bottom-right causal
+        float x[8];
+        bool ok[8];
+        float tmax = NEG_BIG;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int kidx = (r < 4 ? tile_a : tile_b) * 16 + 4 * g + (r & 3);
+            bool v = (r < 4) || b_valid;
+            if (!MASKED) {
+                v = true;
+            } else if (TREE) {
+                const int j = kidx - tm.start;
+                v = v && kidx < sk;
+                if (j >= 0 && v) {
+                    const int mrow = tm.row0 + min(qrow, sq - 1);
+                    v = (tm.rows[(int64_t)mrow * tm.words + (j >> 5)] >> (j & 31)) & 1u;
+                }
+            } else {
+                v = v && kidx <= kmax;
+            }
+            ok[r] = v;
+            x[r] = (r < 4 ? ps.sa[qt][r] : ps.sb[qt][r - 4]) * scale_log2;
+            tmax = v ? fmaxf(tmax, x[r]) : tmax;
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(st.m[qt], tmax);
+        float psum = 0.f;
+        half8 pb;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float p = ok[r] ? exp2f(x[r] - mnew) : 0.f;
+            psum += p;
+            pb[r] = (h16)p;
+        }
+        if (__builtin_amdgcn_ballot_w64(mnew != st.m[qt])) {
+            const float alpha = exp2f(st.m[qt] - mnew);
+            st.l[qt] *= alpha;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                st.acc[qt][t][0] *= alpha; st.acc[qt][t][1] *= alpha;
+                st.acc[qt][t][2] *= alpha; st.acc[qt][t][3] *= alpha;
+            }
+            st.m[qt] = mnew;
+        }
+        st.l[qt] += psum;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ps.va8[t], pb, st.acc[qt][t], 0, 0, 0);
+    }
+}
+
 // Block variant: up to 128 query rows in one pass over the keys — the chunked prefill (graph_infer.py:30-37,
 // TP_llama.py:246-250: q_len = 128) and the Sequoia tree passes (tensor_op.py:171,265: SDPA with a dense
 // additive mask over [prefix | tree]).  The 128 rows are cut into `rg` row groups of 32 (two MFMA q-tiles per
@@ -253,8 +361,14 @@ __global__ __launch_bounds__(256) void attn_split_kernel(
 // TREE = false: bottom-right causal mask.  TREE = true: keys [0, tree_start) are visible to every row, key
 // tree_start + j is visible to row i iff bit j of mask row (mask_row0 + i) is set (the reference's additive mask
 // is 0 / fp16-min over the tree columns: SpecTree_TP.py:65-67,83-87,170; a 0/1 bit loses nothing).
+#ifndef TF_BLOCK_NO_LDS
+#define TF_BLOCK_NO_LDS 0       // 1: 65..128-row blocks use the register-only kernel instead of the LDS-shared one
+#endif
+#ifndef TF_BLOCK_OCC
+#define TF_BLOCK_OCC 1          // waves per SIMD the block kernel is compiled for (A/B: 1 lets it use 512 registers)
+#endif
 template <int D, bool TREE>
-__global__ __launch_bounds__(256) void attn_block_kernel(
+__global__ __launch_bounds__(256, TF_BLOCK_OCC) void attn_block_kernel(
     const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
     int64_t stride_h, int sq, int sk, int H, float scale, int nsplit, int rg, float* __restrict__ ws,
     const uint32_t* __restrict__ mask, int mask_words, int mask_row0, int tree_start) {
@@ -303,19 +417,33 @@ __global__ __launch_bounds__(256) void attn_block_kernel(
     tm.row0 = mask_row0;
     tm.start = tree_start;
     if (wave_active) {
+        // pairs of tiles (t, t + TI): both tiles are requested up front; as soon as their QK^T / transpose MFMAs have
+        // consumed the K/V registers the next pair is requested, so its latency hides under the softmax + PV phase
         half8 ka[NC], va_[NC], kb[NC], vb[NC];
+        const float scale_log2 = scale * 1.4426950408889634f;
+        PairScores<D, QT> ps;
         int t = t_begin + ti;
         if (t < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t, sk, li, g, ka, va_);
+        if (t + TI < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t + TI, sk, li, g, kb, vb);
         while (t < t_end) {
-            const int t1 = t + TI;
-            if (t1 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t1, sk, li, g, kb, vb);
-            attn_tile<D, QT, TREE>(st, ka, va_, sel0, sel1, t, sk, sq, scale, li, g, qbase, tm);
-            if (t1 >= t_end) break;
-            const int t2 = t1 + TI;
-            if (t2 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t2, sk, li, g, ka, va_);
-            attn_tile<D, QT, TREE>(st, kb, vb, sel0, sel1, t1, sk, sq, scale, li, g, qbase, tm);
-            t = t2;
+            const int ta = t, tb = t + TI;
+            const bool b_valid = tb < t_end;
+            if (!b_valid) {                                 // odd tail: B carries no keys (its registers may be stale)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { kb[c] = ka[c]; vb[c] = va_[c]; }
+            }
+            pair_qk<D, QT>(st, ka, va_, kb, vb, sel0, sel1, ps);
+            t += 2 * TI;
+            if (t < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t, sk, li, g, ka, va_);
+            if (t + TI < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t + TI, sk, li, g, kb, vb);
+            // both tiles entirely below this wave's first causal limit / inside the unmasked tree prefix: no mask
+            const int last_key = max(ta, tb) * 16 + 15;
+            const bool clear = b_valid && (TREE ? (last_key < tm.start && last_key < sk) : (last_key <= sk - sq + qbase));
+            if (clear) pair_softmax_pv<D, QT, TREE, false>(st, ps, ta, tb, true, sk, sq, scale_log2, li, g, qbase, tm);
+            else pair_softmax_pv<D, QT, TREE, true>(st, ps, ta, tb, b_valid, sk, sq, scale_log2, li, g, qbase, tm);
         }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) st.m[qt] *= 0.6931471805599453f;     // log2 domain -> natural log for the merge
     }
     const int np = nsplit * TI;                               // partials per head
     float* ws_o = ws;
@@ -335,6 +463,229 @@ __global__ __launch_bounds__(256) void attn_block_kernel(
             ws_l[row] = lsum;
         }
     }
+}
+
+// LDS-shared form of the block kernel for 65..128 query rows (rg = 4: every wave walks every key tile).  In the
+// register-only form above the four waves of a workgroup each fetch the SAME K/V tiles from L2 and each transposes V
+// on the matrix core.  Here the workgroup loads each 32-key K/V slab ONCE (global -> registers -> LDS, double-buffered,
+// the next slab's loads in flight under the current slab's MFMAs):
+//   * K is stored row-major (row stride D+8 halfs); a wave reads its QK^T A operands from rows 8(i>>2)+(i&3) (tile A)
+//     and +4 (tile B), so that after the two MFMAs lane group g holds the scores of the 8 CONSECUTIVE keys 8g..8g+7;
+//   * V is stored TRANSPOSED by the loader threads (sVt[d][key], 2-byte scatter writes), so the PV A operand
+//     V^T[d][8g..8g+7] is one 16-byte LDS read — no transposing MFMAs, no V registers;
+//   * exp(S) of those 8 keys is the B operand of ONE v_mfma_f32_16x16x32_f16 per 16 output columns.
+// Per 32 keys and wave: 16 + 16 MFMAs (the register form needs 48); one barrier per 64-key slab.
+// 128 query rows x 124 928 keys x 32 heads: 1143 us (register form) -> 608 us = 431 TF/s of QK^T + PV.
+#ifndef BLK_SLAB
+#define BLK_SLAB 64           // keys per load / barrier step of the LDS block kernel = two 32-key MFMA sub-steps
+                              // (8 swizzle blocks -> 2-way write conflicts; 32: 4-way, 4 % slower)
+// V^T image in LDS: element (d, key r) lives in row d at 8-key block ((r >> 3) ^ ((d >> 3) & (BLK_SLAB/8 - 1))).
+// Without the XOR the loader's 2-byte scatter writes — 16 lanes with d = 8*lc + e, same key — all fall on ONE bank
+// (row stride and the 8-row lane stride are both multiples of 32 dwords): a 16-way conflict on 16 writes per thread
+// per slab, which bounded the kernel.  Reads stay one 16-byte access per (d, block).
+#endif
+#define BLK_VSWZ(d) (((d) >> 3) & (BLK_SLAB / 8 - 1))
+template <int D, int QT, bool TREE, bool MASKED>
+__device__ __forceinline__ void lds_softmax_pv(AttnState<D, QT>& st, const f32x4 (&sa)[QT], const f32x4 (&sb)[QT],
+                                               const h16* __restrict__ svt, int g0, int key0, int sk, int sq,
+                                               float scale_log2, int li, int g, int qbase, TreeMask tm) {
+    constexpr int NT = D / 16, VS = BLK_SLAB + 8;
+    half8 pb[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int qrow = qbase + qt * 16 + li;
+        const int kmax = (qrow < sq) ? (sk - sq + qrow) : (sk - 1);   // bottom-right causal
+        float x[8];
+        bool ok[8];
+        float tmax = NEG_BIG;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int kidx = key0 + 8 * g + r;
+            bool v = true;
+            if (MASKED) {
+                if (TREE) {
+                    const int j = kidx - tm.start;
+                    v = kidx < sk;
+                    if (j >= 0 && v) {
+                        const int mrow = tm.row0 + min(qrow, sq - 1);
+                        v = (tm.rows[(int64_t)mrow * tm.words + (j >> 5)] >> (j & 31)) & 1u;
+                    }
+                } else {
+                    v = kidx <= kmax;
+                }
+            }
+            ok[r] = v;
+            x[r] = (r < 4 ? sa[qt][r] : sb[qt][r - 4]) * scale_log2;
+            tmax = v ? fmaxf(tmax, x[r]) : tmax;
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(st.m[qt], tmax);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float p = ok[r] ? exp2f(x[r] - mnew) : 0.f;
+            psum += p;
+            pb[qt][r] = (h16)p;
+        }
+        if (__builtin_amdgcn_ballot_w64(mnew != st.m[qt])) {
+            const float alpha = exp2f(st.m[qt] - mnew);
+            st.l[qt] *= alpha;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                st.acc[qt][t][0] *= alpha; st.acc[qt][t][1] *= alpha;
+                st.acc[qt][t][2] *= alpha; st.acc[qt][t][3] *= alpha;
+            }
+            st.m[qt] = mnew;
+        }
+        st.l[qt] += psum;
+    }
+    // PV: every V^T fragment is read from LDS once and feeds the MFMAs of all q-tiles of the wave
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int d = 16 * t + li;                                                  // V^T[d][keys 8(g0+g) .. +7]
+        const half8 vt = load_half8(svt + d * VS + 8 * ((g0 + g) ^ BLK_VSWZ(d)));
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+            st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vt, pb[qt], st.acc[qt][t], 0, 0, 0);
+    }
+}
+
+template <int D, bool TREE>
+__global__ __launch_bounds__(256, 2) void attn_block_lds_kernel(
+    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
+    int64_t stride_h, int sq, int sk, int H, float scale, int nsplit, float* __restrict__ ws,
+    const uint32_t* __restrict__ mask, int mask_words, int mask_row0, int tree_start) {
+    constexpr int NC = D / 32, NT = D / 16, QT = 2, QR = 128;
+    constexpr int SLAB = BLK_SLAB;                          // keys per load step: 64 -> 32 KiB (D=128) in flight per WG
+    constexpr int RS = D + 8;                               // K row stride in LDS (halfs)
+    constexpr int VS = SLAB + 8;                            // V^T row stride in LDS (halfs)
+    constexpr int VPR = D / 8;                              // 16-byte vectors per row
+    constexpr int RPP = 256 / VPR;                          // rows covered by one pass of the 256 threads
+    constexpr int NPASS = SLAB / RPP;                       // passes per slab (4 for D=128, 2 for D=64)
+    extern __shared__ __attribute__((aligned(16))) unsigned char blk_smem[];
+    h16* sK = reinterpret_cast<h16*>(blk_smem);             // [2][SLAB * RS]
+    h16* sVt = sK + 2 * SLAB * RS;                          // [2][D * VS]
+    const int split = blockIdx.x, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int qbase = wave * 32;
+    const int nslabs = (sk + SLAB - 1) / SLAB;
+    const int sps = (nslabs + nsplit - 1) / nsplit;
+    const int s_begin = split * sps;
+    const int s_end = min(nslabs, s_begin + sps);
+
+    AttnState<D, QT> st;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int row = qbase + qt * 16 + li;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            st.qf[qt][c] = (row < sq) ? load_half8(q + ((int64_t)row * H + h) * D + 32 * c + 8 * g) : z;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) st.acc[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        st.m[qt] = NEG_BIG;
+        st.l[qt] = 0.f;
+    }
+    const h16* kbase = k + (int64_t)h * stride_h;
+    const h16* vbase = v + (int64_t)h * stride_h;
+    TreeMask tm;
+    tm.rows = mask;
+    tm.words = mask_words;
+    tm.row0 = mask_row0;
+    tm.start = tree_start;
+    const float scale_log2 = scale * 1.4426950408889634f;
+    const int lr = tid / VPR, lc = tid % VPR;               // this thread's (row, 16-byte column) in a load pass
+    const int row_a = 8 * (li >> 2) + (li & 3);             // slab row behind MFMA row li of tile A (tile B: +4)
+
+    half8 gk[NPASS], gv[NPASS];
+    auto fetch = [&](int slab) {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            int key = slab * SLAB + p * RPP + lr;
+            key = key < sk ? key : sk - 1;                  // clamp: masked below, but must stay in-bounds
+            gk[p] = load_half8_stream(kbase + (int64_t)key * stride_t + 8 * lc);
+            gv[p] = load_half8_stream(vbase + (int64_t)key * stride_t + 8 * lc);
+        }
+    };
+    auto stash = [&](int buf) {
+        h16* dk = sK + buf * SLAB * RS;
+        h16* dv = sVt + buf * D * VS;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int r = p * RPP + lr;
+            store_half8(dk + r * RS + 8 * lc, gk[p]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)                    // d = 8*lc + e -> swizzle key = lc
+                dv[(8 * lc + e) * VS + ((((r >> 3) ^ (lc & (SLAB / 8 - 1))) << 3) | (r & 7))] = gv[p][e];
+        }
+    };
+
+    if (s_begin < s_end) {
+        fetch(s_begin);
+        stash(0);
+    }
+    __syncthreads();
+    for (int sl = s_begin; sl < s_end; ++sl) {
+        const int buf = (sl - s_begin) & 1;
+        if (sl + 1 < s_end) fetch(sl + 1);                  // in flight under this slab's MFMAs
+        const h16* bk = sK + buf * SLAB * RS;
+        const h16* bv = sVt + buf * D * VS;
+#pragma unroll
+        for (int sub = 0; sub < SLAB / 32; ++sub) {
+            const int key0 = sl * SLAB + 32 * sub;
+            if (key0 >= sk) break;
+            f32x4 sa[QT], sb[QT];
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                sa[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                sb[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const half8 ka = load_half8(bk + (32 * sub + row_a) * RS + 32 * c + 8 * g);
+                const half8 kb = load_half8(bk + (32 * sub + row_a + 4) * RS + 32 * c + 8 * g);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    sa[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, st.qf[qt][c], sa[qt], 0, 0, 0);
+                    sb[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kb, st.qf[qt][c], sb[qt], 0, 0, 0);
+                }
+            }
+            const int last_key = key0 + 31;
+            const bool clear = TREE ? (last_key < tm.start && last_key < sk) : (last_key <= sk - sq + qbase);
+            if (clear)
+                lds_softmax_pv<D, QT, TREE, false>(st, sa, sb, bv, 4 * sub, key0, sk, sq, scale_log2, li, g, qbase, tm);
+            else
+                lds_softmax_pv<D, QT, TREE, true>(st, sa, sb, bv, 4 * sub, key0, sk, sq, scale_log2, li, g, qbase, tm);
+        }
+        if (sl + 1 < s_end) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* ws_o = ws;
+    float* ws_m = ws + (int64_t)H * nsplit * QR * D;
+    float* ws_l = ws_m + (int64_t)H * nsplit * QR;
+    const int64_t pbase = ((int64_t)h * nsplit + split) * QR;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float lsum = st.l[qt];
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        const int64_t row = pbase + qbase + qt * 16 + li;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) *reinterpret_cast<f32x4*>(ws_o + row * D + 16 * tt + 4 * g) = st.acc[qt][tt];
+        if (g == 0) {
+            ws_m[row] = st.m[qt] * 0.6931471805599453f;     // log2 domain -> natural log for the merge
+            ws_l[row] = lsum;
+        }
+    }
+}
+
+template <int D>
+static size_t blk_lds_bytes() {
+    return (size_t)2 * (BLK_SLAB * (D + 8) + D * (BLK_SLAB + 8)) * sizeof(h16);
 }
 
 // Merge of the per-split partials.  grid (H, sq), block (D, CG): thread (d, g) folds the splits s == g (mod CG)
@@ -645,9 +996,21 @@ static int launch_block(const void* q, const void* k, const void* v, void* out, 
                         int sq, int sk, int H, float scale, int nsplit, float* ws, const uint32_t* mask,
                         int mask_words, int mask_row0, int tree_start, hipStream_t st) {
     const int rg = sq <= 32 ? 1 : (sq <= 64 ? 2 : 4);
-    hipLaunchKernelGGL((attn_block_kernel<D, TREE>), dim3(nsplit, H), dim3(256), 0, st, (const h16*)q, (const h16*)k,
-                       (const h16*)v, stride_t, stride_h, sq, sk, H, scale, nsplit, rg, ws, mask, mask_words,
-                       mask_row0, tree_start);
+    if (rg == 4 && !TF_BLOCK_NO_LDS) {
+        static bool attr_set = false;                     // 70 KiB of dynamic LDS: above the 64 KiB default limit
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn_block_lds_kernel<D, TREE>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)blk_lds_bytes<D>());
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((attn_block_lds_kernel<D, TREE>), dim3(nsplit, H), dim3(256), blk_lds_bytes<D>(), st,
+                           (const h16*)q, (const h16*)k, (const h16*)v, stride_t, stride_h, sq, sk, H, scale, nsplit, ws,
+                           mask, mask_words, mask_row0, tree_start);
+    } else
+        hipLaunchKernelGGL((attn_block_kernel<D, TREE>), dim3(nsplit, H), dim3(256), 0, st, (const h16*)q,
+                           (const h16*)k, (const h16*)v, stride_t, stride_h, sq, sk, H, scale, nsplit, rg, ws, mask,
+                           mask_words, mask_row0, tree_start);
     TF_LAUNCH_CHECK();
     hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(H, sq), dim3(D, COMBINE_GROUPS), 0, st, (const float*)ws,
                        (h16*)out, sq, H, nsplit * (4 / rg), 32 * rg);
