@@ -26,11 +26,11 @@ LOGIT_MEAN_TOL = 1e-3
 GAP_TOL = 8e-3        # an emitted token's oracle logit may trail the oracle's best by at most ~2 fp16 spacings
 
 
-def _logit_check(what, got, want):
+def _logit_check(what, got, want, spacings=2.0):
     import math
     d = (got - want).abs()
     mag = max(1.0, float(want.abs().max()))
-    bound = max(1e-3, 2.0 * 2.0 ** (math.floor(math.log2(mag)) - 10))
+    bound = max(1e-3, spacings * 2.0 ** (math.floor(math.log2(mag)) - 10))
     assert d.max() <= bound and d.mean() < LOGIT_MEAN_TOL, \
         f"{what}: max |dlogit| {d.max():.2e} (bound {bound:.2e}), mean {d.mean():.2e}"
 

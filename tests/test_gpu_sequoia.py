@@ -211,20 +211,22 @@ def test_tree_forward_logits_teacher_forced(name):
         lg = llm.retrieval_tree_inference(input_ids=toks[a:b].view(1, -1), storage_ids=range(B + a, B + b),
                                           position_ids=(st.depth[a:b] + S).unsqueeze(0),
                                           attention_mask=TreeMask(st.mask_bits, a))[0]
-        _logit_check(f"{name} tree level [{a},{b})", lg.float().cpu(), so.draft_logits[a:b])
+        # a node attends to the device-computed KV rows of up to 15 ancestors (each within fp16 noise of the oracle's):
+        # 3 fp16 spacings at the largest logit instead of the 2 of a single forward
+        _logit_check(f"{name} tree level [{a},{b})", lg.float().cpu(), so.draft_logits[a:b], spacings=3.0)
     # the dense-mask form of the reference API gives the same result as the packed form
     a, b = level[2]
     dense = torch.cat([torch.zeros(b - a, B), RT.additive_tree_mask(gm["mask"])[a:b].float()], dim=-1).half()
     lg2 = llm.retrieval_tree_inference(input_ids=toks[a:b].view(1, -1), storage_ids=torch.arange(B + a, B + b),
                                        position_ids=(st.depth[a:b] + S).unsqueeze(0),
                                        attention_mask=dense[None, None].to(DEV))[0]
-    _logit_check(f"{name} dense-mask API", lg2.float().cpu(), so.draft_logits[a:b])
+    _logit_check(f"{name} dense-mask API", lg2.float().cpu(), so.draft_logits[a:b], spacings=3.0)
     # target verify over the full cache with the tree mask
     pos = (gm["depth"] + S).unsqueeze(0)
     add = torch.cat([torch.zeros(gm["size"], S), so.tree_mask.float()], dim=-1)
     want = oeng.inference(so.verify_tokens.unsqueeze(0), position_ids=pos, attention_mask=add)[0]
     got = llm.inference(input_ids=toks.unsqueeze(0), position_ids=pos.to(DEV), attention_mask=TreeMask(st.mask_bits, 0))[0]
-    _logit_check(f"{name} tree verify", got.float().cpu(), want)
+    _logit_check(f"{name} tree verify", got.float().cpu(), want, spacings=3.0)
     pw = R.norm_logits(want, g["temperature"], -1, g["top_p"])
     pg = norm_logits(got, temperature=g["temperature"], top_k=-1, top_p=g["top_p"]).cpu()
     assert (pw - pg).abs().max() < 2e-2 and ((pw > 0) != (pg > 0)).float().mean() < 2e-3
