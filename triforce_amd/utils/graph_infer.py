@@ -63,6 +63,22 @@ class InferenceEngine:
         self.draft_cache.reset()
 
 
+def _capture_error_mode():
+    """hipStreamCaptureMode for our captures.  Once a torch.distributed NCCL (RCCL) process group exists, its watchdog
+    thread polls hipEventQuery on outstanding collectives; under the default "global" mode such a call from another
+    thread while this thread captures raises hipErrorStreamCaptureUnsupported INSIDE the watchdog, which terminates
+    the process (observed on ROCm 7.2 / torch 2.10: tools/rccl_capture_probe.py).  "thread_local" confines the
+    capture-safety check to the capturing thread — required for capturing anything, collectives included, in a TP
+    process."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return "thread_local"
+    except Exception:
+        pass
+    return "global"
+
+
 def _capture(fn, static_inputs, mempool, n_warmups):
     """Warm up on a side stream, then capture ``fn(*static_inputs)`` into one hipGraph."""
     side = torch.cuda.Stream()
@@ -73,7 +89,7 @@ def _capture(fn, static_inputs, mempool, n_warmups):
         side.synchronize()
     torch.cuda.current_stream().wait_stream(side)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, pool=mempool):
+    with torch.cuda.graph(graph, pool=mempool, capture_error_mode=_capture_error_mode()):
         static_out = fn(*static_inputs)
     return graph, static_out
 
