@@ -48,6 +48,7 @@ def parse_arguments():
     parser.add_argument("--tree_size", type=str, default="512")
     parser.add_argument("--weights", type=str, default="random:1", help="random:<seed> or a local HF checkpoint dir")
     parser.add_argument("--tokenizer", type=str, default="none")
+    parser.add_argument("--no_graphs", action="store_true", help="grow the tree eagerly like the reference")
     return parser.parse_args()
 
 
@@ -93,6 +94,8 @@ else:
     load_target_weights(llm)
     spectree = SpecTree(engine=llm, temperature=temperature, top_p=top_p, max_length=prefill + gen_len,
                         grow_map=grow_map, tokenizer=tokenizer, vocab_size=llm.config.vocab_size)
+    if not args.no_graphs:                                # the whole tree growth as one hipGraph (single rank)
+        spectree.capture_grow_graph()
     all_latency, all_acc_list = [], []
     for prompt in tokenized_prompts:
         prompt = prompt[0, :prefill].to(llm.device)

@@ -232,6 +232,33 @@ def test_tree_forward_logits_teacher_forced(name):
     assert (pw - pg).abs().max() < 2e-2 and ((pw > 0) != (pg > 0)).float().mean() < 2e-3
 
 
+def test_captured_tree_growth_equals_eager():
+    """The whole tree growth (15 sampling steps + 16 level forwards) as ONE hipGraph == the eager level loop."""
+    g = Hh.load_golden("sequoia_tree512")
+    gm = RT.grow_map_from_branches(g["branches"])
+    V = g["tcfg"]["vocab_size"]
+    rand = torch.rand(gm["size"], V, generator=torch.Generator().manual_seed(3)).half()
+    tsd = specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g["head_std"])
+    llm, st = _product(g, gm, tsd, Hh.fixed_uniforms(4096, seed=7), rand)
+    nxt = st.prefill(Hh.prompt_of(g)[0].to(DEV))
+    st.construct_grow_map(nxt)
+    toks, logits = st.verify_tokens.clone(), st.draft_logits.clone()
+    tree_k = llm.retrieval_cache.k[:, :, st.storage0:].clone()
+    assert st.capture_grow_graph()
+    assert int(st.verify_tokens.abs().sum()) == 0
+    st.construct_grow_map(nxt)
+    assert torch.equal(st.verify_tokens, toks) and torch.equal(st.draft_logits, logits)
+    assert torch.equal(llm.retrieval_cache.k[:, :, st.storage0:], tree_k)
+    # a later step (other root token, longer cache) through the same graph == eager
+    nt, acc, _ = st.verify()
+    assert nt is not None
+    st.construct_grow_map(nt.unsqueeze(0))
+    toks2, logits2 = st.verify_tokens.clone(), st.draft_logits.clone()
+    st._grow_graph = None
+    st.construct_grow_map(nt.unsqueeze(0))
+    assert torch.equal(st.verify_tokens, toks2) and torch.equal(st.draft_logits, logits2)
+
+
 @pytest.mark.parametrize("name,on_chip", [("sequoia_tree512", None), ("sequoia_small", None), ("sequoia_small", 1)])
 def test_spectree_loop_on_device(name, on_chip):
     """Free-running product loop (with host-offloaded layers in the last case): structural invariants at every
@@ -248,6 +275,8 @@ def test_spectree_loop_on_device(name, on_chip):
     want, want_counts = RT.run_sequoia(so, prompt, g["gen_len"])
 
     llm, st = _product(g, gm, tsd, uniforms, rand, on_chip=on_chip)
+    if name == "sequoia_tree512":
+        assert st.capture_grow_graph()                    # this case runs the captured tree growth
     next_token = st.prefill(prompt.to(DEV))
     got, counts, n = [int(next_token)], [], 0
     P = g["prefill"]

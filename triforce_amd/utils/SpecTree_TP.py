@@ -134,11 +134,38 @@ class SpecTree:
                            rng=self.rng)
 
     @torch.inference_mode()
+    def capture_grow_graph(self):
+        """Capture the whole tree growth (all levels: sampling without replacement + the retrieval-cache forward of
+        every level) as ONE hipGraph.  Every shape is static — the tree is; only the root token and the cache length
+        change between steps, and both are read from device buffers (``verify_tokens[0]``, ``_seq_base``).  The
+        reference launches ~16 x 32 x 10 kernels per step eagerly.  Single-rank only unless the engine's
+        whole-forward RCCL capture was validated (the level forwards contain the all-reduces)."""
+        from .graph_infer import _capture
+        eng = self.graph_engine
+        if eng.world_size > 1 and getattr(eng, "graph_form", "eager") != "whole":
+            return False
+        self._seq_base = torch.zeros(1, dtype=torch.long, device=self.device)
+        pool = getattr(eng, "_mempool", None) or torch.cuda.graphs.graph_pool_handle()
+        self._grow_graph, _ = _capture(lambda: self._grow(self._seq_base), (), pool, 2)
+        self.draft_logits.zero_()
+        self.verify_tokens.zero_()
+        eng.retrieval_cache.k[:, :, self.storage0:].zero_()          # the warm-up runs wrote tree slots
+        eng.retrieval_cache.v[:, :, self.storage0:].zero_()
+        return True
+
+    @torch.inference_mode()
     def construct_grow_map(self, next_token):
         """Grow the tree level by level with the retrieval-cache model (SpecTree_TP.py:103-145)."""
-        eng = self.graph_engine
-        S = eng.kv_cache.seq_len
         self.verify_tokens[0:1] = next_token.reshape(-1)[:1]
+        if getattr(self, "_grow_graph", None) is not None:
+            self._seq_base.fill_(self.graph_engine.kv_cache.seq_len)
+            self._grow_graph.replay()
+            return
+        self._grow(self.graph_engine.kv_cache.seq_len)
+
+    def _grow(self, S):
+        """S: cache length — a Python int (eager) or a 1-element device tensor (captured)."""
+        eng = self.graph_engine
         logits = eng.retrieval_tree_inference(
             input_ids=self.verify_tokens[0:1].unsqueeze(0), storage_ids=range(self.storage0, self.storage0 + 1),
             position_ids=self.depth[0:1].unsqueeze(0) + S, attention_mask=TreeMask(self.mask_bits, 0))[0]
