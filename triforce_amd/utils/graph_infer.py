@@ -94,87 +94,89 @@ def _capture(fn, static_inputs, mempool, n_warmups):
     return graph, static_out
 
 
+class _GraphedCall:
+    """``fn(*static_inputs)`` captured once; a call copies the live arguments into the static input buffers, replays
+    the hipGraph and returns a fresh copy of the static output (graph_infer.py:91-97,119-127 do exactly this for the
+    two shapes below)."""
+
+    def __init__(self, fn, static_inputs, mempool, n_warmups):
+        self.inputs = static_inputs
+        self.graph, self.output = _capture(fn, static_inputs, mempool, n_warmups)
+
+    def __call__(self, *live):
+        for buf, value in zip(self.inputs, live):
+            buf.copy_(value)
+        self.graph.replay()
+        return self.output.clone()
+
+
 def draft_run_capture_graph(engine: InferenceEngine, gamma_offset: int = 0, mempool=None, n_warmups: int = 3, probs=False,
                             temperature=0.6, top_p=0.9, verbose=True):
-    device = engine.draft.device
-    static_input_ids = torch.zeros((1, gamma_offset + 1), dtype=torch.long, device=device)
+    """One 68M draft step over ``gamma_offset + 1`` tokens (reference graph_infer.py:74-97)."""
     if verbose:
         print(f"[draft run] capturing graph for {gamma_offset} (probs={probs}, temp={temperature}, top_p={top_p})...")
-    graph, static_out = _capture(
-        lambda ids: engine.draft_run(input_ids=ids, gamma_offset=gamma_offset, probs=probs, temperature=temperature,
-                                     top_p=top_p), (static_input_ids,), mempool, n_warmups)
-
-    def run(input_ids):
-        static_input_ids.copy_(input_ids)
-        graph.replay()
-        return static_out.clone()
-
-    return run
+    ids = torch.zeros((1, gamma_offset + 1), dtype=torch.long, device=engine.draft.device)
+    return _GraphedCall(lambda t: engine.draft_run(input_ids=t, gamma_offset=gamma_offset, probs=probs,
+                                                   temperature=temperature, top_p=top_p), (ids,), mempool, n_warmups)
 
 
 def model_verify_capture_graph(engine: InferenceEngine, mempool=None, n_warmups: int = 3, gamma: int = 6, probs=False,
                                temperature=0.6, top_p=0.9, verbose=True):
-    device = engine.model.device
-    static_input_ids = torch.zeros((1, gamma + 1), dtype=torch.long, device=device)
-    static_position_ids = torch.arange(gamma + 1, device=device).unsqueeze(0)
+    """The retrieval-cache verify over ``gamma + 1`` tokens at explicit positions (reference graph_infer.py:99-127)."""
     if verbose:
         print(f"[model verify] capturing graph for spec len {gamma} (probs={probs}, temp={temperature}, top_p={top_p})...")
-    graph, static_out = _capture(
-        lambda ids, pos: engine.model_verify(input_ids=ids, position_ids=pos, probs=probs, temperature=temperature,
-                                             top_p=top_p), (static_input_ids, static_position_ids), mempool, n_warmups)
-
-    def run(input_ids, position_ids):
-        static_input_ids.copy_(input_ids)
-        static_position_ids.copy_(position_ids)
-        graph.replay()
-        return static_out.clone()
-
-    return run
+    dev = engine.model.device
+    ids = torch.zeros((1, gamma + 1), dtype=torch.long, device=dev)
+    pos = torch.arange(gamma + 1, device=dev).unsqueeze(0)
+    return _GraphedCall(lambda t, p: engine.model_verify(input_ids=t, position_ids=p, probs=probs, temperature=temperature,
+                                                         top_p=top_p), (ids, pos), mempool, n_warmups)
 
 
 class GraphInferenceEngine:
+    """The object the decode loops drive (reference graph_infer.py:129-194): ``inference`` /
+    ``graph_draft_prefill`` run eagerly, ``graph_draft_inference`` / ``graph_verify`` replay the captured graphs."""
+
     def __init__(self, model, cache, graph_cache, draft, draft_cache) -> None:
         self.engine = InferenceEngine(model, cache, graph_cache, draft, draft_cache)
-        self.callables = {}
+        self.callables = {}                        # gamma_offset -> draft step
         self.callable_model_verify = None
         self.mempool = None
         self.sampling = dict(probs=False, temperature=0.6, top_p=0.9)
 
     @torch.inference_mode()
     def initialize_cuda_graph(self, gamma=6, probs=False, temperature=0.6, top_p=0.9, verbose=True):
+        """gamma + 3 draft graphs (one per gamma_offset) and one retrieval-verify graph, sharing one memory pool."""
         gc.collect()
         self.mempool = torch.cuda.graphs.graph_pool_handle()
         self.sampling = dict(probs=probs, temperature=temperature, top_p=top_p)
-        for gamma_offset in range(gamma + 3):
-            self.callables[gamma_offset] = draft_run_capture_graph(
-                engine=self.engine, gamma_offset=gamma_offset, mempool=self.mempool, n_warmups=3, verbose=verbose,
-                **self.sampling)
-        self.callable_model_verify = model_verify_capture_graph(
-            engine=self.engine, mempool=self.mempool, n_warmups=3, gamma=gamma, verbose=verbose, **self.sampling)
+        common = dict(engine=self.engine, mempool=self.mempool, n_warmups=3, verbose=verbose, **self.sampling)
+        self.callables = {off: draft_run_capture_graph(gamma_offset=off, **common) for off in range(gamma + 3)}
+        self.callable_model_verify = model_verify_capture_graph(gamma=gamma, **common)
         self.engine.clear_kv()
 
     def initialize_eager(self, gamma=6, probs=True, temperature=0.6, top_p=0.9):
         """Same surface without graph capture (debugging / parity bisecting)."""
         self.sampling = dict(probs=probs, temperature=temperature, top_p=top_p)
-        eng = self.engine
-        for off in range(gamma + 3):
-            self.callables[off] = (lambda ids, off=off: eng.draft_run(input_ids=ids, gamma_offset=off, **self.sampling))
-        self.callable_model_verify = lambda ids, pos: eng.model_verify(input_ids=ids, position_ids=pos, **self.sampling)
+        eng, kw = self.engine, self.sampling
+        self.callables = {off: (lambda ids, off=off: eng.draft_run(input_ids=ids, gamma_offset=off, **kw))
+                          for off in range(gamma + 3)}
+        self.callable_model_verify = lambda ids, pos: eng.model_verify(input_ids=ids, position_ids=pos, **kw)
 
     def clear_kv(self):
         self.engine.clear_kv()
 
+    # -- the surface used by utils/decoding.py ---------------------------------------------------------------
     @torch.inference_mode()
-    def graph_draft_inference(self, input_ids: torch.LongTensor, gamma_offset: int = 0):
-        return self.callables[gamma_offset](input_ids)
+    def inference(self, input_ids: torch.LongTensor):
+        return self.engine.model_run(input_ids=input_ids)
 
     @torch.inference_mode()
     def graph_draft_prefill(self, input_ids: torch.LongTensor):
         return self.engine.draft_run(input_ids=input_ids)
 
     @torch.inference_mode()
-    def inference(self, input_ids: torch.LongTensor):
-        return self.engine.model_run(input_ids=input_ids)
+    def graph_draft_inference(self, input_ids: torch.LongTensor, gamma_offset: int = 0):
+        return self.callables[gamma_offset](input_ids)
 
     @torch.inference_mode()
     def graph_verify(self, input_ids: torch.LongTensor, position_ids: torch.LongTensor):

@@ -16,26 +16,23 @@ def spec_stream(pred_token_idx, tokenizer, color="blue"):
 
 
 def log_csv(file_path, header, entry):
-    try:
-        with open(file_path, "r") as f:
-            contents = f.read()
-    except FileNotFoundError:
-        contents = ""
+    """Append ``entry``; a new (or empty) file gets ``header`` first."""
+    import os
+    fresh = not os.path.exists(file_path) or os.path.getsize(file_path) == 0
     with open(file_path, "a") as f:
-        if not contents:
-            f.write(header)
-        f.write(entry)
+        f.write((header if fresh else "") + entry)
 
 
 def print_config(draft, target, prefill, gen_len, gamma, top_k, top_p, temperature, file_path, method,
                  spec_args=None, dataset=None):
-    bar = "#" * 39
-    print(colored(f"{bar} Config {bar}", "blue"), flush=True)
+    """The banner of the reference scripts, line for line (harnesses grep it)."""
+    fields = {"Dataset": dataset, "Spec Args": spec_args, "Draft": draft.config._name_or_path,
+              "Target": target.config._name_or_path, "Prefill Length": prefill, "Generation Length": gen_len,
+              "Gamma": gamma, "Sampling Method": f"top_k = {top_k}, top_p = {top_p}, temperature = {temperature}",
+              "Log CSV": file_path}
+    rule = "#" * 39
+    print(colored(f"{rule} Config {rule}", "blue"), flush=True)
     print(colored(f"Method: {method}", "red"), flush=True)
-    for line in (f"Dataset: {dataset}", f"Spec Args: {spec_args}", f"Draft: {draft.config._name_or_path}",
-                 f"Target: {target.config._name_or_path}", f"Prefill Length: {prefill}",
-                 f"Generation Length: {gen_len}", f"Gamma: {gamma}",
-                 f"Sampling Method: top_k = {top_k}, top_p = {top_p}, temperature = {temperature}",
-                 f"Log CSV: {file_path}"):
-        print(colored(line, "blue"), flush=True)
+    for key, value in fields.items():
+        print(colored(f"{key}: {value}", "blue"), flush=True)
     print(colored("#" * 86 + "\n", "blue"), flush=True)
