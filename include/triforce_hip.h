@@ -230,6 +230,13 @@ int tf_tree_accept(const float* p_rows, const float* draft_logits, const int64_t
                    const int32_t* succ_off, const int32_t* succ, const float* uniforms, int V,
                    float temperature, int64_t* out, void* stream);
 
+/* Sampling WITHOUT replacement for the tree growth (test/offloading_seqouia.py:29-39):
+ * out[row][0..k) = the k token ids with the largest log(rand[row][i]) / softmax(logits[row] / temperature)[i], in
+ * descending order (= `(rand.log() / q).topk(k).indices`); rand is fp16, logits fp32 [rows][V]; k <= 16, V <= 32768.
+ * One kernel instead of softmax + log + div + multi-block top-k (which also hangs when replayed from a hipGraph). */
+int tf_sample_without_replacement(const float* logits, const void* rand_f16, int64_t* out, int rows, int V, int k,
+                                  float temperature, void* stream);
+
 /* -------------------------------------------------------------------------------------------
  * Offloading tier (models/cache.py:345-351 copy_back_from_buffer, :372-376 copy_kv, :573-575):
  * asynchronous pinned-host <-> device copies of a head-major KV block = H rows of width_elems

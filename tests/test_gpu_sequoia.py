@@ -150,6 +150,29 @@ def test_tree_accept_edge_cases():
     assert terminal and acc == [0] and rec[2] == 1 and rec[0] == 1 and rec[3] == len(gm["Successors"][0])
 
 
+@pytest.mark.parametrize("rows,V,k,T", [(1, 1024, 4, 0.6), (7, 32000, 7, 0.6), (53, 32000, 5, 0.8), (31, 5000, 16, 1.0)])
+def test_sample_without_replacement_matches_oracle(rows, V, k, T):
+    """tf_sample_without_replacement == (rand.log() / softmax(logits / T)).topk(k).indices, row by row and in order
+    (a winner may differ only where two keys are within fp32 rounding of each other)."""
+    from triforce_amd import ops
+    g = torch.Generator().manual_seed(rows + V)
+    logits = torch.randn(rows, V, generator=g) * 2.0
+    rand = torch.rand(rows, V, generator=g).half()
+    rand[0, :3] = 0.0                                      # log(0) = -inf: never drawn
+    want = RT.sample_without_replacement(logits, rand, k, T).view(rows, k)
+    got = ops.sample_without_replacement(logits.to(DEV), rand.to(DEV), k, T).view(rows, k).cpu()
+    agree = (got == want).float().mean().item()
+    assert agree > 0.98, f"only {agree:.3f} of the draws agree"
+    for r in range(rows):
+        assert len(set(got[r].tolist())) == k and int(got[r].min()) >= 0 and int(got[r].max()) < V
+        if not torch.equal(got[r], want[r]):               # a swap must be a near-tie of the race keys
+            q = torch.softmax(logits[r] / T, -1)
+            keys = rand[r].log().float() / q
+            a, b = keys[got[r]], keys[want[r]]
+            assert torch.allclose(a, b, rtol=1e-4), (r, got[r], want[r])
+    assert not (got[0].unsqueeze(1) == torch.arange(3).unsqueeze(0)).any()
+
+
 def test_kv_gather_rows_bit_exact():
     from triforce_amd import ops
     L, H, T, D = 3, 4, 300, 128

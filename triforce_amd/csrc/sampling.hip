@@ -369,6 +369,104 @@ extern "C" int tf_tree_accept(const float* p_rows, const float* draft_logits, co
     return TF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sampling WITHOUT replacement for the Sequoia tree growth (test/offloading_seqouia.py:29-39):
+//   position = (rand.log() / softmax(logits / T)).topk(k).indices
+// — the exponential race: the k largest log(u_i)/q_i (all negative; closest to zero wins) are a draw of k
+// distinct tokens proportional to q.  One workgroup per row: softmax statistics by two block reductions, the keys
+// stay in registers, then k rounds of a block-wide arg-max (ties -> lowest token id) each retiring its winner.
+// The torch formulation (softmax, log, div, multi-block topk over 32 000 columns) is ~6 launches per tree level
+// and its multi-block top-k does not survive hipGraph replay (second replay of a captured growth hangs); this
+// kernel is what makes the whole-growth graph possible.  rand is fp16 like the reference's table; its log is
+// rounded to fp16 exactly as `rand.log()` does.  k <= 16, V <= 32768.
+// ------------------------------------------------------------------------------------------------
+#define SWOR_EPT 32
+__global__ __launch_bounds__(SAMP_THREADS) void sample_wor_kernel(const float* __restrict__ logits,
+                                                                   const h16* __restrict__ rnd,
+                                                                   int64_t* __restrict__ out, int V, int k,
+                                                                   float temperature) {
+    __shared__ float sm[SAMP_THREADS / 64];
+    __shared__ float sm_v[SAMP_THREADS / 64];
+    __shared__ int sm_i[SAMP_THREADS / 64];
+    __shared__ int s_win;
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* lr = logits + (int64_t)row * V;
+    const h16* rr = rnd + (int64_t)row * V;
+    float key[SWOR_EPT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < SWOR_EPT; ++s) {
+        const int i = s * SAMP_THREADS + tid;                       // coalesced; ownership order is irrelevant here
+        key[s] = (i < V) ? lr[i] / temperature : -INFINITY;
+        mx = fmaxf(mx, key[s]);
+    }
+    mx = block_max_s(mx, sm, tid);
+    float zl = 0.f;
+#pragma unroll
+    for (int s = 0; s < SWOR_EPT; ++s) {
+        key[s] = (s * SAMP_THREADS + tid < V) ? expf(key[s] - mx) : 0.f;
+        zl += key[s];
+    }
+    const float Z = block_sum_s(zl, sm, tid);
+#pragma unroll
+    for (int s = 0; s < SWOR_EPT; ++s) {
+        const int i = s * SAMP_THREADS + tid;
+        if (i < V) {
+            const float lu = (float)(h16)logf((float)rr[i]);        // fp16 log like torch's half log
+            key[s] = lu / (key[s] / Z);
+            if (key[s] != key[s]) key[s] = -INFINITY;               // -inf / 0: never a winner
+        } else {
+            key[s] = -INFINITY;
+        }
+    }
+    for (int r = 0; r < k; ++r) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int s = 0; s < SWOR_EPT; ++s) {
+            const int i = s * SAMP_THREADS + tid;
+            if (i < V && (key[s] > bv || (key[s] == bv && i < bi))) { bv = key[s]; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { sm_v[wave] = bv; sm_i[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float wv = sm_v[0];
+            int wi = sm_i[0];
+            for (int w = 1; w < SAMP_THREADS / 64; ++w)
+                if (sm_v[w] > wv || (sm_v[w] == wv && sm_i[w] < wi)) { wv = sm_v[w]; wi = sm_i[w]; }
+            if (wi >= V) wi = 0;                                    // fewer than k finite keys: degenerate row
+            s_win = wi;
+            out[(int64_t)row * k + r] = wi;
+        }
+        __syncthreads();
+        const int win = s_win;
+        if ((win % SAMP_THREADS) == tid) {
+            const int ws = win / SAMP_THREADS;
+#pragma unroll
+            for (int s = 0; s < SWOR_EPT; ++s)
+                if (s == ws) key[s] = -INFINITY;                    // retire the winner
+        }
+    }
+}
+
+extern "C" int tf_sample_without_replacement(const float* logits, const void* rand_f16, int64_t* out, int rows, int V,
+                                             int k, float temperature, void* stream) {
+    if (!logits || !rand_f16 || !out || rows < 1 || V < 1 || k < 1 || k > 16 || !(temperature > 0.f)) return TF_EINVAL;
+    if (V > SAMP_THREADS * SWOR_EPT) return TF_ERANGE;
+    hipLaunchKernelGGL(sample_wor_kernel, dim3(rows), dim3(SAMP_THREADS), 0, (hipStream_t)stream, logits,
+                       (const h16*)rand_f16, out, V, k, temperature);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}
+
+
 extern "C" int tf_sample_inverse_cdf(const float* probs, const float* u, int64_t* token_out, int V, void* stream) {
     if (!probs || !u || !token_out || V < 1) return TF_EINVAL;
     hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(SAMP_THREADS), 0, (hipStream_t)stream, probs, u, token_out, V);

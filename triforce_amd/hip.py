@@ -29,6 +29,7 @@ SIGNATURES = {
     "tf_kv_shift_rows": (_i32, [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "tf_kv_gather_rows": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "tf_tree_accept": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp]),
+    "tf_sample_without_replacement": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "tf_rmsnorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "tf_rope_append": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "tf_silu_mul": (_i32, [_vp, _vp, _i32, _i32, _vp]),

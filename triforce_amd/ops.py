@@ -409,6 +409,19 @@ def kv_gather_rows(k_cache, v_cache, offset, idx):
                                           idx.numel(), L, H, D, _stream()), "tf_kv_gather_rows")
 
 
+def sample_without_replacement(logits, rand, k, temperature):
+    """(rows*k,) int64: per row the k token ids with the largest log(rand)/softmax(logits/T), descending —
+    `(rand.log() / q).topk(k).indices.flatten()` of the reference's sampling callable, one kernel."""
+    _dev(logits, rand)
+    rows, V = logits.shape
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1 and logits.stride(0) == V
+    assert rand.dtype == _HALF and rand.shape == logits.shape and rand.stride(1) == 1 and rand.stride(0) == V
+    out = torch.empty(rows * k, dtype=torch.int64, device=logits.device)
+    hip.check(hip.lib().tf_sample_without_replacement(_ptr(logits), _ptr(rand), _ptr(out), rows, V, int(k),
+                                                      float(temperature), _stream()), "tf_sample_without_replacement")
+    return out
+
+
 TREE_ACCEPT_OUT = 64
 
 

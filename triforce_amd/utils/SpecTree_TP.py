@@ -27,9 +27,13 @@ from .tree import successors_csr
 
 
 def sampling_without_replacement(num_samples, temperature=0.6):
-    """offloading_seqouia.py:29-39 `create_sampling_callable`: (logits (n,V) fp32, rand (n,V)) -> n*num_samples
-    token ids, per row the num_samples largest log(u)/q — a draw without replacement proportional to q."""
+    """offloading_seqouia.py:29-39 `create_sampling_callable`: (logits (n,V) fp32, rand (n,V) fp16) -> n*num_samples
+    token ids, per row the num_samples largest log(u)/q — a draw without replacement proportional to q.  On the
+    device this is one kernel (tf_sample_without_replacement); the torch formulation below is the host-side
+    statement of the same arithmetic."""
     def run(sampling_logits, static_rand):
+        if sampling_logits.is_cuda and sampling_logits.shape[-1] <= ops.TOPP_MAX_VOCAB and num_samples <= 16:
+            return ops.sample_without_replacement(sampling_logits, static_rand, num_samples, temperature)
         q = torch.softmax(sampling_logits / temperature, dim=-1)
         return (static_rand.log() / q).topk(k=num_samples).indices.flatten()
     return run
@@ -172,7 +176,7 @@ class SpecTree:
         self.draft_logits[0:1] = logits
         lo = 0                                            # nodes of level i are [lo, hi)
         hi = 1
-        for i in range(self.draft_step - 1):
+        for i in range(min(self.draft_step - 1, getattr(self, "_debug_max_levels", 1 << 30))):
             total = sum(self.branches[i])
             start = self.level_start[i]
             toks = self.sampling_callables[i](self.draft_logits[lo:hi], self.rand[lo:hi])
