@@ -161,15 +161,23 @@ def test_sample_without_replacement_matches_oracle(rows, V, k, T):
     rand[0, :3] = 0.0                                      # log(0) = -inf: never drawn
     want = RT.sample_without_replacement(logits, rand, k, T).view(rows, k)
     got = ops.sample_without_replacement(logits.to(DEV), rand.to(DEV), k, T).view(rows, k).cpu()
-    agree = (got == want).float().mean().item()
-    assert agree > 0.98, f"only {agree:.3f} of the draws agree"
+    # fp16 uniforms round to exactly 1.0 now and then (log = 0 -> key 0, the best possible): with 32 000 columns a
+    # row holds several such ties and torch.topk's order among equal keys is unspecified (ours: lowest token id).
+    # The race KEYS of the k winners must match position by position; the ids must where keys are distinct.
     for r in range(rows):
         assert len(set(got[r].tolist())) == k and int(got[r].min()) >= 0 and int(got[r].max()) < V
-        if not torch.equal(got[r], want[r]):               # a swap must be a near-tie of the race keys
-            q = torch.softmax(logits[r] / T, -1)
-            keys = rand[r].log().float() / q
-            a, b = keys[got[r]], keys[want[r]]
-            assert torch.allclose(a, b, rtol=1e-4), (r, got[r], want[r])
+        q = torch.softmax(logits[r] / T, -1)
+        keys = rand[r].log().float() / q
+        torch.testing.assert_close(keys[got[r]], keys[want[r]], rtol=1e-4, atol=0.0)
+        distinct = keys[want[r]].unique().numel() == k and (keys == keys[want[r]][-1]).sum() == 1
+        if distinct:
+            differ = (got[r] != want[r]).nonzero().flatten().tolist()
+            for j in differ:                                # only a near-tie may swap two neighbours
+                assert abs(float(keys[got[r][j]] / keys[want[r][j]]) - 1) < 1e-5
+        ties = keys[got[r]][keys[got[r]] == 0]
+        if ties.numel():                                   # among tied zeros: ascending token ids
+            z = got[r][keys[got[r]] == 0].tolist()
+            assert z == sorted(z)
     assert not (got[0].unsqueeze(1) == torch.arange(3).unsqueeze(0)).any()
 
 
