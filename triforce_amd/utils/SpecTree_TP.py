@@ -176,7 +176,7 @@ class SpecTree:
         self.draft_logits[0:1] = logits
         lo = 0                                            # nodes of level i are [lo, hi)
         hi = 1
-        for i in range(min(self.draft_step - 1, getattr(self, "_debug_max_levels", 1 << 30))):
+        for i in range(self.draft_step - 1):
             total = sum(self.branches[i])
             start = self.level_start[i]
             toks = self.sampling_callables[i](self.draft_logits[lo:hi], self.rand[lo:hi])
