@@ -106,3 +106,89 @@ def test_tp2_gloo_matches_oracle():
     gaps = Hh.teacher_forced_gaps(g, outs[0][4])
     assert max(gaps) < 8e-3, f"TP stream leaves the oracle's greedy path: gap {max(gaps):.4f}"
     assert Hh.common_prefix(outs[0][4], g["ar_tokens"]) >= 12
+
+
+# ---- Sequoia tree path at world_size 2 -----------------------------------------------------------------------
+def _seq_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.set_num_threads(2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from tests import cpu_backend, helpers as Hh
+        import triforce_amd.ops as ops
+        for n in cpu_backend.PATCHED:
+            setattr(ops, n, getattr(cpu_backend, n))
+        from oracle import specs
+        from triforce_amd.models.config_yarn import LlamaConfig
+        from triforce_amd.models.TP_llama_tree import DistributedLlama
+        from triforce_amd.utils.SpecTree_TP import SpecTree
+        from triforce_amd.utils.sampling import UniformSource
+        from triforce_amd.utils.tree import grow_map_from_branches
+        g = Hh.load_golden("sequoia_small")
+        V = g["tcfg"]["vocab_size"]
+        gm = grow_map_from_branches(g["branches"])
+        tsd = specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g["head_std"])
+        rand = torch.rand(gm["size"], V, generator=torch.Generator().manual_seed(3)).half()
+        cfg = LlamaConfig.from_dict(g["tcfg"])
+        llm = DistributedLlama("unused", config=cfg, device="cpu", local_rank=rank, world_size=world,
+                               prefill=g["prefill"], gen_len=g["gen_len"], temperature=g["temperature"], top_p=g["top_p"],
+                               retrieval_budget=g["budget"], retrieval_chunk_size=g["chunk"], kv_offload=True,
+                               on_chip_layers=cfg.num_hidden_layers, tree_size=gm["size"])
+        llm.init_parameters(tsd)
+        st = SpecTree(llm, temperature=g["temperature"], top_p=g["top_p"], max_length=g["prefill"] + g["gen_len"],
+                      vocab_size=V, grow_map=gm, rng=UniformSource("cpu", values=Hh.fixed_uniforms(4096, seed=7)),
+                      rand_values=rand)
+        nt = st.prefill(Hh.prompt_of(g)[0])
+        got, counts, n = [int(nt)], [], 0
+        while n < g["gen_len"]:
+            st.construct_grow_map(nt)
+            nt, acc, toks = st.verify()
+            if nt is None:
+                break
+            got.extend(toks[1:].tolist())
+            n += acc
+            counts.append(acc)
+            nt = nt.unsqueeze(0)
+        q.put((rank, "ok", got, counts, llm.kv_cache.seq_len, llm.kv_cache.num_heads))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_sequoia_tp2_gloo_lockstep_and_close_to_oracle():
+    """Head-sharded Sequoia path at world_size 2 (tree attention, per-node retrieval slots and KV compaction on each
+    rank's heads; rank 0's accept record broadcast): both ranks emit the same stream and it follows the single-process
+    oracle (fp16 all-reduce changes the summation order, so a long common prefix rather than equality)."""
+    from oracle import ref_model as M
+    from oracle import ref_tree as RT
+    from oracle import specs
+    from tests import helpers as Hh
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seq_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {}
+    for _ in range(world):
+        item = q.get(timeout=600)
+        assert item[1] == "ok", item[2]
+        outs[item[0]] = item
+    for p in procs:
+        p.join(timeout=60)
+    assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3] and outs[0][4] == outs[1][4]
+    g = Hh.load_golden("sequoia_small")
+    assert outs[0][5] == g["tcfg"]["num_attention_heads"] // world
+    gm = RT.grow_map_from_branches(g["branches"])
+    V = g["tcfg"]["vocab_size"]
+    tsd = specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g["head_std"])
+    rand = torch.rand(gm["size"], V, generator=torch.Generator().manual_seed(3)).half()
+    eng = RT.TreeEngine(g["tcfg"], tsd, g["prefill"], g["gen_len"], g["budget"], g["chunk"], gm["size"])
+    so = RT.SpecTreeO(eng, gm, g["temperature"], g["top_p"], V, M.InjectedRng(Hh.fixed_uniforms(4096, seed=7)), rand)
+    want, want_counts = RT.run_sequoia(so, Hh.prompt_of(g)[0], g["gen_len"])
+    cp = Hh.common_prefix(outs[0][2], want)
+    assert cp >= min(len(want), 1 + want_counts[0]), (cp, outs[0][2][:16], want[:16])   # at least the whole first step
+    assert sum(outs[0][3]) == len(outs[0][2]) - 1 and outs[0][4] == g["prefill"] + sum(outs[0][3])
