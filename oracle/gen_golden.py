@@ -348,6 +348,30 @@ def main():
                   temperature=1.0, top_p=1e-9, repeats=1)
 
 
+def cli_case(name="cli_flags"):
+    """The command lines of the reference's four entry scripts (flag -> type name, default), read from their
+    `add_argument` calls with `ast` (the scripts cannot be imported: they run their benchmark at import time)."""
+    import ast
+    import json
+    out = {}
+    for script in ("on_chip", "offloading", "offloading_TP", "offloading_seqouia"):
+        tree = ast.parse(open(os.path.join(_refshim.REFERENCE_ROOT, "test", script + ".py")).read())
+        flags = {}
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Call) and getattr(node.func, "attr", "") == "add_argument":
+                flag = node.args[0].value
+                kw = {k.arg: k.value for k in node.keywords}
+                if "action" in kw:
+                    flags[flag] = ["flag", None]
+                else:
+                    typ = kw["type"].id if "type" in kw else "str"
+                    flags[flag] = [typ, ast.literal_eval(kw["default"]) if "default" in kw else None]
+        out[script] = flags
+    with open(os.path.join(GOLDEN, name + ".json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(f"[{name}] ok: " + ", ".join(f"{k}: {len(v)} flags" for k, v in out.items()))
+
+
 def main_sequoia():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
@@ -369,6 +393,10 @@ def main_sequoia():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "sequoia":
         main_sequoia()
+    elif len(sys.argv) > 1 and sys.argv[1] == "cli":
+        os.makedirs(GOLDEN, exist_ok=True)
+        cli_case()
     else:
         main()
         main_sequoia()
+        cli_case()

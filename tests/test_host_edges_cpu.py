@@ -105,3 +105,31 @@ def test_middle_spec_standalone_signature(cpu_ops):
     assert ids[0] == 5 and g["gamma"] <= len(ids) - 1 <= g["gamma"] + 1
     assert rows.shape == (len(ids) - 1, g["tcfg"]["vocab_size"]) and 0.0 <= acc <= 1.0
     assert torch.allclose(rows.sum(-1), torch.ones(len(ids) - 1), atol=1e-5)
+
+
+def test_cli_flag_tables_match_the_reference_scripts():
+    """Drop-in boundary of the entry scripts: every flag of the reference's test/*.py exists here with the same type
+    and default (tests/golden/cli_flags.json, read from the reference's add_argument calls by oracle/gen_golden.py).
+    Deliberate differences: --dataset defaults to `synthetic` (the reference's datasets are absent offline), and
+    offline-only flags (--weights, --draft-weights, --tokenizer, --greedy, --no_graphs) are additions."""
+    import json
+    import os
+    from triforce_amd.utils import cli
+    here = os.path.dirname(os.path.abspath(__file__))
+    ref = json.load(open(os.path.join(here, "golden", "cli_flags.json")))
+    names = {int: "int", float: "float", str: "str"}
+    for script, flags in ref.items():
+        ours = {name: (typ if typ == "flag" else names[typ], default) for name, typ, default, _ in cli.SCRIPTS[script]}
+        for flag, (typ, default) in flags.items():
+            assert flag in ours, f"{script}: reference flag {flag} missing"
+            assert ours[flag][0] == typ, f"{script} {flag}: type {ours[flag][0]} != {typ}"
+            if flag == "--dataset":
+                assert ours[flag][1] == "synthetic"
+            elif typ != "flag":
+                assert ours[flag][1] == default, f"{script} {flag}: default {ours[flag][1]!r} != {default!r}"
+        extra = set(ours) - set(flags)
+        assert extra <= {"--weights", "--draft-weights", "--tokenizer", "--greedy", "--no_graphs", "--file"}, (script, extra)
+        args = cli.parse(script, [])                      # every table parses with its defaults
+        assert args.gen_len == 256 and args.temp == 0.6 and args.top_p == 0.9
+    assert cli.parse("on_chip", ["--greedy"]).top_p == 1e-9 and cli.parse("on_chip", ["--greedy"]).temp == 1.0
+    assert cli.parse("offloading_TP", ["--gamma", "16"]).gamma == "16"      # the reference parses --gamma as str here
