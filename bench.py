@@ -244,6 +244,25 @@ def pmc_traffic(alg_bytes, H, D):
             "traffic_source": os.path.relpath(f, ROOT), "traffic_over_algorithmic": j["traffic_over_algorithmic"]}
 
 
+def attn_roofline(timer, retrieval_rows, H, D):
+    """Live roofline of the dominant kernel — target-verify attention over the full KV (the sampled launches with
+    more keys than the retrieval cache holds).  H = heads on THIS rank.  HIP events on the launch stream."""
+    from triforce_amd import ops
+    full = [(a.elapsed_time(b) * 1e-3, sk) for (a, b, sk, _, _) in timer if sk > retrieval_rows]
+    if not full:
+        return None
+    dur = sum(d for d, _ in full) / len(full)
+    byts = sum(2 * sk * H * D * 2 for _, sk in full) / len(full)
+    achieved = byts / dur / 1e9
+    roof = {"bound": "hbm", "kernel": "attn_split_kernel<128,1> (+merge) via tf_attn_decode",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "launches": len(full), "launches_sampled_every": ops.ATTN_TIMER_EVERY,
+            "avg_launch_us": round(dur * 1e6, 1), "algorithmic_bytes_per_launch": int(byts)}
+    roof.update(pmc_traffic(byts, H, D))
+    return roof
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -290,22 +309,7 @@ def main():
     accepted, drafted = run.accepted_count - acc0, run.draft_count - dr0
     value = tokens / seconds
 
-    # dominant kernel: target-verify attention over the full KV (the launches with sk > budget + gamma + 1)
-    H, D = tcfg.num_attention_heads, tcfg.head_dim
-    full = [(a.elapsed_time(b) * 1e-3, sk) for (a, b, sk, _, _) in timer if sk > args.budget + args.gamma + 1]
-    if full:
-        dur = sum(d for d, _ in full) / len(full)
-        byts = sum(2 * sk * H * D * 2 for _, sk in full) / len(full)
-        achieved = byts / dur / 1e9
-        roof = {"bound": "hbm", "kernel": "attn_split_kernel<128,1> (+merge) via tf_attn_decode",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                "launches": len(full), "launches_sampled_every": ops.ATTN_TIMER_EVERY,
-                "avg_launch_us": round(dur * 1e6, 1),
-                "algorithmic_bytes_per_launch": int(byts)}
-        roof.update(pmc_traffic(byts, H, D))
-    else:
-        roof = None
+    roof = attn_roofline(timer, args.budget + args.gamma + 1, tcfg.num_attention_heads, tcfg.head_dim)
 
     stages = stage_latencies(ge, args, device)
     inner_per_step = (run.inner_iters - inner0) / max(args.steps, 1)

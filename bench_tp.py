@@ -13,7 +13,8 @@ import torch.distributed as dist
 
 
 def run_tp(args, rank, world, local):
-    from bench import _Tok, target_config
+    from bench import _Tok, attn_roofline, target_config
+    from triforce_amd import ops
     from triforce_amd.models.cache import StreamingLLMEvictionCache
     from triforce_amd.models.modeling_llama_68m import LlamaForCausalLM as Draft68M
     from triforce_amd.models.TP_llama import DistributedLlama, distributed_init
@@ -53,6 +54,8 @@ def run_tp(args, rank, world, local):
     for _ in range(args.warmup):
         run.step()
     n0, acc0, dr0 = run.n, run.accepted_count, run.draft_count
+    if rank == 0:
+        ops.ATTN_TIMER = []                                     # rank 0 samples its attention launches (HIP events)
     dist.barrier()
     torch.cuda.synchronize()
     t1 = time.time()
@@ -61,12 +64,15 @@ def run_tp(args, rank, world, local):
     torch.cuda.synchronize()
     dist.barrier()
     t2 = time.time()
+    timer, ops.ATTN_TIMER = ops.ATTN_TIMER, None
     elapsed = torch.tensor([t2 - t1], dtype=torch.float64, device=device)
     dist.all_reduce(elapsed, dist.ReduceOp.MAX)                 # slowest rank defines the job time
     seconds = float(elapsed.item())
     tokens = run.n - n0
     accepted, drafted = run.accepted_count - acc0, run.draft_count - dr0
     if rank == 0:
+        # per-rank roofline: this rank's heads only (H / world), against ONE GPU's HBM peak
+        roof = attn_roofline(timer, args.budget + args.gamma + 1, tcfg.num_attention_heads // world, tcfg.head_dim)
         print(json.dumps({
             "metric": "decode tokens/sec + avg accepted len, Llama-7B-128K @124K ctx",
             "value": round(tokens / seconds, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
@@ -81,6 +87,8 @@ def run_tp(args, rank, world, local):
             "avg_accepted_len": round(accepted / max(drafted, 1) * args.gamma, 4),
             "acceptance_rate": round(accepted / max(drafted, 1), 4), "tokens": tokens,
             "tokens_per_step": round(tokens / args.steps, 3), "prefill_seconds": round(t_prefill, 2),
-            "kv_seq_len": llm.kv_cache.seq_len}), flush=True)
+            "kv_seq_len": llm.kv_cache.seq_len, "graph_form": getattr(llm, "graph_form", "eager"),
+            "roofline": roof, "roofline_note": None if roof else "target verify replayed from a hipGraph on this run: "
+            "no per-launch HIP events; see profiles/ for the rocprofv3 kernel trace", "cpu_baseline": None}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
