@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--rebuild-every", type=int, default=0,
+                    help="re-select the retrieval cache every N target verifies (0 = the reference: once per prompt)")
     return ap.parse_args()
 
 
@@ -285,7 +287,7 @@ def main():
     gen = torch.Generator().manual_seed(args.seed)
     input_ids = torch.randint(3, tcfg.vocab_size, (1, args.prefill), generator=gen).to(device)
     run = TriForceRunner(_Tok(), ge, args.gamma, top_k=-1, top_p=args.top_p, temperature=args.temp,
-                         rng=UniformSource(device, seed=args.seed))
+                         rng=UniformSource(device, seed=args.seed), rebuild_every=args.rebuild_every)
     t0 = time.time()
     do_prefill(run, ge, input_ids, args.prefill_mode)
     torch.cuda.synchronize()
@@ -322,7 +324,7 @@ def main():
                                f"{args.prefill}, budget {args.budget}, chunk {args.chunk_size}, gamma {args.gamma}, "
                                f"T={args.temp}, top_p={args.top_p}, 1xMI355X",
                    "prefill_mode": args.prefill_mode, "weights": "random-init N(0,0.02) fp16",
-                   "hipgraphs": not args.no_graphs},
+                   "hipgraphs": not args.no_graphs, "retrieval_rebuild_every": args.rebuild_every},
         "avg_accepted_len": round(accepted / max(drafted, 1) * args.gamma, 4),
         "acceptance_rate": round(accepted / max(drafted, 1), 4),
         "tokens": tokens, "tokens_per_step": round(tokens / args.steps, 3),

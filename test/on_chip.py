@@ -58,7 +58,7 @@ def main():
     spec_args = {"budget": args.budget, "draft": args.draft, "chunk_size": args.chunk_size, "gamma": args.gamma,
                  "temperature": args.temp, "top_p": args.top_p, "baseline": baseline_latency / 1000}
     run = dict(gamma=args.gamma, max_len=args.gen_len, verbose=args.verbose, dataset=args.dataset, spec_args=spec_args,
-               **sampling)
+               rebuild_every=args.rebuild_every, **sampling)
     for _ in range(3):
         TriForce(tokenizer, engine, clip(prompts[0]), **run)
     results = [TriForce(tokenizer, engine, clip(p), file_path=args.file, **run) for p in prompts]

@@ -117,6 +117,30 @@ def test_logits_and_retrieval_stages_match_oracle(name):
     assert (qo - qp).abs().max() < 5e-3, f"draft probs differ by {(qo - qp).abs().max():.3e}"
 
 
+def test_periodic_retrieval_rebuild_stays_lossless_on_device():
+    """--rebuild_every: re-selecting the retrieval chunks inside a target verify changes what the
+    middle model drafts from, never what the target accepts — the greedy stream stays on the oracle's argmax path,
+    and the rebuilt slots hold exactly the chunks the fresh index names."""
+    from triforce_amd.utils.decoding import TriForce
+    g = Hh.load_golden("small_gamma6")
+    ge = Hh.build_product(g, DEV, graphs=True)
+    prompt, tok = Hh.prompt_of(g).to(DEV), Hh.FakeTokenizer()
+    res = TriForce(tok, ge, prompt, gamma=g["gamma"], max_len=g["gen_len"], top_k=-1, top_p=g["top_p"],
+                   temperature=g["temperature"], return_details=True, rebuild_every=2)
+    assert max(Hh.teacher_forced_gaps(g, res["tokens"])) < GAP_TOL
+    assert Hh.common_prefix(res["tokens"], g["ar_tokens"]) >= min(16, len(res["tokens"]))
+    rc, kv = ge.engine.graph_cache, ge.engine.kv_cache
+    gen, cs = kv.seq_len - rc.prefill, rc.chunk_size
+    keep = min(rc.select_sets, (rc.max_budget - gen) // cs)               # sets not overwritten by the generated tail
+    for layer in (0, rc.layers - 1):
+        idx = rc.last_idx[layer].long()[:, :keep]                         # (H, keep)
+        src_k, src_v = kv.layer_kv(layer)
+        rows = (idx.unsqueeze(-1) * cs + torch.arange(cs, device=DEV)).reshape(rc.num_heads, -1)   # (H, keep*cs)
+        pick = rows.unsqueeze(-1).expand(-1, -1, rc.head_dim)
+        assert torch.equal(rc.k[layer, :, :keep * cs], src_k.gather(1, pick))
+        assert torch.equal(rc.v[layer, :, :keep * cs], src_v.gather(1, pick))
+
+
 def test_stochastic_triforce_with_injected_uniforms():
     """cfg3-style sampling (T=0.6, top_p=0.9).  Product and oracle consume the same explicit uniforms; the
     accept masks are bit-exact functions of (p, q, r), so the streams agree until a probability that

@@ -111,7 +111,8 @@ def test_cli_flag_tables_match_the_reference_scripts():
     """Drop-in boundary of the entry scripts: every flag of the reference's test/*.py exists here with the same type
     and default (tests/golden/cli_flags.json, read from the reference's add_argument calls by oracle/gen_golden.py).
     Deliberate differences: --dataset defaults to `synthetic` (the reference's datasets are absent offline), and
-    offline-only flags (--weights, --draft-weights, --tokenizer, --greedy, --no_graphs) are additions."""
+    offline-only flags (--weights, --draft-weights, --tokenizer, --greedy, --no_graphs) and --rebuild_every (SURVEY 8f
+    row 4, off by default) are additions."""
     import json
     import os
     from triforce_amd.utils import cli
@@ -128,7 +129,8 @@ def test_cli_flag_tables_match_the_reference_scripts():
             elif typ != "flag":
                 assert ours[flag][1] == default, f"{script} {flag}: default {ours[flag][1]!r} != {default!r}"
         extra = set(ours) - set(flags)
-        assert extra <= {"--weights", "--draft-weights", "--tokenizer", "--greedy", "--no_graphs", "--file"}, (script, extra)
+        assert extra <= {"--weights", "--draft-weights", "--tokenizer", "--greedy", "--no_graphs", "--file",
+                         "--rebuild_every"}, (script, extra)
         args = cli.parse(script, [])                      # every table parses with its defaults
         assert args.gen_len == 256 and args.temp == 0.6 and args.top_p == 0.9
     assert cli.parse("on_chip", ["--greedy"]).top_p == 1e-9 and cli.parse("on_chip", ["--greedy"]).temp == 1.0

@@ -64,3 +64,33 @@ def test_product_logits_equal_oracle_logits(cpu_ops):
     assert torch.equal(l1[:, -1], g["target_logits"][0])
     assert torch.equal(l2[:, -1], g["target_logits"][1])
     assert torch.equal(l3, g["target_logits"][2])
+
+
+def test_periodic_retrieval_rebuild_is_lossless_and_consistent(cpu_ops):
+    """--rebuild_every: the retrieval cache only steers drafting, so greedy TriForce must still emit
+    the target's greedy continuation, and after a rebuild every retrieved slot must hold the chunk its index names."""
+    from triforce_amd.utils.decoding import TriForce
+    g = Hh.load_golden("small_gamma6")
+    ge = Hh.build_product(g, "cpu")
+    prompt, tok = Hh.prompt_of(g), Hh.FakeTokenizer()
+    res = TriForce(tok, ge, prompt, gamma=g["gamma"], max_len=g["gen_len"], top_k=-1, top_p=g["top_p"],
+                   temperature=g["temperature"], return_details=True, rebuild_every=2)
+    n = min(len(res["tokens"]), len(g["ar_tokens"]))
+    assert res["tokens"][:n] == g["ar_tokens"][:n]                       # lossless
+    rc, kv = ge.engine.graph_cache, ge.engine.kv_cache
+    assert res["outer_steps"] >= 2
+    gen = kv.seq_len - rc.prefill                                        # generated tail occupies [B - gen, B)
+    cs = rc.chunk_size
+    for layer in (0, rc.layers - 1):
+        idx = rc.last_idx[layer]                                         # (H, sets), chunk 0 first
+        assert (idx[:, 0] == 0).all()
+        src_k, _ = kv.layer_kv(layer)
+        for h in range(rc.num_heads):
+            for j in range(min(rc.select_sets, (rc.max_budget - gen) // cs)):
+                c = int(idx[h, j])
+                assert torch.equal(rc.k[layer, h, j * cs:(j + 1) * cs], src_k[h, c * cs:(c + 1) * cs]), (layer, h, j)
+    # the selection did move with the query (otherwise this test would not exercise the rebuild)
+    ge2 = Hh.build_product(g, "cpu")
+    TriForce(tok, ge2, prompt, gamma=g["gamma"], max_len=g["gen_len"], top_k=-1, top_p=g["top_p"],
+             temperature=g["temperature"], return_details=True)
+    assert any(not torch.equal(rc.last_idx[i], ge2.engine.graph_cache.last_idx[i]) for i in range(rc.layers))

@@ -59,10 +59,10 @@ class LlamaForCausalLM:
     # -- forward -----------------------------------------------------------------------------
     @torch.inference_mode()
     def __call__(self, input_ids, kv_cache=None, graph_cache=None, position_ids=None, spec=False,
-                 attention_mask=None, storage_ids=None, gamma_offset=0):
-        return self.forward(input_ids, kv_cache, graph_cache, position_ids, spec)
+                 attention_mask=None, storage_ids=None, gamma_offset=0, rebuild_retrieval=False):
+        return self.forward(input_ids, kv_cache, graph_cache, position_ids, spec, rebuild_retrieval)
 
-    def forward(self, input_ids, kv_cache, graph_cache=None, position_ids=None, spec=False):
+    def forward(self, input_ids, kv_cache, graph_cache=None, position_ids=None, spec=False, rebuild_retrieval=False):
         W = self.weights
         H, D = W.H, W.D
         q_len = input_ids.shape[1]
@@ -72,6 +72,9 @@ class LlamaForCausalLM:
         pos = position_ids.reshape(-1).contiguous()
         x = W.embed[input_ids.reshape(-1)]              # (q, hidden) fp16 gather
         build = (not spec) and q_len == 1 and isinstance(graph_cache, RetrievalCache)
+        # periodic rebuild (described in the reference's blog, absent from its code): during a
+        # target verify, re-select the prefill chunks with the query of the first — already confirmed — token
+        rebuild = (not spec) and q_len > 1 and rebuild_retrieval and isinstance(graph_cache, RetrievalCache)
         streaming = (not spec) and hasattr(kv_cache, "begin_forward")     # host-offloaded KV (test/offloading.py)
         if streaming:
             kv_cache.begin_forward()
@@ -111,6 +114,8 @@ class LlamaForCausalLM:
                         graph_cache.init_graph_cache(kv_cache, q, i)
                     else:
                         graph_cache.update_graph_cache_retrieval(kv_cache, q, i)
+                elif rebuild:                           # generated tail is re-copied by update_graph_cache() after accept
+                    graph_cache.init_graph_cache(kv_cache, q[:1], i)
                 a = ops.attn_prefill(q, kl, vl, sk, self.scale)
                 if streaming:
                     kv_cache.layer_done(i, slot, q_len)

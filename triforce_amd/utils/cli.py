@@ -46,6 +46,7 @@ SCRIPTS = {
         ("--budget", int, 4096, "retrieval budget"),
         ("--greedy", "flag", None, "temperature 1.0, top_p 1e-9 (the only greedy the reference's sampler admits)"),
         ("--file", str, None, "CSV log path"),
+        ("--rebuild_every", int, 0, "re-select the retrieval cache every N target verifies (0 = once per prompt)"),
     ],
     "offloading": _COMMON + _OFFLINE + _SINGLE_GPU + [("--budget", int, 8192, "retrieval budget")],
     "offloading_TP": _COMMON + _OFFLINE + _TENSOR_PARALLEL + [

@@ -145,7 +145,10 @@ class TriForceRunner:
     ``max_len`` tokens, bench.py drives it for an exact number of steps."""
 
     def __init__(self, tokenizer, graph_engine, gamma, top_k=-1, top_p=0.9, temperature=0.6, verbose=False, rng=None,
-                 inclusive_accept=False, sync_record=None):
+                 inclusive_accept=False, sync_record=None, rebuild_every=0):
+        # rebuild_every: N > 0 re-selects the retrieval cache's prefill chunks during every N-th target verify
+        #                (SURVEY 8f row 4); 0 = the reference's behaviour, one build per prompt
+        self.rebuild_every, self.rebuilds = int(rebuild_every), 0
         # inclusive_accept: the TP outer loop tests ``r <=`` (decoding.py:347) where on-chip tests ``r <`` (:99)
         # sync_record: optional callable applied to each device decision record before it is read (TP: broadcast
         #              from rank 0, the role of sample_dist / the r broadcast, decoding.py:230-239,345-346)
@@ -203,7 +206,11 @@ class TriForceRunner:
 
         # target model verifies [next, t1..t_g2] against the full KV cache
         verify_tokens = torch.tensor([ids], dtype=torch.long, device=device)
-        logits = ge.inference(input_ids=verify_tokens)
+        if self.rebuild_every > 0 and (len(self.counts) + 1) % self.rebuild_every == 0:
+            logits = ge.inference(input_ids=verify_tokens, rebuild_retrieval=True)
+            self.rebuilds += 1
+        else:
+            logits = ge.inference(input_ids=verify_tokens)
         probs = norm_logits(logits[0], temperature=self.temperature, top_k=self.top_k, top_p=self.top_p)
         ops.accept_chain(probs, spec_rows, verify_tokens.view(-1)[1:], rng.take(g2 + 1), g2, self.inclusive_accept,
                          self.eos, bufs.chain_out)
@@ -261,8 +268,9 @@ class TriForceRunner:
 
 @torch.inference_mode()
 def TriForce(tokenizer, graph_engine, input_ids, gamma=4, max_len=256, top_k=-1, top_p=0.9, temperature=0.6, verbose=False,
-             file_path=None, dataset=None, spec_args=None, rng=None, return_details=False):
-    run = TriForceRunner(tokenizer, graph_engine, gamma, top_k, top_p, temperature, verbose, rng)
+             file_path=None, dataset=None, spec_args=None, rng=None, return_details=False, rebuild_every=0):
+    run = TriForceRunner(tokenizer, graph_engine, gamma, top_k, top_p, temperature, verbose, rng,
+                         rebuild_every=rebuild_every)
     run.prefill(input_ids)
     eng, device = run.eng, run.device
     _sync(device)

@@ -23,14 +23,15 @@ class InferenceEngine:
         self.draft_cache = draft_cache
 
     @torch.inference_mode()
-    def model_run(self, input_ids: torch.LongTensor):
+    def model_run(self, input_ids: torch.LongTensor, rebuild_retrieval=False):
         n = input_ids.shape[-1]
         if n > 64:                                 # chunked prefill, 128 tokens per forward (graph_infer.py:30-37)
             for i in range(math.ceil(n / 128)):
                 logits = self.model(input_ids=input_ids[:, i * 128:(i + 1) * 128], kv_cache=self.kv_cache,
                                     graph_cache=None).logits
         else:                                      # verification / q_len==1 retrieval build
-            logits = self.model(input_ids=input_ids, kv_cache=self.kv_cache, graph_cache=self.graph_cache).logits
+            logits = self.model(input_ids=input_ids, kv_cache=self.kv_cache, graph_cache=self.graph_cache,
+                                rebuild_retrieval=rebuild_retrieval).logits
         return logits
 
     @torch.inference_mode()
@@ -167,8 +168,8 @@ class GraphInferenceEngine:
 
     # -- the surface used by utils/decoding.py ---------------------------------------------------------------
     @torch.inference_mode()
-    def inference(self, input_ids: torch.LongTensor):
-        return self.engine.model_run(input_ids=input_ids)
+    def inference(self, input_ids: torch.LongTensor, rebuild_retrieval=False):
+        return self.engine.model_run(input_ids=input_ids, rebuild_retrieval=rebuild_retrieval)
 
     @torch.inference_mode()
     def graph_draft_prefill(self, input_ids: torch.LongTensor):
