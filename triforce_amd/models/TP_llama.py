@@ -32,13 +32,11 @@ from .TP_layers import DistributedOffloadingConfig
 def distributed_init(backend=None):
     """torchrun entry: RCCL process group, one device per local rank (reference TP_llama.py:19-25)."""
     backend = backend or os.environ.get("TRIFORCE_DIST_BACKEND", "nccl")
+    if backend == "nccl":                       # bind the device first: RCCL communicators attach to the current one
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", 0))))
     if not dist.is_initialized():
         dist.init_process_group(backend=backend)
-    local_rank = dist.get_rank()
-    world_size = dist.get_world_size()
-    if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", local_rank)))
-    return local_rank, world_size
+    return dist.get_rank(), dist.get_world_size()
 
 
 class TreeMask:
