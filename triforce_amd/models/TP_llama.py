@@ -248,9 +248,8 @@ class DistributedLlama:
 
     @torch.inference_mode()
     def prefill(self, input_ids):
-        for i in range(math.ceil(input_ids.shape[1] / 128)):                   # TP_llama.py:246-250
-            logits = self.inference(input_ids=input_ids[:, i * 128:(i + 1) * 128])
-        return logits
+        from ..utils.graph_infer import chunked_prefill                       # TP_llama.py:246-250
+        return chunked_prefill(lambda ids: self.inference(input_ids=ids), input_ids)
 
     @torch.inference_mode()
     def build_retrieval_cache(self, input_ids):

@@ -7,11 +7,30 @@ through the C ABI, so they are captured together with the hipBLASLt GEMMs.
 """
 import gc
 import math
+import os
 from typing import Optional
 
 import torch
 
 from .sampling import norm_logits
+
+
+# Target prefill: the reference feeds 128 tokens per forward (graph_infer.py:30-37, TP_llama.py:246-250), which at
+# 128 rows leaves every GEMM bound by re-streaming the 13 GB of weights (976 times for a 125K prompt).  On the device
+# the chunk is 512 rows — same causal attention (tf_attn_block takes it as 128-row slabs), a quarter of the weight
+# traffic, and under KV offloading a quarter of the host->device re-streams.  The returned logits keep the
+# reference's shape (the rows of ITS last 128-token chunk).  CPU (oracle-backed tests) keeps 128.
+PREFILL_CHUNK = int(os.environ.get("TRIFORCE_PREFILL_CHUNK", "512"))
+assert PREFILL_CHUNK % 128 == 0 and PREFILL_CHUNK > 0
+
+
+def chunked_prefill(forward, input_ids):
+    """Run ``forward(chunk) -> logits (1, rows, V)`` over the prompt; returns the logits of the reference's last chunk."""
+    n = input_ids.shape[-1]
+    chunk = PREFILL_CHUNK if input_ids.is_cuda else 128
+    for i in range(math.ceil(n / chunk)):
+        logits = forward(input_ids[:, i * chunk:(i + 1) * chunk])
+    return logits[:, -(n - 128 * (math.ceil(n / 128) - 1)):]
 
 
 class InferenceEngine:
@@ -25,10 +44,9 @@ class InferenceEngine:
     @torch.inference_mode()
     def model_run(self, input_ids: torch.LongTensor, rebuild_retrieval=False):
         n = input_ids.shape[-1]
-        if n > 64:                                 # chunked prefill, 128 tokens per forward (graph_infer.py:30-37)
-            for i in range(math.ceil(n / 128)):
-                logits = self.model(input_ids=input_ids[:, i * 128:(i + 1) * 128], kv_cache=self.kv_cache,
-                                    graph_cache=None).logits
+        if n > 64:                                 # chunked prefill (graph_infer.py:30-37)
+            logits = chunked_prefill(lambda ids: self.model(input_ids=ids, kv_cache=self.kv_cache,
+                                                            graph_cache=None).logits, input_ids)
         else:                                      # verification / q_len==1 retrieval build
             logits = self.model(input_ids=input_ids, kv_cache=self.kv_cache, graph_cache=self.graph_cache,
                                 rebuild_retrieval=rebuild_retrieval).logits
