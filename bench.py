@@ -38,7 +38,7 @@ HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--target", default="llama-7B-128K", choices=["llama-7B-128K", "llama-13B-128K", "lwm-128K", "tiny"])
     ap.add_argument("--prefill", type=int, default=124928)
