@@ -57,3 +57,32 @@ def test_ops_refuse_cpu_tensors():
         ops.rmsnorm(x, torch.ones(8, dtype=torch.float16), 1e-6)
     with pytest.raises(hip.TriforceHipError):
         ops.silu_mul(torch.zeros(2, 16, dtype=torch.float16))
+
+
+_QUERIES = {"tf_abi_version", "tf_attn_block_pick_nsplit", "tf_attn_block_ws_floats", "tf_attn_decode_pick_nsplit",
+            "tf_attn_decode_ws_floats"}
+
+
+@pytest.mark.parametrize("fill", [1, 8, -1])
+def test_every_entry_point_rejects_null_buffers(fill):
+    """Boundary contract (include/triforce_hip.h): every launching entry point validates its arguments BEFORE touching
+    the device and returns TF_EINVAL — with all pointers NULL and all sizes = `fill` none may launch, crash or report
+    success (tf_kv_shift_rows with src == dst is the one documented no-op)."""
+    from triforce_amd import hip
+    lib = hip.lib()
+    for name, (_, argtypes) in sorted(hip.SIGNATURES.items()):
+        if name in _QUERIES:
+            continue
+        args = []
+        for t in argtypes:
+            if t is ctypes.c_void_p:
+                args.append(ctypes.c_void_p(0))
+            elif t in (ctypes.c_float, ctypes.c_double):
+                args.append(1.0)
+            else:
+                args.append(t(fill))
+        rc = getattr(lib, name)(*args)
+        if name == "tf_kv_shift_rows":
+            assert rc == 0
+        else:
+            assert rc == -22, f"{name}(NULL..., sizes={fill}) returned {rc}"
