@@ -56,7 +56,11 @@ def parse():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--rebuild-every", type=int, default=0,
                     help="re-select the retrieval cache every N target verifies (0 = the reference: once per prompt)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    # a step emits at most gamma + 2 tokens: size the KV slack for the worst case of the requested run
+    # (never more than the retrieval budget: its tail holds every generated token, reference cache.py:180-182)
+    args.gen_cap = max(args.gen_cap, min((args.steps + args.warmup + 4) * (args.gamma + 2) + 64, args.budget))
+    return args
 
 
 def target_config(name):
