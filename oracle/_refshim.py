@@ -206,3 +206,16 @@ def load_reference_tree():
     spectree = importlib.import_module("utils.SpecTree_TP")
     _loaded.update(tree=tree, spectree=spectree, tp_layers=tp_layers)
     return types.SimpleNamespace(**_loaded)
+
+
+def load_reference_tp():
+    """Reference modules of the tensor-parallel chain path (models/TP_llama.py + utils/decoding.py *_Dist) importable
+    on CPU, with the same runtime shims as load_reference_tree: 1-rank gloo group, pin_memory -> identity, a torch
+    proxy in the globals of models.cache / models.TP_layers / models.TP_llama.  No reference source is edited."""
+    ref = load_reference_tree()                 # group + proxies for cache / TP_layers
+    if "tp" in _loaded:
+        return types.SimpleNamespace(**_loaded)
+    tp = importlib.import_module("models.TP_llama")
+    tp.torch = _TorchProxy()
+    _loaded.update(tp=tp)
+    return types.SimpleNamespace(**_loaded)

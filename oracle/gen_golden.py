@@ -327,6 +327,95 @@ def sequoia_case(name, tcfg, tseed, pseed, prefill, budget, chunk, gen_len, temp
           f"accepts {[s['acc_count'] for s in steps]}")
 
 
+def tp_chain_case(name="tp_chain"):
+    """Tensor-parallel chain path (SURVEY 8 rows a10/a11 `_Dist`, a13): the UNMODIFIED reference TP_llama.
+    DistributedLlama + utils/decoding.TriForce_Dist / Middle_Spec_Dist run on CPU (1-rank gloo, torch proxies for the
+    CUDA-only calls, one offloaded layer so the copy_kv / copy_back pipeline runs) vs ref_model.triforce(dist=True).
+    Sub-cases: stochastic target, greedy target (the draft still samples at 0.6 / 0.9 — the reference's call sites
+    never forward temperature / top_p), and two eos placements (:357-360 accepted eos, :382-383 loop exit)."""
+    import tempfile
+    ref = _refshim.load_reference_tp()
+    tcfg = specs.llama_config(256, 512, 3, 4, vocab_size=1024, max_position_embeddings=4096,
+                              rope_scaling=dict(type="yarn", factor=8.0, original_max_position_embeddings=512),
+                              name="tiny-d64-tp")
+    dcfg = specs.llama_config(128, 256, 2, 2, vocab_size=1024, max_position_embeddings=2048, name="tiny-draft-tp")
+    tseed, dseed, pseed, head_std = 401, 402, 403, 0.05
+    prefill, budget, chunk, gamma, gen_len = 1000, 128, 8, 6, 40
+    tsd = specs.random_state_dict(tcfg, tseed, head_std=head_std)
+    dsd = specs.random_state_dict(dcfg, dseed, head_std=head_std)
+    prompt = specs.random_prompt(tcfg["vocab_size"], prefill, pseed)
+    hf = build_reference_model(ref, tcfg, tsd)
+    draft = build_reference_model(ref, dcfg, dsd, draft=True)
+    tmp = tempfile.mkdtemp()
+    hf.config.save_pretrained(tmp)
+
+    def reference_run(temperature, top_p, rng_seed, eos):
+        dcache = ref.cache.StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - gamma, gamma=gamma)
+        llm = ref.tp.DistributedLlama(model_name_or_path=tmp, local_rank=0, world_size=1, prefill=prefill,
+                                      gen_len=gen_len, temperature=temperature, top_p=top_p, flash_attn=True,
+                                      retrieval_budget=budget, retrieval_chunk_size=chunk, kv_offload=True,
+                                      on_chip_layers=tcfg["num_hidden_layers"] - 1, draft=draft, draft_cache=dcache,
+                                      gamma=gamma)
+        llm.init_parameters(hf_model=hf)
+        events = []
+        real = ref.decoding.spec_stream
+        ref.decoding.spec_stream = lambda t, tok, color="blue": events.append((color, int(torch.as_tensor(t).reshape(-1)[0])))
+        tok = _refshim.FakeTokenizer()
+        tok.eos_token_id = eos
+        torch.manual_seed(rng_seed)
+        try:
+            avg_tokens, _ = ref.decoding.TriForce_Dist(tok, llm, prompt, gamma=gamma, max_len=gen_len, top_k=-1,
+                                                       top_p=top_p, temperature=temperature, verbose=True)
+        finally:
+            ref.decoding.spec_stream = real
+        assert events[0][0] == "cyan"
+        tokens, counts, cur = [events[0][1]], [], 0
+        for color, t in events[1:]:
+            tokens.append(t)
+            if color == "green":
+                cur += 1
+            else:                                   # red: rejection closes the step; blue: bonus token (+1, :392)
+                counts.append(cur + (1 if color == "blue" else 0))
+                cur = 0
+        return dict(tokens=tokens, counts=counts, open_greens=cur, avg_tokens=avg_tokens,
+                    final_seq_len=int(llm.kv_cache.seq_len), draft_seq_len=int(dcache.seq_len))
+
+    def oracle_run(temperature, top_p, rng_seed, eos):
+        eng = M.OracleEngine(M.OracleTarget(tcfg, tsd), M.FullCache(tcfg, prefill + gen_len + 32),
+                             M.RetrievalCacheO(tcfg, budget, prefill, chunk, gamma), M.OracleDraft(dcfg, dsd),
+                             M.StreamingCacheO(dcfg, gamma=gamma, start_size=16, recent_size=256 - 16 - gamma),
+                             temperature, top_p, draft_chunk=128, draft_temperature=0.6, draft_top_p=0.9)
+        torch.manual_seed(rng_seed)
+        res = M.triforce(eng, prompt, gamma, gen_len, temperature, top_p, eos_token_id=eos, dist=True)
+        return res, eng
+
+    cases = []
+    t0 = time.time()
+    for label, temperature, top_p, rng_seed, eos_pick in (("stochastic", 0.6, 0.9, 11, None),
+                                                          ("greedy_target", 1.0, 1e-9, 12, None),
+                                                          ("eos_early", 0.6, 0.9, 11, 5),
+                                                          ("eos_late", 0.6, 0.9, 11, 17)):
+        eos = -1
+        if eos_pick is not None:                    # a token that really occurs in the no-eos stream of this seed
+            eos = cases[0]["tokens"][eos_pick]
+        want = reference_run(temperature, top_p, rng_seed, eos)
+        got, eng = oracle_run(temperature, top_p, rng_seed, eos)
+        assert got["tokens"] == want["tokens"], f"[{name}/{label}] stream mismatch\n{got['tokens']}\n{want['tokens']}"
+        ended_by_eos = eos in want["tokens"][1:]
+        assert got["counts"][:len(want["counts"])] == want["counts"], f"[{name}/{label}] accept counts differ"
+        assert abs(got["avg_tokens"] - want["avg_tokens"]) < 1e-12, f"[{name}/{label}] avg_tokens differ"
+        if eos not in want["tokens"][1:]:
+            assert eng.kv_cache.seq_len == want["final_seq_len"] and eng.draft_cache.seq_len == want["draft_seq_len"]
+        cases.append(dict(label=label, temperature=temperature, top_p=top_p, rng_seed=rng_seed, eos=eos,
+                          ended_by_eos=bool(ended_by_eos), **want))
+        print(f"[{name}/{label}] ok: {len(want['tokens'])} tokens, counts {want['counts']}, avg {want['avg_tokens']:.4f}, "
+              f"eos {eos}")
+    torch.save(dict(name=name, tcfg=tcfg, dcfg=dcfg, tseed=tseed, dseed=dseed, pseed=pseed, head_std=head_std,
+                    prefill=prefill, budget=budget, chunk=chunk, gamma=gamma, gen_len=gen_len, cases=cases),
+               os.path.join(GOLDEN, f"{name}.pt"))
+    print(f"[{name}] saved ({time.time() - t0:.1f}s)")
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
@@ -396,7 +485,12 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "cli":
         os.makedirs(GOLDEN, exist_ok=True)
         cli_case()
+    elif len(sys.argv) > 1 and sys.argv[1] == "tp":
+        os.makedirs(GOLDEN, exist_ok=True)
+        torch.set_num_threads(8)
+        tp_chain_case()
     else:
         main()
         main_sequoia()
         cli_case()
+        tp_chain_case()

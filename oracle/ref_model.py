@@ -255,11 +255,15 @@ class OracleDraft(_Weights):
 # ----------------------------------------------------------------------------------------
 class OracleEngine:
     def __init__(self, target, kv_cache, graph_cache, draft, draft_cache, temperature=0.6, top_p=0.9,
-                 prefill_chunk=128, draft_chunk=64):
+                 prefill_chunk=128, draft_chunk=64, draft_temperature=None, draft_top_p=None):
         self.model, self.kv_cache, self.graph_cache = target, kv_cache, graph_cache
         self.draft, self.draft_cache = draft, draft_cache
         self.temperature, self.top_p = temperature, top_p
         self.prefill_chunk, self.draft_chunk = prefill_chunk, draft_chunk
+        # TP path: DistributedLlama.draft_run is always called with its defaults temperature=0.6, top_p=0.9
+        # (TP_llama.py:117, call sites decoding.py:316,394,453) and prefills the draft 128 tokens at a time (:119-126)
+        self.draft_temperature = temperature if draft_temperature is None else draft_temperature
+        self.draft_top_p = top_p if draft_top_p is None else draft_top_p
 
     def inference(self, input_ids):                       # graph_infer.py:29-41 (model_run)
         if input_ids.shape[-1] > 64:
@@ -279,7 +283,7 @@ class OracleEngine:
         else:
             logits = self.draft.forward(input_ids, self.draft_cache, self.draft_cache, gamma_offset=gamma_offset)
         if probs:
-            return R.norm_logits(logits[0], temperature=self.temperature, top_k=-1, top_p=self.top_p)[-1]
+            return R.norm_logits(logits[0], temperature=self.draft_temperature, top_k=-1, top_p=self.draft_top_p)[-1]
         return logits
 
     def graph_draft_prefill(self, input_ids):
@@ -390,8 +394,14 @@ def middle_spec(next_token, engine, gamma, rng):
 
 
 def triforce(engine, input_ids, gamma, max_len, temperature, top_p, rng=None, top_k=-1, eos_token_id=2,
-             trace=None):
-    """utils/decoding.py:41-160.  Returns dict(tokens, acceptance_rate, accepted, drafted, n, counts)."""
+             trace=None, dist=False):
+    """utils/decoding.py:41-160.  Returns dict(tokens, acceptance_rate, accepted, drafted, n, counts).
+
+    dist=True restates TriForce_Dist (:291-428) with Middle_Spec_Dist (:432-495) at world size 1; it differs from the
+    on-chip loop in exactly three places: the outer accept test is ``r <=`` (:347, on-chip ``r <`` :99), the loop ENDS
+    when the token that closed the accept scan is eos (:382-383 — before the cache updates and before a bonus token;
+    the on-chip loop keeps generating), and the result is (accepted / drafted * gamma, seconds per token) (:426-428).
+    The engine carries the other two (draft sampled at 0.6 / 0.9, draft prefill in 128-token blocks)."""
     rng = rng or TorchRng()
     engine.kv_cache.reset()
     engine.graph_cache.reset()
@@ -421,7 +431,8 @@ def triforce(engine, input_ids, gamma, max_len, temperature, top_p, rng=None, to
         pred = next_token
         for i, q_row, p_row in zip(generated, spec_probs, probs):                    # :96-121
             r = rng.uniform()
-            if torch.tensor([r]) < torch.min(torch.tensor([1.0]), (p_row[i] / q_row[i]).reshape(1)):
+            bound = torch.min(torch.tensor([1.0]), (p_row[i] / q_row[i]).reshape(1))
+            if (torch.tensor([r]) <= bound) if dist else (torch.tensor([r]) < bound):
                 count += 1
                 accepted_count += 1
                 n += 1
@@ -439,6 +450,8 @@ def triforce(engine, input_ids, gamma, max_len, temperature, top_p, rng=None, to
                 break
             if eos_token_id == pred:
                 break
+        if dist and eos_token_id == pred:                                           # :382-383
+            break
         engine.kv_cache.seq_len -= (g2 - count)                                     # :124
         engine.update_graph_cache()                                                 # :125
         if count == g2:                                                             # :127-134
@@ -453,4 +466,4 @@ def triforce(engine, input_ids, gamma, max_len, temperature, top_p, rng=None, to
         dc.evict_for_spec(dc.start_size + dc.recent_size + count)                   # :138-139
         next_token = pred
     return dict(tokens=tokens, acceptance_rate=accepted_count / draft_count, accepted=accepted_count,
-                drafted=draft_count, n=n, counts=counts)
+                drafted=draft_count, n=n, counts=counts, avg_tokens=accepted_count / draft_count * gamma)

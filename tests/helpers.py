@@ -33,6 +33,20 @@ def build_oracle(g, temperature=None, top_p=None):
     return eng, tsd, dsd
 
 
+def build_oracle_tp(g, temperature, top_p):
+    """Oracle engine configured like the reference's TP path (tests/golden/tp_chain.pt): draft prefill in 128-token
+    blocks, draft sampled at 0.6 / 0.9 whatever the target's settings, KV capacity prefill + gen_len + 32."""
+    tsd = specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g["head_std"])
+    dsd = specs.random_state_dict(g["dcfg"], g["dseed"], head_std=g["head_std"])
+    gamma = g["gamma"]
+    eng = M.OracleEngine(M.OracleTarget(g["tcfg"], tsd), M.FullCache(g["tcfg"], g["prefill"] + g["gen_len"] + 32),
+                         M.RetrievalCacheO(g["tcfg"], g["budget"], g["prefill"], g["chunk"], gamma),
+                         M.OracleDraft(g["dcfg"], dsd),
+                         M.StreamingCacheO(g["dcfg"], gamma=gamma, start_size=16, recent_size=256 - 16 - gamma),
+                         temperature, top_p, draft_chunk=128, draft_temperature=0.6, draft_top_p=0.9)
+    return eng, tsd, dsd
+
+
 def build_product(g, device, tsd=None, dsd=None, temperature=None, top_p=None, graphs=False):
     """The product engine (triforce_amd) from the same seeded weights."""
     from triforce_amd.models.cache import FlashSimpleCache, RetrievalCache, StreamingLLMEvictionCache

@@ -94,3 +94,70 @@ def test_periodic_retrieval_rebuild_is_lossless_and_consistent(cpu_ops):
     TriForce(tok, ge2, prompt, gamma=g["gamma"], max_len=g["gen_len"], top_k=-1, top_p=g["top_p"],
              temperature=g["temperature"], return_details=True)
     assert any(not torch.equal(rc.last_idx[i], ge2.engine.graph_cache.last_idx[i]) for i in range(rc.layers))
+
+
+def _tp_product(g, tsd, dsd, temperature, top_p):
+    from triforce_amd.models.cache import StreamingLLMEvictionCache
+    from triforce_amd.models.config_yarn import LlamaConfig
+    from triforce_amd.models.modeling_llama_68m import LlamaForCausalLM as Draft
+    from triforce_amd.models.TP_llama import DistributedLlama
+    gamma = g["gamma"]
+    draft = Draft.from_state_dict(LlamaConfig.from_dict(g["dcfg"]), dsd, "cpu")
+    dcache = StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - gamma, gamma=gamma)
+    tcfg = LlamaConfig.from_dict(g["tcfg"])
+    llm = DistributedLlama("unused", config=tcfg, device="cpu", local_rank=0, world_size=1, prefill=g["prefill"],
+                           gen_len=g["gen_len"], temperature=temperature, top_p=top_p, retrieval_budget=g["budget"],
+                           retrieval_chunk_size=g["chunk"], kv_offload=True, on_chip_layers=tcfg.num_hidden_layers,
+                           draft=draft, draft_cache=dcache, gamma=gamma)
+    llm.init_parameters(tsd)
+    return llm
+
+
+@pytest.mark.parametrize("temperature,top_p", [(0.6, 0.9), (1.0, 1e-9)])
+def test_tp_chain_loop_matches_oracle_with_injected_uniforms(cpu_ops, temperature, top_p):
+    """TriForce_Dist on the product's TP engine (world size 1) against the restatement that
+    tests/golden/tp_chain.pt pins to the reference's TriForce_Dist: same explicit uniforms -> same stream, accept
+    counts, returned average and final cache lengths.  Covers the TP-only rules: inclusive outer accept, draft
+    sampled at 0.6 / 0.9 whatever the target's settings, 128-token draft prefill blocks."""
+    from triforce_amd.utils.decoding import TriForce_Dist
+    from triforce_amd.utils.sampling import UniformSource
+    g = Hh.load_golden("tp_chain")
+    us = Hh.fixed_uniforms(seed=21)
+    prompt = Hh.prompt_of(g)
+    oeng, tsd, dsd = Hh.build_oracle_tp(g, temperature, top_p)
+    want = M.triforce(oeng, prompt, g["gamma"], 30, temperature, top_p, rng=M.InjectedRng(us), eos_token_id=-1, dist=True)
+    llm = _tp_product(g, tsd, dsd, temperature, top_p)
+    tok = Hh.FakeTokenizer()
+    tok.eos_token_id = -1
+    got = TriForce_Dist(tok, llm, prompt, gamma=g["gamma"], max_len=30, top_k=-1, top_p=top_p, temperature=temperature,
+                        rng=UniformSource("cpu", values=us), return_details=True)
+    assert got["tokens"] == want["tokens"] and got["counts"] == want["counts"]
+    assert abs(got["avg_tokens"] - want["avg_tokens"]) < 1e-12
+    assert llm.kv_cache.seq_len == oeng.kv_cache.seq_len and llm.draft_cache.seq_len == oeng.draft_cache.seq_len
+
+
+def test_tp_chain_eos_exits_like_the_reference(cpu_ops):
+    """decoding.py:357-360 / :382-383: the TP loop ends when the token that CLOSED the accept scan (an accepted or a
+    resampled token) is eos — not when a bonus token is (that one is sampled after the check).  Every token of the
+    first steps is tried as eos, so accepted, resampled and bonus placements all occur."""
+    from triforce_amd.utils.decoding import TriForce_Dist
+    from triforce_amd.utils.sampling import UniformSource
+    g = Hh.load_golden("tp_chain")
+    us = Hh.fixed_uniforms(seed=21)
+    prompt = Hh.prompt_of(g)
+    oeng, tsd, dsd = Hh.build_oracle_tp(g, 0.6, 0.9)
+    base = M.triforce(oeng, prompt, g["gamma"], 24, 0.6, 0.9, rng=M.InjectedRng(us), eos_token_id=-1, dist=True)
+    assert any(c >= 2 for c in base["counts"]), "no accepted draft in the probe stream"
+    kinds = set()
+    for pick in sorted(set(base["tokens"][1:16])):
+        oeng, _, _ = Hh.build_oracle_tp(g, 0.6, 0.9)                 # fresh engines: a second prompt carries the
+        llm = _tp_product(g, tsd, dsd, 0.6, 0.9)                     # draft cache's seq_len over (reference quirk)
+        want = M.triforce(oeng, prompt, g["gamma"], 24, 0.6, 0.9, rng=M.InjectedRng(us), eos_token_id=pick, dist=True)
+        tok = Hh.FakeTokenizer()
+        tok.eos_token_id = pick
+        got = TriForce_Dist(tok, llm, prompt, gamma=g["gamma"], max_len=24, top_k=-1, top_p=0.9, temperature=0.6,
+                            rng=UniformSource("cpu", values=us), return_details=True)
+        assert got["tokens"] == want["tokens"], (pick, got["tokens"], want["tokens"])
+        assert got["accepted"] == want["accepted"] and got["drafted"] == want["drafted"], pick
+        kinds.add("stopped" if want["tokens"][-1] == pick and len(want["tokens"]) < len(base["tokens"]) else "ran on")
+    assert kinds == {"stopped", "ran on"}, kinds          # both behaviours were exercised

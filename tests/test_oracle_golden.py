@@ -62,6 +62,26 @@ def test_triforce_streams_match_reference(name):
         assert g["triforce"][0]["tokens"][:n] == g["ar_tokens"][:n]     # lossless: greedy TriForce == greedy AR
 
 
+def test_tp_chain_matches_reference():
+    """TriForce_Dist / Middle_Spec_Dist (decoding.py:291-495) on the reference's TP engine (TP_llama.py), run
+    unmodified on CPU when the golden was made: the restatement reproduces streams, accept counts and the returned
+    average for a stochastic target, a greedy target (stochastic draft) and two eos placements."""
+    g = Hh.load_golden("tp_chain")
+    prompt = Hh.prompt_of(g)
+    for case in g["cases"]:
+        eng, _, _ = Hh.build_oracle_tp(g, case["temperature"], case["top_p"])
+        torch.manual_seed(case["rng_seed"])
+        res = M.triforce(eng, prompt, g["gamma"], g["gen_len"], case["temperature"], case["top_p"],
+                         eos_token_id=case["eos"], dist=True)
+        assert res["tokens"] == case["tokens"], case["label"]
+        assert res["counts"][:len(case["counts"])] == case["counts"], case["label"]
+        assert abs(res["avg_tokens"] - case["avg_tokens"]) < 1e-12, case["label"]
+        if not case["ended_by_eos"]:
+            assert eng.kv_cache.seq_len == case["final_seq_len"] and eng.draft_cache.seq_len == case["draft_seq_len"]
+        else:
+            assert res["tokens"][-1] == case["eos"] and len(res["tokens"]) < g["gen_len"]
+
+
 def test_topk_canonical_tie_rule():
     s = torch.tensor([[9.0, 1, 3, 3, 2, 3, -1, 3]], dtype=torch.float16)
     assert R.retrieval_topk(s, 4).tolist() == [[0, 2, 3, 5]]           # ties -> lowest chunk first

@@ -149,7 +149,8 @@ class TriForceRunner:
         # rebuild_every: N > 0 re-selects the retrieval cache's prefill chunks during every N-th target verify
         #                (SURVEY 8f row 4); 0 = the reference's behaviour, one build per prompt
         self.rebuild_every, self.rebuilds = int(rebuild_every), 0
-        # inclusive_accept: the TP outer loop tests ``r <=`` (decoding.py:347) where on-chip tests ``r <`` (:99)
+        # inclusive_accept: marks the TP outer loop — it tests ``r <=`` (decoding.py:347) where on-chip tests ``r <``
+        #              (:99), and it ends at an eos that closes the accept scan (:382-383) where on-chip keeps going
         # sync_record: optional callable applied to each device decision record before it is read (TP: broadcast
         #              from rank 0, the role of sample_dist / the r broadcast, decoding.py:230-239,345-346)
         self.inclusive_accept, self.sync_record = inclusive_accept, sync_record
@@ -163,7 +164,7 @@ class TriForceRunner:
         self.n = 0
         self.inner_iters = 0          # Middle_Spec iterations = 68M draft calls = retrieval-verify replays
         self.emitted, self.counts, self.acc_rate_middle_list = [], [], []
-        self.next_token = None
+        self.next_token, self.last_reason = None, None
 
     @torch.inference_mode()
     def prefill(self, input_ids):
@@ -217,7 +218,12 @@ class TriForceRunner:
         if self.sync_record is not None:
             self.sync_record(bufs.chain_out)
         count, pred, reason, consumed = bufs.chain_out.tolist()          # the one host sync of the outer step
+        if self.inclusive_accept and reason == 1 and generated[g2 - 1] == self.eos:
+            # TP loop only: an eos accepted as the LAST drafted token ends the loop before the bonus sample
+            # (decoding.py:357-360,382-383); the on-chip loop — and tf_accept_chain — go on to the bonus token (:127)
+            reason, pred, consumed = 2, self.eos, consumed - 1
         rng.advance(consumed)
+        self.last_reason = reason          # 0 rejection + resample, 1 everything accepted (bonus token), 2 accepted eos
 
         pass_tokens = [next_token] + generated[:count] + [PAD_TOKEN] * (g2 + 1 - count)
         self.accepted_count += count
@@ -388,7 +394,9 @@ def TriForce_Dist(tokenizer, llm, input_ids, gamma=4, max_len=256, top_k=-1, top
     time1 = time.time()
     while run.n < max_len:
         run.step()
-        if run.next_token == eos:                            # the TP loop stops at eos (decoding.py:382-383)
+        # the TP loop stops when the token that closed the accept scan — accepted or resampled — is eos
+        # (decoding.py:382-383); a bonus token is sampled after that check and never ends the loop
+        if run.next_token == eos and run.last_reason != 1:
             break
     _sync(llm.device)
     time2 = time.time()
