@@ -327,6 +327,63 @@ def sequoia_case(name, tcfg, tseed, pseed, prefill, budget, chunk, gen_len, temp
           f"accepts {[s['acc_count'] for s in steps]}")
 
 
+def offloading_case(name="offloading_small"):
+    """Single-GPU offloading entry (reference test/offloading.py:85-90): the reference's on-chip
+    TriForce loop over OffloadingFlashSimpleCache (cache.py:63-115; KV in pinned host memory, one on-chip layer buffer,
+    capacity prefill + gen_len + 32), constructed on CPU through the same torch proxy as the TP modules.  Known answer
+    recorded with the stream: offloading changes where the KV lives, never the tokens — the stream must equal the
+    FlashSimpleCache stream of the same seed (stochastic sampling, so every accept test and resample is compared)."""
+    import json
+    ref = _refshim.load_reference_tree()                    # installs the torch proxy in models.cache
+    tcfg = specs.llama_config(256, 512, 3, 4, vocab_size=1024, max_position_embeddings=4096,
+                              rope_scaling=dict(type="yarn", factor=8.0, original_max_position_embeddings=512),
+                              name="tiny-d64-offload")
+    dcfg = specs.llama_config(128, 256, 2, 2, vocab_size=1024, max_position_embeddings=2048, name="tiny-draft-offload")
+    tseed, dseed, pseed, head_std = 501, 502, 503, 0.05
+    prefill, budget, chunk, gamma, gen_len, temperature, top_p, rng_seed = 1000, 128, 8, 6, 32, 0.6, 0.9, 31
+    tsd = specs.random_state_dict(tcfg, tseed, head_std=head_std)
+    dsd = specs.random_state_dict(dcfg, dseed, head_std=head_std)
+    prompt = specs.random_prompt(tcfg["vocab_size"], prefill, pseed)
+    target = build_reference_model(ref, tcfg, tsd)
+    draft = build_reference_model(ref, dcfg, dsd, draft=True)
+    tok = _refshim.FakeTokenizer()
+    tok.eos_token_id = -1
+    emitted = []
+    real = ref.decoding.spec_stream
+    ref.decoding.spec_stream = lambda t, tk, color="blue": emitted.append(int(torch.as_tensor(t).reshape(-1)[0]))
+
+    def run(cache):
+        gcache = ref.cache.RetrievalCache(target, max_budget=budget, prefill=prefill, gamma=gamma, chunk_size=chunk)
+        dcache = ref.cache.StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - gamma, gamma=gamma)
+        eng = _refshim.EagerEngine(ref, target, cache, gcache, draft, dcache, temperature, top_p)
+        emitted.clear()
+        torch.manual_seed(rng_seed)
+        acc, _ = ref.decoding.TriForce(tok, eng, prompt, gamma=gamma, max_len=gen_len, top_k=-1, top_p=top_p,
+                                       temperature=temperature, verbose=True)
+        return list(emitted), acc, int(cache.seq_len)
+
+    try:
+        off = run(ref.cache.OffloadingFlashSimpleCache(target, prefill + gen_len + 32))     # offloading.py:85
+        res = run(ref.cache.FlashSimpleCache(target, prefill + gen_len + 16))               # on_chip.py:78
+    finally:
+        ref.decoding.spec_stream = real
+    assert off == res, f"[{name}] offloading stream differs from the resident one\n{off}\n{res}"
+    # oracle restatement (FullCache is the data model of both)
+    oeng = M.OracleEngine(M.OracleTarget(tcfg, tsd), M.FullCache(tcfg, prefill + gen_len + 32),
+                          M.RetrievalCacheO(tcfg, budget, prefill, chunk, gamma), M.OracleDraft(dcfg, dsd),
+                          M.StreamingCacheO(dcfg, gamma=gamma, start_size=16, recent_size=256 - 16 - gamma),
+                          temperature, top_p)
+    torch.manual_seed(rng_seed)
+    o = M.triforce(oeng, prompt, gamma, gen_len, temperature, top_p, eos_token_id=-1)
+    assert o["tokens"] == off[0] and abs(o["acceptance_rate"] - off[1]) < 1e-12 and oeng.kv_cache.seq_len == off[2]
+    with open(os.path.join(GOLDEN, name + ".json"), "w") as f:
+        json.dump(dict(name=name, tcfg=tcfg, dcfg=dcfg, tseed=tseed, dseed=dseed, pseed=pseed, head_std=head_std,
+                       prefill=prefill, budget=budget, chunk=chunk, gamma=gamma, gen_len=gen_len,
+                       temperature=temperature, top_p=top_p, rng_seed=rng_seed, tokens=off[0], acceptance_rate=off[1],
+                       final_seq_len=off[2], equals_resident_stream=True), f, indent=1)
+    print(f"[{name}] ok: {len(off[0])} tokens, acceptance {off[1]:.3f}; offloading == resident stream")
+
+
 def tp_chain_case(name="tp_chain"):
     """Tensor-parallel chain path (SURVEY 8 rows a10/a11 `_Dist`, a13): the UNMODIFIED reference TP_llama.
     DistributedLlama + utils/decoding.TriForce_Dist / Middle_Spec_Dist run on CPU (1-rank gloo, torch proxies for the
@@ -489,8 +546,13 @@ if __name__ == "__main__":
         os.makedirs(GOLDEN, exist_ok=True)
         torch.set_num_threads(8)
         tp_chain_case()
+    elif len(sys.argv) > 1 and sys.argv[1] == "offloading":
+        os.makedirs(GOLDEN, exist_ok=True)
+        torch.set_num_threads(8)
+        offloading_case()
     else:
         main()
         main_sequoia()
         cli_case()
         tp_chain_case()
+        offloading_case()

@@ -82,6 +82,28 @@ def test_tp_chain_matches_reference():
             assert res["tokens"][-1] == case["eos"] and len(res["tokens"]) < g["gen_len"]
 
 
+def test_offloading_entry_stream_matches_reference():
+    """test/offloading.py's configuration (OffloadingFlashSimpleCache, capacity prefill + gen_len + 32) run with the
+    unmodified reference on CPU: recorded stream == the restatement's, and (asserted when the fixture was made) ==
+    the FlashSimpleCache stream of the same seed — offloading moves the KV, it does not change a token."""
+    import json
+    import os
+    g = json.load(open(os.path.join(Hh.GOLDEN, "offloading_small.json")))
+    assert g["equals_resident_stream"] is True
+    tsd = Hh.specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g["head_std"])
+    dsd = Hh.specs.random_state_dict(g["dcfg"], g["dseed"], head_std=g["head_std"])
+    gamma = g["gamma"]
+    eng = M.OracleEngine(M.OracleTarget(g["tcfg"], tsd), M.FullCache(g["tcfg"], g["prefill"] + g["gen_len"] + 32),
+                         M.RetrievalCacheO(g["tcfg"], g["budget"], g["prefill"], g["chunk"], gamma),
+                         M.OracleDraft(g["dcfg"], dsd),
+                         M.StreamingCacheO(g["dcfg"], gamma=gamma, start_size=16, recent_size=256 - 16 - gamma),
+                         g["temperature"], g["top_p"])
+    torch.manual_seed(g["rng_seed"])
+    res = M.triforce(eng, Hh.prompt_of(g), gamma, g["gen_len"], g["temperature"], g["top_p"], eos_token_id=-1)
+    assert res["tokens"] == g["tokens"] and abs(res["acceptance_rate"] - g["acceptance_rate"]) < 1e-12
+    assert eng.kv_cache.seq_len == g["final_seq_len"]
+
+
 def test_topk_canonical_tie_rule():
     s = torch.tensor([[9.0, 1, 3, 3, 2, 3, -1, 3]], dtype=torch.float16)
     assert R.retrieval_topk(s, 4).tolist() == [[0, 2, 3, 5]]           # ties -> lowest chunk first
