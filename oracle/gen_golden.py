@@ -473,6 +473,137 @@ def tp_chain_case(name="tp_chain"):
     print(f"[{name}] saved ({time.time() - t0:.1f}s)")
 
 
+# ---- tensor-parallel engine at world size 2 (reference run as two gloo processes on CPU) -------------------------
+_TP2 = dict(tcfg=dict(hidden=256, inter=512, layers=3, heads=4), tseed=601, dseed=602, pseed=603, head_std=0.05,
+            prefill=1000, budget=128, chunk=8, gamma=6, gen_len=24, temperature=0.6, top_p=0.9, rng_seed=41)
+
+
+def _tp2_configs():
+    c = _TP2["tcfg"]
+    tcfg = specs.llama_config(c["hidden"], c["inter"], c["layers"], c["heads"], vocab_size=1024,
+                              max_position_embeddings=4096,
+                              rope_scaling=dict(type="yarn", factor=8.0, original_max_position_embeddings=512),
+                              name="tiny-d64-tp2")
+    dcfg = specs.llama_config(128, 256, 2, 2, vocab_size=1024, max_position_embeddings=2048, name="tiny-draft-tp2")
+    return tcfg, dcfg
+
+
+def _tp2_worker(rank, world, port, out_path):
+    """One rank of the reference's TP engine (TP_layers.py:126-147 sharding, tensor_op.py all-reduces) on CPU."""
+    import tempfile
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(4)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ref = _refshim.load_reference_tp()
+    P = _TP2
+    tcfg, dcfg = _tp2_configs()
+    tsd = specs.random_state_dict(tcfg, P["tseed"], head_std=P["head_std"])
+    dsd = specs.random_state_dict(dcfg, P["dseed"], head_std=P["head_std"])
+    prompt = specs.random_prompt(tcfg["vocab_size"], P["prefill"], P["pseed"])
+    gamma = P["gamma"]
+    hf = build_reference_model(ref, tcfg, tsd)
+    draft = build_reference_model(ref, dcfg, dsd, draft=True)
+    dcache = ref.cache.StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - gamma, gamma=gamma)
+    tmp = tempfile.mkdtemp()
+    hf.config.save_pretrained(tmp)
+    llm = ref.tp.DistributedLlama(model_name_or_path=tmp, local_rank=rank, world_size=world, prefill=P["prefill"],
+                                  gen_len=P["gen_len"], temperature=P["temperature"], top_p=P["top_p"], flash_attn=True,
+                                  retrieval_budget=P["budget"], retrieval_chunk_size=P["chunk"], kv_offload=True,
+                                  on_chip_layers=tcfg["num_hidden_layers"] - 1, draft=draft, draft_cache=dcache,
+                                  gamma=gamma)
+    llm.init_parameters(hf_model=hf)
+    shard_shapes = {k: tuple(getattr(llm.layers[0], k).shape) for k in ("wq", "wk", "wv", "wo", "gate_proj", "up_proj",
+                                                                         "down_proj")}
+    llm.reset()
+    prefill_logits = llm.prefill(prompt[:, :-1])[:, -1].clone()
+    build_logits = llm.build_retrieval_cache(prompt[:, -1:]).clone()
+    S = int(llm.kv_cache.seq_len)
+    vt = torch.tensor([[11, 12, 13] + [100] * (gamma - 2)])
+    pos = torch.arange(S, S + gamma + 1).unsqueeze(0)
+    spec_logits = llm.retrieval_inference(vt, pos).clone()
+    verify_logits = llm.inference(vt).clone()
+    llm.kv_cache.seq_len -= gamma + 1
+    events = []
+    ref.decoding.spec_stream = lambda t, tok, color="blue": events.append((color, int(torch.as_tensor(t).reshape(-1)[0])))
+    tok = _refshim.FakeTokenizer()
+    tok.eos_token_id = -1
+    torch.manual_seed(P["rng_seed"])
+    avg, _ = ref.decoding.TriForce_Dist(tok, llm, prompt, gamma=gamma, max_len=P["gen_len"], top_k=-1, top_p=P["top_p"],
+                                        temperature=P["temperature"], verbose=True)
+    tokens, counts, cur = [events[0][1]], [], 0
+    for color, t in events[1:]:
+        tokens.append(t)
+        if color == "green":
+            cur += 1
+        else:
+            counts.append(cur + (1 if color == "blue" else 0))
+            cur = 0
+    torch.save(dict(rank=rank, shard_shapes=shard_shapes, prefill_logits=prefill_logits, build_logits=build_logits,
+                    spec_logits=spec_logits, verify_logits=verify_logits, S=S, tokens=tokens, counts=counts,
+                    avg_tokens=avg, final_seq_len=int(llm.kv_cache.seq_len)), f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def tp_world2_case(name="tp_world2"):
+    """The reference's tensor-parallel engine at WORLD SIZE 2: two gloo processes on CPU run the unmodified
+    TP_llama.DistributedLlama (head / MLP-column shards of TP_layers.py:126-147, fp16 all-reduce after wo and down_proj)
+    and TriForce_Dist (rank 0 samples, tokens and uniforms broadcast).  Recorded: per-stage logits (identical on both
+    ranks), the shard shapes, the token stream.  Checked here: both ranks agree bit-for-bit; the single-process
+    restatement is within fp16 all-reduce rounding of the logits and reproduces the stream."""
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = os.path.join(tempfile.mkdtemp(), "tp2")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_tp2_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=900)
+        assert p.exitcode == 0, f"reference TP rank exited with {p.exitcode}"
+    r0, r1 = (torch.load(f"{out}.{r}", weights_only=False) for r in range(2))
+    for k in ("prefill_logits", "build_logits", "spec_logits", "verify_logits"):
+        assert torch.equal(r0[k], r1[k]), f"[{name}] ranks disagree on {k}"
+    assert r0["tokens"] == r1["tokens"] and r0["counts"] == r1["counts"] and r0["final_seq_len"] == r1["final_seq_len"]
+    P = _TP2
+    tcfg, dcfg = _tp2_configs()
+    g = dict(name=name, tcfg=tcfg, dcfg=dcfg, **{k: v for k, v in P.items() if k != "tcfg"})
+    from tests import helpers as Hh
+    eng, _, _ = Hh.build_oracle_tp(g, P["temperature"], P["top_p"])
+    prompt = specs.random_prompt(tcfg["vocab_size"], P["prefill"], P["pseed"])
+    gamma = P["gamma"]
+    lp = eng.inference(prompt[:, :-1])[:, -1]
+    lb = eng.inference(prompt[:, -1:])
+    S = eng.kv_cache.seq_len
+    vt = torch.tensor([[11, 12, 13] + [100] * (gamma - 2)])
+    ls = eng.model.forward(vt, eng.kv_cache, eng.graph_cache, position_ids=torch.arange(S, S + gamma + 1).unsqueeze(0),
+                           spec=True)
+    lv = eng.inference(vt)
+    gaps = {}
+    for k, ours in (("prefill_logits", lp), ("build_logits", lb), ("spec_logits", ls), ("verify_logits", lv)):
+        gaps[k] = float((ours - r0[k]).abs().max())
+        assert gaps[k] < 4e-3, f"[{name}] single-process restatement off by {gaps[k]:.2e} on {k}"
+    eng, _, _ = Hh.build_oracle_tp(g, P["temperature"], P["top_p"])
+    torch.manual_seed(P["rng_seed"])
+    res = M.triforce(eng, prompt, gamma, P["gen_len"], P["temperature"], P["top_p"], eos_token_id=-1, dist=True)
+    same_stream = res["tokens"] == r0["tokens"]
+    g.update(shard_shapes=r0["shard_shapes"], prefill_logits=r0["prefill_logits"], build_logits=r0["build_logits"],
+             spec_logits=r0["spec_logits"], verify_logits=r0["verify_logits"], S=r0["S"], tokens=r0["tokens"],
+             counts=r0["counts"], avg_tokens=r0["avg_tokens"], final_seq_len=r0["final_seq_len"],
+             single_process_gaps=gaps, single_process_stream_identical=same_stream,
+             common_prefix=next((i for i, (a, b) in enumerate(zip(res["tokens"], r0["tokens"])) if a != b),
+                                min(len(res["tokens"]), len(r0["tokens"]))))
+    torch.save(g, os.path.join(GOLDEN, f"{name}.pt"))
+    print(f"[{name}] ok: ranks bit-identical; single-process gaps {gaps}; stream identical: {same_stream} "
+          f"(common prefix {g['common_prefix']} of {len(r0['tokens'])}); shards {r0['shard_shapes']}")
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
@@ -546,6 +677,9 @@ if __name__ == "__main__":
         os.makedirs(GOLDEN, exist_ok=True)
         torch.set_num_threads(8)
         tp_chain_case()
+    elif len(sys.argv) > 1 and sys.argv[1] == "tp2":
+        os.makedirs(GOLDEN, exist_ok=True)
+        tp_world2_case()
     elif len(sys.argv) > 1 and sys.argv[1] == "offloading":
         os.makedirs(GOLDEN, exist_ok=True)
         torch.set_num_threads(8)
@@ -556,3 +690,4 @@ if __name__ == "__main__":
         cli_case()
         tp_chain_case()
         offloading_case()
+        tp_world2_case()

@@ -192,3 +192,74 @@ def test_sequoia_tp2_gloo_lockstep_and_close_to_oracle():
     cp = Hh.common_prefix(outs[0][2], want)
     assert cp >= min(len(want), 1 + want_counts[0]), (cp, outs[0][2][:16], want[:16])   # at least the whole first step
     assert sum(outs[0][3]) == len(outs[0][2]) - 1 and outs[0][4] == g["prefill"] + sum(outs[0][3])
+
+
+# ---- against the REFERENCE's own engine at world size 2 (tests/golden/tp_world2.pt) --------------------------------
+def _ref2_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.set_num_threads(2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from tests import cpu_backend, helpers as Hh
+        import triforce_amd.ops as ops
+        for n in cpu_backend.PATCHED:
+            setattr(ops, n, getattr(cpu_backend, n))
+        from oracle import specs
+        from triforce_amd.models.config_yarn import LlamaConfig
+        from triforce_amd.models.TP_llama import DistributedLlama
+        g = Hh.load_golden("tp_world2")
+        tsd = specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g["head_std"])
+        tcfg = LlamaConfig.from_dict(g["tcfg"])
+        gamma = g["gamma"]
+        llm = DistributedLlama("unused", config=tcfg, device="cpu", local_rank=rank, world_size=world,
+                               prefill=g["prefill"], gen_len=g["gen_len"], temperature=g["temperature"], top_p=g["top_p"],
+                               retrieval_budget=g["budget"], retrieval_chunk_size=g["chunk"], kv_offload=True,
+                               on_chip_layers=tcfg.num_hidden_layers, gamma=gamma)
+        llm.init_parameters(tsd)
+        prompt = Hh.prompt_of(g)
+        llm.reset()
+        lp = llm.prefill(prompt[:, :-1])[:, -1]
+        lb = llm.build_retrieval_cache(prompt[:, -1:])
+        S = llm.kv_cache.seq_len
+        vt = torch.tensor([[11, 12, 13] + [100] * (gamma - 2)])
+        ls = llm.retrieval_inference(vt, torch.arange(S, S + gamma + 1).unsqueeze(0))
+        lv = llm.inference(vt)
+        q.put((rank, "ok", S, lp, lb, ls, lv))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_tp2_gloo_matches_the_reference_engine_at_world_size_2():
+    """The product's sharded forward against logits the UNMODIFIED reference TP engine produced as two gloo processes
+    on CPU (oracle/gen_golden.py tp2): same head / MLP-column shards (TP_layers.py:126-147) and the same two fp16
+    all-reduces per layer, so the four stages agree to all-reduce rounding — and bit-for-bit where the summation
+    order is the same."""
+    from tests import helpers as Hh
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ref2_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {}
+    for _ in range(world):
+        item = q.get(timeout=600)
+        assert item[1] == "ok", item[2]
+        outs[item[0]] = item
+    for p in procs:
+        p.join(timeout=60)
+    g = Hh.load_golden("tp_world2")
+    assert g["shard_shapes"]["wq"] == (g["tcfg"]["hidden_size"] // 2, g["tcfg"]["hidden_size"])
+    for r in range(world):
+        _, _, S, lp, lb, ls, lv = outs[r]
+        assert S == g["S"]
+        for name, ours in (("prefill_logits", lp), ("build_logits", lb), ("spec_logits", ls), ("verify_logits", lv)):
+            gap = (ours - g[name]).abs().max().item()
+            assert gap < 2e-3, f"rank {r} {name}: {gap:.2e} from the reference's world-2 logits"
+    exact = [name for name, i in (("prefill_logits", 3), ("build_logits", 4), ("spec_logits", 5), ("verify_logits", 6))
+             if torch.equal(outs[0][i].reshape(g[name].shape), g[name])]
+    print("bit-identical stages:", exact)
