@@ -1,7 +1,14 @@
 """Generate tests/golden/*.pt by running the UNMODIFIED reference (/root/reference) on CPU.
 
 TEST INFRASTRUCTURE ONLY.  Run in the build container (the reference tree is absent on the
-GPU box):   python -m oracle.gen_golden
+GPU box):   python -m oracle.gen_golden [sequoia | cli | tp | tp2 | offloading]      (no argument = everything)
+
+  (default)   rope_tables, forward_small, cfg1_greedy, cfg1_stochastic, small_gamma6   on-chip path (test/on_chip.py)
+  sequoia     sequoia_tree512, sequoia_small            SpecTree + TP_llama_tree (test/offloading_seqouia.py)
+  tp          tp_chain                                  TP_llama + TriForce_Dist at world size 1 (test/offloading_TP.py)
+  tp2         tp_world2                                 the same engine as TWO gloo processes: shards + all-reduces
+  offloading  offloading_small                          OffloadingFlashSimpleCache (test/offloading.py)
+  cli         cli_flags                                 the four scripts' command lines
 While generating, every case is also replayed through the CPU restatement (oracle/ref_ops.py,
 oracle/ref_model.py) and must agree (logits bit-identical, token streams identical, top-k
 tie-tolerant) — that is how the oracle is pinned (the reference has no
