@@ -1,12 +1,13 @@
 """Generate tests/golden/*.pt by running the UNMODIFIED reference (/root/reference) on CPU.
 
 TEST INFRASTRUCTURE ONLY.  Run in the build container (the reference tree is absent on the
-GPU box):   python -m oracle.gen_golden [sequoia | cli | tp | tp2 | offloading]      (no argument = everything)
+GPU box):   python -m oracle.gen_golden [sequoia | sequoia2 | cli | tp | tp2 | offloading]      (no argument = everything)
 
   (default)   rope_tables, forward_small, cfg1_greedy, cfg1_stochastic, small_gamma6   on-chip path (test/on_chip.py)
   sequoia     sequoia_tree512, sequoia_small            SpecTree + TP_llama_tree (test/offloading_seqouia.py)
   tp          tp_chain                                  TP_llama + TriForce_Dist at world size 1 (test/offloading_TP.py)
   tp2         tp_world2                                 the same engine as TWO gloo processes: shards + all-reduces
+  sequoia2    sequoia_world2                            the Sequoia loop as TWO gloo processes
   offloading  offloading_small                          OffloadingFlashSimpleCache (test/offloading.py)
   cli         cli_flags                                 the four scripts' command lines
 While generating, every case is also replayed through the CPU restatement (oracle/ref_ops.py,
@@ -611,6 +612,151 @@ def tp_world2_case(name="tp_world2"):
           f"(common prefix {g['common_prefix']} of {len(r0['tokens'])}); shards {r0['shard_shapes']}")
 
 
+# ---- Sequoia tree path at world size 2 (reference run as two gloo processes on CPU) ------------------------------
+_SEQ2 = dict(tseed=711, pseed=712, head_std=0.05, prefill=600 - 600 % 8, budget=64, chunk=8, gen_len=16,
+             temperature=0.8, top_p=0.95, rng_seed=19,
+             branches=[[4], [3, 2, 0, 1], [2, 1, 1, 1, 0, 1], [1, 1, 0, 1, 0, 0], [1, 0, 0]])
+
+
+def _seq2_config():
+    return specs.llama_config(256, 512, 3, 4, vocab_size=1024, max_position_embeddings=4096,
+                              rope_scaling=dict(type="yarn", factor=8.0, original_max_position_embeddings=512),
+                              name="tiny-d64-tree2")
+
+
+def _seq2_worker(rank, world, port, out_path):
+    """One rank of test/offloading_seqouia.py's loop (:155-185) on the reference's TP_llama_tree engine, CPU + gloo."""
+    import tempfile
+    import torch.distributed as dist
+    from oracle import ref_tree as RT
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(4)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ref = _refshim.load_reference_tree()
+    P = _SEQ2
+    tcfg = _seq2_config()
+    tsd = specs.random_state_dict(tcfg, P["tseed"], head_std=P["head_std"])
+    prompt = specs.random_prompt(tcfg["vocab_size"], P["prefill"], P["pseed"])[0]
+    grow_map = RT.grow_map_from_branches(P["branches"])
+    temperature, V = P["temperature"], tcfg["vocab_size"]
+    hf = build_reference_model(ref, tcfg, tsd)
+    tmp = tempfile.mkdtemp()
+    hf.config.save_pretrained(tmp)
+    llm = ref.tree.DistributedLlama(model_name_or_path=tmp, local_rank=rank, world_size=world, prefill=P["prefill"],
+                                    gen_len=P["gen_len"], temperature=temperature, top_p=P["top_p"], flash_attn=True,
+                                    retrieval_budget=P["budget"], retrieval_chunk_size=P["chunk"], kv_offload=True,
+                                    on_chip_layers=tcfg["num_hidden_layers"] - 1, tree_size=grow_map["size"])
+    llm.init_parameters(hf_model=hf)
+
+    def get_residual(p, q):                               # test/offloading_seqouia.py:24-27
+        r = (p - q).relu_()
+        return r / (r.sum(dim=-1).unsqueeze(-1))
+
+    def make_sampler(k):                                  # test/offloading_seqouia.py:29-39, both branches
+        def run(lg, rnd):
+            if dist.get_rank() == 0:
+                position = (rnd.log() / torch.softmax(lg / temperature, dim=-1)).topk(k=k).indices.flatten()
+            else:
+                position = torch.full((k * lg.shape[0],), -1, dtype=torch.long)
+            dist.broadcast(position, src=0)
+            return position
+        return run
+
+    draft_step = len(grow_map["roots"])
+    samplers = {i: make_sampler(max(grow_map["branches"][i])) for i in range(draft_step - 1)}
+    gathers = {i: torch.cat([torch.arange(b) + j * max(grow_map["branches"][i])
+                             for j, b in enumerate(grow_map["branches"][i])]) for i in range(draft_step - 1)}
+    torch.manual_seed(P["rng_seed"])
+    st = ref.spectree.SpecTree(engine=llm, temperature=temperature, top_p=P["top_p"],
+                               max_length=P["prefill"] + P["gen_len"], grow_map=grow_map, residual_graph=get_residual,
+                               sampling_callables=samplers, sample_gather_indices=gathers,
+                               tokenizer=_refshim.FakeTokenizer(), vocab_size=V)
+    seen = []
+    real_inference = llm.inference
+
+    def spy_inference(*a, **k):
+        out = real_inference(*a, **k)
+        seen.append(out.clone())
+        return out
+
+    steps = []
+    with torch.inference_mode():
+        next_token = st.prefill(prefix=prompt)
+        first = int(next_token)
+        rand_table = st.rand.clone()
+        generated, n = [first], 0
+        while n < P["gen_len"]:
+            st.construct_grow_map(next_token=next_token)
+            rec = dict(tree_tokens=st.verify_tokens.clone(), seq_len=int(llm.kv_cache.seq_len))
+            if not steps:
+                rec["draft_logits"] = st.draft_logits.clone()
+                llm.inference = spy_inference
+            next_token, acc, toks = st.verify()
+            if not steps:
+                llm.inference = real_inference
+                rec["verify_logits"] = seen[-1][0].clone()
+            if next_token is None:
+                rec.update(acc_count=acc, terminal=True)
+                steps.append(rec)
+                break
+            generated.extend(toks[1:].tolist())
+            rec.update(acc_count=acc, accept_tokens=toks.tolist(), terminal=False)
+            steps.append(rec)
+            next_token = next_token.unsqueeze(0)
+            n += acc
+    torch.save(dict(rank=rank, first=first, rand_table=rand_table, generated=generated, steps=steps,
+                    final_seq_len=int(llm.kv_cache.seq_len)), f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def sequoia_world2_case(name="sequoia_world2"):
+    """test/offloading_seqouia.py's loop at WORLD SIZE 2: the unmodified reference SpecTree + TP_llama_tree engine as two
+    gloo processes on CPU (rank 0 draws the children and decides the walk, everything is broadcast).  Recorded: the
+    uniform table of the tree growth, the first step's per-node draft logits and 20-row verify logits, every step's
+    tree tokens and accept counts.  Checked here: ranks agree bit-for-bit; the single-process restatement reproduces
+    the stream (reported, the all-reduce may flip a near-tie)."""
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    from oracle import ref_tree as RT
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = os.path.join(tempfile.mkdtemp(), "seq2")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_seq2_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=900)
+        assert p.exitcode == 0, f"reference Sequoia rank exited with {p.exitcode}"
+    r0, r1 = (torch.load(f"{out}.{r}", weights_only=False) for r in range(2))
+    assert r0["generated"] == r1["generated"] and r0["final_seq_len"] == r1["final_seq_len"]
+    for a, b in zip(r0["steps"], r1["steps"]):
+        assert torch.equal(a["tree_tokens"], b["tree_tokens"]) and a["acc_count"] == b["acc_count"]
+    assert torch.equal(r0["steps"][0]["draft_logits"], r1["steps"][0]["draft_logits"])
+    assert torch.equal(r0["steps"][0]["verify_logits"], r1["steps"][0]["verify_logits"])
+    P = _SEQ2
+    tcfg = _seq2_config()
+    grow_map = RT.grow_map_from_branches(P["branches"])
+    tsd = specs.random_state_dict(tcfg, P["tseed"], head_std=P["head_std"])
+    prompt = specs.random_prompt(tcfg["vocab_size"], P["prefill"], P["pseed"])[0]
+    eng = RT.TreeEngine(tcfg, tsd, P["prefill"], P["gen_len"], P["budget"], P["chunk"], grow_map["size"])
+    torch.manual_seed(P["rng_seed"])
+    so = RT.SpecTreeO(eng, grow_map, P["temperature"], P["top_p"], tcfg["vocab_size"], M.TorchRng(), rand=None)
+    o_gen, o_counts = RT.run_sequoia(so, prompt, P["gen_len"])
+    same = o_gen == r0["generated"]
+    cp = next((i for i, (a, b) in enumerate(zip(o_gen, r0["generated"])) if a != b), min(len(o_gen), len(r0["generated"])))
+    g = dict(name=name, tcfg=tcfg, tree_size=grow_map["size"], single_process_stream_identical=same, common_prefix=cp,
+             first=r0["first"], rand_table=r0["rand_table"], generated=r0["generated"], steps=r0["steps"],
+             final_seq_len=r0["final_seq_len"], **P)
+    torch.save(g, os.path.join(GOLDEN, f"{name}.pt"))
+    print(f"[{name}] ok: ranks bit-identical, {len(r0['generated'])} tokens in {len(r0['steps'])} steps, accepts "
+          f"{[s['acc_count'] for s in r0['steps']]}; single-process stream identical: {same} (common prefix {cp})")
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
@@ -687,6 +833,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "tp2":
         os.makedirs(GOLDEN, exist_ok=True)
         tp_world2_case()
+    elif len(sys.argv) > 1 and sys.argv[1] == "sequoia2":
+        os.makedirs(GOLDEN, exist_ok=True)
+        sequoia_world2_case()
     elif len(sys.argv) > 1 and sys.argv[1] == "offloading":
         os.makedirs(GOLDEN, exist_ok=True)
         torch.set_num_threads(8)
@@ -698,3 +847,4 @@ if __name__ == "__main__":
         tp_chain_case()
         offloading_case()
         tp_world2_case()
+        sequoia_world2_case()

@@ -263,3 +263,80 @@ def test_tp2_gloo_matches_the_reference_engine_at_world_size_2():
     exact = [name for name, i in (("prefill_logits", 3), ("build_logits", 4), ("spec_logits", 5), ("verify_logits", 6))
              if torch.equal(outs[0][i].reshape(g[name].shape), g[name])]
     print("bit-identical stages:", exact)
+
+
+# ---- Sequoia against the REFERENCE's own world-2 run (tests/golden/sequoia_world2.pt) ------------------------------
+def _seqref2_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.set_num_threads(2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from tests import cpu_backend, helpers as Hh
+        import triforce_amd.ops as ops
+        for n in cpu_backend.PATCHED:
+            setattr(ops, n, getattr(cpu_backend, n))
+        from oracle import specs
+        from triforce_amd.models.config_yarn import LlamaConfig
+        from triforce_amd.models.TP_llama import TreeMask
+        from triforce_amd.models.TP_llama_tree import DistributedLlama
+        from triforce_amd.utils.SpecTree_TP import SpecTree
+        from triforce_amd.utils.sampling import UniformSource
+        from triforce_amd.utils.tree import grow_map_from_branches
+        g = Hh.load_golden("sequoia_world2")
+        V = g["tcfg"]["vocab_size"]
+        gm = grow_map_from_branches(g["branches"])
+        tsd = specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g["head_std"])
+        cfg = LlamaConfig.from_dict(g["tcfg"])
+        llm = DistributedLlama("unused", config=cfg, device="cpu", local_rank=rank, world_size=world,
+                               prefill=g["prefill"], gen_len=g["gen_len"], temperature=g["temperature"], top_p=g["top_p"],
+                               retrieval_budget=g["budget"], retrieval_chunk_size=g["chunk"], kv_offload=True,
+                               on_chip_layers=cfg.num_hidden_layers, tree_size=gm["size"])
+        llm.init_parameters(tsd)
+        st = SpecTree(llm, temperature=g["temperature"], top_p=g["top_p"], max_length=g["prefill"] + g["gen_len"],
+                      vocab_size=V, grow_map=gm, rng=UniformSource("cpu", values=Hh.fixed_uniforms(4096, seed=7)),
+                      rand_values=g["rand_table"])
+        st.prefill(Hh.prompt_of(g)[0])
+        # teacher-force the reference's first token; the growth then depends on logits and the uniform table only
+        st.construct_grow_map(torch.tensor([[g["first"]]]))
+        tree_tokens, draft_logits = st.verify_tokens.clone(), st.draft_logits.clone()
+        S = llm.kv_cache.seq_len
+        logits = llm.inference(input_ids=st.verify_tokens.unsqueeze(0), position_ids=(st.depth + S).unsqueeze(0),
+                               attention_mask=TreeMask(st.mask_bits, 0))[0]
+        q.put((rank, "ok", tree_tokens, draft_logits, logits.clone(), S))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_sequoia_tp2_gloo_matches_the_reference_run_at_world_size_2():
+    """Tree growth and tree verify of the product at world size 2 against the UNMODIFIED reference's own two-process
+    run (oracle/gen_golden.py sequoia2): same uniform table and first token -> the same token on every one of the tree
+    nodes (children drawn without replacement level by level from sharded-attention logits), per-node draft logits
+    and the all-nodes verify logits within all-reduce rounding."""
+    from tests import helpers as Hh
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seqref2_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {}
+    for _ in range(world):
+        item = q.get(timeout=600)
+        assert item[1] == "ok", item[2]
+        outs[item[0]] = item
+    for p in procs:
+        p.join(timeout=60)
+    g = Hh.load_golden("sequoia_world2")
+    step0 = g["steps"][0]
+    for r in range(world):
+        _, _, tree_tokens, draft_logits, logits, S = outs[r]
+        assert S == step0["seq_len"]
+        assert torch.equal(tree_tokens, step0["tree_tokens"]), f"rank {r}: tree tokens differ from the reference's"
+        gap_d = (draft_logits - step0["draft_logits"]).abs().max().item()
+        gap_v = (logits - step0["verify_logits"]).abs().max().item()
+        assert gap_d < 2e-3 and gap_v < 2e-3, (gap_d, gap_v)
+    print("bit-identical:", torch.equal(outs[0][3], step0["draft_logits"]), torch.equal(outs[0][4], step0["verify_logits"]))
