@@ -22,6 +22,38 @@ def _free_port():
     return p
 
 
+def _run_world(worker, world=2, attempts=2):
+    """Spawn `world` gloo ranks running `worker`; returns {rank: result tuple}.  A rank that reports an error makes the
+    whole group re-run once on a fresh port: rendezvous on a just-released port can fail intermittently, a real
+    defect fails again."""
+    last = None
+    for _ in range(attempts):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        outs, failed = {}, None
+        try:
+            for _ in range(world):
+                item = q.get(timeout=600)
+                if item[1] != "ok":
+                    failed = item[2]
+                    break
+                outs[item[0]] = item
+        except Exception as e:                       # queue timeout
+            failed = repr(e)
+        for p in procs:
+            p.join(timeout=60 if failed is None else 5)
+            if p.is_alive():
+                p.terminate()
+        if failed is None:
+            return outs
+        last = failed
+    raise AssertionError(last)
+
+
 def _worker(rank, world, port, q):
     try:
         sys.path.insert(0, ROOT)
@@ -73,19 +105,7 @@ def test_tp2_gloo_matches_oracle():
     from oracle import ref_model as M
     from tests import helpers as Hh
     world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    outs = {}
-    for _ in range(world):
-        item = q.get(timeout=600)
-        assert item[1] == "ok", item[2]
-        outs[item[0]] = item
-    for p in procs:
-        p.join(timeout=60)
+    outs = _run_world(_worker, world)
     g = Hh.load_golden("small_gamma6")
     oeng, _, _ = Hh.build_oracle(g)
     prompt = Hh.prompt_of(g)
@@ -166,19 +186,7 @@ def test_sequoia_tp2_gloo_lockstep_and_close_to_oracle():
     from oracle import specs
     from tests import helpers as Hh
     world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_seq_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    outs = {}
-    for _ in range(world):
-        item = q.get(timeout=600)
-        assert item[1] == "ok", item[2]
-        outs[item[0]] = item
-    for p in procs:
-        p.join(timeout=60)
+    outs = _run_world(_seq_worker, world)
     assert outs[0][2] == outs[1][2] and outs[0][3] == outs[1][3] and outs[0][4] == outs[1][4]
     g = Hh.load_golden("sequoia_small")
     assert outs[0][5] == g["tcfg"]["num_attention_heads"] // world
@@ -239,19 +247,7 @@ def test_tp2_gloo_matches_the_reference_engine_at_world_size_2():
     order is the same."""
     from tests import helpers as Hh
     world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_ref2_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    outs = {}
-    for _ in range(world):
-        item = q.get(timeout=600)
-        assert item[1] == "ok", item[2]
-        outs[item[0]] = item
-    for p in procs:
-        p.join(timeout=60)
+    outs = _run_world(_ref2_worker, world)
     g = Hh.load_golden("tp_world2")
     assert g["shard_shapes"]["wq"] == (g["tcfg"]["hidden_size"] // 2, g["tcfg"]["hidden_size"])
     for r in range(world):
@@ -317,19 +313,7 @@ def test_sequoia_tp2_gloo_matches_the_reference_run_at_world_size_2():
     and the all-nodes verify logits within all-reduce rounding."""
     from tests import helpers as Hh
     world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_seqref2_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    outs = {}
-    for _ in range(world):
-        item = q.get(timeout=600)
-        assert item[1] == "ok", item[2]
-        outs[item[0]] = item
-    for p in procs:
-        p.join(timeout=60)
+    outs = _run_world(_seqref2_worker, world)
     g = Hh.load_golden("sequoia_world2")
     step0 = g["steps"][0]
     for r in range(world):
