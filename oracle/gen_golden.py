@@ -475,8 +475,34 @@ def tp_chain_case(name="tp_chain"):
                           ended_by_eos=bool(ended_by_eos), **want))
         print(f"[{name}/{label}] ok: {len(want['tokens'])} tokens, counts {want['counts']}, avg {want['avg_tokens']:.4f}, "
               f"eos {eos}")
+    # Baseline_Dist (decoding.py:243-287): the TP autoregressive baseline; torch.cuda.synchronize() is proxied for the
+    # duration of the call only
+    baselines = []
+    for label, temperature, top_p, rng_seed in (("baseline_stochastic", 0.6, 0.9, 13), ("baseline_greedy", 1.0, 1e-9, 14)):
+        llm = ref.tp.DistributedLlama(model_name_or_path=tmp, local_rank=0, world_size=1, prefill=prefill,
+                                      gen_len=gen_len, temperature=temperature, top_p=top_p, flash_attn=True,
+                                      retrieval_budget=0, kv_offload=True,
+                                      on_chip_layers=tcfg["num_hidden_layers"] - 1)      # offloading_TP.py:76
+        llm.init_parameters(hf_model=hf)
+        real_torch = ref.decoding.torch
+        ref.decoding.torch = _refshim._TorchProxy()
+        torch.manual_seed(rng_seed)
+        try:
+            _, gen_tokens = ref.decoding.Baseline_Dist(_refshim.FakeTokenizer(), llm, prompt, max_len=20,
+                                                       temperature=temperature, top_p=top_p, local_rank=0)
+        finally:
+            ref.decoding.torch = real_torch
+        eng = M.OracleEngine(M.OracleTarget(tcfg, tsd), M.FullCache(tcfg, prefill + gen_len + 32), None, None, None,
+                             temperature, top_p)
+        torch.manual_seed(rng_seed)
+        o = M.autoregressive(eng, prompt, 20, temperature, top_p)
+        assert o[1:] == gen_tokens[0].tolist(), f"[{name}/{label}] baseline stream mismatch"
+        baselines.append(dict(label=label, temperature=temperature, top_p=top_p, rng_seed=rng_seed,
+                              gen_tokens=gen_tokens[0].tolist(), final_seq_len=int(llm.kv_cache.seq_len)))
+        print(f"[{name}/{label}] ok: {gen_tokens[0].tolist()[:8]}...")
     torch.save(dict(name=name, tcfg=tcfg, dcfg=dcfg, tseed=tseed, dseed=dseed, pseed=pseed, head_std=head_std,
-                    prefill=prefill, budget=budget, chunk=chunk, gamma=gamma, gen_len=gen_len, cases=cases),
+                    prefill=prefill, budget=budget, chunk=chunk, gamma=gamma, gen_len=gen_len, cases=cases,
+                    baselines=baselines),
                os.path.join(GOLDEN, f"{name}.pt"))
     print(f"[{name}] saved ({time.time() - t0:.1f}s)")
 

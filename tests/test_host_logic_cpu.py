@@ -161,3 +161,20 @@ def test_tp_chain_eos_exits_like_the_reference(cpu_ops):
         assert got["accepted"] == want["accepted"] and got["drafted"] == want["drafted"], pick
         kinds.add("stopped" if want["tokens"][-1] == pick and len(want["tokens"]) < len(base["tokens"]) else "ran on")
     assert kinds == {"stopped", "ran on"}, kinds          # both behaviours were exercised
+
+
+def test_tp_baseline_matches_oracle_with_injected_uniforms(cpu_ops):
+    """Baseline_Dist (decoding.py:243-287; pinned to the reference in tests/golden/tp_chain.pt): whole prompt through
+    the 128-token prefill, then one token per forward; returns the tokens AFTER the first sampled one."""
+    from triforce_amd.utils.decoding import Baseline_Dist
+    from triforce_amd.utils.sampling import UniformSource
+    g = Hh.load_golden("tp_chain")
+    us = Hh.fixed_uniforms(seed=23)
+    prompt = Hh.prompt_of(g)
+    oeng, tsd, dsd = Hh.build_oracle_tp(g, 0.6, 0.9)
+    want = M.autoregressive(oeng, prompt, 16, 0.6, 0.9, rng=M.InjectedRng(us))
+    llm = _tp_product(g, tsd, dsd, 0.6, 0.9)
+    ms, got = Baseline_Dist(Hh.FakeTokenizer(), llm, prompt, max_len=16, top_k=-1, top_p=0.9, temperature=0.6,
+                            rng=UniformSource("cpu", values=us))
+    assert got[0].tolist() == want[1:] and ms > 0
+    assert llm.kv_cache.seq_len == oeng.kv_cache.seq_len == g["prefill"] + 16

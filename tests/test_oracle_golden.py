@@ -80,6 +80,11 @@ def test_tp_chain_matches_reference():
             assert eng.kv_cache.seq_len == case["final_seq_len"] and eng.draft_cache.seq_len == case["draft_seq_len"]
         else:
             assert res["tokens"][-1] == case["eos"] and len(res["tokens"]) < g["gen_len"]
+    for b in g["baselines"]:                                   # Baseline_Dist (decoding.py:243-287)
+        eng, _, _ = Hh.build_oracle_tp(g, b["temperature"], b["top_p"])
+        torch.manual_seed(b["rng_seed"])
+        out = M.autoregressive(eng, prompt, len(b["gen_tokens"]), b["temperature"], b["top_p"])
+        assert out[1:] == b["gen_tokens"], b["label"]
 
 
 def test_offloading_entry_stream_matches_reference():
