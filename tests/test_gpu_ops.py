@@ -459,6 +459,30 @@ def test_norm_logits_routes_to_fused_kernel_and_draft_row_shortcut():
     assert ((full.cpu() > 0) == (want > 0)).float().mean() > 0.9999
 
 
+@pytest.mark.parametrize("M,N,K", [(7, 4096, 1376), (7, 4096, 2752), (7, 4096, 512), (1, 4096, 1376), (8, 4096, 5504),
+                                   (7, 1536, 4096), (7, 5120, 1728), (7, 5120, 640)])
+def test_skinny_gemm_at_tensor_parallel_shard_shapes(M, N, K):
+    """Per-rank shapes of the 7B / 13B models at TP = 2, 4, 8 (TP_layers.py:126-147): down-proj K = I / W (1376 = 43
+    tiles of 32 — odd and prime, so the K-split waves get unequal shares), o-proj K = H_local * D, q|k|v N = 3 * H_local
+    * D.  Relative to an fp32 matmul of the same fp16 operands."""
+    ops = _ops()
+    x, w = rnd(M, K, seed=130 + M).to(DEV), rnd(N, K, seed=131, scale=0.05).to(DEV)
+    got = ops.linear(x, ops.PackedLinear(w)).float()
+    want = x.float() @ w.float().t()
+    assert ((got - want).abs() / (want.abs() + 1)).max().item() < 5e-3
+
+
+@pytest.mark.parametrize("M,I,K", [(7, 1376, 4096), (7, 2752, 4096), (1, 1376, 4096), (7, 5504, 4096)])
+def test_skinny_swiglu_at_tensor_parallel_shard_shapes(M, I, K):
+    ops = _ops()
+    x, wgu = rnd(M, K, seed=140 + M).to(DEV), rnd(2 * I, K, seed=141, scale=0.05).to(DEV)
+    got = ops.mlp_act(x, ops.PackedLinear(wgu, split=2)).float()
+    g = (x.float() @ wgu[:I].float().t()).half().float()
+    u = (x.float() @ wgu[I:].float().t()).half().float()
+    want = torch.nn.functional.silu(g).half().float() * u
+    assert ((got - want).abs() / (want.abs() + 1)).max().item() < 1e-2
+
+
 @pytest.mark.parametrize("M", [1, 7, 8, 16, 17, 32])
 @pytest.mark.parametrize("N,K", [(768, 768), (2304, 768), (4096, 4096), (12288, 4096), (4096, 11008), (32000, 768)])
 def test_skinny_gemm_matches_linear(M, N, K):
