@@ -392,7 +392,7 @@ def offloading_case(name="offloading_small"):
     print(f"[{name}] ok: {len(off[0])} tokens, acceptance {off[1]:.3f}; offloading == resident stream")
 
 
-def tp_chain_case(name="tp_chain"):
+def tp_chain_case(name="tp_chain", gamma=6, with_baselines=True):
     """Tensor-parallel chain path (SURVEY 8 rows a10/a11 `_Dist`, a13): the UNMODIFIED reference TP_llama.
     DistributedLlama + utils/decoding.TriForce_Dist / Middle_Spec_Dist run on CPU (1-rank gloo, torch proxies for the
     CUDA-only calls, one offloaded layer so the copy_kv / copy_back pipeline runs) vs ref_model.triforce(dist=True).
@@ -405,7 +405,7 @@ def tp_chain_case(name="tp_chain"):
                               name="tiny-d64-tp")
     dcfg = specs.llama_config(128, 256, 2, 2, vocab_size=1024, max_position_embeddings=2048, name="tiny-draft-tp")
     tseed, dseed, pseed, head_std = 401, 402, 403, 0.05
-    prefill, budget, chunk, gamma, gen_len = 1000, 128, 8, 6, 40
+    prefill, budget, chunk, gen_len = 1000, 128, 8, 40
     tsd = specs.random_state_dict(tcfg, tseed, head_std=head_std)
     dsd = specs.random_state_dict(dcfg, dseed, head_std=head_std)
     prompt = specs.random_prompt(tcfg["vocab_size"], prefill, pseed)
@@ -478,7 +478,8 @@ def tp_chain_case(name="tp_chain"):
     # Baseline_Dist (decoding.py:243-287): the TP autoregressive baseline; torch.cuda.synchronize() is proxied for the
     # duration of the call only
     baselines = []
-    for label, temperature, top_p, rng_seed in (("baseline_stochastic", 0.6, 0.9, 13), ("baseline_greedy", 1.0, 1e-9, 14)):
+    for label, temperature, top_p, rng_seed in ((("baseline_stochastic", 0.6, 0.9, 13), ("baseline_greedy", 1.0, 1e-9, 14))
+                                                 if with_baselines else ()):
         llm = ref.tp.DistributedLlama(model_name_or_path=tmp, local_rank=0, world_size=1, prefill=prefill,
                                       gen_len=gen_len, temperature=temperature, top_p=top_p, flash_attn=True,
                                       retrieval_budget=0, kv_offload=True,
@@ -856,6 +857,7 @@ if __name__ == "__main__":
         os.makedirs(GOLDEN, exist_ok=True)
         torch.set_num_threads(8)
         tp_chain_case()
+        tp_chain_case("tp_chain_gamma16", gamma=16, with_baselines=False)     # offloading_TP.py's README command
     elif len(sys.argv) > 1 and sys.argv[1] == "tp2":
         os.makedirs(GOLDEN, exist_ok=True)
         tp_world2_case()
@@ -871,6 +873,7 @@ if __name__ == "__main__":
         main_sequoia()
         cli_case()
         tp_chain_case()
+        tp_chain_case("tp_chain_gamma16", gamma=16, with_baselines=False)
         offloading_case()
         tp_world2_case()
         sequoia_world2_case()

@@ -113,15 +113,16 @@ def _tp_product(g, tsd, dsd, temperature, top_p):
     return llm
 
 
+@pytest.mark.parametrize("name", ["tp_chain", "tp_chain_gamma16"])
 @pytest.mark.parametrize("temperature,top_p", [(0.6, 0.9), (1.0, 1e-9)])
-def test_tp_chain_loop_matches_oracle_with_injected_uniforms(cpu_ops, temperature, top_p):
+def test_tp_chain_loop_matches_oracle_with_injected_uniforms(cpu_ops, temperature, top_p, name):
     """TriForce_Dist on the product's TP engine (world size 1) against the restatement that
     tests/golden/tp_chain.pt pins to the reference's TriForce_Dist: same explicit uniforms -> same stream, accept
     counts, returned average and final cache lengths.  Covers the TP-only rules: inclusive outer accept, draft
     sampled at 0.6 / 0.9 whatever the target's settings, 128-token draft prefill blocks."""
     from triforce_amd.utils.decoding import TriForce_Dist
     from triforce_amd.utils.sampling import UniformSource
-    g = Hh.load_golden("tp_chain")
+    g = Hh.load_golden(name)
     us = Hh.fixed_uniforms(seed=21)
     prompt = Hh.prompt_of(g)
     oeng, tsd, dsd = Hh.build_oracle_tp(g, temperature, top_p)

@@ -62,11 +62,12 @@ def test_triforce_streams_match_reference(name):
         assert g["triforce"][0]["tokens"][:n] == g["ar_tokens"][:n]     # lossless: greedy TriForce == greedy AR
 
 
-def test_tp_chain_matches_reference():
+@pytest.mark.parametrize("name", ["tp_chain", "tp_chain_gamma16"])
+def test_tp_chain_matches_reference(name):
     """TriForce_Dist / Middle_Spec_Dist (decoding.py:291-495) on the reference's TP engine (TP_llama.py), run
     unmodified on CPU when the golden was made: the restatement reproduces streams, accept counts and the returned
     average for a stochastic target, a greedy target (stochastic draft) and two eos placements."""
-    g = Hh.load_golden("tp_chain")
+    g = Hh.load_golden(name)                      # gamma 6, and gamma 16 (the README command of offloading_TP.py)
     prompt = Hh.prompt_of(g)
     for case in g["cases"]:
         eng, _, _ = Hh.build_oracle_tp(g, case["temperature"], case["top_p"])
