@@ -135,3 +135,33 @@ def test_cli_flag_tables_match_the_reference_scripts():
         assert args.gen_len == 256 and args.temp == 0.6 and args.top_p == 0.9
     assert cli.parse("on_chip", ["--greedy"]).top_p == 1e-9 and cli.parse("on_chip", ["--greedy"]).temp == 1.0
     assert cli.parse("offloading_TP", ["--gamma", "16"]).gamma == "16"      # the reference parses --gamma as str here
+
+
+@pytest.mark.parametrize("n", [65, 127, 128, 129, 1000, 1024, 1025, 2047, 2048, 3001])
+@pytest.mark.parametrize("on_device", [False, True])
+def test_chunked_prefill_returns_the_reference_last_chunk(n, on_device):
+    """The device feeds the prompt PREFILL_CHUNK rows per forward, the reference 128 (graph_infer.py:30-37): whatever the
+    chunking, every token goes through exactly once, in order, and the returned logits are the rows of the REFERENCE's
+    last 128-token chunk."""
+    from triforce_amd.utils import graph_infer as gi
+
+    class Ids:                                        # shape / slicing / is_cuda are all chunked_prefill touches
+        def __init__(self, lo, hi):
+            self.lo, self.hi, self.is_cuda, self.shape = lo, hi, on_device, (1, hi - lo)
+
+        def __getitem__(self, key):
+            sl = key[1]
+            lo = self.lo + (sl.start or 0)
+            return Ids(lo, min(self.hi, self.lo + sl.stop) if sl.stop is not None else self.hi)
+
+    seen = []
+
+    def forward(chunk):
+        seen.append((chunk.lo, chunk.hi))
+        return torch.arange(chunk.lo, chunk.hi, dtype=torch.float32).reshape(1, -1, 1)
+
+    out = gi.chunked_prefill(forward, Ids(0, n))
+    step = gi.PREFILL_CHUNK if on_device else 128
+    assert seen == [(i, min(n, i + step)) for i in range(0, n, step)]
+    ref_last = 128 * ((n - 1) // 128)                  # first row of the reference's last chunk
+    assert out.reshape(-1).tolist() == list(range(ref_last, n))
