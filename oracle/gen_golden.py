@@ -6,7 +6,7 @@ GPU box):   python -m oracle.gen_golden [sequoia | sequoia2 | cli | tp | tp2 | o
   (default)   rope_tables, forward_small, cfg1_greedy, cfg1_stochastic, small_gamma6   on-chip path (test/on_chip.py)
   sequoia     sequoia_tree512, sequoia_small            SpecTree + TP_llama_tree (test/offloading_seqouia.py)
   tp          tp_chain                                  TP_llama + TriForce_Dist at world size 1 (test/offloading_TP.py)
-  tp2         tp_world2                                 the same engine as TWO gloo processes: shards + all-reduces
+  tp2         tp_world2, tp_world4                      the same engine as 2 / 4 gloo processes: shards + all-reduces
   sequoia2    sequoia_world2                            the Sequoia loop as TWO gloo processes
   offloading  offloading_small                          OffloadingFlashSimpleCache (test/offloading.py)
   cli         cli_flags                                 the four scripts' command lines
@@ -581,7 +581,7 @@ def _tp2_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def tp_world2_case(name="tp_world2"):
+def tp_world2_case(name="tp_world2", world=2):
     """The reference's tensor-parallel engine at WORLD SIZE 2: two gloo processes on CPU run the unmodified
     TP_llama.DistributedLlama (head / MLP-column shards of TP_layers.py:126-147, fp16 all-reduce after wo and down_proj)
     and TriForce_Dist (rank 0 samples, tokens and uniforms broadcast).  Recorded: per-stage logits (identical on both
@@ -596,19 +596,21 @@ def tp_world2_case(name="tp_world2"):
     s.close()
     out = os.path.join(tempfile.mkdtemp(), "tp2")
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_tp2_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_tp2_worker, args=(r, world, port, out)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(timeout=900)
         assert p.exitcode == 0, f"reference TP rank exited with {p.exitcode}"
-    r0, r1 = (torch.load(f"{out}.{r}", weights_only=False) for r in range(2))
-    for k in ("prefill_logits", "build_logits", "spec_logits", "verify_logits"):
-        assert torch.equal(r0[k], r1[k]), f"[{name}] ranks disagree on {k}"
-    assert r0["tokens"] == r1["tokens"] and r0["counts"] == r1["counts"] and r0["final_seq_len"] == r1["final_seq_len"]
+    ranks = [torch.load(f"{out}.{r}", weights_only=False) for r in range(world)]
+    r0 = ranks[0]
+    for r1 in ranks[1:]:
+        for k in ("prefill_logits", "build_logits", "spec_logits", "verify_logits"):
+            assert torch.equal(r0[k], r1[k]), f"[{name}] ranks disagree on {k}"
+        assert r0["tokens"] == r1["tokens"] and r0["counts"] == r1["counts"] and r0["final_seq_len"] == r1["final_seq_len"]
     P = _TP2
     tcfg, dcfg = _tp2_configs()
-    g = dict(name=name, tcfg=tcfg, dcfg=dcfg, **{k: v for k, v in P.items() if k != "tcfg"})
+    g = dict(name=name, world=world, tcfg=tcfg, dcfg=dcfg, **{k: v for k, v in P.items() if k != "tcfg"})
     from tests import helpers as Hh
     eng, _, _ = Hh.build_oracle_tp(g, P["temperature"], P["top_p"])
     prompt = specs.random_prompt(tcfg["vocab_size"], P["prefill"], P["pseed"])
@@ -861,6 +863,7 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "tp2":
         os.makedirs(GOLDEN, exist_ok=True)
         tp_world2_case()
+        tp_world2_case("tp_world4", world=4)              # one attention head per rank: the extreme shard
     elif len(sys.argv) > 1 and sys.argv[1] == "sequoia2":
         os.makedirs(GOLDEN, exist_ok=True)
         sequoia_world2_case()
@@ -876,4 +879,5 @@ if __name__ == "__main__":
         tp_chain_case("tp_chain_gamma16", gamma=16, with_baselines=False)
         offloading_case()
         tp_world2_case()
+        tp_world2_case("tp_world4", world=4)
         sequoia_world2_case()

@@ -204,6 +204,14 @@ def test_sequoia_tp2_gloo_lockstep_and_close_to_oracle():
 
 # ---- against the REFERENCE's own engine at world size 2 (tests/golden/tp_world2.pt) --------------------------------
 def _ref2_worker(rank, world, port, q):
+    _ref_world_worker(rank, world, port, q, "tp_world2")
+
+
+def _ref4_worker(rank, world, port, q):
+    _ref_world_worker(rank, world, port, q, "tp_world4")
+
+
+def _ref_world_worker(rank, world, port, q, golden):
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -216,7 +224,7 @@ def _ref2_worker(rank, world, port, q):
         from oracle import specs
         from triforce_amd.models.config_yarn import LlamaConfig
         from triforce_amd.models.TP_llama import DistributedLlama
-        g = Hh.load_golden("tp_world2")
+        g = Hh.load_golden(golden)
         tsd = specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g["head_std"])
         tcfg = LlamaConfig.from_dict(g["tcfg"])
         gamma = g["gamma"]
@@ -240,22 +248,25 @@ def _ref2_worker(rank, world, port, q):
         q.put((rank, "error", traceback.format_exc()))
 
 
-def test_tp2_gloo_matches_the_reference_engine_at_world_size_2():
-    """The product's sharded forward against logits the UNMODIFIED reference TP engine produced as two gloo processes
-    on CPU (oracle/gen_golden.py tp2): same head / MLP-column shards (TP_layers.py:126-147) and the same two fp16
-    all-reduces per layer, so the four stages agree to all-reduce rounding — and bit-for-bit where the summation
-    order is the same."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_tp_gloo_matches_the_reference_engine_at_the_same_world_size(world):
+    """The product's sharded forward against logits the UNMODIFIED reference TP engine produced as `world` gloo
+    processes on CPU (oracle/gen_golden.py tp2): same head / MLP-column shards (TP_layers.py:126-147; at world 4 one
+    attention head per rank) and the same two fp16 all-reduces per layer.  In the build container the four stages are
+    bit-identical at world 2; at world 4 the CPU GEMM picks another blocking for the product's fused q|k|v weight than
+    for the reference's three separate shards, which moves ~70 % of the logits by one fp16 step of a hidden state
+    (max 2.4e-3 on logits of scale 0.65) — hence a tolerance, not equality."""
     from tests import helpers as Hh
-    world = 2
-    outs = _run_world(_ref2_worker, world)
-    g = Hh.load_golden("tp_world2")
-    assert g["shard_shapes"]["wq"] == (g["tcfg"]["hidden_size"] // 2, g["tcfg"]["hidden_size"])
+    outs = _run_world(_ref2_worker if world == 2 else _ref4_worker, world)
+    g = Hh.load_golden(f"tp_world{world}")
+    assert g["world"] == world
+    assert g["shard_shapes"]["wq"] == (g["tcfg"]["hidden_size"] // world, g["tcfg"]["hidden_size"])
     for r in range(world):
         _, _, S, lp, lb, ls, lv = outs[r]
         assert S == g["S"]
         for name, ours in (("prefill_logits", lp), ("build_logits", lb), ("spec_logits", ls), ("verify_logits", lv)):
             gap = (ours - g[name]).abs().max().item()
-            assert gap < 2e-3, f"rank {r} {name}: {gap:.2e} from the reference's world-2 logits"
+            assert gap < 4e-3, f"rank {r} {name}: {gap:.2e} from the reference's world-{world} logits"
     exact = [name for name, i in (("prefill_logits", 3), ("build_logits", 4), ("spec_logits", 5), ("verify_logits", 6))
              if torch.equal(outs[0][i].reshape(g[name].shape), g[name])]
     print("bit-identical stages:", exact)
