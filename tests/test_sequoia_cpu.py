@@ -134,3 +134,38 @@ def test_gather_kv_incremental_rejects_unsorted_and_handles_identity(cpu_ops):
     assert c.seq_len == 14 and torch.equal(c.k[:, :, 10:14], k0[:, :, [10, 13, 17, 30]])
     with pytest.raises(AssertionError):
         c.gather_kv_incremental([0, 5, 3], 10)
+
+
+def test_tree_builder_agrees_with_oracle_on_random_trees():
+    """grow_map_from_branches (product, utils/tree.py) vs the oracle's builder (pinned to the reference's tree/512.pt)
+    on 40 random ragged trees — zero-child nodes, single chains, wide levels — including the CSR successor table the
+    accept-walk kernel consumes and the packed mask the attention kernel consumes."""
+    import random
+    from triforce_amd.utils import tree as T
+    rnd = random.Random(5)
+    for _ in range(40):
+        branches, width = [], 1
+        for _level in range(rnd.randint(1, 6)):
+            level = [rnd.choice([0, 0, 1, 1, 2, 3, 5]) for _ in range(width)]
+            if sum(level) == 0:
+                level[rnd.randrange(width)] = 1
+            branches.append(level)
+            width = sum(level)
+            if width > 40:
+                break
+        ours, theirs = T.grow_map_from_branches(branches), RT.grow_map_from_branches(branches)
+        for k in ("roots", "branches", "Successors", "size"):
+            assert ours[k] == theirs[k], (k, branches)
+        assert torch.equal(ours["mask"], theirs["mask"]) and torch.equal(ours["depth"], theirs["depth"])
+        n = ours["size"]
+        off, flat = T.successors_csr(ours["Successors"])
+        assert off.tolist()[0] == 0 and off.tolist()[-1] == n - 1 and sorted(flat.tolist()) == list(range(1, n))
+        for node in range(n):                             # a node sees exactly itself and its ancestors
+            row = ours["mask"][node]
+            seen, cur = {node}, node
+            parents = {c: p for p in range(n) for c in ours["Successors"][p]}
+            while cur in parents:
+                cur = parents[cur]
+                seen.add(cur)
+            assert set(torch.nonzero(row).reshape(-1).tolist()) == seen
+            assert int(ours["depth"][node]) == len(seen) - 1
