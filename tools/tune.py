@@ -60,4 +60,15 @@ for (sq, sk, H, tagk) in ([] if only_gemm else [(8, 124936, 32, "attn_target"), 
         us = timeit([(lambda kv=kv: ops.attn_decode(q, kv[0], kv[1], sk, 0.08837890625, nsplit=ns)) for kv in kvs], iters=24)
         res[f"{tagk}_ns{ns}"] = {"us": round(us, 2), "GBps": round(2 * sk * H * 128 * 2 / us / 1e3, 1)}
     del kvs
+if not only_gemm:
+    # Sequoia verify: 512 tree nodes (4 slabs of 128 rows) over a 124 928-token prefix; random lower-triangular tree mask
+    T, P, H = 512, 124928, 32
+    kvs = [(torch.randn(H, P + T, 128, generator=g, device=DEV, dtype=torch.float16),
+            torch.randn(H, P + T, 128, generator=g, device=DEV, dtype=torch.float16)) for _ in range(2)]
+    q = torch.randn(T, H, 128, generator=g, device=DEV, dtype=torch.float16)
+    vis = torch.tril(torch.rand(T, T, generator=g, device=DEV) < 0.2) | torch.eye(T, dtype=torch.bool, device=DEV)
+    bits = ops.pack_tree_mask(vis)
+    us = timeit([(lambda kv=kv: ops.attn_tree(q, kv[0], kv[1], P + T, 0.08838834764831845, bits, P)) for kv in kvs], iters=8)
+    res["attn_tree_verify_512"] = {"us": round(us, 2), "us_per_slab": round(us / 4, 2)}
+    del kvs
 print(json.dumps(res), flush=True)

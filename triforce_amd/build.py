@@ -27,7 +27,8 @@ def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "triforce_hip.h")]
+    deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "tree_mask.h"),
+                        os.path.join(HERE, "..", "include", "triforce_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 

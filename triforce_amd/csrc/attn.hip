@@ -20,8 +20,20 @@
 //   * online softmax in fp32 (running max / sum per query column), partial (m, l, O) per split
 //     merged by a second tiny kernel.
 #include "common.h"
+#include "tree_mask.h"
 
 #define NEG_BIG (-1.0e30f)
+#ifndef TF_TREE_MASK_FUNNEL
+#define TF_TREE_MASK_FUNNEL 0  // 1: the LDS block kernel reads a tree row's 8 visibility bits with one funnel shift (tree_mask.h)
+#endif
+#ifndef TF_ATTN_LATE_VT
+#define TF_ATTN_LATE_VT 0      // 1: decode (QT = 1) tiles transpose each V fragment just before its PV MFMA (fewer live registers)
+#endif
+#ifdef TF_ATTN_OCC             // waves per SIMD the split-KV kernel is compiled for (default: the compiler's choice, 2;
+#define ATTN_SPLIT_BOUNDS __launch_bounds__(256, TF_ATTN_OCC)      // 3 spills unless TF_ATTN_LATE_VT frees registers)
+#else
+#define ATTN_SPLIT_BOUNDS __launch_bounds__(256)
+#endif
 #ifndef TF_ATTN_DEPTH
 #define TF_ATTN_DEPTH 2        // KV tiles in flight per wave in the split-KV kernel (3 = 24 KiB; A/B in tools/tune.py)
 #endif
@@ -64,12 +76,15 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
                                           TreeMask tm = TreeMask{nullptr, 0, 0, 0}) {
     constexpr int NC = D / 32, NT = D / 16;
     // V tile -> key-contiguous fragments through the matrix core (exact: multiplies by 0/1)
-    half4 va[NT];
+    constexpr bool LATE_VT = TF_ATTN_LATE_VT && QT == 1;      // transpose each V fragment right before its PV MFMA
+    half4 va[LATE_VT ? 1 : NT];
+    if (!LATE_VT) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[t >> 1], (t & 1) ? sel1 : sel0, z, 0, 0, 0);
-        va[t] = half4{(h16)r[0], (h16)r[1], (h16)r[2], (h16)r[3]};
+        for (int t = 0; t < NT; ++t) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[t >> 1], (t & 1) ? sel1 : sel0, z, 0, 0, 0);
+            va[LATE_VT ? 0 : t] = half4{(h16)r[0], (h16)r[1], (h16)r[2], (h16)r[3]};
+        }
     }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -125,14 +140,22 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
         }
         st.l[qt] += psum;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-            st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(va[t], pb, st.acc[qt][t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) {
+            if (LATE_VT) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[t >> 1], (t & 1) ? sel1 : sel0, z, 0, 0, 0);
+                const half4 vt = half4{(h16)r[0], (h16)r[1], (h16)r[2], (h16)r[3]};
+                st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(vt, pb, st.acc[qt][t], 0, 0, 0);
+            } else {
+                st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(va[LATE_VT ? 0 : t], pb, st.acc[qt][t], 0, 0, 0);
+            }
+        }
     }
 }
 
 // ws layout: o[H][nsplit][QR][D] | m[H][nsplit][QR] | l[H][nsplit][QR],  QR = QT*16
 template <int D, int QT>
-__global__ __launch_bounds__(256) void attn_split_kernel(
+__global__ ATTN_SPLIT_BOUNDS void attn_split_kernel(
     const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
     int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
     float* __restrict__ ws) {
@@ -498,18 +521,30 @@ __device__ __forceinline__ void lds_softmax_pv(AttnState<D, QT>& st, const f32x4
         float x[8];
         bool ok[8];
         float tmax = NEG_BIG;
+#if TF_TREE_MASK_FUNNEL
+        uint32_t vis8 = 0xFFu;                 // the lane's 8 keys are consecutive: 8 consecutive bits of the mask row
+        if (MASKED && TREE) {
+            const int kidx0 = key0 + 8 * g;
+            vis8 = tf_tree_vis8(tm.rows + (int64_t)(tm.row0 + min(qrow, sq - 1)) * tm.words, tm.words,
+                                kidx0 - tm.start, sk - kidx0);
+        }
+#endif
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int kidx = key0 + 8 * g + r;
             bool v = true;
             if (MASKED) {
                 if (TREE) {
+#if TF_TREE_MASK_FUNNEL
+                    v = (vis8 >> r) & 1u;
+#else
                     const int j = kidx - tm.start;
                     v = kidx < sk;
                     if (j >= 0 && v) {
                         const int mrow = tm.row0 + min(qrow, sq - 1);
                         v = (tm.rows[(int64_t)mrow * tm.words + (j >> 5)] >> (j & 31)) & 1u;
                     }
+#endif
                 } else {
                     v = kidx <= kmax;
                 }
