@@ -165,3 +165,39 @@ def test_chunked_prefill_returns_the_reference_last_chunk(n, on_device):
     assert seen == [(i, min(n, i + step)) for i in range(0, n, step)]
     ref_last = 128 * ((n - 1) // 128)                  # first row of the reference's last chunk
     assert out.reshape(-1).tolist() == list(range(ref_last, n))
+
+
+def test_bench_helpers_on_cpu():
+    """bench.py's host-side arithmetic: the acceptance projection at zero acceptance reduces to the closed form the
+    measured run is priced with, the roofline helper divides algorithmic bytes by the sampled launch durations, and
+    the KV slack is sized from the requested steps."""
+    import sys
+    import bench
+    stages = {"target_verify_us": 13600.0, "retrieval_verify_us": 3400.0, "draft_step_us": 140.0}
+    p0 = bench.projection(stages, gamma=6, overhead_us=600.0, pairs=((0.0, 0.0),))["draft_acc=0.0,retrieval_acc=0.0"]
+    step_us = 13600.0 + 6 * (3400.0 + 140.0) + 140.0 + 600.0          # gamma inner iterations, one token per step
+    assert p0["tokens_per_step"] == 1.0 and abs(p0["tokens_per_s"] - 1e6 / step_us) < 0.06
+    p1 = bench.projection(stages, gamma=6, overhead_us=600.0, pairs=((1.0, 1.0),))["draft_acc=1.0,retrieval_acc=1.0"]
+    assert p1["tokens_per_step"] == 7.0                                 # 3 inner iterations x 2 tokens, all kept, + bonus
+    assert abs(p1["tokens_per_s"] - 7e6 / (13600.0 + 3 * 3540.0 + 140.0 + 600.0)) < 0.06
+
+    class Ev:                                                          # stands in for a pair of HIP events
+        def __init__(self, ms):
+            self.ms = ms
+
+        def elapsed_time(self, other):
+            return other.ms
+
+    timer = [(Ev(0), Ev(0.350), 124936, 32, 128), (Ev(0), Ev(0.022), 4103, 32, 128), (Ev(0), Ev(0.354), 124944, 32, 128)]
+    roof = bench.attn_roofline(timer, retrieval_rows=4103, H=32, D=128)
+    alg = (2 * 124936 * 32 * 128 * 2 + 2 * 124944 * 32 * 128 * 2) / 2
+    assert roof["launches"] == 2 and roof["algorithmic_bytes_per_launch"] == int(alg)
+    assert abs(roof["achieved"] - alg / 0.352e-3 / 1e9) < 0.2 and abs(roof["frac"] - roof["achieved"] / 8000.0) < 1e-3
+    assert bench.attn_roofline(timer[1:2], retrieval_rows=4103, H=32, D=128) is None      # no full-KV launch sampled
+
+    argv, sys.argv = sys.argv, ["bench.py", "--steps", "400"]
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = argv
+    assert a.gen_cap == (400 + a.warmup + 4) * (a.gamma + 2) + 64 and a.gen_cap <= a.budget
