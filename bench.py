@@ -2,23 +2,30 @@
 """bench.py — TriForce decode throughput on MI355X (BASELINE.json metric).
 
   python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N ...                      (re-executes itself under torch.distributed.run, one rank per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (N=1): BASELINE.json configs[1] — Llama2-7B-128K (YaRN) on-chip, prefill 124 928, retrieval
-budget 4 096, chunk 8, gamma 6, T=0.6 / top_p=0.9 (README.md:49-55), random-init weights and random
-prompt tokens (no checkpoints / datasets offline).  A *step* is one outer TriForce iteration
-(utils/decoding.py:70-141): gamma-bounded Middle_Spec drafting (68M draft graphs + retrieval-verify
-graph), one target verify over the full 125K-token KV cache, device-side accept/rollback and the
-cache fix-ups.  The timed region starts after prefill + retrieval build + draft prefill, exactly
-like the reference's time1/time2 (decoding.py:69,143), with device syncs added on both sides.
+Workload (N=1): BASELINE.json configs[1] — Llama2-7B-128K (YaRN) on-chip, prefill 124 928, retrieval budget 4 096,
+chunk 8, gamma 6, T=0.6 / top_p=0.9 (reference README.md:49-55).  A *step* is one outer TriForce iteration
+(utils/decoding.py:70-141): gamma-bounded Middle_Spec drafting (68M draft graphs + retrieval-verify graph), one target
+verify over the full 125K-token KV cache (hipGraph, device-resident lengths), device-side accept/rollback and the cache
+fix-ups.  The timed region starts after prefill + retrieval build + draft prefill, exactly like the reference's
+time1/time2 (decoding.py:69,143), with device syncs added on both sides.
+
+Weights (--weights): real checkpoints when both are found locally (zoo.find_checkpoint); otherwise — no hub access
+offline — ALIGNED SYNTHETIC weights (triforce_amd/models/aligned.py): real shapes, dense values, every kernel streams
+the bytes it streams for a trained model, and the draft -> retrieval-model -> full-model acceptance rates are set to
+the requested values (default 0.7 / 0.9), so the loop runs in the regime speculative decoding exists for.  The
+random-init number of round 1 (acceptance ~0.01: the loop's worst case) is measured in the same process afterwards and
+reported as ``random_weights``.
 
 value = tokens emitted in the K timed steps / wall time (tokens/s, whole job).
-roofline = the dominant kernel (split-KV target-verify attention, tf_attn_decode): algorithmic bytes per
-launch 2*S*H*D*2 / mean launch duration from HIP events recorded on the launch stream
-inside the timed region (every 8th launch is bracketed: an event record is a queue packet of its own, and
-bracketing all 32 per target verify would add ~0.4 ms of gaps to the step being measured).
-cpu_baseline = the CPU oracle (oracle/, kind "port") timed on this host for a bounded per-layer sample
-of the same step, extrapolated to the step.
+roofline = the dominant kernel (split-KV target-verify attention, tf_attn_decode): algorithmic bytes per launch
+2*S*H*D*2 / mean launch duration from HIP events recorded on the launch stream INSIDE the timed region:
+every --roofline-every-th step runs its target verify eagerly instead of replaying the hipGraph, and every 8th
+attention launch of such a verify is bracketed (an event record is a queue packet of its own).
+cpu_baseline = the CPU oracle (oracle/, kind "port") timed on this host for a bounded per-layer sample of the same
+step, extrapolated to the step.
 """
 import argparse
 import json
@@ -33,12 +40,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+REFERENCE_SPEEDUP = 2.2       # reference README.md:49-55: TriForce vs autoregressive, 1x A100, same config, trained weights
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--target", default="llama-7B-128K", choices=["llama-7B-128K", "llama-13B-128K", "lwm-128K", "tiny"])
     ap.add_argument("--prefill", type=int, default=124928)
@@ -48,6 +56,15 @@ def parse():
     ap.add_argument("--temp", type=float, default=0.6)
     ap.add_argument("--top_p", type=float, default=0.9)
     ap.add_argument("--gen_cap", type=int, default=512, help="KV slack reserved for generated tokens")
+    ap.add_argument("--weights", default="auto",
+                    help="auto = local checkpoints if present, else aligned:0.7:0.9 | aligned[:draft_acc[:retrieval_acc"
+                         "[:seed]]] | random[:seed] | <local HF dir of the target> (draft: --draft-weights)")
+    ap.add_argument("--draft-weights", default=None, help="local HF dir of the 68M draft (with a checkpoint target)")
+    ap.add_argument("--random-steps", type=int, default=-1,
+                    help="steps of the secondary random-init measurement (-1 = min(steps, 12); 0 = skip)")
+    ap.add_argument("--ar-steps", type=int, default=16, help="autoregressive steps timed for the AR baseline")
+    ap.add_argument("--roofline-every", type=int, default=4,
+                    help="every N-th step's target verify runs eagerly with HIP-event brackets (0 = never)")
     ap.add_argument("--prefill-mode", default="real", choices=["real", "synthetic"],
                     help="real = chunked prefill through the model; synthetic = N(0,1) KV fill "
                          "(the reference's own filler, DistributedSimpleCache.normal_, cache.py:303-308)")
@@ -56,16 +73,39 @@ def parse():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--rebuild-every", type=int, default=0,
                     help="re-select the retrieval cache every N target verifies (0 = the reference: once per prompt)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.random_steps < 0:
+        args.random_steps = min(args.steps, 12)
     # a step emits at most gamma + 2 tokens: size the KV slack for the worst case of the requested run
     # (never more than the retrieval budget: its tail holds every generated token, reference cache.py:180-182)
-    args.gen_cap = max(args.gen_cap, min((args.steps + args.warmup + 4) * (args.gamma + 2) + 64, args.budget))
+    total = args.steps + args.warmup + args.random_steps + 8
+    args.gen_cap = max(args.gen_cap, min(total * (args.gamma + 2) + args.ar_steps + 64, args.budget))
     return args
 
 
 def target_config(name):
     from triforce_amd.models import zoo
     return zoo.config(name), zoo.config("llama-68M")
+
+
+def resolve_weights(args):
+    """-> (kind, target_spec, draft_spec, label): kind in {"checkpoint", "aligned", "random"}."""
+    from triforce_amd.models import zoo
+    w = args.weights
+    if w == "auto":
+        t, d = zoo.find_checkpoint(args.target) if args.target in zoo.CONFIGS else None, zoo.find_checkpoint("llama-68M")
+        if t and d:
+            return "checkpoint", t, d, f"checkpoints {t} + {d}"
+        w = "aligned:0.7:0.9"
+    if w.startswith("aligned"):
+        return "aligned", w, w, w
+    if w.startswith("random"):
+        seed = int(w.split(":")[1]) if ":" in w and w.split(":")[1] else args.seed
+        return "random", f"random:{seed + 1}", f"random:{seed + 2}", "random-init N(0,0.02) fp16"
+    d = args.draft_weights or zoo.find_checkpoint("llama-68M")
+    if not d:
+        raise SystemExit("--weights <dir> needs --draft-weights <dir> (no local llama-68m checkpoint found)")
+    return "checkpoint", w, d, f"checkpoints {w} + {d}"
 
 
 class _Tok:
@@ -75,14 +115,24 @@ class _Tok:
         return ""
 
 
-def build_engine(args, device):
-    from triforce_amd.models.cache import FlashSimpleCache, RetrievalCache, StreamingLLMEvictionCache
+def load_models(args, device, kind, tspec, dspec):
+    from triforce_amd.models.aligned import parse_spec
     from triforce_amd.models.modeling_llama import LlamaForCausalLM
     from triforce_amd.models.modeling_llama_68m import LlamaForCausalLM as Draft68M
-    from triforce_amd.utils.graph_infer import GraphInferenceEngine
     tcfg, dcfg = target_config(args.target)
-    target = LlamaForCausalLM(tcfg, device).init_random(args.seed + 1)
-    draft = Draft68M(dcfg, device).init_random(args.seed + 2)
+    if kind == "checkpoint":
+        return LlamaForCausalLM.from_pretrained(tspec, device_map=device), Draft68M.from_pretrained(dspec, device_map=device)
+    if kind == "aligned":
+        spec = parse_spec(tspec)
+        return (LlamaForCausalLM(tcfg, device).init_aligned(spec, attn_keys=args.budget),
+                Draft68M(dcfg, device).init_aligned(spec, attn_keys=256))
+    return (LlamaForCausalLM(tcfg, device).init_random(int(tspec.split(":")[1])),
+            Draft68M(dcfg, device).init_random(int(dspec.split(":")[1])))
+
+
+def build_engine(args, device, target, draft):
+    from triforce_amd.models.cache import FlashSimpleCache, RetrievalCache, StreamingLLMEvictionCache
+    from triforce_amd.utils.graph_infer import GraphInferenceEngine
     cache = FlashSimpleCache(target, args.prefill + args.gen_cap + 16)
     gcache = RetrievalCache(target, max_budget=args.budget, prefill=args.prefill, gamma=args.gamma,
                             chunk_size=args.chunk_size)
@@ -112,41 +162,66 @@ def do_prefill(run, ge, input_ids, mode):
     eng.kv_cache.seq_len = P - 1
     logits = ge.inference(input_ids=input_ids[:, -1:])           # last prompt token: builds the retrieval cache
     ge.graph_draft_prefill(input_ids=input_ids)
+    run.calibrate_aligned()
     run.start(logits)
 
 
+def _timed(fn, n):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+
+
 def stage_latencies(ge, args, device):
-    """Per-stage latency (us) of the three model calls of a step, HIP events on the launch stream."""
+    """Per-stage latency (us) of the model calls of a step as the loop issues them (graph replays where captured),
+    HIP events on the launch stream."""
     eng = ge.engine
     gamma = args.gamma
-
-    def t(fn, n=5):
-        fn()
-        torch.cuda.synchronize()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(n):
-            fn()
-        e.record()
-        torch.cuda.synchronize()
-        return s.elapsed_time(e) / n * 1e3
-
     S = eng.kv_cache.seq_len
     ids = torch.full((1, gamma + 1), 100, dtype=torch.long, device=device)
     pos = torch.arange(S, S + gamma + 1, device=device).unsqueeze(0)
-    out = {"draft_step_us": t(lambda: ge.graph_draft_inference(ids[:, :3], gamma_offset=2)),
-           "retrieval_verify_us": t(lambda: ge.graph_verify(ids, pos))}
+    out = {"draft_step_us": _timed(lambda: ge.graph_draft_inference(ids[:, :3], gamma_offset=2), 5),
+           "retrieval_verify_us": _timed(lambda: ge.graph_verify(ids, pos), 5)}
 
-    def tv():
-        ge.inference(ids)
-        eng.kv_cache.seq_len = S                   # roll the probe back
-    out["target_verify_us"] = t(tv, n=3)
-
-    def ar():
-        ge.engine.model(input_ids=ids[:, :1], kv_cache=eng.kv_cache, graph_cache=None)
-        eng.kv_cache.seq_len = S
-    out["ar_decode_step_us"] = t(ar, n=3)
+    def tv(eager):
+        def f():
+            ge.verify_probs(ids, args.temp, args.top_p, eager=eager)
+            eng.kv_cache.seq_len = S                   # roll the probe back
+        return f
+    out["target_verify_us"] = _timed(tv(False), 3)
+    out["target_verify_eager_us"] = _timed(tv(True), 3)
     return {k: round(v, 1) for k, v in out.items()}
+
+
+def autoregressive_baseline(ge, args, first_token):
+    """The reference's autoregressive loop (decoding.py:14-37) on the same engine and cache: one full-cache forward of
+    one token (hipGraph when captured), temperature / top-p, sample — per token, no host sync inside the loop."""
+    from triforce_amd.utils.sampling import UniformSource, norm_logits, sample
+    eng = ge.engine
+    S = eng.kv_cache.seq_len
+    rng = UniformSource(eng.model.device, seed=1)
+    tok = torch.tensor([[int(first_token)]], dtype=torch.long, device=eng.model.device)
+
+    def loop(n):
+        t = tok
+        for _ in range(n):
+            logits = ge.decode_step(t)
+            t = sample(norm_logits(logits[:, -1, :], temperature=args.temp, top_k=-1, top_p=args.top_p), rng=rng)
+        return t
+    loop(2)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    loop(args.ar_steps)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    eng.kv_cache.seq_len = S
+    return args.ar_steps / dt
 
 
 def cpu_baseline(args, tokens_per_step, inner_per_step):
@@ -201,33 +276,6 @@ def cpu_baseline(args, tokens_per_step, inner_per_step):
             "step_seconds_est": round(step, 2)}
 
 
-def projection(stages, gamma, overhead_us, pairs=((0.5, 0.9), (0.7, 0.9), (0.9, 0.95))):
-    """NOT a measurement: tokens/s the measured stage latencies would give if the models agreed like trained ones do.
-    Random-init weights make the 68M draft and the target disagree (acceptance ~1 %), which pins every step at the
-    worst case (gamma inner iterations, ~1 token).  For a (draft->retrieval, retrieval->target) per-token acceptance
-    pair the loop of utils/decoding.py:70-141,163-223 is simulated 20 000 times and priced with
-    step = target_verify + k * (retrieval_verify + draft) + draft + measured per-step overhead."""
-    import random
-    rnd = random.Random(0)
-    out = {}
-    for a1, a2 in pairs:
-        tok = t_us = 0.0
-        for _ in range(20000):
-            n = k = 0
-            while n < gamma:                                  # Middle_Spec: +2 tokens on accept, +1 on reject
-                k += 1
-                n += 2 if rnd.random() < a1 else 1
-            count = 0
-            while count < n and rnd.random() < a2:            # accepted prefix, then the resample / bonus token
-                count += 1
-            tok += count + 1
-            t_us += stages["target_verify_us"] + k * (stages["retrieval_verify_us"] + stages["draft_step_us"]) \
-                + stages["draft_step_us"] + overhead_us
-        out[f"draft_acc={a1},retrieval_acc={a2}"] = {"tokens_per_s": round(tok / t_us * 1e6, 1),
-                                                     "tokens_per_step": round(tok / 20000, 2)}
-    return out
-
-
 def pmc_traffic(alg_bytes, H, D):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, KiB units, FETCH_SIZE doubled for gfx950 — MI355X_MICROARCH.md §HBM).
@@ -254,7 +302,7 @@ def attn_roofline(timer, retrieval_rows, H, D):
     """Live roofline of the dominant kernel — target-verify attention over the full KV (the sampled launches with
     more keys than the retrieval cache holds).  H = heads on THIS rank.  HIP events on the launch stream."""
     from triforce_amd import ops
-    full = [(a.elapsed_time(b) * 1e-3, sk) for (a, b, sk, _, _) in timer if sk > retrieval_rows]
+    full = [(a.elapsed_time(b) * 1e-3, sk) for (a, b, sk, _, _) in (timer or []) if sk > retrieval_rows]
     if not full:
         return None
     dur = sum(d for d, _ in full) / len(full)
@@ -269,29 +317,79 @@ def attn_roofline(timer, retrieval_rows, H, D):
     return roof
 
 
+def timed_steps(run, steps, eager_every=0, sample_attn=False):
+    """Exactly ``steps`` outer iterations bracketed by device syncs -> dict of counters over the timed region.
+    eager_every = N > 0: every N-th target verify runs eagerly (instead of its hipGraph) so that its attention launches
+    can be bracketed with HIP events; sample_attn switches the event sampling of eager attention launches on."""
+    from triforce_amd import ops
+    n0, acc0, dr0, in0 = run.n, run.accepted_count, run.draft_count, run.inner_iters
+    rs0, mid0 = run.resample_count, len(run.acc_rate_middle_list)
+    run.eager_every = eager_every
+    ops.ATTN_TIMER = [] if sample_attn else None
+    torch.cuda.synchronize()
+    t1 = time.time()
+    for _ in range(steps):
+        run.step()
+    torch.cuda.synchronize()
+    t2 = time.time()
+    timer, ops.ATTN_TIMER = ops.ATTN_TIMER, None
+    run.eager_every = 0
+    accepted, drafted = run.accepted_count - acc0, run.draft_count - dr0
+    tests = accepted + (run.resample_count - rs0)           # accept tests the target ran (one per examined token)
+    mids = run.acc_rate_middle_list[mid0:]
+    inner = run.inner_iters - in0
+    return dict(seconds=t2 - t1, tokens=run.n - n0, accepted=accepted, drafted=drafted, inner=inner, timer=timer,
+                per_token_acceptance=accepted / max(tests, 1),
+                middle_acceptance=sum(mids) / max(len(mids), 1))
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` without a launcher: re-execute under torch.distributed.run, one rank per GPU
+    (the reference's own launch line: torchrun --nproc_per_node=N test/offloading_TP.py, README.md:62)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     if world > 1 or os.environ.get("TRIFORCE_BENCH_FORCE_TP") == "1":
         from bench_tp import run_tp                  # tensor-parallel decode (heads sharded, RCCL all-reduce)
         return run_tp(args, rank, world, local)
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
 
-    from triforce_amd import ops
     from triforce_amd.utils.decoding import TriForceRunner
     from triforce_amd.utils.sampling import UniformSource
 
     t_setup = time.time()
-    ge = build_engine(args, device)
+    kind, tspec, dspec, wlabel = resolve_weights(args)
+    target, draft = load_models(args, device, kind, tspec, dspec)
+    ge = build_engine(args, device, target, draft)
     tcfg, _ = target_config(args.target)
     gen = torch.Generator().manual_seed(args.seed)
     input_ids = torch.randint(3, tcfg.vocab_size, (1, args.prefill), generator=gen).to(device)
-    run = TriForceRunner(_Tok(), ge, args.gamma, top_k=-1, top_p=args.top_p, temperature=args.temp,
-                         rng=UniformSource(device, seed=args.seed), rebuild_every=args.rebuild_every)
+
+    def new_runner(seed):
+        return TriForceRunner(_Tok(), ge, args.gamma, top_k=-1, top_p=args.top_p, temperature=args.temp,
+                              rng=UniformSource(device, seed=seed), rebuild_every=args.rebuild_every)
+
+    run = new_runner(args.seed)
+    torch.cuda.synchronize()
     t0 = time.time()
     do_prefill(run, ge, input_ids, args.prefill_mode)
     torch.cuda.synchronize()
@@ -299,26 +397,17 @@ def main():
 
     for _ in range(args.warmup):
         run.step()
-    torch.cuda.synchronize()
-    n0, steps0, acc0, dr0 = run.n, len(run.counts), run.accepted_count, run.draft_count
-    inner0 = run.inner_iters
-    ops.ATTN_TIMER = []
-    torch.cuda.synchronize()
-    t1 = time.time()
-    for _ in range(args.steps):
-        run.step()
-    torch.cuda.synchronize()
-    t2 = time.time()
-    timer, ops.ATTN_TIMER = ops.ATTN_TIMER, None
-    seconds = t2 - t1
-    tokens = run.n - n0
-    accepted, drafted = run.accepted_count - acc0, run.draft_count - dr0
+    # graphs: every --roofline-every-th verify is eager and sampled; --no-graphs: every verify is eager already
+    m = timed_steps(run, args.steps, 0 if args.no_graphs else args.roofline_every,
+                    sample_attn=args.no_graphs or args.roofline_every > 0)
+    seconds, tokens = m["seconds"], m["tokens"]
     value = tokens / seconds
-
-    roof = attn_roofline(timer, args.budget + args.gamma + 1, tcfg.num_attention_heads, tcfg.head_dim)
+    roof = attn_roofline(m["timer"], args.budget + args.gamma + 1, tcfg.num_attention_heads, tcfg.head_dim)
 
     stages = stage_latencies(ge, args, device)
-    inner_per_step = (run.inner_iters - inner0) / max(args.steps, 1)
+    ar_tps = autoregressive_baseline(ge, args, run.next_token)
+    inner_per_step = m["inner"] / max(args.steps, 1)
+    cal = (target.weights.aligned or {}).get("calibration") if kind == "aligned" else None
     result = {
         "metric": "decode tokens/sec + avg accepted len, Llama-7B-128K @124K ctx",
         "value": round(value, 3), "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -327,28 +416,53 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: {tcfg._name_or_path} on-chip TriForce decode, prefill "
                                f"{args.prefill}, budget {args.budget}, chunk {args.chunk_size}, gamma {args.gamma}, "
                                f"T={args.temp}, top_p={args.top_p}, 1xMI355X",
-                   "prefill_mode": args.prefill_mode, "weights": "random-init N(0,0.02) fp16",
-                   "hipgraphs": not args.no_graphs, "retrieval_rebuild_every": args.rebuild_every},
-        "avg_accepted_len": round(accepted / max(drafted, 1) * args.gamma, 4),
-        "acceptance_rate": round(accepted / max(drafted, 1), 4),
+                   "prefill_mode": args.prefill_mode, "weights": wlabel, "weights_kind": kind,
+                   "hipgraphs": not args.no_graphs, "target_verify_graph": bool(ge.target_graphs),
+                   "retrieval_rebuild_every": args.rebuild_every},
+        "avg_accepted_len": round(m["accepted"] / max(m["drafted"], 1) * args.gamma, 4),
+        "acceptance_rate": round(m["accepted"] / max(m["drafted"], 1), 4),
+        "per_token_acceptance_target": round(m["per_token_acceptance"], 4),
+        "per_token_acceptance_middle": round(m["middle_acceptance"], 4),
         "tokens": tokens, "tokens_per_step": round(tokens / args.steps, 3),
-        "drafted_per_step": round(drafted / max(args.steps, 1), 3),
+        "drafted_per_step": round(m["drafted"] / max(args.steps, 1), 3),
         "inner_iterations_per_step": round(inner_per_step, 3),
         "stage_latency_us": stages,
-        "ar_baseline_tokens_per_s": round(1e6 / stages["ar_decode_step_us"], 2),
+        "ar_baseline_tokens_per_s": round(ar_tps, 2),
+        "speedup_vs_autoregressive": round(value / ar_tps, 3),
+        "reference_speedup_vs_autoregressive": {"value": REFERENCE_SPEEDUP, "hardware": "1x A100, trained weights",
+                                                "source": "reference README.md:49-55"},
         "prefill_seconds": round(t_prefill, 2), "setup_seconds": round(t0 - t_setup, 2),
         "kv_seq_len": ge.engine.kv_cache.seq_len,
         "roofline": roof,
     }
-    modelled = stages["target_verify_us"] + inner_per_step * (stages["retrieval_verify_us"] + stages["draft_step_us"]) \
-        + stages["draft_step_us"]
-    overhead_us = max(0.0, seconds / args.steps * 1e6 - modelled)
-    result["step_overhead_us"] = round(overhead_us, 1)          # accept kernels, cache fix-ups, host round trips
-    result["projection_not_measured"] = projection(stages, args.gamma, overhead_us)
+    if cal is not None:
+        result["aligned_calibration"] = cal
+    # what a step costs beyond its model calls (accept kernels, cache fix-ups, host round trips); the eager verifies
+    # sampled for the roofline are priced at their own latency
+    n_eager = (args.steps // args.roofline_every) if (args.roofline_every > 0 and not args.no_graphs) else 0
+    tv_mean = (stages["target_verify_us"] * (args.steps - n_eager) + stages["target_verify_eager_us"] * n_eager) / max(args.steps, 1)
+    modelled = tv_mean + inner_per_step * (stages["retrieval_verify_us"] + stages["draft_step_us"]) + stages["draft_step_us"]
+    result["step_overhead_us"] = round(max(0.0, seconds / args.steps * 1e6 - modelled), 1)
+
+    if args.random_steps > 0 and kind != "random":
+        # the round-1 regime, same process, same graphs: weights re-drawn IN PLACE as N(0, 0.02), prompt re-prefilled
+        target.weights.overwrite_random_(args.seed + 1)
+        draft.weights.overwrite_random_(args.seed + 2)
+        run2 = new_runner(args.seed + 7)
+        do_prefill(run2, ge, input_ids, args.prefill_mode)
+        for _ in range(2):
+            run2.step()
+        r = timed_steps(run2, args.random_steps)
+        result["random_weights"] = {
+            "tokens_per_s": round(r["tokens"] / r["seconds"], 3), "steps": args.random_steps,
+            "ms_per_step": round(r["seconds"] / args.random_steps * 1e3, 3),
+            "acceptance_rate": round(r["accepted"] / max(r["drafted"], 1), 4),
+            "tokens_per_step": round(r["tokens"] / args.random_steps, 3),
+            "inner_iterations_per_step": round(r["inner"] / args.random_steps, 3),
+            "note": "random-init N(0,0.02) weights: draft and target disagree on ~every token (worst case of the loop)"}
     if not args.no_cpu_baseline:
-        inner_iters = (run.inner_iters - inner0) / max(args.steps, 1)   # 68M drafts + retrieval verifies per step
         try:
-            result["cpu_baseline"] = cpu_baseline(args, tokens / args.steps, inner_iters)
+            result["cpu_baseline"] = cpu_baseline(args, tokens / args.steps, inner_per_step)
         except Exception as ex:                                    # host too small for the sample: report, don't fake
             result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(),
                                       "kind": "port", "sample": f"failed: {type(ex).__name__}: {ex}"}

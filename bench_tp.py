@@ -13,7 +13,8 @@ import torch.distributed as dist
 
 
 def run_tp(args, rank, world, local):
-    from bench import _Tok, attn_roofline, target_config
+    from bench import _Tok, attn_roofline, resolve_weights, target_config
+    from triforce_amd.models.aligned import parse_spec
     from triforce_amd import ops
     from triforce_amd.models.cache import StreamingLLMEvictionCache
     from triforce_amd.models.modeling_llama_68m import LlamaForCausalLM as Draft68M
@@ -24,13 +25,20 @@ def run_tp(args, rank, world, local):
     distributed_init("nccl")
     device = torch.device("cuda", local)
     tcfg, dcfg = target_config(args.target)
-    draft = Draft68M(dcfg, device).init_random(args.seed + 2)
+    kind, tspec, dspec, wlabel = resolve_weights(args)
+    if kind == "checkpoint":
+        from triforce_amd.models.llama_core import load_checkpoint_state_dict
+        draft = Draft68M.from_pretrained(dspec, device_map=device)
+    elif kind == "aligned":
+        draft = Draft68M(dcfg, device).init_aligned(parse_spec(dspec), attn_keys=256)
+    else:
+        draft = Draft68M(dcfg, device).init_random(int(dspec.split(":")[1]))
     dcache = StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - args.gamma, gamma=args.gamma)
-    llm = DistributedLlama(f"random:{args.seed + 1}", config=tcfg, local_rank=rank, world_size=world, device=device,
+    llm = DistributedLlama(tspec, config=tcfg, local_rank=rank, world_size=world, device=device,
                            prefill=args.prefill, gen_len=args.gen_cap, temperature=args.temp, top_p=args.top_p,
                            retrieval_budget=args.budget, retrieval_chunk_size=args.chunk_size, kv_offload=True,
                            on_chip_layers=tcfg.num_hidden_layers, draft=draft, draft_cache=dcache, gamma=args.gamma)
-    llm.init_parameters(f"random:{args.seed + 1}")
+    llm.init_parameters(load_checkpoint_state_dict(tspec) if kind == "checkpoint" else tspec)
     if not args.no_graphs:
         llm.initialize_graphs(args.gamma)
     gen = torch.Generator().manual_seed(args.seed)
@@ -46,6 +54,10 @@ def run_tp(args, rank, world, local):
     else:
         llm.kv_cache.normal_(seq_len=args.prefill - 1)
     logits = llm.build_retrieval_cache(input_ids=input_ids[:, -1:])
+    cal = None
+    if kind == "aligned":                                       # same calibration on every rank (replicated lm_head)
+        from triforce_amd.models.aligned import calibrate_llm
+        cal = calibrate_llm(llm, args.gamma, args.temp, args.top_p)
     run.start(logits)
     llm.draft_run(input_ids=input_ids)
     torch.cuda.synchronize()
@@ -82,8 +94,9 @@ def run_tp(args, rank, world, local):
                                    f"prefill {args.prefill}, budget {args.budget}, chunk {args.chunk_size}, gamma "
                                    f"{args.gamma}, T={args.temp}, top_p={args.top_p}, TP={world} over RCCL/xGMI, "
                                    f"KV resident in HBM",
-                       "parallelism": f"tp{world}", "prefill_mode": args.prefill_mode,
-                       "weights": "random-init N(0,0.02) fp16"},
+                       "parallelism": f"tp{world}", "world_size_observed": dist.get_world_size(),
+                       "prefill_mode": args.prefill_mode, "weights": wlabel, "weights_kind": kind},
+            "aligned_calibration": cal,
             "avg_accepted_len": round(accepted / max(drafted, 1) * args.gamma, 4),
             "acceptance_rate": round(accepted / max(drafted, 1), 4), "tokens": tokens,
             "tokens_per_step": round(tokens / args.steps, 3), "prefill_seconds": round(t_prefill, 2),

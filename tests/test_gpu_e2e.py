@@ -200,3 +200,102 @@ def test_full_scale_7b_greedy_triforce_is_lossless_on_device():
     assert sum(1 for x in gaps if x == 0.0) >= len(gaps) - 2
     del ge, run, eng
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name", ["small_gamma6", "cfg1_greedy"])
+def test_captured_target_verify_equals_eager(name):
+    """The full-cache forward replayed from its hipGraph (append slot and key count read from device memory, launch
+    sized by the cache capacity) against the eager forward of the same block: same logits up to the fp32 summation
+    order of a different split-KV partition, same rows appended, same probabilities; and the q_len == 1 graph used by
+    the autoregressive baseline against the eager step."""
+    from triforce_amd.utils.sampling import norm_logits
+    g = Hh.load_golden(name)
+    ge = Hh.build_product(g, DEV, graphs=True)
+    gamma = g["gamma"]
+    assert sorted(ge.target_graphs) == sorted({1, gamma + 1, gamma + 2})
+    prompt = Hh.prompt_of(g).to(DEV)
+    ge.inference(prompt[:, :-1])
+    ge.inference(prompt[:, -1:])
+    kvc = ge.engine.kv_cache
+    S = kvc.seq_len
+    for q_len in (gamma + 1, gamma + 2):
+        ids = torch.randint(3, g["tcfg"]["vocab_size"], (1, q_len), generator=torch.Generator().manual_seed(q_len)).to(DEV)
+        want = ge.inference(ids, eager=True)
+        rows_k = kvc.k[:, :, S:S + q_len].clone()
+        assert kvc.seq_len == S + q_len
+        kvc.seq_len = S
+        kvc.k[:, :, S:S + q_len].zero_()
+        got = ge.inference(ids)
+        assert kvc.seq_len == S + q_len
+        _logit_check(f"captured verify q={q_len}", got.cpu(), want.cpu())
+        dk = (kvc.k[:, :, S:S + q_len].float() - rows_k.float()).abs()
+        assert float(dk[0].max()) == 0.0 and float(dk.max()) < 2e-2           # layer 0 rows do not depend on attention
+        kvc.seq_len = S
+        p_graph = ge.verify_probs(ids, g["temperature"], g["top_p"]).clone()
+        kvc.seq_len = S
+        p_eager = norm_logits(want[0], temperature=g["temperature"], top_k=-1, top_p=g["top_p"])
+        assert float((p_graph - p_eager).abs().max()) < 2e-2
+        kvc.seq_len = S
+    tok = prompt[:, -1:]
+    a = ge.decode_step(tok).clone()
+    kvc.seq_len = S
+    b = ge.engine.model(input_ids=tok, kv_cache=kvc, graph_cache=None).logits
+    _logit_check("captured AR step", a.cpu(), b.cpu())
+    # a cache one row short of the block must refuse the replay, not write past the end
+    kvc.seq_len = kvc.max_budget - gamma
+    with pytest.raises(IndexError):
+        ge.inference(torch.zeros((1, gamma + 1), dtype=torch.long, device=DEV))
+    kvc.seq_len = S
+
+
+@pytest.mark.parametrize("spec_str,lo_mid,hi_mid,lo_tgt,hi_tgt", [
+    ("aligned:0.7:0.9:0", 0.50, 0.85, 0.78, 0.97),
+    ("aligned:0.3:0.97:0", 0.15, 0.45, 0.90, 1.00),
+])
+def test_aligned_weights_set_the_acceptance_on_device(spec_str, lo_mid, hi_mid, lo_tgt, hi_tgt):
+    """Aligned synthetic weights (models/aligned.py) through the HIP kernels and hipGraphs: the calibration lands on the
+    requested retrieval -> target acceptance and the decode loop then sees both requested rates (same bands as the CPU
+    test of the host logic, tests/test_aligned_cpu.py)."""
+    from oracle import specs
+    from triforce_amd.models import aligned
+    from triforce_amd.models.cache import FlashSimpleCache, RetrievalCache, StreamingLLMEvictionCache
+    from triforce_amd.models.config_yarn import LlamaConfig
+    from triforce_amd.models.modeling_llama import LlamaForCausalLM
+    from triforce_amd.models.modeling_llama_68m import LlamaForCausalLM as Draft
+    from triforce_amd.utils.decoding import TriForceRunner
+    from triforce_amd.utils.graph_infer import GraphInferenceEngine
+    from triforce_amd.utils.sampling import UniformSource
+    V, P, B, gamma = 4096, 2048, 256, 4
+    tcfg = LlamaConfig.from_dict(specs.tiny_target_config(vocab_size=V, layers=2, hidden=256, heads=2, max_pos=8192))
+    dcfg = LlamaConfig.from_dict(specs.draft_68m_config(vocab_size=V))
+    spec = aligned.parse_spec(spec_str)
+    target = LlamaForCausalLM(tcfg, DEV).init_aligned(spec, attn_keys=B)
+    draft = Draft(dcfg, DEV).init_aligned(spec, attn_keys=256)
+    ge = GraphInferenceEngine(target, FlashSimpleCache(target, P + 400),
+                              RetrievalCache(target, max_budget=B, prefill=P, gamma=gamma, chunk_size=8), draft,
+                              StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - gamma, gamma=gamma))
+    ge.initialize_cuda_graph(gamma, probs=True, temperature=0.6, top_p=0.9, verbose=False)
+    run = TriForceRunner(Hh.FakeTokenizer(), ge, gamma, top_k=-1, top_p=0.9, temperature=0.6,
+                         rng=UniformSource(DEV, seed=3))
+    run.prefill(specs.random_prompt(V, P, 11).to(DEV))
+    cal = target.weights.aligned["calibration"]
+    assert abs(cal["probe_acceptance"] - spec.retrieval_acc) < 0.02 and cal["probe_acceptance_gain0"] > 0.98
+    steps = 48
+    for i in range(steps):
+        run.eager_every = 4                                            # mix graph replays and eager verifies
+        run.step()
+    per_token = run.accepted_count / (run.accepted_count + run.resample_count)
+    middle = sum(run.acc_rate_middle_list) / len(run.acc_rate_middle_list)
+    assert lo_tgt <= per_token <= hi_tgt, per_token
+    assert lo_mid <= middle <= hi_mid, middle
+    assert run.n / steps > (2.0 if spec.retrieval_acc < 0.95 else 2.5)
+    assert 2 not in run.emitted and all(3 <= t < V for t in run.emitted)
+    # the in-place re-draw used by bench.py's secondary measurement: graphs keep working, acceptance collapses
+    target.weights.overwrite_random_(1)
+    draft.weights.overwrite_random_(2)
+    run2 = TriForceRunner(Hh.FakeTokenizer(), ge, gamma, top_k=-1, top_p=0.9, temperature=0.6,
+                          rng=UniformSource(DEV, seed=4))
+    run2.prefill(specs.random_prompt(V, P, 11).to(DEV))
+    for _ in range(12):
+        run2.step()
+    assert run2.accepted_count / max(run2.draft_count, 1) < 0.35

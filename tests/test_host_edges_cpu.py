@@ -168,18 +168,10 @@ def test_chunked_prefill_returns_the_reference_last_chunk(n, on_device):
 
 
 def test_bench_helpers_on_cpu():
-    """bench.py's host-side arithmetic: the acceptance projection at zero acceptance reduces to the closed form the
-    measured run is priced with, the roofline helper divides algorithmic bytes by the sampled launch durations, and
-    the KV slack is sized from the requested steps."""
-    import sys
+    """bench.py's host-side arithmetic: the roofline helper divides algorithmic bytes by the sampled launch durations,
+    the KV slack is sized from the requested steps (timed + warm-up + the secondary random-weight run + the AR probe),
+    and the weight resolution falls back to aligned synthetic weights when no checkpoint is on disk."""
     import bench
-    stages = {"target_verify_us": 13600.0, "retrieval_verify_us": 3400.0, "draft_step_us": 140.0}
-    p0 = bench.projection(stages, gamma=6, overhead_us=600.0, pairs=((0.0, 0.0),))["draft_acc=0.0,retrieval_acc=0.0"]
-    step_us = 13600.0 + 6 * (3400.0 + 140.0) + 140.0 + 600.0          # gamma inner iterations, one token per step
-    assert p0["tokens_per_step"] == 1.0 and abs(p0["tokens_per_s"] - 1e6 / step_us) < 0.06
-    p1 = bench.projection(stages, gamma=6, overhead_us=600.0, pairs=((1.0, 1.0),))["draft_acc=1.0,retrieval_acc=1.0"]
-    assert p1["tokens_per_step"] == 7.0                                 # 3 inner iterations x 2 tokens, all kept, + bonus
-    assert abs(p1["tokens_per_s"] - 7e6 / (13600.0 + 3 * 3540.0 + 140.0 + 600.0)) < 0.06
 
     class Ev:                                                          # stands in for a pair of HIP events
         def __init__(self, ms):
@@ -194,10 +186,17 @@ def test_bench_helpers_on_cpu():
     assert roof["launches"] == 2 and roof["algorithmic_bytes_per_launch"] == int(alg)
     assert abs(roof["achieved"] - alg / 0.352e-3 / 1e9) < 0.2 and abs(roof["frac"] - roof["achieved"] / 8000.0) < 1e-3
     assert bench.attn_roofline(timer[1:2], retrieval_rows=4103, H=32, D=128) is None      # no full-KV launch sampled
+    assert bench.attn_roofline(None, retrieval_rows=4103, H=32, D=128) is None
 
-    argv, sys.argv = sys.argv, ["bench.py", "--steps", "400"]
-    try:
-        a = bench.parse()
-    finally:
-        sys.argv = argv
-    assert a.gen_cap == (400 + a.warmup + 4) * (a.gamma + 2) + 64 and a.gen_cap <= a.budget
+    a = bench.parse(["--steps", "200"])
+    assert a.random_steps == 12
+    assert a.gen_cap == (200 + a.warmup + 12 + 8) * (a.gamma + 2) + a.ar_steps + 64 and a.gen_cap <= a.budget
+    assert bench.parse(["--steps", "5000"]).gen_cap == 4096            # never more than the retrieval budget
+    assert bench.parse(["--steps", "20", "--random-steps", "0"]).random_steps == 0
+
+    kind, tspec, dspec, label = bench.resolve_weights(bench.parse([]))   # no checkpoints in this container
+    assert kind == "aligned" and tspec == dspec == "aligned:0.7:0.9"
+    kind, tspec, dspec, _ = bench.resolve_weights(bench.parse(["--weights", "random:3"]))
+    assert (kind, tspec, dspec) == ("random", "random:4", "random:5")
+    kind, tspec, _, _ = bench.resolve_weights(bench.parse(["--weights", "aligned:0.5:0.95:7"]))
+    assert kind == "aligned" and tspec == "aligned:0.5:0.95:7"

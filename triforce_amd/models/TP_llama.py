@@ -115,7 +115,12 @@ class DistributedLlama:
         W = LlamaWeights(cfg, self.device, rank=self.local_rank, world_size=self.world_size)
         seed = parse_random_spec(hf_model if isinstance(hf_model, str) else self.model_name_or_path) \
             if (hf_model is None or isinstance(hf_model, str)) else None
-        if hf_model is None or isinstance(hf_model, str):
+        from .aligned import parse_spec
+        spec = parse_spec(hf_model if isinstance(hf_model, str) else self.model_name_or_path) \
+            if (hf_model is None or isinstance(hf_model, str)) else None
+        if spec is not None:                              # aligned synthetic weights (models/aligned.py)
+            W.init_aligned(spec, "target", attn_keys=max(self.retrieval_budget, 1))
+        elif hf_model is None or isinstance(hf_model, str):
             W.init_random(seed if seed is not None else 0)
         else:
             sd = hf_model if isinstance(hf_model, dict) else hf_model.state_dict()
@@ -179,6 +184,8 @@ class DistributedLlama:
     def _finish(self, x, d):
         W = self.weights
         h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)
+        if W.capture is not None:
+            W.capture.append(x.clone())
         return ops.linear(h, W.lm_head, out_f32=True).unsqueeze(0)
 
     @torch.inference_mode()

@@ -84,6 +84,8 @@ class LlamaWeights:
         self.eps = cfg.rms_norm_eps
         self.embed = self.lm_head = self.norm = None
         self.wqkv, self.wo, self.wgu, self.wd, self.ln1, self.ln2 = [], [], [], [], [], []
+        self.aligned = None       # models/aligned.py: spec + read-out state of an aligned synthetic pair
+        self.capture = None       # list -> the forward appends its final residual stream (pre-norm), for calibration
 
     # -- loading ---------------------------------------------------------------------------
     def _shard_rows(self, w, n_local):
@@ -140,6 +142,38 @@ class LlamaWeights:
             self.ln1.append(torch.ones(hid, dtype=torch.float16, device=dev))
             self.ln2.append(torch.ones(hid, dtype=torch.float16, device=dev))
         return self.finalize()
+
+    def overwrite_random_(self, seed, std=0.02):
+        """Re-draw every matrix IN PLACE with the values ``init_random(seed)`` would give (same storage, so captured
+        hipGraphs and packed-weight pointers stay valid): lets one process measure two weight sets back to back."""
+        dev, cfg = self.device, self.cfg
+        assert isinstance(self.lm_head, ops.PackedLinear), "finalize() first"
+
+        def draw_into(dst, tag):
+            g = torch.Generator(device=dev)
+            g.manual_seed((seed * 1000003 + zlib.crc32(repr(tag).encode())) % (2 ** 31))
+            dst.copy_((torch.randn(*dst.shape, generator=g, device=dev, dtype=torch.float32) * std).to(torch.float16))
+
+        tied = self.embed is self.lm_head.w
+        draw_into(self.lm_head.w, "lm_head")
+        self.lm_head.refresh_()
+        if not tied:
+            draw_into(self.embed, "embed")
+        self.norm.fill_(1.0)
+        for i in range(self.L):
+            for lst, tag in ((self.wqkv, "qkv"), (self.wo, "o"), (self.wgu, "gu"), (self.wd, "d")):
+                draw_into(lst[i].w, (tag, i, self.rank))
+                lst[i].refresh_()
+            self.ln1[i].fill_(1.0)
+            self.ln2[i].fill_(1.0)
+        self.aligned = None
+        return self
+
+    def init_aligned(self, spec, role, attn_keys=4096):
+        """Aligned synthetic weights (models/aligned.py): real shapes, dense values, planted successor table so that
+        draft / retrieval / full-cache forwards agree to a tunable degree."""
+        from . import aligned
+        return aligned.init_weights(self, spec, role, attn_keys=attn_keys)
 
     def finalize(self):
         """Wrap the GEMM weights: on a HIP device each gets its MFMA-packed copy for the decode kernel."""

@@ -38,6 +38,11 @@ class LlamaForCausalLM:
         if seed is not None:
             assert config is not None, "random:<seed> needs config="
             return cls(config, device_map).init_random(seed)
+        from .aligned import parse_spec
+        spec = parse_spec(name_or_path)
+        if spec is not None:                                # aligned[:draft_acc[:retrieval_acc[:seed]]]
+            assert config is not None, "aligned:... needs config="
+            return cls(config, device_map).init_aligned(spec, attn_keys=_.get("attn_keys", 4096))
         cfg = config or LlamaConfig.from_pretrained(name_or_path)
         m = cls(cfg, device_map)
         m.weights.load_state_dict(load_checkpoint_state_dict(name_or_path))
@@ -53,19 +58,31 @@ class LlamaForCausalLM:
         self.weights.init_random(seed)
         return self
 
+    def init_aligned(self, spec, attn_keys=4096):
+        """Aligned synthetic weights (models/aligned.py), this model in the target role."""
+        self.weights.init_aligned(spec, "target", attn_keys=attn_keys)
+        return self
+
     def eval(self):
         return self
 
     # -- forward -----------------------------------------------------------------------------
     @torch.inference_mode()
     def __call__(self, input_ids, kv_cache=None, graph_cache=None, position_ids=None, spec=False,
-                 attention_mask=None, storage_ids=None, gamma_offset=0, rebuild_retrieval=False):
-        return self.forward(input_ids, kv_cache, graph_cache, position_ids, spec, rebuild_retrieval)
+                 attention_mask=None, storage_ids=None, gamma_offset=0, rebuild_retrieval=False, dev_len=None):
+        return self.forward(input_ids, kv_cache, graph_cache, position_ids, spec, rebuild_retrieval, dev_len)
 
-    def forward(self, input_ids, kv_cache, graph_cache=None, position_ids=None, spec=False, rebuild_retrieval=False):
+    def forward(self, input_ids, kv_cache, graph_cache=None, position_ids=None, spec=False, rebuild_retrieval=False,
+                dev_len=None):
+        """dev_len = (slot_dev, sk_dev) int32 device scalars: the hipGraph-capturable form of the full-cache decode
+        forward — the append slot and the key count are read from device memory by the kernels (tf_skinny_qkv_rope
+        slot0_dev, tf_attn_decode sk_dev), position_ids must be given, the launch is sized by the cache capacity and
+        kv_cache.seq_len is NOT advanced (the caller does that after the replay)."""
         W = self.weights
         H, D = W.H, W.D
         q_len = input_ids.shape[1]
+        if dev_len is not None:
+            assert position_ids is not None and not spec and q_len <= ops.SKINNY_MAX_ROWS
         if position_ids is None:                        # reference modeling_llama.py:345-349
             position_ids = torch.arange(kv_cache.seq_len, kv_cache.seq_len + q_len, dtype=torch.long,
                                         device=self.device).unsqueeze(0)
@@ -90,13 +107,16 @@ class LlamaForCausalLM:
                 kl, vl = graph_cache.layer_kv(i)
                 assert q_len == graph_cache.gamma + 1, "spec forward takes exactly gamma+1 tokens (cache.py:184-189)"
                 slot, sk = graph_cache.spec_slot, graph_cache.real_budget
+            elif dev_len is not None:                   # captured full-cache forward: lengths live on the device
+                kl, vl = kv_cache.layer_kv(i)
+                slot, sk = 0, kv_cache.max_budget
             else:                                       # :228-238  full-cache forward
                 kl, vl = kv_cache.layer_kv(i)
                 slot = kv_cache.append_slot(i, q_len)
                 sk = slot + q_len
             if fused:
                 q = ops.qkv_rope(x, W.wqkv[i], W.ln1[i], W.eps, self.cos, self.sin, pos, kl, vl, slot, H, D,
-                                 ss_in=ss if i > 0 else None)
+                                 ss_in=ss if i > 0 else None, slot0_dev=dev_len[0] if dev_len is not None else None)
             else:
                 if d is None:
                     h = ops.rmsnorm(x, W.ln1[i], W.eps)
@@ -108,6 +128,9 @@ class LlamaForCausalLM:
                     q = ops.rope_append(ops.linear(h, W.wqkv[i]), self.cos, self.sin, pos, kl, vl, slot, H, D)
             if spec:
                 a = ops.attn_decode(q, kl, vl, sk, self.scale)
+            elif dev_len is not None:
+                assert fused, "the captured full-cache forward needs the fused decode kernels"
+                a = ops.attn_decode(q, kl, vl, sk, self.scale, sk_dev=dev_len[1])
             else:
                 if build:
                     if not graph_cache.init_graph:
@@ -131,8 +154,12 @@ class LlamaForCausalLM:
         if streaming:
             kv_cache.end_forward()
         if fused:
+            if W.capture is not None:
+                W.capture.append(x.clone())
             logits = ops.linear(x, W.lm_head, out_f32=True, ln=W.norm, eps=W.eps, ss_in=ss).unsqueeze(0)
         else:
             h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)
+            if W.capture is not None:
+                W.capture.append(x.clone())
             logits = ops.linear(h, W.lm_head, out_f32=True).unsqueeze(0)           # (1, q, V) fp32  (:408-409)
         return CausalLMOutput(logits)

@@ -30,6 +30,11 @@ class LlamaForCausalLM:
         if seed is not None:
             assert config is not None, "random:<seed> needs config="
             return cls(config, device_map).init_random(seed)
+        from .aligned import parse_spec
+        spec = parse_spec(name_or_path)
+        if spec is not None:                                # aligned[:draft_acc[:retrieval_acc[:seed]]]
+            assert config is not None, "aligned:... needs config="
+            return cls(config, device_map).init_aligned(spec, attn_keys=_.get("attn_keys", 256))
         cfg = config or LlamaConfig.from_pretrained(name_or_path)
         m = cls(cfg, device_map)
         m.weights.load_state_dict(load_checkpoint_state_dict(name_or_path))
@@ -43,6 +48,11 @@ class LlamaForCausalLM:
 
     def init_random(self, seed):
         self.weights.init_random(seed)
+        return self
+
+    def init_aligned(self, spec, attn_keys=256):
+        """Aligned synthetic weights (models/aligned.py), this model in the draft role."""
+        self.weights.init_aligned(spec, "draft", attn_keys=attn_keys)
         return self
 
     def eval(self):

@@ -36,3 +36,27 @@ def config(name):
     if name not in CONFIGS:
         raise NotImplementedError(f"unknown model {name!r}; known: {sorted(CONFIGS)}")
     return LlamaConfig.from_dict(CONFIGS[name])
+
+
+def find_checkpoint(name):
+    """Local directory holding the real checkpoint of a named model, or None (there is no hub access offline).
+    Looked up, in order: $TRIFORCE_CKPT_DIR/<repo basename>, the HF cache ($HF_HOME/hub, ~/.cache/huggingface/hub:
+    models--<org>--<repo>/snapshots/*), /root/models, /models, /data/models."""
+    import glob
+    import os
+    repo = CONFIGS[name]["_name_or_path"]
+    base = repo.split("/")[-1]
+    cands = []
+    if os.environ.get("TRIFORCE_CKPT_DIR"):
+        cands += [os.path.join(os.environ["TRIFORCE_CKPT_DIR"], base), os.path.join(os.environ["TRIFORCE_CKPT_DIR"], repo)]
+    hubs = [os.path.join(os.environ["HF_HOME"], "hub")] if os.environ.get("HF_HOME") else []
+    hubs.append(os.path.expanduser("~/.cache/huggingface/hub"))
+    for hub in hubs:
+        cands += sorted(glob.glob(os.path.join(hub, "models--" + repo.replace("/", "--"), "snapshots", "*")))
+    for root in ("/root/models", "/models", "/data/models"):
+        cands += [os.path.join(root, base), os.path.join(root, repo)]
+    for c in cands:
+        if os.path.isfile(os.path.join(c, "config.json")) and \
+                (glob.glob(os.path.join(c, "*.safetensors")) or glob.glob(os.path.join(c, "*.bin"))):
+            return c
+    return None

@@ -85,6 +85,15 @@ class PackedLinear:
         if ok and rope is not None and rope[1] % 32 == 0 and self.N == 3 * rope[0] * rope[1]:
             self.wp_rope = pack_weight(w[rope_row_order(rope[0], rope[1], w.device)])
 
+    def refresh_(self):
+        """Re-pack IN PLACE after ``self.w`` was modified in place (captured hipGraphs keep their pointers)."""
+        if self.parts is not None:
+            for dst, blk in zip(self.parts, self.w.chunk(self.split, dim=0)):
+                dst.copy_(pack_weight(blk))
+        if self.wp_rope is not None:
+            self.wp_rope.copy_(pack_weight(self.w[rope_row_order(self.rope[0], self.rope[1], self.w.device)]))
+        return self
+
 
 def _w(w):
     return w.w if isinstance(w, PackedLinear) else w

@@ -45,8 +45,10 @@ def Autoregressive(tokenizer, graph_engine, input_ids, max_len=256, top_k=-1, to
     n = 0
     _sync(device)
     time1 = time.time()
+    step = getattr(graph_engine, "decode_step", None) or \
+        (lambda t: eng.model(input_ids=t, kv_cache=eng.kv_cache, graph_cache=None).logits)
     while n < max_len:      # no host sync inside the loop: the sampled token never leaves the device
-        logits = eng.model(input_ids=next_token, kv_cache=eng.kv_cache, graph_cache=None).logits
+        logits = step(next_token)
         next_token = sample(norm_logits(logits[:, -1, :], temperature=temperature, top_k=top_k, top_p=top_p), rng=rng)
         toks.append(next_token)
         n += 1
@@ -70,6 +72,25 @@ class _SpecBuffers:
         self.spec_rows = torch.empty(gamma + 2, vocab, dtype=torch.float32, device=device)
         self.mid_out = torch.zeros(4, dtype=torch.int64, device=device)
         self.chain_out = torch.zeros(4, dtype=torch.int64, device=device)
+        self.positions = torch.zeros((1, gamma + 1), dtype=torch.long, device=device)
+        self.pos_base = torch.arange(gamma + 1, dtype=torch.long, device=device).unsqueeze(0)
+        # host -> device token lists go through one pinned staging row (a pageable source makes the copy synchronous)
+        cuda = torch.device(device).type == "cuda"
+        self.stage = torch.zeros(2, gamma + 4, dtype=torch.long, pin_memory=cuda)
+        self.dev_tokens = torch.zeros(2, gamma + 4, dtype=torch.long, device=device)
+        self._flip = 0
+
+    def to_device(self, ids):
+        """(1, len(ids)) int64 device tensor holding the python list ``ids``.  Two (staging, device) row pairs
+        alternate: the row handed out by the previous call stays intact while this one is filled, and a staging row is
+        rewritten only after a host sync (every decode step reads a decision record between two calls) has retired the
+        copy that read it."""
+        n = len(ids)
+        self._flip ^= 1
+        stage, row = self.stage[self._flip, :n], self.dev_tokens[self._flip, :n]
+        stage.copy_(torch.tensor(ids, dtype=torch.long))
+        row.copy_(stage, non_blocking=True)
+        return row.unsqueeze(0)
 
 
 def _buffers(graph_engine, gamma, vocab, device):
@@ -95,13 +116,16 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
     vt = buffers.verify_tokens
     vt.fill_(PAD_TOKEN)
     vt[0, 0] = ids[0]
-    position_ids = torch.arange(S, S + gamma + 1, device=device).unsqueeze(0)
+    position_ids = torch.add(buffers.pos_base, S, out=buffers.positions)
+    # the engines' graph replays can hand out their static output buffers (valid until the same graph replays again):
+    # q_d and p are consumed by tf_middle_accept / the spec_rows copies before the next iteration asks for new ones
+    noclone = dict(clone=False) if getattr(graph_engine, "static_outputs", False) else {}
     while n < gamma:
-        q_d = graph_engine.graph_draft_inference(input_ids=vt[:, :n + 1], gamma_offset=n)
+        q_d = graph_engine.graph_draft_inference(input_ids=vt[:, :n + 1], gamma_offset=n, **noclone)
         flat = vt.view(-1)
         u = rng.take(3)
         ops.sample_inverse_cdf(q_d, u[0:1], flat[n + 1:n + 2])               # d ~ q_d, written into verify_tokens
-        p = graph_engine.graph_verify(input_ids=vt, position_ids=position_ids)
+        p = graph_engine.graph_verify(input_ids=vt, position_ids=position_ids, **noclone)
         ops.middle_accept(p, q_d, flat, u[1:3], n, gamma, buffers.mid_out)   # accept test + follow-up sample
         if sync_record is not None:                                           # TP: rank 0's decision wins
             sync_record(buffers.mid_out)
@@ -149,6 +173,9 @@ class TriForceRunner:
         # rebuild_every: N > 0 re-selects the retrieval cache's prefill chunks during every N-th target verify
         #                (SURVEY 8f row 4); 0 = the reference's behaviour, one build per prompt
         self.rebuild_every, self.rebuilds = int(rebuild_every), 0
+        # eager_every: N > 0 runs every N-th target verify eagerly instead of replaying its hipGraph, so that
+        #              bench.py can bracket individual attention launches with HIP events inside the timed region
+        self.eager_every = 0
         # inclusive_accept: marks the TP outer loop — it tests ``r <=`` (decoding.py:347) where on-chip tests ``r <``
         #              (:99), and it ends at an eos that closes the accept scan (:382-383) where on-chip keeps going
         # sync_record: optional callable applied to each device decision record before it is read (TP: broadcast
@@ -179,7 +206,17 @@ class TriForceRunner:
             eng.kv_cache.print_status()
             eng.graph_cache.print_status()
             eng.draft_cache.print_status()
+        self.calibrate_aligned()
         self.start(logits)
+
+    def calibrate_aligned(self):
+        """Aligned synthetic weights (models/aligned.py) need one calibration of the lm_head's attention read-out once
+        a prompt's full and retrieval caches exist; real or random weights: no-op."""
+        info = getattr(getattr(getattr(self.eng, "model", None), "weights", None), "aligned", None)
+        if info is None or info.get("role") != "target" or "calibration" in info:
+            return None
+        from ..models import aligned
+        return aligned.calibrate_engine(self.ge, self.gamma, self.temperature, self.top_p)
 
     @torch.inference_mode()
     def start(self, logits):
@@ -206,13 +243,16 @@ class TriForceRunner:
         self.inner_iters += int(round(g2 / (1.0 + acc_mid)))        # g2 = iterations + accepted drafts
 
         # target model verifies [next, t1..t_g2] against the full KV cache
-        verify_tokens = torch.tensor([ids], dtype=torch.long, device=device)
-        if self.rebuild_every > 0 and (len(self.counts) + 1) % self.rebuild_every == 0:
-            logits = ge.inference(input_ids=verify_tokens, rebuild_retrieval=True)
-            self.rebuilds += 1
+        verify_tokens = bufs.to_device(ids)
+        rebuild = self.rebuild_every > 0 and (len(self.counts) + 1) % self.rebuild_every == 0
+        self.rebuilds += int(rebuild)
+        eager = self.eager_every > 0 and (len(self.counts) + 1) % self.eager_every == 0
+        if self.top_k <= 0 and hasattr(ge, "verify_probs"):          # one hipGraph: forward + temperature / top-p
+            probs = ge.verify_probs(verify_tokens, self.temperature, self.top_p, rebuild_retrieval=rebuild, eager=eager)
         else:
-            logits = ge.inference(input_ids=verify_tokens)
-        probs = norm_logits(logits[0], temperature=self.temperature, top_k=self.top_k, top_p=self.top_p)
+            logits = ge.inference(input_ids=verify_tokens, rebuild_retrieval=True) if rebuild \
+                else ge.inference(input_ids=verify_tokens)
+            probs = norm_logits(logits[0], temperature=self.temperature, top_k=self.top_k, top_p=self.top_p)
         ops.accept_chain(probs, spec_rows, verify_tokens.view(-1)[1:], rng.take(g2 + 1), g2, self.inclusive_accept,
                          self.eos, bufs.chain_out)
         if self.sync_record is not None:
@@ -256,8 +296,7 @@ class TriForceRunner:
         self.counts.append(count)
 
         # bring the 68M cache up to date (:137-139)
-        ge.graph_draft_inference(input_ids=torch.tensor([pass_tokens], dtype=torch.long, device=device),
-                                 gamma_offset=g2 + 1)
+        ge.graph_draft_inference(input_ids=bufs.to_device(pass_tokens), gamma_offset=g2 + 1)
         dc = eng.draft_cache
         dc.evict_for_spec(dc.start_size + dc.recent_size + count)
         self.next_token = pred
@@ -387,6 +426,10 @@ def TriForce_Dist(tokenizer, llm, input_ids, gamma=4, max_len=256, top_k=-1, top
     llm.reset()
     llm.prefill(input_ids=input_ids[:, :-1])
     logits = llm.build_retrieval_cache(input_ids=input_ids[:, -1:])
+    info = getattr(llm.weights, "aligned", None)
+    if info is not None and "calibration" not in info:        # aligned synthetic weights: one-off read-out calibration
+        from ..models import aligned
+        aligned.calibrate_llm(llm, gamma, temperature, top_p)
     run.start(logits)
     llm.draft_run(input_ids=input_ids)
     eos = run.eos

@@ -99,6 +99,11 @@ def _capture_error_mode():
     return "global"
 
 
+def _graphable_cache():
+    from ..models.cache import FlashSimpleCache
+    return FlashSimpleCache
+
+
 def _capture(fn, static_inputs, mempool, n_warmups):
     """Warm up on a side stream, then capture ``fn(*static_inputs)`` into one hipGraph."""
     side = torch.cuda.Stream()
@@ -123,11 +128,13 @@ class _GraphedCall:
         self.inputs = static_inputs
         self.graph, self.output = _capture(fn, static_inputs, mempool, n_warmups)
 
-    def __call__(self, *live):
+    def __call__(self, *live, clone=True):
         for buf, value in zip(self.inputs, live):
             buf.copy_(value)
         self.graph.replay()
-        return self.output.clone()
+        # clone=False hands out the static output buffer itself: valid until THIS graph is replayed again (the decode
+        # loops consume a draft / verify result before they ask for the next one)
+        return self.output.clone() if clone else self.output
 
 
 def draft_run_capture_graph(engine: InferenceEngine, gamma_offset: int = 0, mempool=None, n_warmups: int = 3, probs=False,
@@ -152,6 +159,45 @@ def model_verify_capture_graph(engine: InferenceEngine, mempool=None, n_warmups:
                                                          top_p=top_p), (ids, pos), mempool, n_warmups)
 
 
+class _TargetGraph:
+    """The full-cache decode forward of ``q_len`` tokens (a target verify, or the q_len == 1 autoregressive step) as
+    ONE hipGraph.  The reference keeps this forward eager because its key count changes every call
+    (graph_infer.py:22-38); here the append slot and the key count are device scalars read by the kernels
+    (tf_skinny_qkv_rope slot0_dev, tf_attn_decode sk_dev) and the launch is sized by the cache capacity, so one
+    capture serves every cache length.  With ``probs`` the temperature / top-p normalisation is part of the graph."""
+
+    def __init__(self, engine, q_len, mempool, n_warmups, probs, temperature, top_p):
+        dev = engine.model.device
+        self.engine, self.q_len, self.probs = engine, q_len, probs
+        self.ids = torch.zeros((1, q_len), dtype=torch.long, device=dev)
+        self.base = torch.arange(q_len, dtype=torch.long, device=dev)
+        self.pos = torch.arange(q_len, dtype=torch.long, device=dev)
+        self.slot = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.sk = torch.full((1,), q_len, dtype=torch.int32, device=dev)
+
+        def run():
+            logits = engine.model(input_ids=self.ids, kv_cache=engine.kv_cache, graph_cache=None,
+                                  position_ids=self.pos.unsqueeze(0), dev_len=(self.slot, self.sk)).logits
+            if probs:
+                return logits, norm_logits(logits[0], temperature=temperature, top_k=-1, top_p=top_p)
+            return logits, None
+
+        self.graph, (self.logits, self.out_probs) = _capture(run, (), mempool, n_warmups)
+
+    def __call__(self, input_ids):
+        kvc = self.engine.kv_cache
+        S = kvc.seq_len
+        if S + self.q_len > kvc.max_budget:
+            raise IndexError(f"FlashSimpleCache overflow: {S}+{self.q_len} > {kvc.max_budget}")
+        self.ids.copy_(input_ids)
+        torch.add(self.base, S, out=self.pos)
+        self.slot.fill_(S)
+        self.sk.fill_(S + self.q_len)
+        self.graph.replay()
+        kvc.seq_len = S + self.q_len
+        return self.logits, self.out_probs
+
+
 class GraphInferenceEngine:
     """The object the decode loops drive (reference graph_infer.py:129-194): ``inference`` /
     ``graph_draft_prefill`` run eagerly, ``graph_draft_inference`` / ``graph_verify`` replay the captured graphs."""
@@ -160,11 +206,14 @@ class GraphInferenceEngine:
         self.engine = InferenceEngine(model, cache, graph_cache, draft, draft_cache)
         self.callables = {}                        # gamma_offset -> draft step
         self.callable_model_verify = None
+        self.target_graphs = {}                    # q_len -> _TargetGraph (full-cache forward, device-resident lengths)
+        self.static_outputs = True                 # graph_draft_inference / graph_verify accept clone=False
         self.mempool = None
         self.sampling = dict(probs=False, temperature=0.6, top_p=0.9)
 
     @torch.inference_mode()
-    def initialize_cuda_graph(self, gamma=6, probs=False, temperature=0.6, top_p=0.9, verbose=True):
+    def initialize_cuda_graph(self, gamma=6, probs=False, temperature=0.6, top_p=0.9, verbose=True,
+                              capture_target=True):
         """gamma + 3 draft graphs (one per gamma_offset) and one retrieval-verify graph, sharing one memory pool."""
         gc.collect()
         self.mempool = torch.cuda.graphs.graph_pool_handle()
@@ -172,6 +221,13 @@ class GraphInferenceEngine:
         common = dict(engine=self.engine, mempool=self.mempool, n_warmups=3, verbose=verbose, **self.sampling)
         self.callables = {off: draft_run_capture_graph(gamma_offset=off, **common) for off in range(gamma + 3)}
         self.callable_model_verify = model_verify_capture_graph(gamma=gamma, **common)
+        self.target_graphs = {}
+        if capture_target and os.environ.get("TRIFORCE_TARGET_GRAPH", "1") != "0" \
+                and isinstance(self.engine.kv_cache, _graphable_cache()):
+            # target verify (gamma+1 / gamma+2 tokens: Middle_Spec ends at n = gamma or gamma + 1) and the AR step
+            for q_len in sorted({1, gamma + 1, gamma + 2}):
+                self.target_graphs[q_len] = _TargetGraph(self.engine, q_len, self.mempool, 3, probs and q_len > 1,
+                                                         temperature, top_p)
         self.engine.clear_kv()
 
     def initialize_eager(self, gamma=6, probs=True, temperature=0.6, top_p=0.9):
@@ -187,20 +243,52 @@ class GraphInferenceEngine:
 
     # -- the surface used by utils/decoding.py ---------------------------------------------------------------
     @torch.inference_mode()
-    def inference(self, input_ids: torch.LongTensor, rebuild_retrieval=False):
+    def inference(self, input_ids: torch.LongTensor, rebuild_retrieval=False, eager=False):
+        tg = None if (eager or rebuild_retrieval) else self._target_graph(input_ids)
+        if tg is not None:
+            return tg(input_ids)[0].clone()
         return self.engine.model_run(input_ids=input_ids, rebuild_retrieval=rebuild_retrieval)
+
+    def _target_graph(self, input_ids):
+        """The captured full-cache forward for a verify block, if there is one.  q_len == 1 through ``inference`` is the
+        call that (re)builds the retrieval cache (reference modeling_llama.py:226-238) and stays eager; the plain
+        autoregressive step has its own entry, ``decode_step``."""
+        if input_ids.shape[0] != 1 or input_ids.shape[-1] == 1:
+            return None
+        return self.target_graphs.get(input_ids.shape[-1])
+
+    @torch.inference_mode()
+    def verify_probs(self, input_ids, temperature, top_p, rebuild_retrieval=False, eager=False):
+        """Target verify -> (rows, V) probabilities after temperature / top-p: one graph replay when captured with
+        these settings, else the eager forward + norm_logits.  The result is valid until the next target forward."""
+        tg = None if (eager or rebuild_retrieval) else self._target_graph(input_ids)
+        if tg is not None and tg.probs and (temperature, top_p) == (self.sampling["temperature"], self.sampling["top_p"]):
+            return tg(input_ids)[1]
+        logits = self.inference(input_ids, rebuild_retrieval=rebuild_retrieval, eager=eager)
+        return norm_logits(logits[0], temperature=temperature, top_k=-1, top_p=top_p)
+
+    @torch.inference_mode()
+    def decode_step(self, input_ids):
+        """One autoregressive step (q_len == 1, no retrieval build) over the full cache: the captured graph when there
+        is one, else the eager forward the reference runs (decoding.py:28)."""
+        tg = self.target_graphs.get(1)
+        if tg is not None and input_ids.shape == (1, 1):
+            return tg(input_ids)[0]
+        return self.engine.model(input_ids=input_ids, kv_cache=self.engine.kv_cache, graph_cache=None).logits
 
     @torch.inference_mode()
     def graph_draft_prefill(self, input_ids: torch.LongTensor):
         return self.engine.draft_run(input_ids=input_ids)
 
     @torch.inference_mode()
-    def graph_draft_inference(self, input_ids: torch.LongTensor, gamma_offset: int = 0):
-        return self.callables[gamma_offset](input_ids)
+    def graph_draft_inference(self, input_ids: torch.LongTensor, gamma_offset: int = 0, clone=True):
+        fn = self.callables[gamma_offset]
+        return fn(input_ids, clone=clone) if isinstance(fn, _GraphedCall) else fn(input_ids)
 
     @torch.inference_mode()
-    def graph_verify(self, input_ids: torch.LongTensor, position_ids: torch.LongTensor):
-        return self.callable_model_verify(input_ids, position_ids)
+    def graph_verify(self, input_ids: torch.LongTensor, position_ids: torch.LongTensor, clone=True):
+        fn = self.callable_model_verify
+        return fn(input_ids, position_ids, clone=clone) if isinstance(fn, _GraphedCall) else fn(input_ids, position_ids)
 
     def init_graph_cache(self):
         self.engine.graph_cache.init_graph_cache(kv_cache=self.engine.kv_cache)
