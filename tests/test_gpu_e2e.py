@@ -176,7 +176,9 @@ def test_full_scale_7b_greedy_triforce_is_lossless_on_device():
     args = argparse.Namespace(target="llama-7B-128K", prefill=124928, budget=4096, chunk_size=8, gamma=6, temp=1.0,
                               top_p=1e-9, gen_cap=256, seed=0, no_graphs=False)
     dev = torch.device(DEV)
-    ge = bench.build_engine(args, dev)
+    target, draft = bench.load_models(args, dev, "random", "random:1", "random:2")
+    ge = bench.build_engine(args, dev, target, draft)
+    assert sorted(ge.target_graphs) == [1, 7, 8]               # the target verify is replayed from its hipGraph here
     tcfg, _ = bench.target_config(args.target)
     ids = torch.randint(3, tcfg.vocab_size, (1, args.prefill), generator=torch.Generator().manual_seed(0)).to(dev)
     run = TriForceRunner(bench._Tok(), ge, args.gamma, top_k=-1, top_p=args.top_p, temperature=args.temp,
@@ -198,7 +200,7 @@ def test_full_scale_7b_greedy_triforce_is_lossless_on_device():
         gaps.append(float(logits.max() - logits[stream[i + 1]]))
     assert max(gaps) < GAP_TOL, f"token {gaps.index(max(gaps)) + 1} trails the autoregressive argmax by {max(gaps):.4f}"
     assert sum(1 for x in gaps if x == 0.0) >= len(gaps) - 2
-    del ge, run, eng
+    del ge, run, eng, target, draft
     torch.cuda.empty_cache()
 
 

@@ -497,28 +497,37 @@ extern "C" int tf_middle_accept(const float* p, const float* q_d, int64_t* token
 //
 // The reference sorts the whole vocabulary (torch.sort + softmax + cumsum + scatter + softmax: ~10 kernels,
 // ~350 us for 8 x 32000 on MI355X).  The kept set is a threshold set, so no sort is needed:
-//   e_i = exp(l_i/T - max), Z = sum e.  With G(u) = mass of the entries strictly greater than u, an entry of
-//   value w is kept iff G(w) + (mass of equal entries with a lower index) <= top_p * Z  — exactly the
-//   "drop rank r when the inclusive cumulative mass of rank r-1 exceeds top_p" rule with a stable descending
-//   sort.  The smallest u with G(u) <= top_p*Z is found by a 31-step search over the fp32 bit pattern (G is
-//   monotone), each step one block-wide deterministic reduction; ties at u are resolved by one index-ordered
-//   block scan.  One workgroup per row, the row lives in registers (V <= 32768).
+//   e_i = exp(l_i/T - max).  With M(i) = mass of the entries strictly greater than e_i plus the mass of equal entries
+//   with a lower index, entry i is kept iff M(i) <= top_p * Z — exactly the "drop rank r when the inclusive cumulative
+//   mass of rank r-1 exceeds top_p" rule with a stable descending sort.
+// The boundary value is found by a 3-round radix select over the fp32 bit pattern of e (10 bits per round; patterns
+// order like values for e >= 0, and e <= 1.0f = 0x3F800000 leaves 30 significant bits): every round builds a 1024-bin
+// histogram of MASS in LDS, one wavefront scans it from the top and names the bin in which the cumulative mass
+// crosses top_p * Z, and the next round looks only at the entries of that bin.  Masses are accumulated as 2^-40
+// fixed-point integers with LDS integer atomics, so the sums are exact and independent of the order in which the
+// atomics land (a float histogram would make the kept set depend on scheduling), and the normaliser of the kept set
+// falls out of the select (mass above the boundary + kept ties) without another reduction.
+// One workgroup per row, the row lives in registers (V <= 32768), global traffic is 16 bytes per lane both ways.
+// (The first version decided one bit of the boundary per block-wide reduction — 12 reductions of 16 waves, then a
+// single-wave finish — behind a 132 KiB LDS staging of the row: 50 us per call, every draft step and every verify.)
 // ------------------------------------------------------------------------------------------------
 #define TOPP_THREADS 1024
-#define TOPP_EPT 32
-#define TOPP_BLOCK_BITS 12       // bits decided with block-wide reductions before the single-wave finish
-#define TOPP_CAND_CAP 2048       // undecided entries the finishing wave can hold (32 per lane)
+#define TOPP_SLABS 8                       // 16-byte slabs per thread: 8 * 4 * 1024 = 32768 entries
+#define TOPP_EPT (4 * TOPP_SLABS)
+#define TOPP_BINS 1024
+#define TOPP_HB(b) ((b) + ((b) >> 4))      // one pad slot per 16 bins: the scan's 16-bins-per-lane reads spread over banks
+#define TOPP_FIX_SHIFT 40                  // masses in units of 2^-40 (row total < 2^15 * 2^40)
 
-__device__ __forceinline__ float block_sum_1024(float v, float* sm, int tid) {
-    v = wave_sum(v);
-    __syncthreads();                       // sm reuse across consecutive calls
-    if ((tid & 63) == 0) sm[tid >> 6] = v;
-    __syncthreads();
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < TOPP_THREADS / 64; ++w) t += sm[w];
-    return t;
-}
+struct ToppShared {
+    unsigned long long hist[TOPP_BINS + TOPP_BINS / 16];
+    unsigned cnt[TOPP_BINS + TOPP_BINS / 16];
+    float red[TOPP_THREADS / 64];
+    int red_i[TOPP_THREADS / 64];
+    unsigned long long S, tau, nkeep, zk;
+    unsigned ties;
+    int digit;
+};
+
 __device__ __forceinline__ float block_max_1024(float v, float* sm, int tid) {
     v = wave_max(v);
     __syncthreads();
@@ -530,181 +539,291 @@ __device__ __forceinline__ float block_max_1024(float v, float* sm, int tid) {
     return t;
 }
 
+// floor(e * 2^40) for 0 <= e <= 1 straight from the bit pattern (monotone in e; 0 below 2^-40)
+__device__ __forceinline__ unsigned long long topp_fix(float e) {
+    const unsigned b = __float_as_uint(e);
+    const int ex = (int)(b >> 23);
+    const unsigned long long man = (unsigned long long)((b & 0x7FFFFFu) | 0x800000u);
+    const int sh = ex - (127 + 23 - TOPP_FIX_SHIFT);
+    if (ex == 0 || sh <= -24) return 0ull;
+    return sh >= 0 ? (man << sh) : (man >> (-sh));
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, o, 64);
+        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o, 64);
+        v += ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+
+// hist[digit] += m for the active lanes of a wave (wave-uniform call).  When more than 8 lanes are active and all of
+// them name the same bin (degenerate rows: huge tie groups) the wave adds ONE pre-summed value instead of serialising up
+// to 64 same-address atomics.
+__device__ __forceinline__ void topp_hist_add(ToppShared* sh, bool active, int digit, unsigned long long m, bool count) {
+    const unsigned long long act = __ballot(active);
+    if (!act) return;
+    const int first = __ffsll((long long)act) - 1;
+    const int dref = __shfl(digit, first, 64);
+    if (__popcll(act) > 8 && __all(!active || digit == dref)) {
+        const unsigned long long tot = wave_sum_u64(active ? m : 0ull);
+        if ((int)(threadIdx.x & 63) == first) {
+            atomicAdd(&sh->hist[TOPP_HB(dref)], tot);
+            if (count) atomicAdd(&sh->cnt[TOPP_HB(dref)], (unsigned)__popcll(act));
+        }
+    } else if (active) {
+        atomicAdd(&sh->hist[TOPP_HB(digit)], m);
+        if (count) atomicAdd(&sh->cnt[TOPP_HB(digit)], 1u);
+    }
+}
+
+// One wavefront scans the histogram from the top: lane l owns bins [16l, 16l+16).  Names the bin d with
+//   S(d) <= tau < S(d) + mass(d),   S(d) = base + mass of the bins above d
+// (sh->digit, sh->S = S(d)); no such bin (tau >= total: top_p >= 1) -> digit = -1.  The first round also fixes
+// tau = floor(top_p * Z); the last round resolves the ties at the boundary pattern: the j-th tie (index order) is
+// kept iff S + j * m <= tau.  Clears the bins it read for the next round.
+__device__ __forceinline__ void topp_scan(ToppShared* sh, int lane, bool first_round, bool last_round, float top_p) {
+    unsigned long long h[16];
+    unsigned long long tot = 0ull;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        h[k] = sh->hist[TOPP_HB(16 * lane + k)];
+        sh->hist[TOPP_HB(16 * lane + k)] = 0ull;
+        tot += h[k];
+    }
+    unsigned long long inc = tot;                                   // inclusive suffix sum over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned lo = (unsigned)__shfl_down((int)(unsigned)inc, o, 64);
+        const unsigned hi = (unsigned)__shfl_down((int)(unsigned)(inc >> 32), o, 64);
+        if (lane + o < 64) inc += ((unsigned long long)hi << 32) | lo;
+    }
+    unsigned long long base, tau;
+    if (first_round) {
+        const unsigned zlo = (unsigned)__shfl((int)(unsigned)inc, 0, 64), zhi = (unsigned)__shfl((int)(unsigned)(inc >> 32), 0, 64);
+        const unsigned long long Z = ((unsigned long long)zhi << 32) | zlo;
+        const double t = (double)top_p * (double)Z;
+        tau = (t >= 18446744073709549568.0) ? ~0ull : __double2ull_rd(t);
+        base = 0ull;
+        if (lane == 0) {
+            sh->tau = tau;
+            sh->zk = Z;
+        }
+    } else {
+        base = sh->S;
+        tau = sh->tau;
+    }
+    unsigned long long S = base + (inc - tot);
+    int found = -1;
+    unsigned long long Sf = 0ull, hf = 0ull;
+#pragma unroll
+    for (int k = 15; k >= 0; --k) {
+        if (found < 0 && h[k] != 0ull && S <= tau && tau - S < h[k]) {
+            found = k;
+            Sf = S;
+            hf = h[k];
+        }
+        S += h[k];
+    }
+    const unsigned long long hit = __ballot(found >= 0);
+    if (!hit) {
+        if (lane == 0) sh->digit = -1;
+    } else if (found >= 0) {
+        sh->digit = 16 * lane + found;
+        sh->S = Sf;
+        if (last_round) {
+            const unsigned T = sh->cnt[TOPP_HB(16 * lane + found)];
+            const unsigned long long m = hf / (unsigned long long)T;      // all ties share one pattern, hence one mass
+            unsigned long long nk = (tau - Sf) / m + 1ull;
+            if (nk > (unsigned long long)T) nk = T;
+            sh->ties = T;
+            sh->nkeep = nk;
+            sh->zk = Sf + nk * m;
+        }
+    }
+    if (last_round) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sh->cnt[TOPP_HB(16 * lane + k)] = 0u;
+    }
+}
+
 __global__ __launch_bounds__(TOPP_THREADS) void topp_probs_kernel(const float* __restrict__ logits,
                                                                   float* __restrict__ probs, int V,
-                                                                  float inv_temperature_is_div, float temperature,
-                                                                  float top_p) {
-    __shared__ float sm[TOPP_THREADS / 64];
-    __shared__ int sm_i[TOPP_THREADS / 64];
-    __shared__ float sm_cand[TOPP_CAND_CAP];
-    __shared__ unsigned sm_v;
+                                                                  float temperature, float top_p) {
+    // dynamic LDS only (a static block in front would push the 16-byte row accesses off their alignment):
+    // [ row: nslab * 4096 floats | ToppShared ]
+    extern __shared__ __attribute__((aligned(16))) unsigned char topp_smem[];
+    const int nslab = (V + 4095) >> 12;
+    float* rowe = reinterpret_cast<float*>(topp_smem);
+    ToppShared* sh = reinterpret_cast<ToppShared*>(topp_smem + (size_t)nslab * 4096 * sizeof(float));
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* lr = logits + (int64_t)row * V;
     float* pr = probs + (int64_t)row * V;
-    // thread t owns the CONTIGUOUS indices [t*EPT, (t+1)*EPT): index order == (thread, slot) order
-    const int i0 = tid * TOPP_EPT;
-    // The row goes through LDS so that global traffic is coalesced while every thread still owns a CONTIGUOUS slice
-    // (thread t, slot s) <-> index 32t + s at LDS word 33t + s (one word of padding per thread: conflict-free both
-    // ways).  Reading the slice straight from global memory costs 32 loads per lane with a 128-byte lane stride, i.e.
-    // 64 cache lines per instruction on ONE CU: 2/3 of the 66 us this kernel used to take.
-    extern __shared__ float row_lds[];                  // TOPP_THREADS * (TOPP_EPT + 1) floats
-    for (int i = tid; i < TOPP_THREADS * TOPP_EPT; i += TOPP_THREADS)
-        row_lds[(i / TOPP_EPT) * (TOPP_EPT + 1) + (i % TOPP_EPT)] = (i < V) ? lr[i] : 0.f;
-    __syncthreads();
-    float e[TOPP_EPT];
+    // thread t owns entries 4096 s + 4 t + j (s < nslab slabs, j < 4): one 16-byte access per slab, global and LDS
+    // alike; index order is (s, t, j) lexicographic — only the tie ranking at the boundary ever needs it
+    const bool vec = (V % 4) == 0 && ((reinterpret_cast<uintptr_t>(lr) | reinterpret_cast<uintptr_t>(pr)) & 15) == 0;
+    f32x4* mine = reinterpret_cast<f32x4*>(rowe) + tid;                  // slab s at mine[1024 * s]
+
+    // ---- pass 0: all loads in flight, then x = l / T (sampling.py:56) one slab at a time, row -> LDS, row max ----
+    f32x4 a[TOPP_SLABS];
+#pragma unroll
+    for (int s = 0; s < TOPP_SLABS; ++s) {
+        const int i0 = 4096 * s + 4 * tid;
+        a[s] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // entries past V: exp(-inf) = 0 mass
+        if (s < nslab) {
+            if (vec) {
+                if (i0 < V) a[s] = *reinterpret_cast<const f32x4*>(lr + i0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i0 + j < V) a[s][j] = lr[i0 + j];
+            }
+        }
+    }
     float mx = -INFINITY;
 #pragma unroll
-    for (int s = 0; s < TOPP_EPT; ++s) {
-        const int i = i0 + s;
-        const float x = (i < V) ? row_lds[tid * (TOPP_EPT + 1) + s] / temperature : -INFINITY;   // sampling.py:56
-        e[s] = x;
-        mx = fmaxf(mx, x);
-    }
-    mx = block_max_1024(mx, sm, tid);
-    float zl = 0.f;
+    for (int s = 0; s < TOPP_SLABS; ++s) {
+        if (s < nslab) {
+            f32x4 x;
 #pragma unroll
-    for (int s = 0; s < TOPP_EPT; ++s) {
-        e[s] = (i0 + s < V) ? expf(e[s] - mx) : 0.f;
-        zl += e[s];
-    }
-    const float Z = block_sum_1024(zl, sm, tid);
-    const float tau = top_p * Z;
-    // v = largest bit pattern with G(v) > tau  (G(0) = Z > tau for top_p < 1; e >= 0 so patterns order like values).
-    // e <= 1.0f = 0x3F800000, so bit 30 is never part of the answer.  The first TOPP_BLOCK_BITS bits are decided with
-    // block-wide reductions (two barriers each, ~2 us per bit); by then the open interval (v, v + 2^(bit+1)) holds a few
-    // hundred of the 32000 entries, which are compacted into LDS and finished by ONE wave with shuffle reductions only
-    // (31 block-wide steps cost 67 us per call — a third of a 68M draft step).
-    unsigned v = 0u;
-    int bit = 29;
-    for (; bit > 29 - TOPP_BLOCK_BITS; --bit) {
-        const unsigned cand = v | (1u << bit);
-        float g = 0.f;
-#pragma unroll
-        for (int s = 0; s < TOPP_EPT; ++s) g += (__float_as_uint(e[s]) > cand) ? e[s] : 0.f;
-        g = block_sum_1024(g, sm, tid);
-        if (g > tau) v = cand;
-    }
-    {
-        const unsigned span = 1u << (bit + 1);               // remaining candidates: v | x, x < span
-        float gh = 0.f;
-        int cnt = 0;
-#pragma unroll
-        for (int s = 0; s < TOPP_EPT; ++s) {
-            const unsigned b = __float_as_uint(e[s]);
-            if (b - v >= span && b > v) gh += e[s];          // above every remaining candidate
-            else if (b > v) ++cnt;                           // undecided: v < b < v + span
+            for (int j = 0; j < 4; ++j) {
+                x[j] = a[s][j] / temperature;
+                mx = fmaxf(mx, x[j]);
+            }
+            mine[1024 * s] = x;
         }
-        const float Ghigh = block_sum_1024(gh, sm, tid);
-        // exclusive prefix of cnt over the block (wave scan + wave totals)
-        int inc = cnt;
+        __builtin_amdgcn_sched_barrier(0);                                // interleaving 32 IEEE divisions spills
+    }
+    sh->hist[TOPP_HB(tid)] = 0ull;
+    sh->cnt[TOPP_HB(tid)] = 0u;
+    mx = block_max_1024(mx, sh->red, tid);
+
+    // ---- round 1: e = exp(x - max) back to LDS; mass histogram over bits 29..20 ----
+#pragma unroll 1
+    for (int s = 0; s < nslab; ++s) {
+        f32x4 x = mine[1024 * s];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int n = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += n;
+        for (int j = 0; j < 4; ++j) x[j] = expf(x[j] - mx);
+        mine[1024 * s] = x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned long long m = topp_fix(x[j]);
+            topp_hist_add(sh, m != 0ull, (int)(__float_as_uint(x[j]) >> 20), m, false);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) topp_scan(sh, lane, true, false, top_p);
+    __syncthreads();
+    const int d1 = sh->digit;
+    unsigned ustar = 0u, ties = 0u;
+    unsigned long long nkeep = 0ull;
+    if (d1 >= 0) {                                               // block-uniform; -1: top_p >= 1 keeps everything
+        // ---- round 2: bits 19..10 of the entries inside the boundary bin ----
+#pragma unroll 1
+        for (int s = 0; s < nslab; ++s) {
+            const f32x4 x = mine[1024 * s];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned b = __float_as_uint(x[j]);
+                const bool in = (int)(b >> 20) == d1;
+                topp_hist_add(sh, in, (int)((b >> 10) & 1023u), in ? topp_fix(x[j]) : 0ull, false);
+            }
         }
         __syncthreads();
-        if (lane == 63) sm_i[wave] = inc;
+        if (wave == 0) topp_scan(sh, lane, false, false, top_p);
         __syncthreads();
-        int before = inc - cnt, total = 0;
+        const unsigned pre = ((unsigned)d1 << 10) | (unsigned)sh->digit;
+        // ---- round 3: bits 9..0, with tie counts ----
+#pragma unroll 1
+        for (int s = 0; s < nslab; ++s) {
+            const f32x4 x = mine[1024 * s];
 #pragma unroll
-        for (int w = 0; w < TOPP_THREADS / 64; ++w) {
-            const int t = sm_i[w];
-            if (w < wave) before += t;
-            total += t;
+            for (int j = 0; j < 4; ++j) {
+                const unsigned b = __float_as_uint(x[j]);
+                const bool in = (b >> 10) == pre;
+                topp_hist_add(sh, in, (int)(b & 1023u), in ? topp_fix(x[j]) : 0ull, true);
+            }
         }
-        if (total <= TOPP_CAND_CAP) {                        // block-uniform
+        __syncthreads();
+        if (wave == 0) topp_scan(sh, lane, false, true, top_p);
+        __syncthreads();
+        ustar = (pre << 10) | (unsigned)sh->digit;
+        ties = sh->ties;
+        nkeep = sh->nkeep;
+    }
+    const float Zk = (float)((double)sh->zk * (1.0 / 1099511627776.0));
+    // kept: everything above the boundary pattern, and the first nkeep entries equal to it in INDEX order.  Usually
+    // nkeep == ties (one entry carries the boundary value); otherwise the ties are ranked slab by slab with a
+    // block-wide exclusive scan (block-uniform branch).
+    const bool rank_ties = d1 >= 0 && nkeep < (unsigned long long)ties;
+    const unsigned ulow = d1 < 0 ? 0u : (rank_ties ? ustar + 1u : ustar);      // patterns >= ulow stay unconditionally
+    int basecnt = 0;
+#pragma unroll 1
+    for (int s = 0; s < nslab; ++s) {
+        const f32x4 x = mine[1024 * s];
+        unsigned tiekeep = 0u;
+        if (rank_ties) {
+            int c = 0;
 #pragma unroll
-            for (int s = 0; s < TOPP_EPT; ++s) {
-                const unsigned b = __float_as_uint(e[s]);
-                if (b > v && b - v < span) sm_cand[before++] = e[s];
+            for (int j = 0; j < 4; ++j) c += (__float_as_uint(x[j]) == ustar) ? 1 : 0;
+            int inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int n = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += n;
             }
             __syncthreads();
-            if (wave == 0) {
-                float x[TOPP_CAND_CAP / 64];
-#pragma unroll
-                for (int j = 0; j < TOPP_CAND_CAP / 64; ++j) {
-                    const int i = lane + 64 * j;
-                    x[j] = (i < total) ? sm_cand[i] : 0.f;   // pattern 0 is never > cand
-                }
-                for (int b2 = bit; b2 >= 0; --b2) {
-                    const unsigned cand = v | (1u << b2);
-                    float g = 0.f;
-#pragma unroll
-                    for (int j = 0; j < TOPP_CAND_CAP / 64; ++j) g += (__float_as_uint(x[j]) > cand) ? x[j] : 0.f;
-                    g = Ghigh + wave_sum(g);
-                    if (g > tau) v = cand;
-                }
-                if (lane == 0) sm_v = v;
-            }
+            if (lane == 63) sh->red_i[wave] = inc;
             __syncthreads();
-            v = sm_v;
-        } else {                                             // degenerate rows (huge tie groups): stay block-wide
-            for (; bit >= 0; --bit) {
-                const unsigned cand = v | (1u << bit);
-                float g = 0.f;
+            int rank = basecnt + inc - c, total = 0;
 #pragma unroll
-                for (int s = 0; s < TOPP_EPT; ++s) g += (__float_as_uint(e[s]) > cand) ? e[s] : 0.f;
-                g = block_sum_1024(g, sm, tid);
-                if (g > tau) v = cand;
+            for (int w = 0; w < TOPP_THREADS / 64; ++w) {
+                const int t = sh->red_i[w];
+                if (w < wave) rank += t;
+                total += t;
             }
+            basecnt += total;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (__float_as_uint(x[j]) == ustar) {
+                    if ((unsigned long long)rank < nkeep) tiekeep |= 1u << j;
+                    ++rank;
+                }
+        }
+        const int i0 = 4096 * s + 4 * tid;
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool keep = __float_as_uint(x[j]) >= ulow || ((tiekeep >> j) & 1u);
+            o[j] = keep ? x[j] / Zk : 0.f;
+        }
+        if (vec) {
+            if (i0 < V) *reinterpret_cast<f32x4*>(pr + i0) = o;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i0 + j < V) pr[i0 + j] = o[j];
         }
     }
-    const unsigned u = v + 1u;                       // smallest pattern with G(u) <= tau
-    float gl = 0.f, tl = 0.f;
-#pragma unroll
-    for (int s = 0; s < TOPP_EPT; ++s) {
-        const unsigned b = __float_as_uint(e[s]);
-        gl += (b > u) ? e[s] : 0.f;
-        tl += (b == u) ? e[s] : 0.f;
-    }
-    const float G = block_sum_1024(gl, sm, tid);
-    // exclusive prefix (index order) of the tie mass held by earlier threads
-    float inc = tl;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float n = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += n;
-    }
-    __syncthreads();
-    if (lane == 63) sm[wave] = inc;
-    __syncthreads();
-    float before = inc - tl;
-    for (int w = 0; w < wave; ++w) before += sm[w];
-    // keep: > u always; == u while G + (ties before) <= tau.  Always keep rank 0 (filter[...,0] = 0).
-    float kept_sum = 0.f;
-    unsigned keepmask = 0u;
-    float run = before;
-#pragma unroll
-    for (int s = 0; s < TOPP_EPT; ++s) {
-        const unsigned b = __float_as_uint(e[s]);
-        bool keep = b > u;
-        if (b == u) {
-            keep = (G + run <= tau) || (G == 0.f && run == 0.f);
-            run += e[s];
-        }
-        if (keep && e[s] > 0.f) { keepmask |= (1u << s); kept_sum += e[s]; }
-    }
-    const float Zk = block_sum_1024(kept_sum, sm, tid);
-#pragma unroll
-    for (int s = 0; s < TOPP_EPT; ++s) row_lds[tid * (TOPP_EPT + 1) + s] = ((keepmask >> s) & 1u) ? e[s] / Zk : 0.f;
-    __syncthreads();
-    for (int i = tid; i < V; i += TOPP_THREADS) pr[i] = row_lds[(i / TOPP_EPT) * (TOPP_EPT + 1) + (i % TOPP_EPT)];
 }
+
+static size_t topp_lds_bytes(int V) { return (size_t)((V + 4095) >> 12) * 4096 * sizeof(float) + sizeof(ToppShared); }
 
 extern "C" int tf_topp_probs(const float* logits, float* probs, int rows, int V, float temperature, float top_p,
                              void* stream) {
     if (!logits || !probs || rows < 1 || V < 1 || !(temperature > 0.f) || !(top_p > 0.f)) return TF_EINVAL;
     if (V > TOPP_THREADS * TOPP_EPT) return TF_ERANGE;
-    const size_t lds = (size_t)TOPP_THREADS * (TOPP_EPT + 1) * sizeof(float);          // 132 KiB: above the 64 KiB default
-    static bool attr_set = false;
+    static bool attr_set = false;                     // up to 141 KiB of dynamic LDS: above the 64 KiB default limit
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)topp_probs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
+                                           (int)topp_lds_bytes(TOPP_THREADS * TOPP_EPT));
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(topp_probs_kernel, dim3(rows), dim3(TOPP_THREADS), lds, (hipStream_t)stream, logits, probs, V,
-                       0.f, temperature, top_p);
+    hipLaunchKernelGGL(topp_probs_kernel, dim3(rows), dim3(TOPP_THREADS), topp_lds_bytes(V), (hipStream_t)stream, logits,
+                       probs, V, temperature, top_p);
     TF_LAUNCH_CHECK();
     return TF_OK;
 }

@@ -8,8 +8,9 @@ the algorithm exists for (the reference's README.md:49-55 quotes 2.2x over autor
 These weights keep every tensor at its real shape and dense (each kernel streams exactly the bytes it streams for a
 trained checkpoint) and plant just enough structure to set the two acceptance rates:
 
-  * hidden = S1 | S2 | S3 (h/2, h/4, h/4 coordinates).  Embeddings live in S1; attention outputs (o_proj rows) are
-    written to S2, MLP outputs (down_proj rows) to S3; everything else is dense noise a factor ``leak`` smaller.
+  * hidden = S1 | S2 | S3 (h/2, h/4, h/4 coordinates).  Embeddings live in S1 and are the only block q/k/v and
+    gate/up read; attention outputs (o_proj rows) are written to S2, MLP outputs (down_proj rows) to S3; everything
+    else is dense noise a factor ``leak`` smaller.
   * lm_head columns over S1 carry a planted bigram table: token t has K successors succ_k(t) with logits
     peak + off_k(t) (one rank-1 term beta * unit(E[t]) per pair, then a few Jacobi sweeps remove the cross-talk between
     terms, so the logits at the planted pairs are exact for the fp16 weights).  Target and draft share the table for a
@@ -186,11 +187,16 @@ def init_weights(W, spec, role, attn_keys=4096):
     W.embed = E
     W.norm = torch.ones(hid, dtype=torch.float16, device=dev)
     for i in range(L):
-        qkv = draw(("qkv", i, W.rank), 3 * hd, hid) * base_std
+        # q/k/v and gate/up READ the embedding block only: a layer's attention / MLP output is then a function of the
+        # attended tokens' embeddings, not of what earlier layers wrote.  (Reading S2 closes a loop — the part of S2
+        # common to all positions survives the attention average undiminished and is re-amplified by every layer: 32
+        # layers of that drown the embedding.)
+        qkv = col_scaled(draw(("qkv", i, W.rank), 3 * hd, hid), s1, base_std, base_std * spec.leak)
         qkv[:hd] *= spec.q_gain
         W.wqkv.append(qkv.to(torch.float16))
         W.wo.append(row_scaled(draw(("o", i, W.rank), hid, hd), s2, o_std, o_std * spec.leak).to(torch.float16))
-        W.wgu.append((draw(("gu", i, W.rank), 2 * W.I_local, hid) * base_std).to(torch.float16))
+        W.wgu.append(col_scaled(draw(("gu", i, W.rank), 2 * W.I_local, hid), s1, base_std,
+                                base_std * spec.leak).to(torch.float16))
         W.wd.append(row_scaled(draw(("d", i, W.rank), hid, W.I_local), s3, d_std, d_std * spec.leak).to(torch.float16))
         W.ln1.append(torch.ones(hid, dtype=torch.float16, device=dev))
         W.ln2.append(torch.ones(hid, dtype=torch.float16, device=dev))
