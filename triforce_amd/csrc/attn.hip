@@ -34,6 +34,12 @@
 #else
 #define ATTN_SPLIT_BOUNDS __launch_bounds__(256)
 #endif
+#ifndef TF_ATTN_QT2_OCC
+#define TF_ATTN_QT2_OCC 0      // > 0: waves per SIMD the two-q-tile form (17..32 query rows: gamma = 16 verifies) is compiled for
+#endif
+#ifndef TF_ATTN_QT2_LATE_VT
+#define TF_ATTN_QT2_LATE_VT 0  // 1: the two-q-tile form also transposes each V fragment right before its PV MFMAs
+#endif
 #ifndef TF_ATTN_DEPTH
 #define TF_ATTN_DEPTH 2        // KV tiles in flight per wave in the split-KV kernel (3 = 24 KiB; A/B in tools/tune.py)
 #endif
@@ -76,7 +82,8 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
                                           TreeMask tm = TreeMask{nullptr, 0, 0, 0}) {
     constexpr int NC = D / 32, NT = D / 16;
     // V tile -> key-contiguous fragments through the matrix core (exact: multiplies by 0/1)
-    constexpr bool LATE_VT = TF_ATTN_LATE_VT && QT == 1;      // transpose each V fragment right before its PV MFMA
+    // transpose each V fragment right before its PV MFMA(s) instead of all NT of them up front
+    constexpr bool LATE_VT = (TF_ATTN_LATE_VT && QT == 1) || (TF_ATTN_QT2_LATE_VT && QT == 2);
     half4 va[LATE_VT ? 1 : NT];
     if (!LATE_VT) {
 #pragma unroll
@@ -86,6 +93,7 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
             va[LATE_VT ? 0 : t] = half4{(h16)r[0], (h16)r[1], (h16)r[2], (h16)r[3]};
         }
     }
+    half4 pb[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -119,12 +127,11 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mnew = fmaxf(st.m[qt], tmax);
         float psum = 0.f;
-        half4 pb;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float p = ok[r] ? __expf(x[r] - mnew) : 0.f;
             psum += p;
-            pb[r] = (h16)p;
+            pb[qt][r] = (h16)p;
         }
         // The running maximum settles after the first tiles of a stream; rescaling the 32 accumulator registers
         // (alpha == 1 exactly when no query column of the wave raised its maximum) is skipped wave-uniformly then.
@@ -139,23 +146,28 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
             st.m[qt] = mnew;
         }
         st.l[qt] += psum;
+    }
+    // PV: one V fragment (transposed here when LATE_VT) feeds the MFMAs of every q-tile
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (LATE_VT) {
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[t >> 1], (t & 1) ? sel1 : sel0, z, 0, 0, 0);
-                const half4 vt = half4{(h16)r[0], (h16)r[1], (h16)r[2], (h16)r[3]};
-                st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(vt, pb, st.acc[qt][t], 0, 0, 0);
-            } else {
-                st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(va[LATE_VT ? 0 : t], pb, st.acc[qt][t], 0, 0, 0);
-            }
+    for (int t = 0; t < NT; ++t) {
+        half4 vt;
+        if (LATE_VT) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[t >> 1], (t & 1) ? sel1 : sel0, z, 0, 0, 0);
+            vt = half4{(h16)r[0], (h16)r[1], (h16)r[2], (h16)r[3]};
+        } else {
+            vt = va[LATE_VT ? 0 : t];
         }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+            st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(vt, pb[qt], st.acc[qt][t], 0, 0, 0);
     }
 }
 
+
 // ws layout: o[H][nsplit][QR][D] | m[H][nsplit][QR] | l[H][nsplit][QR],  QR = QT*16
 template <int D, int QT>
-__global__ ATTN_SPLIT_BOUNDS void attn_split_kernel(
+__device__ __forceinline__ void attn_split_body(
     const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
     int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
     float* __restrict__ ws) {
@@ -274,6 +286,26 @@ __global__ ATTN_SPLIT_BOUNDS void attn_split_kernel(
         __syncthreads();
     }
 }
+
+template <int D, int QT>
+__global__ ATTN_SPLIT_BOUNDS void attn_split_kernel(
+    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
+    int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
+    float* __restrict__ ws) {
+    attn_split_body<D, QT>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws);
+}
+
+// The two-q-tile form (17..32 query rows: the gamma = 16 verifies of the offloading / TP configs) compiled for a stated
+// occupancy: left to itself the compiler takes 298 registers for it (1 wave per SIMD, 4 KV tiles in flight per CU).
+#if TF_ATTN_QT2_OCC > 0
+template <int D>
+__global__ __launch_bounds__(256, TF_ATTN_QT2_OCC) void attn_split_q2_kernel(
+    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
+    int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
+    float* __restrict__ ws) {
+    attn_split_body<D, 2>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws);
+}
+#endif
 
 // ---- 32-key step of the block kernel: two 16-key tiles A, B per softmax update ----------------------------
 // The QK^T products of both tiles give a lane 8 keys of one query (A keys 4g..4g+3, B keys 4g..4g+3); the V tiles
@@ -1047,6 +1079,12 @@ static int launch_attn(const void* q, const void* k, const void* v, void* out, i
                        int sq, int sk, const int32_t* sk_dev, int H, float scale, int nsplit, float* ws,
                        hipStream_t st) {
     dim3 grid(nsplit, H), block(256);
+#if TF_ATTN_QT2_OCC > 0
+    if (QT == 2)
+        hipLaunchKernelGGL((attn_split_q2_kernel<D>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
+                           stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws);
+    else
+#endif
     hipLaunchKernelGGL((attn_split_kernel<D, QT>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
                        stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws);
     TF_LAUNCH_CHECK();
