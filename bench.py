@@ -69,6 +69,9 @@ def parse(argv=None):
                     help="real = chunked prefill through the model; synthetic = N(0,1) KV fill "
                          "(the reference's own filler, DistributedSimpleCache.normal_, cache.py:303-308)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="tensor-parallel path only: build the process group, the sharded engine and its weights, agree "
+                         "across ranks, print the JSON line with dry_run=true and exit (no decode; runs on CPU under gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--rebuild-every", type=int, default=0,
@@ -354,7 +357,7 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: required for RCCL / P2P buffers on this driver
     return subprocess.call(cmd, env=env)
 
 

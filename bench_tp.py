@@ -22,8 +22,11 @@ def run_tp(args, rank, world, local):
     from triforce_amd.utils.decoding import TriForceRunner, _DistEngine, _bcast_record
     from triforce_amd.utils.sampling import UniformSource
 
-    distributed_init("nccl")
-    device = torch.device("cuda", local)
+    on_gpu = torch.cuda.is_available()
+    distributed_init("nccl" if on_gpu else "gloo")              # gloo: the CPU plumbing test (--dry-run)
+    device = torch.device("cuda", local) if on_gpu else torch.device("cpu")
+    if not on_gpu and not args.dry_run:
+        raise SystemExit("bench.py --gpus N needs GPUs (use --dry-run for the CPU plumbing check)")
     tcfg, dcfg = target_config(args.target)
     kind, tspec, dspec, wlabel = resolve_weights(args)
     if kind == "checkpoint":
@@ -39,6 +42,18 @@ def run_tp(args, rank, world, local):
                            retrieval_budget=args.budget, retrieval_chunk_size=args.chunk_size, kv_offload=True,
                            on_chip_layers=tcfg.num_hidden_layers, draft=draft, draft_cache=dcache, gamma=args.gamma)
     llm.init_parameters(load_checkpoint_state_dict(tspec) if kind == "checkpoint" else tspec)
+    if args.dry_run:                                            # launcher / rendezvous / sharding plumbing only
+        shard = torch.tensor([llm.weights.H_local, llm.weights.I_local, rank], dtype=torch.int64, device=device)
+        got = [torch.zeros_like(shard) for _ in range(world)]
+        dist.all_gather(got, shard)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "decode tokens/sec + avg accepted len, Llama-7B-128K @124K ctx", "dry_run": True,
+                              "n_gpus": world, "world_size_observed": dist.get_world_size(),
+                              "backend": dist.get_backend(), "shards": [g.tolist() for g in got],
+                              "config": {"workload": f"{tcfg._name_or_path} TP={world}", "weights": wlabel}}), flush=True)
+        dist.destroy_process_group()
+        return
     if not args.no_graphs:
         llm.initialize_graphs(args.gamma)
     gen = torch.Generator().manual_seed(args.seed)

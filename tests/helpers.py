@@ -47,7 +47,7 @@ def build_oracle_tp(g, temperature, top_p):
     return eng, tsd, dsd
 
 
-def build_product(g, device, tsd=None, dsd=None, temperature=None, top_p=None, graphs=False):
+def build_product(g, device, tsd=None, dsd=None, temperature=None, top_p=None, graphs=False, target_graph=True):
     """The product engine (triforce_amd) from the same seeded weights."""
     from triforce_amd.models.cache import FlashSimpleCache, RetrievalCache, StreamingLLMEvictionCache
     from triforce_amd.models.config_yarn import LlamaConfig
@@ -67,7 +67,7 @@ def build_product(g, device, tsd=None, dsd=None, temperature=None, top_p=None, g
     T = g["temperature"] if temperature is None else temperature
     P = g["top_p"] if top_p is None else top_p
     if graphs:
-        ge.initialize_cuda_graph(gamma, probs=True, temperature=T, top_p=P, verbose=False)
+        ge.initialize_cuda_graph(gamma, probs=True, temperature=T, top_p=P, verbose=False, capture_target=target_graph)
     else:
         ge.initialize_eager(gamma, probs=True, temperature=T, top_p=P)
     return ge

@@ -300,4 +300,5 @@ def test_aligned_weights_set_the_acceptance_on_device(spec_str, lo_mid, hi_mid, 
     run2.prefill(specs.random_prompt(V, P, 11).to(DEV))
     for _ in range(12):
         run2.step()
-    assert run2.accepted_count / max(run2.draft_count, 1) < 0.35
+    assert sum(run2.acc_rate_middle_list) / len(run2.acc_rate_middle_list) < 0.2     # the draft no longer tracks the target
+    assert run2.inner_iters / 12 > 3.0                                               # ~gamma inner iterations per step again

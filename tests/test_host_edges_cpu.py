@@ -200,3 +200,31 @@ def test_bench_helpers_on_cpu():
     assert (kind, tspec, dspec) == ("random", "random:4", "random:5")
     kind, tspec, _, _ = bench.resolve_weights(bench.parse(["--weights", "aligned:0.5:0.95:7"]))
     assert kind == "aligned" and tspec == "aligned:0.5:0.95:7"
+
+
+def test_bench_self_launches_for_more_than_one_gpu():
+    """``python bench.py --gpus 2`` without a launcher (the driver's command form) re-executes itself under
+    torch.distributed.run with one rank per device, builds the process group and the sharded engine on every rank
+    (gloo + CPU here, --dry-run stops before any kernel) and rank 0 alone prints the one JSON line, carrying the
+    world size the process group observed.  Mirrors the reference's launch line (README.md:62,
+    test/offloading_TP.py:23: torchrun --nproc_per_node=2)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--target", "tiny", "--prefill",
+                          "512", "--budget", "64", "--gamma", "4", "--dry-run", "--weights", "random:3"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["dry_run"] and j["n_gpus"] == 2 and j["world_size_observed"] == 2 and j["backend"] == "gloo"
+    assert [s[2] for s in j["shards"]] == [0, 1] and all(s[0] == 1 and s[1] == 384 for s in j["shards"])   # 2 heads, I=768
+    assert j["config"]["weights"].startswith("random-init")
+    # a launcher whose world size disagrees with --gpus is refused with a message, not an assertion trace
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
+                         text=True, timeout=120, env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), cwd=root)
+    assert bad.returncode != 0 and "WORLD_SIZE=4" in (bad.stderr + bad.stdout)

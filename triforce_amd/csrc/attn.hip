@@ -26,19 +26,14 @@
 #ifndef TF_TREE_MASK_FUNNEL
 #define TF_TREE_MASK_FUNNEL 0  // 1: the LDS block kernel reads a tree row's 8 visibility bits with one funnel shift (tree_mask.h)
 #endif
-#ifndef TF_ATTN_LATE_VT
-#define TF_ATTN_LATE_VT 0      // 1: decode (QT = 1) tiles transpose each V fragment just before its PV MFMA (fewer live registers)
-#endif
-#ifdef TF_ATTN_OCC             // waves per SIMD the split-KV kernel is compiled for (default: the compiler's choice, 2;
-#define ATTN_SPLIT_BOUNDS __launch_bounds__(256, TF_ATTN_OCC)      // 3 spills unless TF_ATTN_LATE_VT frees registers)
-#else
 #define ATTN_SPLIT_BOUNDS __launch_bounds__(256)
-#endif
+// Waves per SIMD the two-q-tile form of the split-KV kernel (17..32 query rows: the gamma = 16 verifies) is compiled
+// for.  Left to itself the compiler takes 298 registers for it (1 wave per SIMD, 4 KV tiles in flight per CU); held to
+// 2 waves it fits 236 without scratch and streams 8-15 % faster at every shape of profiles/r02_nsplit_sweep.json
+// (16 heads x 130 066 keys x 17 rows: 225 -> 206 us).  Measured and dropped in the same sweep: transposing each V
+// fragment right before its PV MFMA to run the one-q-tile form at 3 waves per SIMD — no gain beyond run-to-run noise.
 #ifndef TF_ATTN_QT2_OCC
-#define TF_ATTN_QT2_OCC 0      // > 0: waves per SIMD the two-q-tile form (17..32 query rows: gamma = 16 verifies) is compiled for
-#endif
-#ifndef TF_ATTN_QT2_LATE_VT
-#define TF_ATTN_QT2_LATE_VT 0  // 1: the two-q-tile form also transposes each V fragment right before its PV MFMAs
+#define TF_ATTN_QT2_OCC 2
 #endif
 #ifndef TF_ATTN_DEPTH
 #define TF_ATTN_DEPTH 2        // KV tiles in flight per wave in the split-KV kernel (3 = 24 KiB; A/B in tools/tune.py)
@@ -82,16 +77,12 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
                                           TreeMask tm = TreeMask{nullptr, 0, 0, 0}) {
     constexpr int NC = D / 32, NT = D / 16;
     // V tile -> key-contiguous fragments through the matrix core (exact: multiplies by 0/1)
-    // transpose each V fragment right before its PV MFMA(s) instead of all NT of them up front
-    constexpr bool LATE_VT = (TF_ATTN_LATE_VT && QT == 1) || (TF_ATTN_QT2_LATE_VT && QT == 2);
-    half4 va[LATE_VT ? 1 : NT];
-    if (!LATE_VT) {
+    half4 va[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[t >> 1], (t & 1) ? sel1 : sel0, z, 0, 0, 0);
-            va[LATE_VT ? 0 : t] = half4{(h16)r[0], (h16)r[1], (h16)r[2], (h16)r[3]};
-        }
+    for (int t = 0; t < NT; ++t) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[t >> 1], (t & 1) ? sel1 : sel0, z, 0, 0, 0);
+        va[t] = half4{(h16)r[0], (h16)r[1], (h16)r[2], (h16)r[3]};
     }
     half4 pb[QT];
 #pragma unroll
@@ -147,21 +138,12 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
         }
         st.l[qt] += psum;
     }
-    // PV: one V fragment (transposed here when LATE_VT) feeds the MFMAs of every q-tile
+    // PV: one V fragment feeds the MFMAs of every q-tile
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        half4 vt;
-        if (LATE_VT) {
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            f32x4 r = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[t >> 1], (t & 1) ? sel1 : sel0, z, 0, 0, 0);
-            vt = half4{(h16)r[0], (h16)r[1], (h16)r[2], (h16)r[3]};
-        } else {
-            vt = va[LATE_VT ? 0 : t];
-        }
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
-            st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(vt, pb[qt], st.acc[qt][t], 0, 0, 0);
-    }
+            st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(va[t], pb[qt], st.acc[qt][t], 0, 0, 0);
 }
 
 
@@ -295,8 +277,7 @@ __global__ ATTN_SPLIT_BOUNDS void attn_split_kernel(
     attn_split_body<D, QT>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws);
 }
 
-// The two-q-tile form (17..32 query rows: the gamma = 16 verifies of the offloading / TP configs) compiled for a stated
-// occupancy: left to itself the compiler takes 298 registers for it (1 wave per SIMD, 4 KV tiles in flight per CU).
+// The two-q-tile form compiled for TF_ATTN_QT2_OCC waves per SIMD (see the note at the top of the file).
 #if TF_ATTN_QT2_OCC > 0
 template <int D>
 __global__ __launch_bounds__(256, TF_ATTN_QT2_OCC) void attn_split_q2_kernel(
@@ -1064,10 +1045,15 @@ extern "C" int64_t tf_attn_decode_ws_floats(int H, int sq, int D, int nsplit) {
     return (int64_t)H * nsplit * QR * (D + 2);
 }
 
+// Split count of the split-KV kernel.  Measured over heads-per-rank 4..40 x 4K..130K keys x one / two q-tiles
+// (tools/nsplit_sweep.py, profiles/r02_nsplit_sweep.json): the fastest grid is ONE workgroup per CU — nsplit * H ~ 256 —
+// as long as a workgroup keeps >= 8 key tiles (2 per wave); more splits only add partials for the merge kernel to
+// re-read, fewer leave CUs idle.  (The first rule — up to 4 workgroups per CU, >= 32 tiles each — was 5-25 % slower
+// on the TP-shard shapes: 16 heads x 130K keys 237 vs 206 us, 32 heads x 12 305 keys 66 vs 54 us.)
 extern "C" int tf_attn_decode_pick_nsplit(int H, int sk) {
     const int tiles = (sk + 15) / 16;
-    int by_work = tiles / 32;                        // >= 8 tiles per wave
-    int by_grid = 1024 / (H > 0 ? H : 1);            // ~4 workgroups per CU on 256 CUs
+    int by_grid = 256 / (H > 0 ? H : 1);
+    int by_work = tiles / 8;
     int n = by_work < by_grid ? by_work : by_grid;
     if (n < 1) n = 1;
     if (n > 128) n = 128;
@@ -1080,13 +1066,13 @@ static int launch_attn(const void* q, const void* k, const void* v, void* out, i
                        hipStream_t st) {
     dim3 grid(nsplit, H), block(256);
 #if TF_ATTN_QT2_OCC > 0
-    if (QT == 2)
+    if constexpr (QT == 2)
         hipLaunchKernelGGL((attn_split_q2_kernel<D>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
                            stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws);
     else
 #endif
-    hipLaunchKernelGGL((attn_split_kernel<D, QT>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
-                       stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws);
+        hipLaunchKernelGGL((attn_split_kernel<D, QT>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
+                           stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws);
     TF_LAUNCH_CHECK();
     hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(H, sq), dim3(D, COMBINE_GROUPS), 0, st, (const float*)ws,
                        (h16*)out, sq, H, nsplit, QT * 16);

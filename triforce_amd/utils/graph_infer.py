@@ -169,6 +169,7 @@ class _TargetGraph:
     def __init__(self, engine, q_len, mempool, n_warmups, probs, temperature, top_p):
         dev = engine.model.device
         self.engine, self.q_len, self.probs = engine, q_len, probs
+        self.cache = engine.kv_cache               # the graph reads and appends THIS cache's storage
         self.ids = torch.zeros((1, q_len), dtype=torch.long, device=dev)
         self.base = torch.arange(q_len, dtype=torch.long, device=dev)
         self.pos = torch.arange(q_len, dtype=torch.long, device=dev)
@@ -255,7 +256,8 @@ class GraphInferenceEngine:
         autoregressive step has its own entry, ``decode_step``."""
         if input_ids.shape[0] != 1 or input_ids.shape[-1] == 1:
             return None
-        return self.target_graphs.get(input_ids.shape[-1])
+        tg = self.target_graphs.get(input_ids.shape[-1])
+        return tg if (tg is not None and tg.cache is self.engine.kv_cache) else None   # cache swapped after capture: eager
 
     @torch.inference_mode()
     def verify_probs(self, input_ids, temperature, top_p, rebuild_retrieval=False, eager=False):
@@ -272,7 +274,7 @@ class GraphInferenceEngine:
         """One autoregressive step (q_len == 1, no retrieval build) over the full cache: the captured graph when there
         is one, else the eager forward the reference runs (decoding.py:28)."""
         tg = self.target_graphs.get(1)
-        if tg is not None and input_ids.shape == (1, 1):
+        if tg is not None and tg.cache is self.engine.kv_cache and input_ids.shape == (1, 1):
             return tg(input_ids)[0]
         return self.engine.model(input_ids=input_ids, kv_cache=self.engine.kv_cache, graph_cache=None).logits
 
