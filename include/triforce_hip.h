@@ -157,12 +157,6 @@ int tf_silu_mul(const void* gate_up, void* out, int rows, int I, void* stream);
  * tf_skinny_gemm        : y [M][ldy] fp16, or fp32 when out_f32 != 0 (the fp16 result cast to float — `logits.float()`).
  * tf_skinny_gemm_swiglu : act [M][I] = fp16(silu(fp16(x.Wg^T))) * fp16(x.Wu^T)  — gate/up GEMMs + SwiGLU fused.
  * ------------------------------------------------------------------------------------------- */
-/* tf_skinny_set_next: optional hint consumed by the NEXT tf_skinny_* launch on the calling thread — the packed weights
- * (w1: second matrix of a gate|up pair or NULL) and shape of the skinny GEMM that will follow it in the forward.  That
- * launch then pulls the first `depth` KiB of every K-split of the follower's panels into the L2 of the XCD that will
- * run them, so the follower's weight stream starts from cache hits.  mode_next: 0 plain / fp32-out, 1 gate|up, 3 q|k|v
- * + RoPE.  w0 == NULL clears the hint.  No reference counterpart: the reference's GEMMs are cuBLAS calls. */
-int tf_skinny_set_next(const void* w0, const void* w1, int N, int K, int mode_next, int depth);
 int tf_skinny_gemm(const void* w_packed, const void* x, int64_t ldx, void* y, int64_t ldy, int M, int N, int K,
                    int out_f32, void* stream);
 int tf_skinny_gemm_swiglu(const void* gate_packed, const void* up_packed, const void* x, int64_t ldx, void* act,

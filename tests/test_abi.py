@@ -49,11 +49,6 @@ def test_bad_arguments_are_rejected_without_launching():
     assert lib.tf_rmsnorm(null, null, null, null, null, 1, 8, 1e-6, null) == -22
     assert lib.tf_retrieval_topk(null, null, 10, 2, 1, null) == -22
     assert lib.tf_kv_copy_rows(null, 0, 0, 0, null, 0, 0, 0, 0, 0, 0, 1, 1, 8, null) == 0      # n == 0 is a no-op
-    dummy = ctypes.c_void_p(64)                                       # never dereferenced on the host
-    assert lib.tf_skinny_set_next(dummy, null, 100, 4096, 0, 4) == -22     # N not a multiple of 16
-    assert lib.tf_skinny_set_next(dummy, null, 4096, 4096, 0, 0) == -22    # depth out of range
-    assert lib.tf_skinny_set_next(dummy, null, 4096, 4096, 0, 4) == 0
-    assert lib.tf_skinny_set_next(null, null, 0, 0, 0, 0) == 0             # cleared again
     with pytest.raises(hip.TriforceHipError):
         hip.check(-22, "x")
 
@@ -93,8 +88,6 @@ def test_every_entry_point_rejects_null_buffers(fill):
                 args.append(t(fill))
         rc = getattr(lib, name)(*args)
         if name == "tf_kv_shift_rows":
-            assert rc == 0
-        elif name == "tf_skinny_set_next":                       # NULL weights = "clear the hint": documented no-op
             assert rc == 0
         else:
             assert rc == -22, f"{name}(NULL..., sizes={fill}) returned {rc}"

@@ -23,8 +23,11 @@
 #include "tree_mask.h"
 
 #define NEG_BIG (-1.0e30f)
+// The LDS block kernel reads a tree row's 8 visibility bits (8 consecutive keys per lane) with one 64-bit funnel shift
+// (tree_mask.h) instead of 8 address computations and loads: 512-node Sequoia verify over a 125K prefix 3 140 -> 2 900 us
+// (profiles/r02_gemm_pipeline_ab.jsonl, tune.py "attn_tree_verify_512"); 0 keeps the per-key form for bisecting.
 #ifndef TF_TREE_MASK_FUNNEL
-#define TF_TREE_MASK_FUNNEL 0  // 1: the LDS block kernel reads a tree row's 8 visibility bits with one funnel shift (tree_mask.h)
+#define TF_TREE_MASK_FUNNEL 1
 #endif
 #define ATTN_SPLIT_BOUNDS __launch_bounds__(256)
 // Waves per SIMD the two-q-tile form of the split-KV kernel (17..32 query rows: the gamma = 16 verifies) is compiled

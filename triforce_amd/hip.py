@@ -33,7 +33,6 @@ SIGNATURES = {
     "tf_rmsnorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "tf_rope_append": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "tf_silu_mul": (_i32, [_vp, _vp, _i32, _i32, _vp]),
-    "tf_skinny_set_next": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32]),
     "tf_skinny_gemm": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "tf_skinny_gemm_ex": (_i32, [_vp, _vp, _i64, _vp, _f32, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "tf_skinny_gemm_swiglu_ex": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),

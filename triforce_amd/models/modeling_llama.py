@@ -142,11 +142,10 @@ class LlamaForCausalLM:
                 a = ops.attn_prefill(q, kl, vl, sk, self.scale)
                 if streaming:
                     kv_cache.layer_done(i, slot, q_len)
-            if fused:      # nxt = the GEMM that follows: its first weight tiles are prefetched under this one's epilogue
-                ops.linear(a, W.wo[i], resid=x, out=x, ss_out=ss, nxt=("gateup", W.wgu[i]))     # x += attn_out
-                act = ops.mlp_act(x, W.wgu[i], ln=W.ln2[i], eps=W.eps, ss_in=ss, nxt=W.wd[i])
-                ops.linear(act, W.wd[i], resid=x, out=x, ss_out=ss,                             # x += mlp_out
-                           nxt=("qkv", W.wqkv[i + 1]) if i + 1 < W.L else W.lm_head)
+            if fused:
+                ops.linear(a, W.wo[i], resid=x, out=x, ss_out=ss)                               # x += attn_out
+                act = ops.mlp_act(x, W.wgu[i], ln=W.ln2[i], eps=W.eps, ss_in=ss)
+                ops.linear(act, W.wd[i], resid=x, out=x, ss_out=ss)                             # x += mlp_out
             else:
                 o = ops.linear(a, W.wo[i])
                 h = ops.rmsnorm(o, W.ln2[i], W.eps, residual=x, sum_out=x)           # x += attn_out

@@ -105,10 +105,9 @@ class LlamaForCausalLM:
                                         rotate_k=False)
             a = ops.attn_rope_on_read(q, kl, vl, self.cos, self.sin, kv_len, self.scale)
             if fused:
-                ops.linear(a, W.wo[i], resid=x, out=x, ss_out=ss, nxt=("gateup", W.wgu[i]))
-                act = ops.mlp_act(x, W.wgu[i], ln=W.ln2[i], eps=W.eps, ss_in=ss, nxt=W.wd[i])
-                ops.linear(act, W.wd[i], resid=x, out=x, ss_out=ss,
-                           nxt=("qkv", W.wqkv[i + 1]) if i + 1 < W.L else W.lm_head)
+                ops.linear(a, W.wo[i], resid=x, out=x, ss_out=ss)
+                act = ops.mlp_act(x, W.wgu[i], ln=W.ln2[i], eps=W.eps, ss_in=ss)
+                ops.linear(act, W.wd[i], resid=x, out=x, ss_out=ss)
             else:
                 o = ops.linear(a, W.wo[i])
                 h = ops.rmsnorm(o, W.ln2[i], W.eps, residual=x, sum_out=x)

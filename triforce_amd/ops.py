@@ -105,28 +105,7 @@ def can_fuse(x, *ws):
             and all(isinstance(w, PackedLinear) and w.parts is not None for w in ws))
 
 
-# Cross-kernel weight prefetch (tf_skinny_set_next): KiB per K-split of the FOLLOWING GEMM that a skinny GEMM pulls into
-# L2 while its own epilogue runs; 0 disables (env TRIFORCE_PREFETCH_NEXT, A/B switch).
-PREFETCH_NEXT = int(_os.environ.get("TRIFORCE_PREFETCH_NEXT", "0"))
-
-
-def _hint_next(nxt):
-    """nxt: None | PackedLinear (plain / fp32-out follower) | ("gateup", PackedLinear) | ("qkv", PackedLinear)."""
-    if PREFETCH_NEXT <= 0 or nxt is None:
-        return
-    kind, pl = nxt if isinstance(nxt, tuple) else ("plain", nxt)
-    if kind == "gateup":
-        w0, w1, N, mode = pl.parts[0], pl.parts[1], pl.N // 2, 1
-    elif kind == "qkv":
-        w0, w1, N, mode = pl.wp_rope, None, pl.N, 3
-    else:
-        w0, w1, N, mode = pl.wp, None, pl.N, 0
-    if w0 is None:
-        return
-    hip.check(hip.lib().tf_skinny_set_next(_ptr(w0), _ptr(w1), N, pl.K, mode, PREFETCH_NEXT), "tf_skinny_set_next")
-
-
-def linear(x, w, out_f32=False, ln=None, eps=0.0, resid=None, out=None, ss_in=None, ss_out=None, nxt=None):
+def linear(x, w, out_f32=False, ln=None, eps=0.0, resid=None, out=None, ss_in=None, ss_out=None):
     """y = x . W^T, fp16 with fp32 accumulation — the reference's nn.Linear / F.linear.  <=32 rows against a
     PackedLinear run the hand-written weight-streaming kernel; larger blocks (prefill) go to hipBLASLt.
     Fused forms of the skinny kernel (only valid when ``can_fuse``): ``ln`` = RMSNorm weight applied to x first
@@ -144,7 +123,6 @@ def linear(x, w, out_f32=False, ln=None, eps=0.0, resid=None, out=None, ss_in=No
             assert ss_in.dtype == torch.float32 and ss_in.shape == (w.K // 16, 32) and ss_in.is_contiguous()
         if ss_out is not None:
             assert ss_out.dtype == torch.float32 and ss_out.shape == (w.N // 16, 32) and ss_out.is_contiguous()
-        _hint_next(nxt)
         hip.check(hip.lib().tf_skinny_gemm_ex(_ptr(w.wp), _ptr(x), x.stride(0), _ptr(ln), float(eps), _ptr(ss_in),
                                               _ptr(resid), resid.stride(0) if resid is not None else 0, _ptr(ss_out),
                                               _ptr(out), out.stride(0), x.shape[0], w.N, w.K, 1 if out_f32 else 0,
@@ -156,14 +134,13 @@ def linear(x, w, out_f32=False, ln=None, eps=0.0, resid=None, out=None, ss_in=No
     return y.float() if out_f32 else y
 
 
-def mlp_act(h, wgu, ln=None, eps=0.0, ss_in=None, nxt=None):
+def mlp_act(h, wgu, ln=None, eps=0.0, ss_in=None):
     """fp16(silu(gate(h))) * up(h) for a fused gate|up weight: one kernel for <=32 rows (optionally with the
     RMSNorm of h folded in, ``ln``), GEMM + silu_mul otherwise."""
     if isinstance(wgu, PackedLinear) and wgu.parts is not None and wgu.split == 2 and h.shape[0] <= SKINNY_MAX_ROWS \
             and h.is_cuda:
         I = wgu.N // 2
         act = torch.empty(h.shape[0], I, dtype=_HALF, device=h.device)
-        _hint_next(nxt)
         hip.check(hip.lib().tf_skinny_gemm_swiglu_ex(_ptr(wgu.parts[0]), _ptr(wgu.parts[1]), _ptr(h), h.stride(0),
                                                      _ptr(ln), float(eps), _ptr(ss_in), _ptr(act), I, h.shape[0], I,
                                                      wgu.K, _stream()), "tf_skinny_gemm_swiglu_ex")
