@@ -121,7 +121,7 @@ def attn_tree(q, k_layer, v_layer, sk, scale, tree_mask, tree_start, mask_row0=0
     return attn_block(q, k_layer, v_layer, sk, scale, tree_mask=tree_mask, mask_row0=mask_row0, tree_start=tree_start)
 
 
-def kv_gather_rows(k_cache, v_cache, offset, idx):
+def kv_gather_rows(k_cache, v_cache, offset, idx, max_index=None):
     src = [offset + int(i) for i in idx.tolist()]
     for t in (k_cache, v_cache):
         t[:, :, offset:offset + len(src)] = t[:, :, src].clone()

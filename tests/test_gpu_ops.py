@@ -637,3 +637,27 @@ def test_swiglu_norm_prologue(M, I, K):
     dd = (got.float().cpu() - want.float()).abs()
     tolw = 6 * want.float().abs() * 2 ** -10 + 4e-3
     assert bool((dd <= tolw).all()) and dd.mean() < 5e-4, (float(dd.max()), float(dd.mean()))
+
+
+def test_row_copy_wrappers_refuse_out_of_range_rows():
+    """kv_copy_rows / kv_shift_rows / kv_gather_rows move whole token rows with no bounds check on the device: the
+    wrappers refuse ranges that leave the tensors (a prompt longer than the declared prefill, a run past the
+    generated-token capacity) instead of overwriting neighbouring device memory."""
+    ops = _ops()
+    src = torch.zeros(2, 3, 16, 64, dtype=torch.float16, device=DEV)
+    dst = torch.zeros(2, 3, 8, 64, dtype=torch.float16, device=DEV)
+    ops.kv_copy_rows(src, dst, 8, 0, 8)                          # exactly fits
+    for args in ((8, 1, 8), (9, 0, 8), (0, 0, 9), (-1, 0, 2)):
+        with pytest.raises(IndexError):
+            ops.kv_copy_rows(src, dst, *args)
+    ops.kv_shift_rows(src, 8, 0, 8)
+    with pytest.raises(IndexError):
+        ops.kv_shift_rows(src, 9, 0, 8)
+    with pytest.raises(IndexError):
+        ops.kv_shift_rows(src, 0, 12, 8)
+    idx = torch.tensor([0, 2, 5], dtype=torch.int32, device=DEV)
+    ops.kv_gather_rows(src, src.clone(), 10, idx, max_index=5)
+    with pytest.raises(IndexError):
+        ops.kv_gather_rows(src, src.clone(), 10, idx, max_index=6)   # source row 16 does not exist
+    with pytest.raises(IndexError):
+        ops.kv_gather_rows(src, src.clone(), 14, idx)                # destination rows 14..16

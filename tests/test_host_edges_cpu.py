@@ -228,3 +228,24 @@ def test_bench_self_launches_for_more_than_one_gpu():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
                          text=True, timeout=120, env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), cwd=root)
     assert bad.returncode != 0 and "WORLD_SIZE=4" in (bad.stderr + bad.stdout)
+
+
+def test_tree_walk_limits_and_atomic_grow_map_cache(tmp_path):
+    """The device-side Sequoia accept walk reads one uniform per examined child from a fixed window and records a
+    bounded path: SpecTree refuses grow maps that could exceed either (_worst_walk); a grow map built on demand is
+    published with an atomic rename, so concurrent torchrun ranks never read a half-written file."""
+    import os
+    from triforce_amd.utils import tree as T
+    from triforce_amd.utils.SpecTree_TP import _worst_walk
+    assert _worst_walk([[]]) == (0, 0)
+    #        0 -> 1,2,3 ; 1 -> 4,5 ; 4 -> 6 ; 2 -> 7
+    succ = [[1, 2, 3], [4, 5], [7], [], [6], [], [], []]
+    assert _worst_walk(succ) == (3 + 2 + 1, 3)
+    gm = T.load_grow_map(512)
+    c, d = _worst_walk(gm["Successors"])
+    assert c < 255 and d < 59                                   # the shipped 512-node tree fits with room to spare
+    small = T.load_grow_map(24, cache_dir=str(tmp_path))
+    files = os.listdir(tmp_path)
+    assert files == ["24.json"], files                          # no temp file left behind
+    again = T.load_grow_map(24, cache_dir=str(tmp_path))
+    assert again["branches"] == small["branches"] and again["size"] == 24

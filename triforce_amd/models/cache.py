@@ -398,14 +398,14 @@ class DistributedSimpleCache(Cache):
         if n and idx != list(range(n)):
             dev_idx = torch.tensor(idx, dtype=torch.int32, device=self.device)
             if self.on_chip_layers > 0:
-                ops.kv_gather_rows(self.k, self.v, offset, dev_idx)
+                ops.kv_gather_rows(self.k, self.v, offset, dev_idx, max_index=idx[-1])
             if self.on_chip_layers < self.layers:
                 src = torch.tensor([offset + i for i in idx], dtype=torch.long)
                 for t in (self.cpu_k, self.cpu_v):
                     t[:, :, offset:offset + n] = t[:, :, src]
             tm = getattr(self, "tail_mirror", None)
             if tm is not None and tm.tail_k is not None:
-                ops.kv_gather_rows(tm.tail_k, tm.tail_v, offset - tm.prefill, dev_idx)
+                ops.kv_gather_rows(tm.tail_k, tm.tail_v, offset - tm.prefill, dev_idx, max_index=idx[-1])
         self.seq_len = offset + n
 
 

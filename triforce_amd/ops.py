@@ -390,6 +390,9 @@ def kv_copy_rows(src, dst, src_t0, dst_t0, n):
     _dev(src, dst)
     L, H, _, D = src.shape
     assert dst.shape[0] == L and dst.shape[1] == H and dst.shape[3] == D
+    if src_t0 < 0 or dst_t0 < 0 or src_t0 + n > src.shape[2] or dst_t0 + n > dst.shape[2]:
+        raise IndexError(f"kv_copy_rows: rows [{src_t0}, {src_t0 + n}) of {src.shape[2]} -> [{dst_t0}, {dst_t0 + n}) of "
+                         f"{dst.shape[2]} leave the cache (the kernel does not bounds-check)")
     ssl, sst, ssh = _lhtd(src)
     dsl, dst_t, dsh = _lhtd(dst)
     hip.check(hip.lib().tf_kv_copy_rows(_ptr(src), ssl, sst, ssh, _ptr(dst), dsl, dst_t, dsh, int(src_t0), int(dst_t0),
@@ -401,19 +404,26 @@ def kv_shift_rows(cache, src_t0, dst_t0, n):
     if n <= 0 or src_t0 == dst_t0:
         return
     _dev(cache)
-    L, H, _, D = cache.shape
+    L, H, T, D = cache.shape
+    if src_t0 < 0 or dst_t0 < 0 or src_t0 + n > T or dst_t0 + n > T:
+        raise IndexError(f"kv_shift_rows: rows [{src_t0}, {src_t0 + n}) -> [{dst_t0}, {dst_t0 + n}) leave the {T}-row cache")
     sl, st, sh = _lhtd(cache)
     hip.check(hip.lib().tf_kv_shift_rows(_ptr(cache), sl, st, sh, int(src_t0), int(dst_t0), int(n), L, H, D,
                                          _stream()), "tf_kv_shift_rows")
 
 
-def kv_gather_rows(k_cache, v_cache, offset, idx):
+def kv_gather_rows(k_cache, v_cache, offset, idx, max_index=None):
     """Rows offset+idx[j] -> offset+j of every layer/head of the (L,H,T,D) K and V views (idx: device int32,
-    strictly increasing) — gather_kv_incremental (reference cache.py:333-343)."""
+    strictly increasing) — gather_kv_incremental (reference cache.py:333-343).  max_index: the largest entry of idx as
+    the host knows it (the list the device tensor was built from), so that the source rows can be bounds-checked
+    without reading the device tensor back."""
     _dev(k_cache, v_cache, idx)
-    L, H, _, D = k_cache.shape
+    L, H, T, D = k_cache.shape
     sl, st, sh = _lhtd(k_cache)
     assert _lhtd(v_cache) == (sl, st, sh) and idx.dtype == torch.int32 and idx.is_contiguous()
+    if offset < 0 or offset + idx.numel() > T or (max_index is not None and offset + max_index >= T):
+        raise IndexError(f"kv_gather_rows: {idx.numel()} rows at offset {offset} (largest index {max_index}) leave the "
+                         f"{T}-row cache")
     hip.check(hip.lib().tf_kv_gather_rows(_ptr(k_cache), _ptr(v_cache), sl, st, sh, int(offset), _ptr(idx),
                                           idx.numel(), L, H, D, _stream()), "tf_kv_gather_rows")
 
@@ -432,6 +442,7 @@ def sample_without_replacement(logits, rand, k, temperature):
 
 
 TREE_ACCEPT_OUT = 64
+TREE_ACCEPT_MAX_PATH = 60       # accepted nodes the record can hold (TREE_MAX_PATH in csrc/sampling.hip)
 
 
 def tree_accept(p_rows, draft_logits, tokens, succ_off, succ, uniforms, temperature, out):

@@ -66,6 +66,17 @@ def sample_dist(probs, rng=None):
     return tok
 
 
+def _worst_walk(successors):
+    """(most children any root-to-leaf walk can examine, deepest path) of a tree given as per-node successor lists."""
+    best_c, best_d = [0] * len(successors), [0] * len(successors)
+    for node in range(len(successors) - 1, -1, -1):          # children have larger ids than their parent
+        kids = successors[node]
+        if kids:
+            best_c[node] = len(kids) + max(best_c[k] for k in kids)
+            best_d[node] = 1 + max(best_d[k] for k in kids)
+    return best_c[0], best_d[0]
+
+
 class SpecTree:
     def __init__(self, engine, temperature: float = 0.6, top_p: float = 0.9, max_length=256, vocab_size=32000,
                  grow_map=None, residual_graph=None, sampling_callables=None, sample_gather_indices=None,
@@ -93,6 +104,13 @@ class SpecTree:
             self.level_start.append(start)
             start += sum(self.branches[i])
         assert start == self.tree_size
+        # tf_tree_accept walks one root-to-leaf path: it reads one uniform per examined child out of a MAX_TAKE-wide
+        # window and records at most TREE_ACCEPT_MAX_PATH accepted nodes — refuse trees that could exceed either
+        worst_children, worst_depth = _worst_walk(self.Successors)
+        if worst_children + 1 > UniformSource.MAX_TAKE or worst_depth + 1 > ops.TREE_ACCEPT_MAX_PATH:
+            raise ValueError(f"grow map too deep / wide for the device-side accept walk: a path can examine "
+                             f"{worst_children} children over {worst_depth} levels (limits {UniformSource.MAX_TAKE - 1} / "
+                             f"{ops.TREE_ACCEPT_MAX_PATH - 1})")
         self.sampling_callables = sampling_callables or {
             i: sampling_without_replacement(max(self.branches[i]), temperature) for i in range(self.draft_step - 1)}
         if sample_gather_indices is None:                # offloading_seqouia.py:124-134
@@ -132,6 +150,8 @@ class SpecTree:
         self._refresh_rand()
         eng = self.graph_engine
         eng.reset()
+        if prefix.numel() != eng.prefill_len:
+            raise ValueError(f"prompt length {prefix.numel()} != the engine's prefill length {eng.prefill_len}")
         eng.prefill(input_ids=prefix.unsqueeze(0)[:, :-1])
         logits = eng.build_retrieval_cache(input_ids=prefix.unsqueeze(0)[:, -1:])
         return sample_dist(norm_logits(logits[:, -1, :], temperature=self.temperature, top_k=-1, top_p=self.top_p),

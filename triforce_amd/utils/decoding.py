@@ -125,6 +125,8 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
         flat = vt.view(-1)
         u = rng.take(3)
         ops.sample_inverse_cdf(q_d, u[0:1], flat[n + 1:n + 2])               # d ~ q_d, written into verify_tokens
+        if sync_record is not None:           # TP: rank 0's draft token is everyone's BEFORE the all-reduced verify runs
+            sync_record(flat[n + 1:n + 2])    # on it (the reference's sample_dist, decoding.py:230-239,452)
         p = graph_engine.graph_verify(input_ids=vt, position_ids=position_ids, **noclone)
         ops.middle_accept(p, q_d, flat, u[1:3], n, gamma, buffers.mid_out)   # accept test + follow-up sample
         if sync_record is not None:                                           # TP: rank 0's decision wins
@@ -424,6 +426,10 @@ def TriForce_Dist(tokenizer, llm, input_ids, gamma=4, max_len=256, top_k=-1, top
     run = TriForceRunner(tokenizer, ge, gamma, top_k, top_p, temperature, verbose, rng, inclusive_accept=True,
                          sync_record=_bcast_record)
     llm.reset()
+    if input_ids.shape[1] != llm.prefill_len:
+        # the retrieval cache's chunk grid and the device mirror of the generated rows are laid out for exactly this
+        # prompt length (the entry scripts clip / generate prompts to --prefill)
+        raise ValueError(f"prompt length {input_ids.shape[1]} != the engine's prefill length {llm.prefill_len}")
     llm.prefill(input_ids=input_ids[:, :-1])
     logits = llm.build_retrieval_cache(input_ids=input_ids[:, -1:])
     info = getattr(llm.weights, "aligned", None)

@@ -158,10 +158,12 @@ def load_grow_map(spec, cache_dir=None):
         with open(path) as f:
             return grow_map_from_branches(json.load(f)["branches"])
     gm = build_grow_map(size=size, max_depth=min(16, size))     # 16 levels like the reference's tree/512.pt
-    try:
+    try:                                   # every torchrun rank may get here at once: write aside, publish atomically
         os.makedirs(cache_dir, exist_ok=True)
-        with open(path, "w") as f:
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
             json.dump({"branches": gm["branches"], "size": gm["size"]}, f)
+        os.replace(tmp, path)
     except OSError:
         pass
     return gm
