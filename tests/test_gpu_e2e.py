@@ -142,24 +142,110 @@ def test_periodic_retrieval_rebuild_stays_lossless_on_device():
 
 
 def test_stochastic_triforce_with_injected_uniforms():
-    """cfg3-style sampling (T=0.6, top_p=0.9).  Product and oracle consume the same explicit uniforms; the
-    accept masks are bit-exact functions of (p, q, r), so the streams agree until a probability that
-    differs by device rounding crosses a uniform — tolerated only after a healthy common prefix, and the
-    acceptance statistics must stay close."""
+    """cfg3-style sampling (T=0.6, top_p=0.9) over 20 uniform streams.  Product and oracle consume the same explicit
+    uniforms; every accept / resample decision is a bit-exact function of (p, q, r) (tests/test_gpu_ops.py), so the two
+    loops take identical decisions until a probability that differs by device rounding (~1e-3 relative, fp16 logits)
+    crosses one of the uniforms — after which the streams are two different draws from the same distributions.  Hence:
+      * accept masks: most runs never diverge, and then the per-step accepted counts are identical too; a divergence,
+        where there is one, happens late (rounding-level crossings are rare), not at token 1;
+      * statistics: the acceptance pooled over all runs sits inside a 4-sigma binomial band around the oracle's."""
+    import math
     from triforce_amd.utils.decoding import TriForce
     from triforce_amd.utils.sampling import UniformSource
     g = Hh.load_golden("small_gamma6")
-    us = Hh.fixed_uniforms()
     oeng, tsd, dsd = Hh.build_oracle(g, temperature=0.6, top_p=0.9)
-    prompt = Hh.prompt_of(g)
-    want = M.triforce(oeng, prompt, g["gamma"], 32, 0.6, 0.9, rng=M.InjectedRng(us))
     ge = Hh.build_product(g, DEV, tsd, dsd, temperature=0.6, top_p=0.9, graphs=True)
-    got = TriForce(Hh.FakeTokenizer(), ge, prompt.to(DEV), gamma=g["gamma"], max_len=32, top_k=-1, top_p=0.9,
-                   temperature=0.6, rng=UniformSource(DEV, values=us), return_details=True)
-    common = Hh.common_prefix(got["tokens"], want["tokens"])
-    assert common >= 6, f"stochastic streams share only {common} tokens: {got['tokens'][:10]} vs {want['tokens'][:10]}"
-    assert abs(got["acceptance_rate"] - want["acceptance_rate"]) < 0.25
-    assert got["accepted"] > 0
+    prompt = Hh.prompt_of(g)
+    runs, max_len = 32, 24
+    identical, prefixes = 0, []
+    acc_w = dr_w = acc_g = dr_g = 0
+    for seed in range(runs):
+        us = Hh.fixed_uniforms(n=2048, seed=500 + seed)
+        want = M.triforce(oeng, prompt, g["gamma"], max_len, 0.6, 0.9, rng=M.InjectedRng(us))
+        got = TriForce(Hh.FakeTokenizer(), ge, prompt.to(DEV), gamma=g["gamma"], max_len=max_len, top_k=-1, top_p=0.9,
+                       temperature=0.6, rng=UniformSource(DEV, values=us), return_details=True)
+        n = min(len(got["tokens"]), len(want["tokens"]))
+        common = Hh.common_prefix(got["tokens"][:n], want["tokens"][:n])
+        prefixes.append(common)
+        if common == n:          # same tokens => the same accept / reject decisions must have produced them
+            k = min(len(got["counts"]), len(want["counts"]))
+            assert got["counts"][:k - 1] == want["counts"][:k - 1], (seed, got["counts"], want["counts"])
+            identical += 1
+        acc_w, dr_w = acc_w + want["accepted"], dr_w + want["drafted"]
+        acc_g, dr_g = acc_g + got["accepted"], dr_g + got["drafted"]
+    prefixes.sort()
+    assert identical >= runs // 2, f"only {identical}/{runs} streams identical end to end; common prefixes {prefixes}"
+    assert prefixes[runs // 4] >= 8, f"divergences come too early for rounding-level crossings: {prefixes}"
+    p_w = acc_w / dr_w
+    sigma = math.sqrt(max(p_w * (1 - p_w), 1e-4) / dr_g)
+    assert abs(acc_g / dr_g - p_w) <= 4 * sigma + 1e-9, (acc_g / dr_g, p_w, sigma)
+    assert acc_g > 0
+
+
+def test_greedy_divergence_from_golden_happens_only_at_near_ties():
+    """Where (if anywhere) the device's greedy stream leaves the reference's golden stream, the ORACLE itself must see a
+    near-tie there: its logits for the two candidate tokens, given the common prefix, differ by less than one fp16
+    spacing of their magnitude.  Reports the full-stream common prefix."""
+    import math
+    from triforce_amd.utils.decoding import TriForce
+    for name in ("small_gamma6", "cfg1_greedy"):
+        g = Hh.load_golden(name)
+        ge = Hh.build_product(g, DEV, graphs=True)
+        res = TriForce(Hh.FakeTokenizer(), ge, Hh.prompt_of(g).to(DEV), gamma=g["gamma"], max_len=g["gen_len"], top_k=-1,
+                       top_p=g["top_p"], temperature=g["temperature"], return_details=True)
+        gold, dev = g["triforce"][0]["tokens"], res["tokens"]
+        n = min(len(gold), len(dev))
+        common = Hh.common_prefix(dev[:n], gold[:n])
+        print(f"[parity] {name}: device greedy stream == golden stream for {common}/{n} tokens")
+        if common == n:
+            continue
+        eng, _, _ = Hh.build_oracle(g)
+        prompt = Hh.prompt_of(g)
+        eng.kv_cache.reset()
+        logits = eng.inference(prompt)[0, -1]
+        for i in range(common - 1):                                  # oracle forced along the common prefix
+            logits = eng.model.forward(torch.tensor([[dev[i]]]), eng.kv_cache, None)[0, -1]
+        if common > 0:
+            logits = eng.model.forward(torch.tensor([[dev[common - 1]]]), eng.kv_cache, None)[0, -1]
+        a, b = float(logits[dev[common]]), float(logits[gold[common]])
+        spacing = 2.0 ** (math.floor(math.log2(max(abs(a), abs(b), 2.0 ** -14))) - 10)
+        assert abs(a - b) <= spacing, (f"{name}: streams split at token {common} ({dev[common]} vs {gold[common]}) where "
+                                       f"the oracle's logits differ by {abs(a - b):.5f} > one fp16 spacing {spacing:.5f}")
+
+
+def test_7b_dimension_layer_logits_match_oracle():
+    """One decoder layer at the 7B's real widths (hidden 4096, 32 heads x 128, intermediate 11008, vocabulary 32000,
+    YaRN tables) over a 4 103-slot retrieval cache: the fused decode kernels (norm / RoPE / residual epilogues, split-KV
+    attention, fp32-out lm_head) against the oracle's op-by-op forward, at the logit bar of the small configs."""
+    from oracle import specs
+    from triforce_amd.models.cache import FlashSimpleCache, RetrievalCache
+    from triforce_amd.models.config_yarn import LlamaConfig
+    from triforce_amd.models.modeling_llama import LlamaForCausalLM
+    cfg = specs.llama2_7b_128k_config()
+    cfg["num_hidden_layers"] = 1
+    sd = specs.random_state_dict(cfg, 31, head_std=0.05)
+    gamma, budget, prefill = 6, 4096, 8192
+    ot = M.OracleTarget(cfg, sd)
+    ogc = M.RetrievalCacheO(cfg, budget, prefill, 8, gamma)
+    gen = torch.Generator().manual_seed(5)
+    ogc.key_cache.copy_(torch.randn(ogc.key_cache.shape, generator=gen).half())
+    ogc.value_cache.copy_(torch.randn(ogc.value_cache.shape, generator=gen).half())
+    okv = M.FullCache(cfg, 64)
+    model = LlamaForCausalLM.from_state_dict(LlamaConfig.from_dict(cfg), sd, DEV)
+    pg = RetrievalCache(model, max_budget=budget, prefill=prefill, gamma=gamma, chunk_size=8)
+    pg.k.copy_(ogc.key_cache.permute(0, 2, 1, 3))
+    pg.v.copy_(ogc.value_cache.permute(0, 2, 1, 3))
+    pkv = FlashSimpleCache(model, 64)
+    ids = torch.randint(3, 32000, (1, gamma + 1), generator=gen)
+    pos = torch.arange(100000, 100000 + gamma + 1).unsqueeze(0)
+    want = ot.forward(ids, okv, ogc, position_ids=pos, spec=True)
+    got = model(input_ids=ids.to(DEV), kv_cache=pkv, graph_cache=pg, position_ids=pos.to(DEV), spec=True).logits.cpu()
+    _logit_check("7B-width layer, retrieval-cache forward", got, want)
+    s = pg.spec_slot                                                     # the gamma+1 rows written by the fused epilogue
+    dk = (pg.k[0, :, s:].permute(1, 0, 2).cpu().float() - ogc.key_cache[0, s:].float()).abs()
+    assert float(dk.max()) < 2e-2 and float(dk.mean()) < 2e-4
+    trail = want.max(-1).values - want.gather(-1, got.argmax(-1, keepdim=True))[..., 0]   # device argmax vs oracle's best
+    assert float(trail.max()) < GAP_TOL
 
 
 def test_full_scale_7b_greedy_triforce_is_lossless_on_device():
