@@ -69,6 +69,12 @@ def parse(argv=None):
                     help="real = chunked prefill through the model; synthetic = N(0,1) KV fill "
                          "(the reference's own filler, DistributedSimpleCache.normal_, cache.py:303-308)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--on-chip", type=int, default=-1,
+                    help="tensor-parallel / offloading engine: layers whose KV stays in HBM (-1 = all; fewer = the "
+                         "offloading tier: the rest streams from pinned host memory every target forward)")
+    ap.add_argument("--engine", default="auto", choices=["auto", "single", "tp"],
+                    help="auto = single-GPU engine at --gpus 1, tensor-parallel engine above; tp forces the "
+                         "TP / offloading engine (test/offloading_TP.py's) at any world size")
     ap.add_argument("--dry-run", action="store_true",
                     help="tensor-parallel path only: build the process group, the sharded engine and its weights, agree "
                          "across ranks, print the JSON line with dry_run=true and exit (no decode; runs on CPU under gloo)")
@@ -370,7 +376,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
-    if world > 1 or os.environ.get("TRIFORCE_BENCH_FORCE_TP") == "1":
+    if world > 1 or args.engine == "tp" or args.on_chip >= 0 or os.environ.get("TRIFORCE_BENCH_FORCE_TP") == "1":
         from bench_tp import run_tp                  # tensor-parallel decode (heads sharded, RCCL all-reduce)
         return run_tp(args, rank, world, local)
     torch.cuda.set_device(local)

@@ -12,6 +12,67 @@ import torch
 import torch.distributed as dist
 
 
+def offload_report(llm, args, tcfg, world, device):
+    """The offloading tier in numbers (this rank): bytes a target verify pulls over PCIe, its latency, the H2D rate that
+    implies, the rate of the same copies with nothing else running, and how much of the shorter of (copy, compute) is
+    hidden under the longer one."""
+    from triforce_amd import ops
+    L, n_on = tcfg.num_hidden_layers, llm.on_chip_layers
+    S = llm.kv_cache.seq_len
+    q = args.gamma + 2
+    ids = torch.full((1, q), 100, dtype=torch.long, device=device)
+
+    def timed(fn, n=2):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n
+
+    def verify():
+        llm.inference(input_ids=ids)
+        llm.kv_cache.seq_len = S                               # probe: roll back (the written-back rows are scratch)
+    t_verify = timed(verify)
+    Hl, D = tcfg.num_attention_heads // world, tcfg.head_dim
+    per_layer = 2 * S * Hl * D * 2
+    h2d = per_layer * (L - n_on)
+
+    def pure_copy():                                           # one offloaded layer's K and V, copy stream only
+        llm.kv_buffer[0].copy_kv(llm.kv_cache, n_on, llm.load_stream)
+        torch.cuda.current_stream().wait_stream(llm.load_stream)
+    t_copy_layer = timed(pure_copy, n=3)
+    pure_rate = per_layer / t_copy_layer / 1e6                 # GB/s
+    t_copy = t_copy_layer * (L - n_on)
+    # compute alone: the same forward over HBM-resident layers only, scaled to all layers
+    llm_on = max(n_on, 1)
+    t_compute = None
+    try:
+        x = llm.embed_tokens[ids.reshape(-1)]
+        pos = (S + torch.arange(q, device=device)).contiguous()
+
+        def resident():
+            d = None
+            for idx in range(llm_on):
+                kl, vl = llm.kv_cache.layer_kv(idx)
+                d = llm._layer(idx, x.clone(), d, pos, kl, vl, S, S + q, q)
+        t_compute = timed(resident) * L / llm_on
+    except Exception:
+        pass
+    out = {"on_chip_layers": n_on, "offloaded_layers": L - n_on, "kv_tokens": S,
+           "h2d_bytes_per_target_verify": h2d, "target_verify_ms": round(t_verify, 2),
+           "h2d_GBps_during_verify": round(h2d / t_verify / 1e6, 2), "pure_h2d_GBps": round(pure_rate, 2),
+           "pcie_link_GBps_spec": 63.0, "copy_alone_ms": round(t_copy, 2),
+           "compute_alone_ms_est": round(t_compute, 2) if t_compute else None}
+    if t_compute:
+        hidden = t_copy + t_compute - t_verify
+        out["overlap_fraction"] = round(max(0.0, min(1.0, hidden / min(t_copy, t_compute))), 3)
+    return out
+
+
 def run_tp(args, rank, world, local):
     from bench import _Tok, attn_roofline, resolve_weights, target_config
     from triforce_amd.models.aligned import parse_spec
@@ -40,7 +101,8 @@ def run_tp(args, rank, world, local):
     llm = DistributedLlama(tspec, config=tcfg, local_rank=rank, world_size=world, device=device,
                            prefill=args.prefill, gen_len=args.gen_cap, temperature=args.temp, top_p=args.top_p,
                            retrieval_budget=args.budget, retrieval_chunk_size=args.chunk_size, kv_offload=True,
-                           on_chip_layers=tcfg.num_hidden_layers, draft=draft, draft_cache=dcache, gamma=args.gamma)
+                           on_chip_layers=tcfg.num_hidden_layers if args.on_chip < 0 else args.on_chip,
+                           draft=draft, draft_cache=dcache, gamma=args.gamma)
     llm.init_parameters(load_checkpoint_state_dict(tspec) if kind == "checkpoint" else tspec)
     if args.dry_run:                                            # launcher / rendezvous / sharding plumbing only
         shard = torch.tensor([llm.weights.H_local, llm.weights.I_local, rank], dtype=torch.int64, device=device)
@@ -92,6 +154,7 @@ def run_tp(args, rank, world, local):
     dist.barrier()
     t2 = time.time()
     timer, ops.ATTN_TIMER = ops.ATTN_TIMER, None
+    offload = offload_report(llm, args, tcfg, world, device) if llm.on_chip_layers < tcfg.num_hidden_layers else None
     elapsed = torch.tensor([t2 - t1], dtype=torch.float64, device=device)
     dist.all_reduce(elapsed, dist.ReduceOp.MAX)                 # slowest rank defines the job time
     seconds = float(elapsed.item())
@@ -108,10 +171,12 @@ def run_tp(args, rank, world, local):
             "config": {"workload": f"BASELINE configs[1] shapes, tensor-parallel: {tcfg._name_or_path} TriForce decode, "
                                    f"prefill {args.prefill}, budget {args.budget}, chunk {args.chunk_size}, gamma "
                                    f"{args.gamma}, T={args.temp}, top_p={args.top_p}, TP={world} over RCCL/xGMI, "
-                                   f"KV resident in HBM",
+                                   + ("KV resident in HBM" if offload is None else
+                                      f"KV of {offload['offloaded_layers']} layers in pinned host memory (on_chip "
+                                      f"{offload['on_chip_layers']})"),
                        "parallelism": f"tp{world}", "world_size_observed": dist.get_world_size(),
                        "prefill_mode": args.prefill_mode, "weights": wlabel, "weights_kind": kind},
-            "aligned_calibration": cal,
+            "aligned_calibration": cal, "offload": offload,
             "avg_accepted_len": round(accepted / max(drafted, 1) * args.gamma, 4),
             "acceptance_rate": round(accepted / max(drafted, 1), 4), "tokens": tokens,
             "tokens_per_step": round(tokens / args.steps, 3), "prefill_seconds": round(t_prefill, 2),

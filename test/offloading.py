@@ -22,7 +22,7 @@ def main():
     args = cli.parse("offloading")
     cli.target_config(args.target)
     target = cli.load_causal_lm(LlamaForCausalLM, args.weights, args.target, DEVICE)
-    draft = cli.load_causal_lm(LlamaForCausalLM_68M, args.draft_weights, "llama-68M", DEVICE)
+    draft = cli.load_causal_lm(LlamaForCausalLM_68M, cli.draft_weights(args), "llama-68M", DEVICE)
     tokenizer, prompts = cli.load_prompts(args, target.config.vocab_size)
     sampling = dict(top_k=-1, top_p=args.top_p, temperature=args.temp)
     print_config(draft, target, args.prefill, args.gen_len, args.gamma, file_path=None, method="TriForce (Offloading)",

@@ -38,7 +38,7 @@ def run_baseline(args, tcfg, tokenizer, prompts, rank, world, device):
 
 def run_triforce(args, tcfg, tokenizer, prompts, rank, world, device):
     gamma = int(args.gamma)
-    draft = cli.load_causal_lm(LlamaForCausalLM_68M, args.draft_weights, "llama-68M", device)      # replicated on every rank
+    draft = cli.load_causal_lm(LlamaForCausalLM_68M, cli.draft_weights(args), "llama-68M", device)      # replicated on every rank
     draft_cache = StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - gamma, gamma=gamma)
     llm = make_engine(args, tcfg, rank, world, device, retrieval_budget=args.budget, draft=draft,
                       draft_cache=draft_cache, gamma=gamma)

@@ -114,8 +114,8 @@ class OffloadingFlashSimpleCache(Cache):
         self.hidden_size = model.config.hidden_size
         self.device = model.device
         L, H, T, D = self.layers, self.num_heads, max_budget, self.head_dim
-        self.cpu_k = _pin(torch.zeros(L, H, T, D, dtype=torch.float16))
-        self.cpu_v = _pin(torch.zeros(L, H, T, D, dtype=torch.float16))
+        self.cpu_k = _pinned_zeros(L, H, T, D)
+        self.cpu_v = _pinned_zeros(L, H, T, D)
         self.key_cache, self.value_cache = _ref_view(self.cpu_k), _ref_view(self.cpu_v)
         self.buf_k = [torch.zeros(H, T, D, dtype=torch.float16, device=self.device) for _ in range(2)]
         self.buf_v = [torch.zeros(H, T, D, dtype=torch.float16, device=self.device) for _ in range(2)]
@@ -338,6 +338,12 @@ def _pin(t):
     return t.pin_memory() if torch.cuda.is_available() else t
 
 
+def _pinned_zeros(*shape):
+    """fp16 zeros in pinned host memory, allocated pinned from the start (t.pin_memory() would hold a pageable AND a
+    pinned copy of a 50 GB offloaded cache for a moment)."""
+    return torch.zeros(*shape, dtype=torch.float16, pin_memory=torch.cuda.is_available())
+
+
 class DistributedSimpleCache(Cache):
     """This rank's heads of the full KV cache: layers < on_chip_layers live in HBM, the rest in pinned host
     memory and are streamed through two DistributedKVCacheBuffer's (reference cache.py:268-351).
@@ -357,8 +363,8 @@ class DistributedSimpleCache(Cache):
         self.seq_len = 0
         n_on, n_off = self.on_chip_layers, self.layers - self.on_chip_layers
         self.k, self.v = _alloc(n_on, self.num_heads, max_budget, self.head_dim, self.device)
-        self.cpu_k = _pin(torch.zeros(n_off, self.num_heads, max_budget, self.head_dim, dtype=torch.float16))
-        self.cpu_v = _pin(torch.zeros(n_off, self.num_heads, max_budget, self.head_dim, dtype=torch.float16))
+        self.cpu_k = _pinned_zeros(n_off, self.num_heads, max_budget, self.head_dim)
+        self.cpu_v = _pinned_zeros(n_off, self.num_heads, max_budget, self.head_dim)
         self.key_cache, self.value_cache = _ref_view(self.k), _ref_view(self.v)
         self.cpu_key_cache, self.cpu_value_cache = _ref_view(self.cpu_k), _ref_view(self.cpu_v)
 

@@ -34,6 +34,13 @@ def _dev(*ts):
             raise hip.TriforceHipError("triforce_amd ops need HIP device tensors (no CPU fallback)")
 
 
+def _dev_or_pinned(t):
+    """Small result records may live in pinned host memory (device-writable under unified addressing): the host then
+    polls the record instead of copying it back."""
+    if not (t.is_cuda or t.is_pinned()):
+        raise hip.TriforceHipError("result record must be a HIP device tensor or pinned host memory")
+
+
 def _kv(t):
     assert t.dim() == 3 and t.stride(2) == 1 and t.dtype == _HALF, "KV layer view must be (H,T,D) fp16, D contiguous"
     return t.stride(1), t.stride(0)          # stride_t, stride_h
@@ -474,7 +481,8 @@ def topp_probs(logits, temperature, top_p):
 
 def sample_inverse_cdf(probs, u, token_out):
     """token_out[0] <- first index with inclusive cumsum(probs) > u[0]*sum(probs).  All device tensors."""
-    _dev(probs, u, token_out)
+    _dev(probs, u)
+    _dev_or_pinned(token_out)
     assert probs.dtype == torch.float32 and probs.is_contiguous() and probs.dim() == 1
     assert u.dtype == torch.float32 and token_out.dtype == torch.int64
     hip.check(hip.lib().tf_sample_inverse_cdf(_ptr(probs), _ptr(u), _ptr(token_out), probs.numel(), _stream()),
@@ -483,7 +491,8 @@ def sample_inverse_cdf(probs, u, token_out):
 
 def accept_chain(p, q, tokens, uniforms, g2, inclusive, eos_token_id, out):
     """out[4] int64 <- (count, next_token, reason, uniforms_consumed); see include/triforce_hip.h."""
-    _dev(p, q, tokens, uniforms, out)
+    _dev(p, q, tokens, uniforms)
+    _dev_or_pinned(out)
     V = p.shape[-1]
     assert p.dtype == torch.float32 and p.is_contiguous() and p.shape[0] >= g2 + 1
     assert q.dtype == torch.float32 and q.is_contiguous() and q.shape[0] >= g2 and q.shape[-1] == V
@@ -496,7 +505,8 @@ def accept_chain(p, q, tokens, uniforms, g2, inclusive, eos_token_id, out):
 
 def middle_accept(p, q_d, tokens, uniforms, n, gamma, out):
     """One Middle_Spec step on device: out[3] int64 <- (accepted, follow_up_token, drafted_token)."""
-    _dev(p, q_d, tokens, uniforms, out)
+    _dev(p, q_d, tokens, uniforms)
+    _dev_or_pinned(out)
     V = p.shape[-1]
     assert p.dtype == torch.float32 and p.is_contiguous() and q_d.dtype == torch.float32 and q_d.numel() == V
     assert tokens.dtype == torch.int64 and tokens.numel() >= gamma + 1 and uniforms.numel() >= 2

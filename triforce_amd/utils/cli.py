@@ -19,7 +19,8 @@ _COMMON = [
 ]
 # ---- offline additions (the reference hard-codes hub ids) -------------------------------------------------------
 _OFFLINE = [
-    ("--weights", str, "random:1", "random:<seed> or a local HF checkpoint dir"),
+    ("--weights", str, "random:1", "random:<seed>, aligned[:draft_acc[:retrieval_acc[:seed]]] (synthetic pair with set "
+                                   "acceptance rates, models/aligned.py) or a local HF checkpoint dir"),
     ("--tokenizer", str, "none", "local tokenizer dir, or none"),
 ]
 _SINGLE_GPU = [
@@ -83,8 +84,13 @@ def target_config(name):
 def load_causal_lm(cls, weights, config_name, device):
     """``random:<seed>`` -> random init of the named architecture; anything else is a local HF checkpoint directory."""
     from ..models import zoo
-    cfg = zoo.config(config_name) if weights.startswith("random") else None
+    cfg = zoo.config(config_name) if weights.startswith(("random", "aligned")) else None
     return cls.from_pretrained(weights, torch_dtype=torch.float16, device_map=device, config=cfg).eval()
+
+
+def draft_weights(args):
+    """The 68M draft's weight spec: an aligned synthetic target brings its aligned draft (same planted table)."""
+    return args.weights if args.weights.startswith("aligned") else args.draft_weights
 
 
 def load_prompts(args, vocab_size):
@@ -100,7 +106,8 @@ def shard_weights(llm, weights, local_rank, world_size):
     from ..models.llama_core import load_checkpoint_state_dict
     for rank in range(world_size):
         if local_rank == rank:
-            llm.init_parameters(weights if weights.startswith("random") else load_checkpoint_state_dict(weights))
+            llm.init_parameters(weights if weights.startswith(("random", "aligned"))
+                                else load_checkpoint_state_dict(weights))
         dist.barrier()
 
 

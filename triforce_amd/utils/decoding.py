@@ -64,15 +64,83 @@ def Autoregressive(tokenizer, graph_engine, input_ids, max_len=256, top_k=-1, to
     return n / (time2 - time1)
 
 
+class _Record:
+    """A small int64 decision record written by a kernel and read by the host once per (inner / outer) step.
+    mailbox=True: the record lives in PINNED HOST memory that the kernel writes directly (unified addressing); the host
+    arms it with a sentinel before the launch and polls — no device-to-host copy, no stream synchronisation (~20 us of
+    idle GPU per read otherwise, 5 reads per step).  Else: a device tensor read with .tolist() (what TP needs: the
+    record is broadcast over RCCL first)."""
+
+    SENTINEL = -(1 << 62)
+
+    def __init__(self, device, n, mailbox):
+        self.n = n
+        self.mailbox = bool(mailbox) and torch.device(device).type == "cuda"
+        if self.mailbox:
+            self.tensor = torch.zeros(n, dtype=torch.int64).pin_memory()
+            self._np = self.tensor.numpy()
+        else:
+            self.tensor = torch.zeros(n, dtype=torch.int64, device=device)
+
+    def arm(self, k):
+        if self.mailbox:
+            self._np[:k] = self.SENTINEL
+
+    def read(self, k):
+        if not self.mailbox:
+            return self.tensor[:k].tolist()
+        view, s, spins = self._np[:k], self.SENTINEL, 0
+        while (view == s).any():
+            spins += 1
+            if spins > 50_000_000:
+                raise RuntimeError("decision record never arrived (kernel failed?)")
+        return view.tolist()
+
+
+_MAILBOX_OK = {}
+
+
+def _mailbox_supported(device):
+    """One-off probe per device: a kernel writes a pinned host record and the host sees it without any synchronisation
+    (coherent pinned memory).  TRIFORCE_MAILBOX=0 forces the copy-back path."""
+    import os
+    key = str(torch.device(device))
+    if key not in _MAILBOX_OK:
+        ok = False
+        if torch.device(device).type == "cuda" and os.environ.get("TRIFORCE_MAILBOX", "1") != "0":
+            try:
+                rec = _Record(device, 4, True)
+                probs = torch.zeros(64, dtype=torch.float32, device=device)
+                probs[5] = 1.0
+                rec.arm(1)
+                ops.sample_inverse_cdf(probs, torch.full((1,), 0.5, device=device), rec.tensor[:1])
+                t0 = time.time()
+                while int(rec._np[0]) == rec.SENTINEL and time.time() - t0 < 0.25:
+                    pass
+                ok = int(rec._np[0]) == 5
+                torch.cuda.synchronize(device)
+            except Exception:
+                ok = False
+        _MAILBOX_OK[key] = ok
+    return _MAILBOX_OK[key]
+
+
 class _SpecBuffers:
     """Per-engine device scratch reused across iterations (allocated once)."""
 
-    def __init__(self, device, gamma, vocab):
-        self.verify_tokens = torch.full((1, gamma + 1), PAD_TOKEN, dtype=torch.long, device=device)
+    def __init__(self, device, gamma, vocab, graph_engine=None, mailbox=False):
+        tok_buf = getattr(graph_engine, "tok_buf", None)
+        if tok_buf is not None and tok_buf.shape[1] >= gamma + 1:
+            # the engine's graphs read their tokens / positions from these very buffers: no input copies per replay
+            self.verify_tokens = tok_buf[:, :gamma + 1]
+            self.positions = graph_engine.pos_buf
+        else:
+            self.verify_tokens = torch.full((1, gamma + 1), PAD_TOKEN, dtype=torch.long, device=device)
+            self.positions = torch.zeros((1, gamma + 1), dtype=torch.long, device=device)
         self.spec_rows = torch.empty(gamma + 2, vocab, dtype=torch.float32, device=device)
-        self.mid_out = torch.zeros(4, dtype=torch.int64, device=device)
-        self.chain_out = torch.zeros(4, dtype=torch.int64, device=device)
-        self.positions = torch.zeros((1, gamma + 1), dtype=torch.long, device=device)
+        mailbox = bool(mailbox) and _mailbox_supported(device)
+        self.mid_out = _Record(device, 4, mailbox)
+        self.chain_out = _Record(device, 4, mailbox)
         self.pos_base = torch.arange(gamma + 1, dtype=torch.long, device=device).unsqueeze(0)
         # host -> device token lists go through one pinned staging row (a pageable source makes the copy synchronous)
         cuda = torch.device(device).type == "cuda"
@@ -93,10 +161,13 @@ class _SpecBuffers:
         return row.unsqueeze(0)
 
 
-def _buffers(graph_engine, gamma, vocab, device):
+def _buffers(graph_engine, gamma, vocab, device, mailbox=False):
     b = getattr(graph_engine, "_tf_spec_buffers", None)
-    if b is None or b.verify_tokens.shape[1] != gamma + 1 or b.spec_rows.shape[1] != vocab:
-        b = _SpecBuffers(device, gamma, vocab)
+    stale = b is not None and getattr(graph_engine, "tok_buf", None) is not None \
+        and b.verify_tokens.data_ptr() != graph_engine.tok_buf.data_ptr()        # graphs were re-captured
+    if b is None or stale or b.verify_tokens.shape[1] != gamma + 1 or b.spec_rows.shape[1] != vocab \
+            or b.mid_out.mailbox != (bool(mailbox) and _mailbox_supported(device)):
+        b = _SpecBuffers(device, gamma, vocab, graph_engine, mailbox)
         graph_engine._tf_spec_buffers = b
     return b
 
@@ -109,7 +180,7 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
     device = eng.model.device
     rng = rng or UniformSource(device)
     if buffers is None:
-        buffers = _buffers(graph_engine, gamma, eng.model.config.vocab_size, device)
+        buffers = _buffers(graph_engine, gamma, eng.model.config.vocab_size, device, mailbox=sync_record is None)
     S = eng.kv_cache.seq_len
     n = accepted = drafted = 0
     ids = [int(next_token)]
@@ -128,18 +199,22 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
         if sync_record is not None:           # TP: rank 0's draft token is everyone's BEFORE the all-reduced verify runs
             sync_record(flat[n + 1:n + 2])    # on it (the reference's sample_dist, decoding.py:230-239,452)
         p = graph_engine.graph_verify(input_ids=vt, position_ids=position_ids, **noclone)
-        ops.middle_accept(p, q_d, flat, u[1:3], n, gamma, buffers.mid_out)   # accept test + follow-up sample
+        rec = buffers.mid_out
+        rec.arm(3)
+        ops.middle_accept(p, q_d, flat, u[1:3], n, gamma, rec.tensor)         # accept test + follow-up sample
         if sync_record is not None:                                           # TP: rank 0's decision wins
-            sync_record(buffers.mid_out)
+            sync_record(rec.tensor)
             if n + 1 < flat.numel():
-                flat[n + 1:n + 3].copy_(_mid_tokens(buffers.mid_out, n, gamma, flat))
-        acc, b, d = buffers.mid_out[:3].tolist()                              # the one host sync of this step
+                flat[n + 1:n + 3].copy_(_mid_tokens(rec.tensor, n, gamma, flat))
+        acc, b, d = rec.read(3)                                               # the one host read of this step
         rng.advance(3)
         drafted += 1
-        g = len(ids) - 1
+        g = len(ids) - 1                                                      # == n: verify_tokens holds exactly ids
+        if not noclone:
+            buffers.spec_rows[g].copy_(p[n])                                  # decoding.py:193-220: q row(s) of this step
+            if acc:
+                buffers.spec_rows[g + 1].copy_(p[n + 1])
         if acc:                                                               # decoding.py:193-209
-            buffers.spec_rows[g].copy_(p[n])
-            buffers.spec_rows[g + 1].copy_(p[n + 1])
             ids += [d, b]
             accepted += 1
             n += 2
@@ -147,11 +222,15 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
                 spec_stream(d, tokenizer, "green")
                 spec_stream(b, tokenizer, "blue")
         else:                                                                 # decoding.py:211-220
-            buffers.spec_rows[g].copy_(p[n])
             ids.append(b)
             n += 1
             if verbose:
                 spec_stream(b, tokenizer, "red")
+    if noclone:
+        # Static verify output: row i of the LAST replay is the retrieval model's distribution after tokens 0..i —
+        # the very row an earlier replay produced when position i was decided (same graph, same tokens <= i, same
+        # cache; the kernels are deterministic), so the rows need not be copied out step by step.
+        return ids, p[:len(ids) - 1], accepted / drafted
     return ids, buffers.spec_rows[:len(ids) - 1], accepted / drafted
 
 
@@ -188,7 +267,8 @@ class TriForceRunner:
         self.device = self.eng.model.device
         self.rng = rng or UniformSource(self.device)
         self.eos = _eos(tokenizer)
-        self.bufs = _buffers(graph_engine, gamma, self.eng.model.config.vocab_size, self.device)
+        self.bufs = _buffers(graph_engine, gamma, self.eng.model.config.vocab_size, self.device,
+                             mailbox=sync_record is None)
         self.resample_count = self.accepted_count = self.target_sample_count = self.draft_count = 0
         self.n = 0
         self.inner_iters = 0          # Middle_Spec iterations = 68M draft calls = retrieval-verify replays
@@ -255,11 +335,13 @@ class TriForceRunner:
             logits = ge.inference(input_ids=verify_tokens, rebuild_retrieval=True) if rebuild \
                 else ge.inference(input_ids=verify_tokens)
             probs = norm_logits(logits[0], temperature=self.temperature, top_k=self.top_k, top_p=self.top_p)
+        rec = bufs.chain_out
+        rec.arm(4)
         ops.accept_chain(probs, spec_rows, verify_tokens.view(-1)[1:], rng.take(g2 + 1), g2, self.inclusive_accept,
-                         self.eos, bufs.chain_out)
+                         self.eos, rec.tensor)
         if self.sync_record is not None:
-            self.sync_record(bufs.chain_out)
-        count, pred, reason, consumed = bufs.chain_out.tolist()          # the one host sync of the outer step
+            self.sync_record(rec.tensor)
+        count, pred, reason, consumed = rec.read(4)                      # the one host read of the outer step
         if self.inclusive_accept and reason == 1 and generated[g2 - 1] == self.eos:
             # TP loop only: an eos accepted as the LAST drafted token ends the loop before the bonus sample
             # (decoding.py:357-360,382-383); the on-chip loop — and tf_accept_chain — go on to the bonus token (:127)

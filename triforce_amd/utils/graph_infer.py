@@ -130,7 +130,8 @@ class _GraphedCall:
 
     def __call__(self, *live, clone=True):
         for buf, value in zip(self.inputs, live):
-            buf.copy_(value)
+            if not (value.data_ptr() == buf.data_ptr() and value.shape == buf.shape and value.stride() == buf.stride()):
+                buf.copy_(value)                   # the caller may also write the static input buffer directly
         self.graph.replay()
         # clone=False hands out the static output buffer itself: valid until THIS graph is replayed again (the decode
         # loops consume a draft / verify result before they ask for the next one)
@@ -138,23 +139,27 @@ class _GraphedCall:
 
 
 def draft_run_capture_graph(engine: InferenceEngine, gamma_offset: int = 0, mempool=None, n_warmups: int = 3, probs=False,
-                            temperature=0.6, top_p=0.9, verbose=True):
-    """One 68M draft step over ``gamma_offset + 1`` tokens (reference graph_infer.py:74-97)."""
+                            temperature=0.6, top_p=0.9, verbose=True, ids=None):
+    """One 68M draft step over ``gamma_offset + 1`` tokens (reference graph_infer.py:74-97).  ``ids``: static input
+    buffer to capture over (default: a fresh one)."""
     if verbose:
         print(f"[draft run] capturing graph for {gamma_offset} (probs={probs}, temp={temperature}, top_p={top_p})...")
-    ids = torch.zeros((1, gamma_offset + 1), dtype=torch.long, device=engine.draft.device)
+    if ids is None:
+        ids = torch.zeros((1, gamma_offset + 1), dtype=torch.long, device=engine.draft.device)
     return _GraphedCall(lambda t: engine.draft_run(input_ids=t, gamma_offset=gamma_offset, probs=probs,
                                                    temperature=temperature, top_p=top_p), (ids,), mempool, n_warmups)
 
 
 def model_verify_capture_graph(engine: InferenceEngine, mempool=None, n_warmups: int = 3, gamma: int = 6, probs=False,
-                               temperature=0.6, top_p=0.9, verbose=True):
+                               temperature=0.6, top_p=0.9, verbose=True, ids=None, pos=None):
     """The retrieval-cache verify over ``gamma + 1`` tokens at explicit positions (reference graph_infer.py:99-127)."""
     if verbose:
         print(f"[model verify] capturing graph for spec len {gamma} (probs={probs}, temp={temperature}, top_p={top_p})...")
     dev = engine.model.device
-    ids = torch.zeros((1, gamma + 1), dtype=torch.long, device=dev)
-    pos = torch.arange(gamma + 1, device=dev).unsqueeze(0)
+    if ids is None:
+        ids = torch.zeros((1, gamma + 1), dtype=torch.long, device=dev)
+    if pos is None:
+        pos = torch.arange(gamma + 1, device=dev).unsqueeze(0)
     return _GraphedCall(lambda t, p: engine.model_verify(input_ids=t, position_ids=p, probs=probs, temperature=temperature,
                                                          top_p=top_p), (ids, pos), mempool, n_warmups)
 
@@ -209,6 +214,7 @@ class GraphInferenceEngine:
         self.callable_model_verify = None
         self.target_graphs = {}                    # q_len -> _TargetGraph (full-cache forward, device-resident lengths)
         self.static_outputs = True                 # graph_draft_inference / graph_verify accept clone=False
+        self.tok_buf = self.pos_buf = None         # shared static inputs of the draft / verify graphs (graphs only)
         self.mempool = None
         self.sampling = dict(probs=False, temperature=0.6, top_p=0.9)
 
@@ -220,8 +226,16 @@ class GraphInferenceEngine:
         self.mempool = torch.cuda.graphs.graph_pool_handle()
         self.sampling = dict(probs=probs, temperature=temperature, top_p=top_p)
         common = dict(engine=self.engine, mempool=self.mempool, n_warmups=3, verbose=verbose, **self.sampling)
-        self.callables = {off: draft_run_capture_graph(gamma_offset=off, **common) for off in range(gamma + 3)}
-        self.callable_model_verify = model_verify_capture_graph(gamma=gamma, **common)
+        # ONE token buffer is the static input of every draft graph (its first gamma_offset + 1 entries) and of the
+        # retrieval-verify graph (its first gamma + 1): the decode loop writes drafted tokens straight into it (the
+        # sampling / accept kernels do) and no per-replay input copy is left.  Same for the verify positions.
+        dev = self.engine.model.device
+        self.tok_buf = torch.zeros((1, gamma + 3), dtype=torch.long, device=dev)
+        self.pos_buf = torch.arange(gamma + 1, device=dev).unsqueeze(0).clone()
+        self.callables = {off: draft_run_capture_graph(gamma_offset=off, ids=self.tok_buf[:, :off + 1], **common)
+                          for off in range(gamma + 3)}
+        self.callable_model_verify = model_verify_capture_graph(gamma=gamma, ids=self.tok_buf[:, :gamma + 1],
+                                                                pos=self.pos_buf, **common)
         self.target_graphs = {}
         if capture_target and os.environ.get("TRIFORCE_TARGET_GRAPH", "1") != "0" \
                 and isinstance(self.engine.kv_cache, _graphable_cache()):
