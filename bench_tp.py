@@ -6,6 +6,7 @@ exchange step.  Total work is fixed, so scaling is "strong".  All layers stay re
 with 288 GB per MI355X the offloading tier is never needed for these shapes (it is exercised by the tests and
 by test/offloading_TP.py --on_chip)."""
 import json
+import os
 import time
 
 import torch
@@ -84,6 +85,12 @@ def run_tp(args, rank, world, local):
     from triforce_amd.utils.sampling import UniformSource
 
     on_gpu = torch.cuda.is_available()
+    if "RANK" not in os.environ:                                # one process, no launcher (--engine tp / --on-chip at N=1)
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     distributed_init("nccl" if on_gpu else "gloo")              # gloo: the CPU plumbing test (--dry-run)
     device = torch.device("cuda", local) if on_gpu else torch.device("cpu")
     if not on_gpu and not args.dry_run:
