@@ -249,6 +249,29 @@ int tf_kv_h2d_async(void* dst_dev, int64_t dst_pitch_elems, const void* src_host
 int tf_kv_d2h_async(void* dst_host, int64_t dst_pitch_elems, const void* src_dev, int64_t src_pitch_elems,
                     int64_t width_elems, int H, void* copy_stream);
 
+/* -------------------------------------------------------------------------------------------
+ * One-shot all-reduce over peer-mapped buffers (xGMI) — replaces dist.all_reduce at models/tensor_op.py:179,326,359
+ * for the 57..184 KB decode messages of the tensor-parallel path (2 per layer and forward; a ring collective pays
+ * 2(W-1) latency hops on each).  Every rank stages its fp16 partial in a FINE-GRAINED buffer its peers have mapped
+ * (tf_ar_alloc + tf_ar_get_ipc_handle / tf_ar_open_ipc_handle), exchanges one READY flag, reads all partials and adds
+ * them in rank order with fp32 accumulation (bit-identical on every rank), then exchanges one DONE flag so the staging
+ * buffer can be reused when the kernel ends.  The epoch lives in the control block: capturable in a hipGraph.  All
+ * spins are bounded (tf_ar_error != 0 afterwards = a peer never arrived).
+ *   peer_data / peer_flags : `world` device-visible pointers (own entry included); this rank's partial must already be
+ *                            in peer_data[rank], written by an earlier kernel of `stream`; n % 8 == 0 fp16 elements;
+ *                            `out` is ordinary device memory, not the staging buffer.
+ * ------------------------------------------------------------------------------------------- */
+int tf_ar_flags_bytes(void);
+int tf_ar_ipc_handle_bytes(void);
+int tf_ar_alloc(int64_t bytes, void** ptr);
+int tf_ar_free(void* ptr);
+int tf_ar_get_ipc_handle(void* ptr, void* handle_out);
+int tf_ar_open_ipc_handle(const void* handle, void** ptr_out);
+int tf_ar_close_ipc_handle(void* ptr);
+int tf_allreduce_oneshot(void* const* peer_data, void* const* peer_flags, int rank, int world, void* out, int64_t n,
+                         void* stream);
+int tf_ar_error(const void* flags_local);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,7 +65,7 @@ def test_ops_refuse_cpu_tensors():
 
 
 _QUERIES = {"tf_abi_version", "tf_attn_block_pick_nsplit", "tf_attn_block_ws_floats", "tf_attn_decode_pick_nsplit",
-            "tf_attn_decode_ws_floats"}
+            "tf_attn_decode_ws_floats", "tf_ar_flags_bytes", "tf_ar_ipc_handle_bytes"}
 
 
 @pytest.mark.parametrize("fill", [1, 8, -1])

@@ -148,8 +148,10 @@ def test_stochastic_triforce_with_injected_uniforms():
     ~1e-3 relative) move a CDF boundary across the uniform — measured: a stream survives 5 draws at the median — after
     which the two runs are different draws from the same distributions.  So the end-to-end claim is distributional:
       * the first token (one draw from the prefill distribution) agrees in almost every run, and runs share a prefix;
-      * the acceptance pooled over all runs sits inside a 4-sigma binomial band around the oracle's, and so do the
-        tokens emitted per outer step (a wrong sampler or accept rule moves both far outside)."""
+      * acceptance and tokens per outer step, run by run against the oracle's run on the same uniforms: the mean of the
+        paired differences stays within 4 standard errors of zero (accepted counts within a step are correlated, so the
+        spread is taken from the runs themselves, not from a binomial formula), and the pooled values within 20 %
+        (a wrong sampler or accept rule moves both far outside)."""
     import math
     from triforce_amd.utils.decoding import TriForce
     from triforce_amd.utils.sampling import UniformSource
@@ -158,7 +160,7 @@ def test_stochastic_triforce_with_injected_uniforms():
     ge = Hh.build_product(g, DEV, tsd, dsd, temperature=0.6, top_p=0.9, graphs=True)
     prompt = Hh.prompt_of(g)
     runs, max_len = 32, 24
-    prefixes = []
+    prefixes, d_acc, d_tok = [], [], []
     acc_w = dr_w = acc_g = dr_g = tok_w = tok_g = steps_w = steps_g = 0
     for seed in range(runs):
         us = Hh.fixed_uniforms(n=2048, seed=500 + seed)
@@ -171,14 +173,20 @@ def test_stochastic_triforce_with_injected_uniforms():
         acc_g, dr_g = acc_g + got["accepted"], dr_g + got["drafted"]
         tok_w, steps_w = tok_w + want["n"], steps_w + len(want["counts"])
         tok_g, steps_g = tok_g + got["n"], steps_g + len(got["counts"])
+        d_acc.append(got["accepted"] / max(got["drafted"], 1) - want["accepted"] / max(want["drafted"], 1))
+        d_tok.append(got["n"] / len(got["counts"]) - want["n"] / len(want["counts"]))
     print(f"[parity] stochastic common prefixes (of {max_len}+ tokens, {runs} runs): {sorted(prefixes)}")
     assert sum(1 for c in prefixes if c >= 1) >= runs - 3, prefixes          # the first draw agrees (near-)always
     assert sum(prefixes) / runs >= 3.0, prefixes
-    p_w = acc_w / dr_w
-    sigma = math.sqrt(max(p_w * (1 - p_w), 1e-4) / dr_g)
-    assert abs(acc_g / dr_g - p_w) <= 4 * sigma + 1e-9, (acc_g / dr_g, p_w, sigma)
+    for what, d in (("acceptance", d_acc), ("tokens per step", d_tok)):
+        mean = sum(d) / runs
+        se = math.sqrt(sum((x - mean) ** 2 for x in d) / (runs - 1) / runs)
+        print(f"[parity] stochastic {what}: mean paired difference {mean:+.4f} +- {se:.4f} (standard error)")
+        assert abs(mean) <= 4 * se + 1e-9, (what, mean, se)
+    p_w, p_g = acc_w / dr_w, acc_g / dr_g
     per_w, per_g = tok_w / steps_w, tok_g / steps_g
-    assert abs(per_g - per_w) <= 0.15 * per_w, (per_g, per_w)
+    print(f"[parity] stochastic pooled acceptance device {p_g:.3f} vs oracle {p_w:.3f}; tokens/step {per_g:.2f} vs {per_w:.2f}")
+    assert abs(p_g - p_w) <= 0.2 * max(p_w, 0.05) + 0.02 and abs(per_g - per_w) <= 0.2 * per_w
     assert acc_g > 0
 
 

@@ -178,3 +178,39 @@ def test_single_gpu_offloading_cache_equals_resident_cache():
     _, ar_res = Autoregressive(tok, ge_res, prompt, max_len=12, top_k=-1, top_p=g["top_p"], temperature=g["temperature"],
                                return_tokens=True)
     assert ar_off == ar_res
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_oneshot_allreduce_protocol_on_one_device(world):
+    """tf_allreduce_oneshot with `world` virtual ranks inside this process — each rank's kernel on its own stream, real
+    READY / DONE flag exchange between concurrently running kernels, fine-grained staging buffers — against the
+    arithmetic it promises: fp32 accumulation in rank order, one rounding, bit-identical on every rank (at world 2 that
+    is also exactly dist.all_reduce's fp16 sum).  Many back-to-back epochs on every size the decode path sends;
+    no wait may ever time out."""
+    from triforce_amd.utils.oneshot_ar import OneShotAllReduce, reference_sum
+    hidden, max_rows = 4096, 32
+    group = OneShotAllReduce.local_group(world, DEV, max_rows * hidden)
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(world)]
+    gen = torch.Generator(device=DEV).manual_seed(world)
+    try:
+        for it, rows in enumerate([1, 7, 8, 17, 18, 32, 7, 7, 18, 1] * 3):
+            parts = [torch.randn(rows, hidden, generator=gen, device=DEV).to(torch.float16) for _ in range(world)]
+            outs = [torch.empty(rows, hidden, dtype=torch.float16, device=DEV) for _ in range(world)]
+            torch.cuda.synchronize()
+            for r in range(world):
+                with torch.cuda.stream(streams[r]):
+                    st = group[r].staging(rows, hidden)
+                    st.copy_(parts[r])                               # the "producer kernel" of this rank
+                    group[r].reduce(st, outs[r])
+            torch.cuda.synchronize()
+            want = reference_sum(parts)
+            for r in range(world):
+                assert torch.equal(outs[r], want), f"epoch {it}, rank {r}: max err {(outs[r].float() - want.float()).abs().max()}"
+            if world == 2:
+                assert torch.equal(want, parts[0] + parts[1])       # one correctly rounded fp16 addition == the ring's
+        assert [g.error() for g in group] == [0] * world
+        with pytest.raises(AssertionError):
+            group[0].reduce(group[0].staging(8, hidden), group[0].staging(8, hidden))     # out must not alias the staging
+    finally:
+        for g in group:
+            g.close()

@@ -335,3 +335,38 @@ def test_sequoia_tp2_gloo_matches_the_reference_run_at_world_size_2():
         gap_v = (logits - step0["verify_logits"]).abs().max().item()
         assert gap_d < 2e-3 and gap_v < 2e-3, (gap_d, gap_v)
     print("bit-identical:", torch.equal(outs[0][3], step0["draft_logits"]), torch.equal(outs[0][4], step0["verify_logits"]))
+
+
+def _ar_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from triforce_amd.utils.oneshot_ar import reference_sum
+        g = torch.Generator().manual_seed(100 + rank)
+        ok = True
+        for rows in (1, 7, 18):
+            part = torch.randn(rows, 512, generator=g).to(torch.float16)
+            parts = [torch.zeros_like(part) for _ in range(world)]
+            dist.all_gather(parts, part)
+            ring = part.clone()
+            dist.all_reduce(ring, dist.ReduceOp.SUM)
+            ours = reference_sum(parts)                       # the one-shot kernel's arithmetic (rank order, fp32, one rounding)
+            if world == 2:
+                ok = ok and torch.equal(ours, ring)
+            else:
+                ok = ok and float((ours.float() - ring.float()).abs().max()) <= 2.0 ** -8 * float(ring.float().abs().max())
+        q.put((rank, "ok", ok))
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_oneshot_allreduce_arithmetic_matches_the_collective(world):
+    """CPU stand-in for tf_allreduce_oneshot's reduction (utils.oneshot_ar.reference_sum: fp32 accumulation in rank
+    order, one fp16 rounding) against dist.all_reduce over gloo: bit-identical at world 2 (the configuration the
+    reference's own launch line uses), within one fp16 rounding step of the ring's sequential order above that — the
+    tolerance DistributedLlama.enable_oneshot_allreduce applies in its self-check."""
+    outs = _run_world(_ar_worker, world=world)
+    assert all(o[2] for o in outs.values())

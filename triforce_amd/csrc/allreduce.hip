@@ -1,0 +1,196 @@
+// One-shot all-reduce over peer-mapped buffers (xGMI) for the decode-sized messages of the tensor-parallel path.
+//
+// Replaces dist.all_reduce at models/tensor_op.py:179,326,359 (after o_proj and after down_proj of every layer).  A
+// decode forward issues 2 * L of them on 7..18 rows x hidden fp16 = 57..184 KB each: pure latency.  A ring collective
+// pays 2 (W - 1) hops per call; here every rank stages its partial in a buffer its peers have mapped (hipIpc) and
+// each rank reads ALL partials itself and adds them — one exchange of flags, one pass of remote reads:
+//
+//   producer GEMM  -> writes this rank's partial into its staging buffer (kernel boundary = visible system-wide)
+//   phase READY    -> a rank tells every peer "my partial of epoch e is staged", waits for all peers' READY
+//   reduce         -> out[i] = fp16( sum over ranks r = 0..W-1 (in THIS order, fp32) of staging_r[i] )
+//   phase DONE     -> the last workgroup tells every peer "I have read your partial", waits for all peers' DONE:
+//                     when the kernel ends the staging buffer may be overwritten by the next producer
+//
+// Every rank adds the same values in the same order, so all ranks hold bit-identical results (the reference's NCCL
+// ring gives each rank the same bits too, with a different — sequential fp16 — rounding order; at world size 2 the two
+// are identical: one correctly rounded fp16 addition).  The epoch lives in device memory and is advanced by the kernel
+// itself, so a captured launch replays correctly.  Staging and flag buffers must be FINE-GRAINED device memory
+// (tf_ar_alloc): peers' stores and loads bypass the caches; plain device memory is only coherent across GPUs at kernel
+// boundaries.  Every spin is bounded; a timeout sets the error word instead of hanging the GPU.
+#include "common.h"
+#include <string.h>
+
+#define AR_MAX_WORLD 8
+#define AR_THREADS 256
+#define AR_SPIN_LIMIT (1u << 24)
+
+// One rank's control block (fine-grained memory, mapped by every peer)
+struct ArFlags {
+    unsigned ready[AR_MAX_WORLD];     // ready[p] = last epoch for which peer p staged its partial   (written by p)
+    unsigned done[AR_MAX_WORLD];      // done[p]  = last epoch whose reads of MY staging peer p finished (written by p)
+    unsigned epoch;                   // completed all-reduces on this rank (owner only)
+    unsigned ticket;                  // workgroups of the running launch that finished reducing (owner only)
+    unsigned error;                   // sticky: 1 = READY wait timed out, 2 = DONE wait timed out
+    unsigned pad[13];
+};
+
+struct ArComm {
+    const h16* data[AR_MAX_WORLD];    // staging buffer of every rank (own entry = local pointer)
+    ArFlags* flags[AR_MAX_WORLD];     // control block of every rank
+    int rank, world;
+};
+
+__device__ __forceinline__ unsigned ar_load(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void ar_store(unsigned* p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// lane p < world waits until *slot(p) reaches `epoch` (epochs only grow; wrap-safe compare); false on timeout
+__device__ __forceinline__ bool ar_wait(const unsigned* slot, unsigned epoch) {
+    for (unsigned spins = 0; spins < AR_SPIN_LIMIT; ++spins) {
+        if ((int)(ar_load(slot) - epoch) >= 0) return true;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c, h16* __restrict__ out, int64_t n_vec8) {
+    __shared__ unsigned s_epoch;
+    __shared__ int s_ok;
+    const int tid = threadIdx.x;
+    ArFlags* mine = c.flags[c.rank];
+    if (tid == 0) {
+        s_epoch = ar_load(&mine->epoch) + 1u;       // bumped only after every workgroup of this launch has read it
+        s_ok = 1;
+    }
+    __syncthreads();
+    const unsigned epoch = s_epoch;
+    // ---- READY: my partial was staged by the previous kernel in this stream ----
+    if (blockIdx.x == 0 && tid < c.world) ar_store(&c.flags[tid]->ready[c.rank], epoch);
+    if (tid < c.world && !ar_wait(&mine->ready[tid], epoch)) {
+        ar_store(&mine->error, 1u);
+        s_ok = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");    // system scope: nothing read below may predate the flags
+    __syncthreads();
+    // ---- reduce: 16-byte vectors, fixed rank order, fp32 accumulation, one rounding ----
+    if (s_ok) {
+        for (int64_t i = (int64_t)blockIdx.x * AR_THREADS + tid; i < n_vec8; i += (int64_t)gridDim.x * AR_THREADS) {
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            half8 v[AR_MAX_WORLD];
+#pragma unroll
+            for (int r = 0; r < AR_MAX_WORLD; ++r)
+                if (r < c.world) v[r] = *reinterpret_cast<const half8*>(c.data[r] + 8 * i);
+#pragma unroll
+            for (int r = 0; r < AR_MAX_WORLD; ++r)
+                if (r < c.world) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += (float)v[r][e];
+                }
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (h16)acc[e];
+            *reinterpret_cast<half8*>(out + 8 * i) = o;
+        }
+    }
+    // ---- DONE: the last workgroup of this launch releases the peers' staging buffers and waits for mine ----
+    __syncthreads();
+    __shared__ int s_last;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        const unsigned t = __hip_atomic_fetch_add(&mine->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid < c.world) ar_store(&c.flags[tid]->done[c.rank], epoch);
+    if (tid < c.world && !ar_wait(&mine->done[tid], epoch)) ar_store(&mine->error, 2u);
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(&mine->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ar_store(&mine->epoch, epoch);               // next launch (stream-ordered after this one) sees epoch + 1
+    }
+}
+
+// ---- C ABI -------------------------------------------------------------------------------------------------------
+extern "C" int tf_ar_flags_bytes(void) { return (int)sizeof(ArFlags); }
+extern "C" int tf_ar_ipc_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+
+// Fine-grained (cross-device coherent) device memory for staging / control blocks, zero-filled.
+extern "C" int tf_ar_alloc(int64_t bytes, void** ptr) {
+    if (!ptr || bytes < 1) return TF_EINVAL;
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemset(p, 0, (size_t)bytes);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return (int)e;
+    }
+    *ptr = p;
+    return TF_OK;
+}
+
+extern "C" int tf_ar_free(void* ptr) {
+    if (!ptr) return TF_EINVAL;
+    hipError_t e = hipFree(ptr);
+    return e == hipSuccess ? TF_OK : (int)e;
+}
+
+extern "C" int tf_ar_get_ipc_handle(void* ptr, void* handle_out) {
+    if (!ptr || !handle_out) return TF_EINVAL;
+    hipError_t e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(handle_out), ptr);
+    return e == hipSuccess ? TF_OK : (int)e;
+}
+
+extern "C" int tf_ar_open_ipc_handle(const void* handle, void** ptr_out) {
+    if (!handle || !ptr_out) return TF_EINVAL;
+    hipIpcMemHandle_t h;
+    memcpy((void*)&h, handle, sizeof(h));
+    hipError_t e = hipIpcOpenMemHandle(ptr_out, h, hipIpcMemLazyEnablePeerAccess);
+    return e == hipSuccess ? TF_OK : (int)e;
+}
+
+extern "C" int tf_ar_close_ipc_handle(void* ptr) {
+    if (!ptr) return TF_EINVAL;
+    hipError_t e = hipIpcCloseMemHandle(ptr);
+    return e == hipSuccess ? TF_OK : (int)e;
+}
+
+// out[0, n) = sum over ranks of staging_r[0, n) (fp16, fp32 accumulation in rank order).  peer_data / peer_flags: `world`
+// device-visible pointers (own entry included) to every rank's staging buffer / ArFlags block; this rank's partial must
+// already be in peer_data[rank] (written by an earlier kernel of `stream`); `out` is ordinary device memory and must not
+// alias the staging buffer.  n % 8 == 0.  Capturable: the epoch is kept in the control block.
+extern "C" int tf_allreduce_oneshot(void* const* peer_data, void* const* peer_flags, int rank, int world, void* out,
+                                    int64_t n, void* stream) {
+    if (!peer_data || !peer_flags || !out || world < 1 || world > AR_MAX_WORLD || rank < 0 || rank >= world) return TF_EINVAL;
+    if (n < 8 || (n % 8)) return TF_EINVAL;
+    ArComm c;
+    for (int r = 0; r < AR_MAX_WORLD; ++r) {
+        c.data[r] = (r < world) ? (const h16*)peer_data[r] : nullptr;
+        c.flags[r] = (r < world) ? (ArFlags*)peer_flags[r] : nullptr;
+        if (r < world && (!c.data[r] || !c.flags[r])) return TF_EINVAL;
+    }
+    if ((const h16*)out == c.data[rank]) return TF_EINVAL;
+    c.rank = rank;
+    c.world = world;
+    const int64_t n_vec8 = n / 8;
+    int blocks = (int)((n_vec8 + AR_THREADS - 1) / AR_THREADS);
+    if (blocks > 64) blocks = 64;                     // <= 64 workgroups: co-resident with anything, latency-bound anyway
+    hipLaunchKernelGGL(allreduce_oneshot_kernel, dim3(blocks), dim3(AR_THREADS), 0, (hipStream_t)stream, c, (h16*)out, n_vec8);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}
+
+// Error word of a control block (0 = never timed out); host-side read for the self-check.
+extern "C" int tf_ar_error(const void* flags_local) {
+    if (!flags_local) return TF_EINVAL;
+    ArFlags f;
+    hipError_t e = hipMemcpy(&f, flags_local, sizeof(f), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
+    return (int)f.error;
+}

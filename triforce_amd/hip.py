@@ -45,6 +45,15 @@ SIGNATURES = {
     "tf_middle_accept": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "tf_kv_h2d_async": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "tf_kv_d2h_async": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _vp]),
+    "tf_ar_flags_bytes": (_i32, []),
+    "tf_ar_ipc_handle_bytes": (_i32, []),
+    "tf_ar_alloc": (_i32, [_i64, _vp]),
+    "tf_ar_free": (_i32, [_vp]),
+    "tf_ar_get_ipc_handle": (_i32, [_vp, _vp]),
+    "tf_ar_open_ipc_handle": (_i32, [_vp, _vp]),
+    "tf_ar_close_ipc_handle": (_i32, [_vp]),
+    "tf_allreduce_oneshot": (_i32, [_vp, _vp, _i32, _i32, _vp, _i64, _vp]),
+    "tf_ar_error": (_i32, [_vp]),
 }
 
 ABI_VERSION = 1

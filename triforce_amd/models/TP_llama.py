@@ -106,6 +106,7 @@ class DistributedLlama:
         self.weights = None
         self.num_layers = model_config.num_hidden_layers
         self._ev_ready = self._ev_done = None
+        self._ar = None                               # utils.oneshot_ar.OneShotAllReduce once enabled (world_size > 1)
 
     # ---------------------------------------------------------------------------------------
     def init_parameters(self, hf_model=None):
@@ -130,6 +131,47 @@ class DistributedLlama:
         self.cos_cache, self.sin_cache = cos.to(self.device), sin.to(self.device)
         self.embed_tokens, self.lm_head, self.norm_weight = W.embed, W.lm_head, W.norm
         self.norm_variance_epsilon = W.eps
+        if self.world_size > 1 and self.device.type == "cuda" and os.environ.get("TRIFORCE_ONESHOT_AR", "1") != "0":
+            self.enable_oneshot_allreduce()
+
+    # ---------------------------------------------------------------------------------------
+    ONESHOT_MAX_ROWS = 32                             # decode-sized blocks; prefill chunks (>= 1 MB) stay on RCCL
+
+    @torch.inference_mode()
+    def enable_oneshot_allreduce(self, verbose=False):
+        """Switch the decode-sized all-reduces (<= ONESHOT_MAX_ROWS rows x hidden fp16: 8..330 KB) from RCCL to the
+        one-shot peer-read kernel (utils/oneshot_ar.py).  Collective.  The kernel is checked here against
+        dist.all_reduce on random data — every rank must agree that it was exact (world 2) / within one fp16 rounding of
+        the ring's result and that no wait timed out — else the engine stays on RCCL."""
+        from ..utils.oneshot_ar import OneShotAllReduce
+        ok, ar = True, None
+        try:
+            ar = OneShotAllReduce(self.local_rank, self.world_size, self.device, self.ONESHOT_MAX_ROWS * self.hidden_size)
+            g = torch.Generator(device=self.device).manual_seed(1234 + self.local_rank)
+            for rows in (1, 7, self.ONESHOT_MAX_ROWS):
+                part = torch.randn(rows, self.hidden_size, generator=g, device=self.device).to(torch.float16)
+                want = part.clone()
+                dist.all_reduce(want, dist.ReduceOp.SUM)
+                stage = ar.staging(rows, self.hidden_size)
+                stage.copy_(part)
+                got = ar.reduce(stage, torch.empty_like(part))
+                torch.cuda.synchronize(self.device)
+                err = (got.float() - want.float()).abs()
+                tol = 0.0 if self.world_size == 2 else 2.0 ** -8 * float(want.float().abs().max())
+                ok = ok and bool(torch.isfinite(got).all()) and float(err.max()) <= tol
+            ok = ok and ar.error() == 0
+        except Exception as ex:
+            ok = False
+            if verbose or self.local_rank == 0:
+                print(f"[TP] one-shot all-reduce unavailable, staying on RCCL: {type(ex).__name__}: {ex}", flush=True)
+        ok = self._agree(ok)
+        if ok:
+            self._ar = ar
+        elif ar is not None:
+            ar.close()
+        if verbose or self.local_rank == 0:
+            print(f"[TP] decode all-reduce: {'one-shot peer reads (xGMI)' if ok else 'RCCL'}", flush=True)
+        return ok
 
     def reset(self):
         self.kv_cache.reset()
@@ -143,6 +185,29 @@ class DistributedLlama:
         if self.world_size > 1:
             dist.all_reduce(t, dist.ReduceOp.SUM)
         return t
+
+    def _partial_out(self, rows, default=None):
+        """Where a block's partial o_proj / down_proj output should be written: this rank's one-shot staging buffer for
+        decode-sized blocks (the all-reduce then needs no copy), else ``default`` (None = a fresh tensor)."""
+        if self._ar is not None and rows <= self.ONESHOT_MAX_ROWS and (rows * self.hidden_size) % 8 == 0:
+            return self._ar.staging(rows, self.hidden_size)
+        return default
+
+    def _reduce(self, partial, dst=None):
+        """Sum ``partial`` over the ranks.  Staged partials go through the one-shot kernel into ``dst`` (a fresh tensor
+        when None); anything else is reduced in place by RCCL (and copied to ``dst`` if one is given)."""
+        if self.world_size == 1:
+            if dst is not None and dst.data_ptr() != partial.data_ptr():
+                dst.copy_(partial)
+                return dst
+            return partial
+        if self._ar is not None and partial.data_ptr() == self._ar.data_ptr:
+            return self._ar.reduce(partial, torch.empty_like(partial) if dst is None else dst)
+        self._all_reduce(partial)
+        if dst is not None and dst.data_ptr() != partial.data_ptr():
+            dst.copy_(partial)
+            return dst
+        return partial
 
     def _attn_half(self, i, x, d, pos, kl, vl, slot, sk, retrieval_build=False, tree=None, out=None, slot_dev=None,
                    sk_dev=None):
@@ -178,8 +243,9 @@ class DistributedLlama:
     def _layer(self, i, x, d, pos, kl, vl, slot, sk, q_len, retrieval_build=False, tree=None):
         """One decoder layer on this rank's shard.  x: residual stream (updated in place), d: pending MLP output
         of the previous layer (None for layer 0).  Returns the (all-reduced) MLP output of this layer."""
-        o = self._all_reduce(self._attn_half(i, x, d, pos, kl, vl, slot, sk, retrieval_build, tree))   # tensor_op.py:176-179
-        return self._all_reduce(self._mlp_half(i, x, o))                                               # tensor_op.py:353-359
+        o = self._reduce(self._attn_half(i, x, d, pos, kl, vl, slot, sk, retrieval_build, tree,
+                                         out=self._partial_out(q_len)))                                # tensor_op.py:176-179
+        return self._reduce(self._mlp_half(i, x, o, out=self._partial_out(q_len)))                     # tensor_op.py:353-359
 
     def _finish(self, x, d):
         W = self.weights
@@ -294,6 +360,9 @@ class DistributedLlama:
         L = self.num_layers
         rc, kvc = self.retrieval_cache, self.kv_cache
 
+        q_len = st["x"].shape[0]
+        part_o, part_d = self._partial_out(q_len, st["o"]), self._partial_out(q_len, st["d"])   # staging, or in place
+
         def attn(i):
             def run():
                 if i == 0:
@@ -301,17 +370,17 @@ class DistributedLlama:
                 d = None if i == 0 else st["d"]
                 if kind == "retrieval":
                     kl, vl = rc.layer_kv(i)
-                    self._attn_half(i, st["x"], d, st["pos"], kl, vl, rc.spec_slot, rc.real_budget, out=st["o"])
+                    self._attn_half(i, st["x"], d, st["pos"], kl, vl, rc.spec_slot, rc.real_budget, out=part_o)
                 else:
                     kl, vl = kvc.layer_kv(i)
-                    self._attn_half(i, st["x"], d, st["pos"], kl, vl, 0, kvc.max_budget, out=st["o"],
+                    self._attn_half(i, st["x"], d, st["pos"], kl, vl, 0, kvc.max_budget, out=part_o,
                                     slot_dev=st["slot"], sk_dev=st["sk"])
-                return st["o"]
+                return part_o
             return run
 
         def mlp(i):
             def run():
-                return self._mlp_half(i, st["x"], st["o"], out=st["d"])
+                return self._mlp_half(i, st["x"], st["o"], out=part_d)
             return run
 
         def finish():
@@ -320,10 +389,10 @@ class DistributedLlama:
                 return norm_logits(logits[0], temperature=self.temperature, top_k=-1, top_p=self.top_p)
             return logits
 
-        stages = []
+        stages = []                                   # (collective-free stage, its exchange step | None)
         for i in range(L):
-            stages.append((attn(i), st["o"]))
-            stages.append((mlp(i), st["d"]))
+            stages.append((attn(i), lambda: self._reduce(part_o, st["o"])))
+            stages.append((mlp(i), lambda: self._reduce(part_d, st["d"])))
         stages.append((finish, None))
         return stages
 
@@ -334,28 +403,28 @@ class DistributedLlama:
         if form == "whole":
             def run_all():
                 out = None
-                for fn, buf in stages:
+                for fn, exchange in stages:
                     out = fn()
-                    if buf is not None:
-                        self._all_reduce(buf)
+                    if exchange is not None:
+                        exchange()
                 return out
             graph, out = _capture(run_all, (), self._mempool, 3)
             return dict(form="whole", graph=graph, out=out, st=st, T=self.temperature, P=self.top_p)
         graphs = []
         out = None
-        for fn, buf in stages:
+        for fn, exchange in stages:
             g, out = _capture(fn, (), self._mempool, 2)
-            graphs.append((g, buf))
+            graphs.append((g, exchange))
         return dict(form="segments", graphs=graphs, out=out, st=st, T=self.temperature, P=self.top_p)
 
     def _replay(self, cap):
         if cap["form"] == "whole":
             cap["graph"].replay()
         else:
-            for g, buf in cap["graphs"]:
+            for g, exchange in cap["graphs"]:
                 g.replay()
-                if buf is not None:
-                    self._all_reduce(buf)
+                if exchange is not None:
+                    exchange()
         return cap["out"].clone()
 
     def _agree(self, ok):

@@ -1,0 +1,125 @@
+"""One-shot all-reduce for the decode-sized messages of the tensor-parallel path (csrc/allreduce.hip, C ABI
+tf_allreduce_oneshot) — replaces dist.all_reduce at the reference's models/tensor_op.py:179,326,359 for messages up to
+``max_elems`` fp16 values; larger ones (prefill chunks) stay on RCCL.
+
+Per rank: one fine-grained staging buffer + one control block, exported to the peers with hipIpc handles (exchanged
+through torch.distributed) and mapped once.  The producer GEMM writes this rank's partial straight into ``staging()``;
+``reduce(staged, out)`` then runs the READY / reduce / DONE kernel on the current stream.  Results are bit-identical on
+every rank (same values, same order, fp32 accumulation, one rounding).
+"""
+import ctypes
+
+import torch
+
+from .. import hip
+
+
+class _RawBuffer:
+    """Exposes a raw device pointer to torch through the CUDA array interface (no copy, no ownership)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": tuple(shape), "typestr": typestr, "version": 2,
+                                         "strides": None}
+
+
+def reference_sum(partials):
+    """The arithmetic of the kernel: fp32 accumulation in rank order, one rounding to fp16."""
+    acc = torch.zeros_like(partials[0], dtype=torch.float32)
+    for p in partials:
+        acc = acc + p.float()
+    return acc.to(torch.float16)
+
+
+class OneShotAllReduce:
+    def __init__(self, rank, world, device, max_elems, peer_data=None, peer_flags=None, own=None):
+        """Collective constructor (every rank of the default process group calls it) unless ``peer_data`` /
+        ``peer_flags`` are given (single-process groups of virtual ranks: tests)."""
+        self.rank, self.world, self.device, self.max_elems = rank, world, torch.device(device), int(max_elems)
+        L = hip.lib()
+        self._opened = []
+        if own is None:
+            own = (self._alloc(self.max_elems * 2), self._alloc(L.tf_ar_flags_bytes()))
+            self._owned = own
+        else:
+            self._owned = ()
+        self.data_ptr, self.flags_ptr = own
+        if peer_data is None:
+            peer_data, peer_flags = self._exchange()
+        self._data = (ctypes.c_void_p * world)(*peer_data)
+        self._flags = (ctypes.c_void_p * world)(*peer_flags)
+        self._stage = torch.as_tensor(_RawBuffer(self.data_ptr, (self.max_elems,), "<f2"), device=self.device)
+
+    @staticmethod
+    def _alloc(nbytes):
+        p = ctypes.c_void_p()
+        hip.check(hip.lib().tf_ar_alloc(int(nbytes), ctypes.byref(p)), "tf_ar_alloc")
+        return p.value
+
+    def _exchange(self):
+        import torch.distributed as dist
+        L = hip.lib()
+        n = L.tf_ar_ipc_handle_bytes()
+        mine = []
+        for ptr in (self.data_ptr, self.flags_ptr):
+            buf = ctypes.create_string_buffer(n)
+            hip.check(L.tf_ar_get_ipc_handle(ctypes.c_void_p(ptr), buf), "tf_ar_get_ipc_handle")
+            mine.append(bytes(buf.raw))
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine)
+        data, flags = [], []
+        for r, (hd, hf) in enumerate(everyone):
+            if r == self.rank:
+                data.append(self.data_ptr)
+                flags.append(self.flags_ptr)
+                continue
+            for handle, dst in ((hd, data), (hf, flags)):
+                p = ctypes.c_void_p()
+                hip.check(L.tf_ar_open_ipc_handle(ctypes.create_string_buffer(handle, n), ctypes.byref(p)),
+                          "tf_ar_open_ipc_handle")
+                self._opened.append(p.value)
+                dst.append(p.value)
+        return data, flags
+
+    # ------------------------------------------------------------------------------------------------------
+    def staging(self, rows, cols):
+        """(rows, cols) fp16 view of this rank's staging buffer: the producer kernel's output tensor."""
+        assert rows * cols <= self.max_elems and (rows * cols) % 8 == 0
+        return self._stage[:rows * cols].view(rows, cols)
+
+    def fits(self, t):
+        return t.dtype == torch.float16 and t.numel() <= self.max_elems and t.numel() % 8 == 0
+
+    def reduce(self, staged, out):
+        """out <- sum over ranks of their staged partials.  ``staged`` must be (a prefix view of) ``staging()``."""
+        assert staged.data_ptr() == self.data_ptr and out.dtype == torch.float16 and out.is_contiguous()
+        assert out.numel() == staged.numel() and out.data_ptr() != self.data_ptr
+        hip.check(hip.lib().tf_allreduce_oneshot(self._data, self._flags, self.rank, self.world,
+                                                 ctypes.c_void_p(out.data_ptr()), staged.numel(),
+                                                 ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                  "tf_allreduce_oneshot")
+        return out
+
+    def error(self):
+        """0, or which wait timed out (1 READY, 2 DONE) at some point since creation."""
+        return hip.lib().tf_ar_error(ctypes.c_void_p(self.flags_ptr))
+
+    def close(self):
+        L = hip.lib()
+        for p in self._opened:
+            L.tf_ar_close_ipc_handle(ctypes.c_void_p(p))
+        for p in self._owned:
+            L.tf_ar_free(ctypes.c_void_p(p))
+        self._opened, self._owned = [], ()
+
+    # ------------------------------------------------------------------------------------------------------
+    @classmethod
+    def local_group(cls, world, device, max_elems):
+        """``world`` virtual ranks inside ONE process on ONE device (their kernels must run on different streams):
+        exercises the flag protocol and the arithmetic without peer mappings."""
+        L = hip.lib()
+        owned = [(cls._alloc(max_elems * 2), cls._alloc(L.tf_ar_flags_bytes())) for _ in range(world)]
+        data, flags = [o[0] for o in owned], [o[1] for o in owned]
+        group = [cls(r, world, device, max_elems, peer_data=data, peer_flags=flags, own=owned[r]) for r in range(world)]
+        for g, o in zip(group, owned):
+            g._owned = o
+        return group
