@@ -105,7 +105,21 @@ def _graphable_cache():
 
 
 def _capture(fn, static_inputs, mempool, n_warmups):
-    """Warm up on a side stream, then capture ``fn(*static_inputs)`` into one hipGraph."""
+    """Warm up on a side stream, then capture ``fn(*static_inputs)`` into one hipGraph.  Python's garbage collector is
+    run first and held off while capturing: a collection that frees pinned host memory (decision-record mailboxes,
+    offloaded caches of an engine that went out of scope) makes the host allocator record events on the capturing
+    stream, which aborts the process."""
+    gc.collect()
+    gc_was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        return _capture_nogc(fn, static_inputs, mempool, n_warmups)
+    finally:
+        if gc_was_enabled:
+            gc.enable()
+
+
+def _capture_nogc(fn, static_inputs, mempool, n_warmups):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
