@@ -180,7 +180,7 @@ def test_single_gpu_offloading_cache_equals_resident_cache():
     assert ar_off == ar_res
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [2, 4])      # one device runs 4 streams concurrently (hardware queues); 8 would serialise
 def test_oneshot_allreduce_protocol_on_one_device(world):
     """tf_allreduce_oneshot with `world` virtual ranks inside this process — each rank's kernel on its own stream, real
     READY / DONE flag exchange between concurrently running kernels, fine-grained staging buffers — against the

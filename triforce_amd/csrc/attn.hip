@@ -19,7 +19,6 @@
 //     v_mfma_f32_16x16x16_f16.  The extra MFMAs are free (the kernel uses a few % of MFMA peak).
 //   * online softmax in fp32 (running max / sum per query column), partial (m, l, O) per split
 //     merged by a second tiny kernel.
-#include <stdlib.h>
 #include "common.h"
 #include "tree_mask.h"
 
@@ -152,7 +151,7 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
 
 
 // ws layout: o[H][nsplit][QR][D] | m[H][nsplit][QR] | l[H][nsplit][QR],  QR = QT*16
-template <int D, int QT, int NW = 4>
+template <int D, int QT>
 __device__ __forceinline__ void attn_split_body(
     const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
     int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
@@ -223,11 +222,11 @@ __device__ __forceinline__ void attn_split_body(
     int t = t_begin + wave;
     if (t < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t, sk, li, g, ka, va_);
     while (t < t_end) {
-        const int t1 = t + NW;
+        const int t1 = t + 4;
         if (t1 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t1, sk, li, g, kb, vb);
         ATTN_TILE_AUTO(ka, va_, t);
         if (t1 >= t_end) break;
-        const int t2 = t1 + NW;
+        const int t2 = t1 + 4;
         if (t2 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t2, sk, li, g, ka, va_);
         ATTN_TILE_AUTO(kb, vb, t1);
         t = t2;
@@ -235,12 +234,10 @@ __device__ __forceinline__ void attn_split_body(
 #endif
 
 #undef ATTN_TILE_AUTO
-    // ---- merge the NW waves of this split through LDS, one q-tile (and, for 8 waves, one column half) at a time ----
-    constexpr int HALVES = (NW * 16 * (D + 1) * 4 > 48 * 1024) ? 2 : 1;      // keep the static LDS block under 48 KiB
-    constexpr int COLS = D / HALVES;
-    __shared__ float sm_o[NW][16][COLS + 1];
-    __shared__ float sm_m[NW][16];
-    __shared__ float sm_l[NW][16];
+    // ---- merge the 4 waves of this split through LDS, one q-tile at a time ----
+    __shared__ float sm_o[4][16][D + 1];
+    __shared__ float sm_m[4][16];
+    __shared__ float sm_l[4][16];
     float* ws_o = ws;
     float* ws_m = ws + (int64_t)H * nsplit * QR * D;
     float* ws_l = ws_m + (int64_t)H * nsplit * QR;
@@ -250,37 +247,28 @@ __device__ __forceinline__ void attn_split_body(
         float lsum = st.l[qt];
         lsum += __shfl_xor(lsum, 16, 64);
         lsum += __shfl_xor(lsum, 32, 64);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm_o[wave][li][16 * tt + 4 * g + r] = st.acc[qt][tt][r];
         if (g == 0) {
             sm_m[wave][li] = st.m[qt];
             sm_l[wave][li] = lsum;
         }
-#pragma unroll
-        for (int hf = 0; hf < HALVES; ++hf) {
-#pragma unroll
-            for (int tt = 0; tt < NT / HALVES; ++tt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sm_o[wave][li][16 * tt + 4 * g + r] = st.acc[qt][hf * (NT / HALVES) + tt][r];
-            __syncthreads();
-            for (int e = tid; e < 16 * COLS; e += NW * 64) {
-                const int qq = e / COLS, d = e - qq * COLS;
-                float mm = sm_m[0][qq];
-#pragma unroll
-                for (int w = 1; w < NW; ++w) mm = fmaxf(mm, sm_m[w][qq]);
-                float o = 0.f, l = 0.f;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    const float ww = __expf(sm_m[w][qq] - mm);
-                    o += sm_o[w][qq][d] * ww;
-                    l += sm_l[w][qq] * ww;
-                }
-                ws_o[(pbase + qt * 16 + qq) * D + hf * COLS + d] = o;
-                if (d == 0 && hf == 0) {
-                    ws_m[pbase + qt * 16 + qq] = mm;
-                    ws_l[pbase + qt * 16 + qq] = l;
-                }
+        __syncthreads();
+        for (int e = tid; e < 16 * D; e += 256) {
+            const int qq = e / D, d = e - qq * D;
+            const float m0 = sm_m[0][qq], m1 = sm_m[1][qq], m2 = sm_m[2][qq], m3 = sm_m[3][qq];
+            const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+            const float w0 = __expf(m0 - mm), w1 = __expf(m1 - mm), w2 = __expf(m2 - mm), w3 = __expf(m3 - mm);
+            const float o = sm_o[0][qq][d] * w0 + sm_o[1][qq][d] * w1 + sm_o[2][qq][d] * w2 + sm_o[3][qq][d] * w3;
+            ws_o[(pbase + qt * 16 + qq) * D + d] = o;
+            if (d == 0) {
+                ws_m[pbase + qt * 16 + qq] = mm;
+                ws_l[pbase + qt * 16 + qq] = sm_l[0][qq] * w0 + sm_l[1][qq] * w1 + sm_l[2][qq] * w2 + sm_l[3][qq] * w3;
             }
-            __syncthreads();
         }
+        __syncthreads();
     }
 }
 
@@ -290,16 +278,6 @@ __global__ ATTN_SPLIT_BOUNDS void attn_split_kernel(
     int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
     float* __restrict__ ws) {
     attn_split_body<D, QT>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws);
-}
-
-// Short streams (a retrieval verify: 4 103 keys = 257 tiles over 8 splits): with 4 waves a wave walks 8 tiles two at a
-// time — four dependent HBM round trips per launch; 8 waves per workgroup halve that chain.
-template <int D>
-__global__ __launch_bounds__(512) void attn_split_w8_kernel(
-    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
-    int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
-    float* __restrict__ ws) {
-    attn_split_body<D, 1, 8>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws);
 }
 
 // The two-q-tile form compiled for TF_ATTN_QT2_OCC waves per SIMD (see the note at the top of the file).
@@ -1090,22 +1068,6 @@ static int launch_attn(const void* q, const void* k, const void* v, void* out, i
                        int sq, int sk, const int32_t* sk_dev, int H, float scale, int nsplit, float* ws,
                        hipStream_t st) {
     dim3 grid(nsplit, H), block(256);
-    static const int nw8_max_tiles = [] {                    // A/B switch: TF_ATTN_NW8=<tiles per split up to which 8 waves run>
-        const char* e = getenv("TF_ATTN_NW8");
-        return e ? atoi(e) : 0;
-    }();
-    if constexpr (QT == 1) {
-        const int tiles = ((sk + 15) / 16 + nsplit - 1) / nsplit;
-        if (tiles <= nw8_max_tiles) {
-            hipLaunchKernelGGL((attn_split_w8_kernel<D>), grid, dim3(512), 0, st, (const h16*)q, (const h16*)k,
-                               (const h16*)v, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws);
-            TF_LAUNCH_CHECK();
-            hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(H, sq), dim3(D, COMBINE_GROUPS), 0, st, (const float*)ws,
-                               (h16*)out, sq, H, nsplit, QT * 16);
-            TF_LAUNCH_CHECK();
-            return TF_OK;
-        }
-    }
 #if TF_ATTN_QT2_OCC > 0
     if constexpr (QT == 2)
         hipLaunchKernelGGL((attn_split_q2_kernel<D>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
