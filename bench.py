@@ -78,6 +78,8 @@ def parse(argv=None):
     ap.add_argument("--dry-run", action="store_true",
                     help="tensor-parallel path only: build the process group, the sharded engine and its weights, agree "
                          "across ranks, print the JSON line with dry_run=true and exit (no decode; runs on CPU under gloo)")
+    ap.add_argument("--eager-comparator", action="store_true",
+                    help="also time the same-hardware un-tuned comparator (eager PyTorch-ROCm restatement, ~20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--rebuild-every", type=int, default=0,
@@ -285,6 +287,93 @@ def cpu_baseline(args, tokens_per_step, inner_per_step):
             "step_seconds_est": round(step, 2)}
 
 
+def eager_comparator(ge, args, inner_per_step, tokens_per_step, device):
+    """Same-hardware UN-TUNED comparator: the reference's algorithm as plain eager PyTorch-ROCm ops on
+    this GPU — the oracle's op-by-op restatement (fp32 softmax attention where the reference calls flash-attn, which
+    does not exist for this platform; F.linear; sort-based top-p) over the product's own weights and KV caches (views,
+    nothing copied).  Baseline leg only: the oracle is the thing timed here, never the product path."""
+    from oracle import ref_model as M
+    from oracle import ref_ops as R
+    eng = ge.engine
+
+    def state_dict(W):
+        hd = W.H * W.D
+        sd = {"model.embed_tokens.weight": W.embed, "model.norm.weight": W.norm, "lm_head.weight": W.lm_head.w}
+        for i in range(W.L):
+            p = f"model.layers.{i}."
+            qkv, gu = W.wqkv[i].w, W.wgu[i].w
+            sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"] = qkv[:hd], qkv[hd:2 * hd]
+            sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.o_proj.weight"] = qkv[2 * hd:], W.wo[i].w
+            sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"] = gu[:gu.shape[0] // 2], gu[gu.shape[0] // 2:]
+            sd[p + "mlp.down_proj.weight"] = W.wd[i].w
+            sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = W.ln1[i], W.ln2[i]
+        return sd
+
+    def view_cache(cls, src, **attrs):
+        c = object.__new__(cls)
+        c.key_cache, c.value_cache = src.k.permute(0, 2, 1, 3), src.v.permute(0, 2, 1, 3)     # (L, T, H, D) views
+        c.layers = src.layers
+        for k, v in attrs.items():
+            setattr(c, k, v)
+        return c
+
+    def timed(fn, n=2):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n
+
+    gamma = args.gamma
+    with torch.device(device):                               # the oracle builds its index tensors with default factories
+        tcfg, dcfg = eng.model.config.to_dict(), eng.draft.config.to_dict()
+        ot, od = M.OracleTarget(tcfg, state_dict(eng.model.weights)), M.OracleDraft(dcfg, state_dict(eng.draft.weights))
+        S = eng.kv_cache.seq_len
+        okv = view_cache(M.FullCache, eng.kv_cache, max_budget=eng.kv_cache.max_budget, seq_len=S)
+        gc_ = eng.graph_cache
+        ogc = view_cache(M.RetrievalCacheO, gc_, chunk_size=gc_.chunk_size, prefill=gc_.prefill, gamma=gamma,
+                         chunks=gc_.chunks, select_sets=gc_.select_sets, max_budget=gc_.max_budget,
+                         real_budget=gc_.real_budget, init_graph=True, last_scores=[None] * gc_.layers,
+                         last_idx=[None] * gc_.layers)
+        dc = eng.draft_cache
+        odc = view_cache(M.StreamingCacheO, dc, gamma=gamma, start_size=dc.start_size, recent_size=dc.recent_size,
+                         real_budget=dc.real_budget, seq_len=dc.start_size + dc.recent_size)
+        ids = torch.full((1, gamma + 2), 100, dtype=torch.long)
+        pos = torch.arange(S, S + gamma + 1).unsqueeze(0)
+
+        def ar():
+            okv.seq_len = S
+            lg = ot.forward(ids[:, :1], okv, None)
+            R.norm_logits(lg[0], args.temp, -1, args.top_p)
+
+        def tv():
+            okv.seq_len = S
+            lg = ot.forward(ids, okv, None)
+            R.norm_logits(lg[0], args.temp, -1, args.top_p)
+
+        def rv():
+            lg = ot.forward(ids[:, :gamma + 1], okv, ogc, position_ids=pos, spec=True)
+            R.norm_logits(lg[0], args.temp, -1, args.top_p)
+
+        def dr():
+            lg = od.forward(ids[:, :3], odc, odc, gamma_offset=2)
+            R.norm_logits(lg[0], args.temp, -1, args.top_p)
+
+        t_ar, t_tv, t_rv, t_dr = timed(ar), timed(tv), timed(rv), timed(dr, 3)
+        okv.seq_len = S
+    step_ms = t_tv + inner_per_step * (t_rv + t_dr) + t_dr
+    return {"what": "the reference's algorithm as plain eager PyTorch-ROCm ops (oracle restatement, fp32 softmax "
+                    "attention in place of flash-attn, F.linear, sort-based top-p) on this GPU, product weights and KV "
+                    "caches shared as views; stage latencies by HIP events, step composed with the measured inner count",
+            "ar_step_ms": round(t_ar, 2), "ar_tokens_per_s": round(1e3 / t_ar, 2),
+            "target_verify_ms": round(t_tv, 2), "retrieval_verify_ms": round(t_rv, 2), "draft_step_ms": round(t_dr, 3),
+            "triforce_step_ms_est": round(step_ms, 2), "triforce_tokens_per_s_est": round(tokens_per_step / step_ms * 1e3, 2)}
+
+
 def pmc_traffic(alg_bytes, H, D):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, KiB units, FETCH_SIZE doubled for gfx950 — MI355X_MICROARCH.md §HBM).
@@ -453,6 +542,15 @@ def main():
     modelled = tv_mean + inner_per_step * (stages["retrieval_verify_us"] + stages["draft_step_us"]) + stages["draft_step_us"]
     result["step_overhead_us"] = round(max(0.0, seconds / args.steps * 1e6 - modelled), 1)
 
+    if args.eager_comparator:
+        try:
+            result["eager_torch_comparator"] = eager_comparator(ge, args, inner_per_step, tokens / args.steps, device)
+            e = result["eager_torch_comparator"]
+            e["product_speedup_vs_eager_triforce"] = round(value / e["triforce_tokens_per_s_est"], 2)
+            e["product_ar_speedup_vs_eager_ar"] = round(ar_tps / e["ar_tokens_per_s"], 2)
+        except Exception as ex:
+            result["eager_torch_comparator"] = {"failed": f"{type(ex).__name__}: {ex}"[:400]}
+        torch.cuda.empty_cache()
     if args.random_steps > 0 and kind != "random":
         # the round-1 regime, same process, same graphs: weights re-drawn IN PLACE as N(0, 0.02), prompt re-prefilled
         target.weights.overwrite_random_(args.seed + 1)
