@@ -270,6 +270,11 @@ int tf_ar_open_ipc_handle(const void* handle, void** ptr_out);
 int tf_ar_close_ipc_handle(void* ptr);
 int tf_allreduce_oneshot(void* const* peer_data, void* const* peer_flags, int rank, int world, void* out, int64_t n,
                          void* stream);
+/* out = resid + all_reduce(partials): `hidden_states = residual + all_reduce(...)` (tensor_op.py:179-181,359-360) in the
+ * same launch; the residual is added in fp16 to the ROUNDED sum (the reference's two rounding points); resid may be
+ * `out` itself (in-place residual stream), NULL = plain all-reduce. */
+int tf_allreduce_oneshot_add(void* const* peer_data, void* const* peer_flags, int rank, int world, const void* resid,
+                             void* out, int64_t n, void* stream);
 int tf_ar_error(const void* flags_local);
 
 #ifdef __cplusplus

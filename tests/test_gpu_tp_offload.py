@@ -208,6 +208,18 @@ def test_oneshot_allreduce_protocol_on_one_device(world):
                 assert torch.equal(outs[r], want), f"epoch {it}, rank {r}: max err {(outs[r].float() - want.float()).abs().max()}"
             if world == 2:
                 assert torch.equal(want, parts[0] + parts[1])       # one correctly rounded fp16 addition == the ring's
+            # residual form: x = x + all_reduce(partials) in the same launch, x updated in place on every rank
+            xs = [torch.randn(rows, hidden, generator=gen, device=DEV).to(torch.float16) for _ in range(world)]
+            want_x = [reference_sum(parts, resid=x) for x in xs]
+            torch.cuda.synchronize()
+            for r in range(world):
+                with torch.cuda.stream(streams[r]):
+                    st = group[r].staging(rows, hidden)
+                    st.copy_(parts[r])
+                    group[r].reduce(st, xs[r], resid=xs[r])
+            torch.cuda.synchronize()
+            for r in range(world):
+                assert torch.equal(xs[r], want_x[r]), f"epoch {it}, rank {r}: residual form"
         assert [g.error() for g in group] == [0] * world
         with pytest.raises(AssertionError):
             group[0].reduce(group[0].staging(8, hidden), group[0].staging(8, hidden))     # out must not alias the staging

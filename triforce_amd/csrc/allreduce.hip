@@ -56,7 +56,7 @@ __device__ __forceinline__ bool ar_wait(const unsigned* slot, unsigned epoch) {
     return false;
 }
 
-__global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c, h16* __restrict__ out, int64_t n_vec8) {
+__global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c, const h16* resid, h16* out, int64_t n_vec8) {
     __shared__ unsigned s_epoch;
     __shared__ int s_ok;
     const int tid = threadIdx.x;
@@ -94,6 +94,11 @@ __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c,
             half8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (h16)acc[e];
+            if (resid) {                                      // hidden = residual + all_reduce(partial): fp16 add of the
+                const half8 rv = *reinterpret_cast<const half8*>(resid + 8 * i);   // ROUNDED sum (tensor_op.py:179-181)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = hadd_rn(rv[e], o[e]);
+            }
             *reinterpret_cast<half8*>(out + 8 * i) = o;
         }
     }
@@ -165,8 +170,11 @@ extern "C" int tf_ar_close_ipc_handle(void* ptr) {
 // device-visible pointers (own entry included) to every rank's staging buffer / ArFlags block; this rank's partial must
 // already be in peer_data[rank] (written by an earlier kernel of `stream`); `out` is ordinary device memory and must not
 // alias the staging buffer.  n % 8 == 0.  Capturable: the epoch is kept in the control block.
-extern "C" int tf_allreduce_oneshot(void* const* peer_data, void* const* peer_flags, int rank, int world, void* out,
-                                    int64_t n, void* stream) {
+// tf_allreduce_oneshot_add: out = resid + (sum over ranks), the residual added in fp16 to the rounded sum — the
+// `hidden_states = residual + all_reduce(o)` of tensor_op.py:179-181,359-360 in the same launch.  resid may equal out
+// (in-place residual stream); resid == NULL is the plain all-reduce.
+extern "C" int tf_allreduce_oneshot_add(void* const* peer_data, void* const* peer_flags, int rank, int world,
+                                        const void* resid, void* out, int64_t n, void* stream) {
     if (!peer_data || !peer_flags || !out || world < 1 || world > AR_MAX_WORLD || rank < 0 || rank >= world) return TF_EINVAL;
     if (n < 8 || (n % 8)) return TF_EINVAL;
     ArComm c;
@@ -175,15 +183,21 @@ extern "C" int tf_allreduce_oneshot(void* const* peer_data, void* const* peer_fl
         c.flags[r] = (r < world) ? (ArFlags*)peer_flags[r] : nullptr;
         if (r < world && (!c.data[r] || !c.flags[r])) return TF_EINVAL;
     }
-    if ((const h16*)out == c.data[rank]) return TF_EINVAL;
+    if ((const h16*)out == c.data[rank] || (const h16*)resid == c.data[rank]) return TF_EINVAL;
     c.rank = rank;
     c.world = world;
     const int64_t n_vec8 = n / 8;
     int blocks = (int)((n_vec8 + AR_THREADS - 1) / AR_THREADS);
     if (blocks > 64) blocks = 64;                     // <= 64 workgroups: co-resident with anything, latency-bound anyway
-    hipLaunchKernelGGL(allreduce_oneshot_kernel, dim3(blocks), dim3(AR_THREADS), 0, (hipStream_t)stream, c, (h16*)out, n_vec8);
+    hipLaunchKernelGGL(allreduce_oneshot_kernel, dim3(blocks), dim3(AR_THREADS), 0, (hipStream_t)stream, c,
+                       (const h16*)resid, (h16*)out, n_vec8);
     TF_LAUNCH_CHECK();
     return TF_OK;
+}
+
+extern "C" int tf_allreduce_oneshot(void* const* peer_data, void* const* peer_flags, int rank, int world, void* out,
+                                    int64_t n, void* stream) {
+    return tf_allreduce_oneshot_add(peer_data, peer_flags, rank, world, nullptr, out, n, stream);
 }
 
 // Error word of a control block (0 = never timed out); host-side read for the self-check.

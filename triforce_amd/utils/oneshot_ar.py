@@ -22,12 +22,14 @@ class _RawBuffer:
                                          "strides": None}
 
 
-def reference_sum(partials):
-    """The arithmetic of the kernel: fp32 accumulation in rank order, one rounding to fp16."""
+def reference_sum(partials, resid=None):
+    """The arithmetic of the kernel: fp32 accumulation in rank order, one rounding to fp16; then (optionally) the
+    residual added in fp16."""
     acc = torch.zeros_like(partials[0], dtype=torch.float32)
     for p in partials:
         acc = acc + p.float()
-    return acc.to(torch.float16)
+    out = acc.to(torch.float16)
+    return out if resid is None else resid + out
 
 
 class OneShotAllReduce:
@@ -89,14 +91,18 @@ class OneShotAllReduce:
     def fits(self, t):
         return t.dtype == torch.float16 and t.numel() <= self.max_elems and t.numel() % 8 == 0
 
-    def reduce(self, staged, out):
-        """out <- sum over ranks of their staged partials.  ``staged`` must be (a prefix view of) ``staging()``."""
+    def reduce(self, staged, out, resid=None):
+        """out <- [resid +] sum over ranks of their staged partials.  ``staged`` must be (a prefix view of)
+        ``staging()``; ``resid`` (fp16, may be ``out`` itself) is added in fp16 to the rounded sum."""
         assert staged.data_ptr() == self.data_ptr and out.dtype == torch.float16 and out.is_contiguous()
         assert out.numel() == staged.numel() and out.data_ptr() != self.data_ptr
-        hip.check(hip.lib().tf_allreduce_oneshot(self._data, self._flags, self.rank, self.world,
-                                                 ctypes.c_void_p(out.data_ptr()), staged.numel(),
-                                                 ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
-                  "tf_allreduce_oneshot")
+        if resid is not None:
+            assert resid.dtype == torch.float16 and resid.is_contiguous() and resid.numel() == out.numel()
+        hip.check(hip.lib().tf_allreduce_oneshot_add(self._data, self._flags, self.rank, self.world,
+                                                     ctypes.c_void_p(resid.data_ptr()) if resid is not None else None,
+                                                     ctypes.c_void_p(out.data_ptr()), staged.numel(),
+                                                     ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                  "tf_allreduce_oneshot_add")
         return out
 
     def error(self):
