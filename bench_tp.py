@@ -161,6 +161,9 @@ def run_tp(args, rank, world, local):
     dist.barrier()
     t2 = time.time()
     timer, ops.ATTN_TIMER = ops.ATTN_TIMER, None
+    if getattr(llm, "_ar", None) is not None and llm._ar.error():
+        raise SystemExit(f"rank {rank}: one-shot all-reduce timed out waiting for a peer (code {llm._ar.error()}); "
+                         "results invalid — rerun with TRIFORCE_ONESHOT_AR=0")
     offload = offload_report(llm, args, tcfg, world, device) if llm.on_chip_layers < tcfg.num_hidden_layers else None
     elapsed = torch.tensor([t2 - t1], dtype=torch.float64, device=device)
     dist.all_reduce(elapsed, dist.ReduceOp.MAX)                 # slowest rank defines the job time
@@ -188,6 +191,8 @@ def run_tp(args, rank, world, local):
             "acceptance_rate": round(accepted / max(drafted, 1), 4), "tokens": tokens,
             "tokens_per_step": round(tokens / args.steps, 3), "prefill_seconds": round(t_prefill, 2),
             "kv_seq_len": llm.kv_cache.seq_len, "graph_form": getattr(llm, "graph_form", "eager"),
+            "decode_allreduce": "one-shot peer reads (tf_allreduce_oneshot)" if getattr(llm, "_ar", None) is not None
+            else ("rccl" if world > 1 else "none (one rank)"),
             "roofline": roof, "roofline_note": None if roof else "target verify replayed from a hipGraph on this run: "
             "no per-launch HIP events; see profiles/ for the rocprofv3 kernel trace", "cpu_baseline": None}), flush=True)
     dist.barrier()

@@ -16,7 +16,8 @@
 // are identical: one correctly rounded fp16 addition).  The epoch lives in device memory and is advanced by the kernel
 // itself, so a captured launch replays correctly.  Staging and flag buffers must be FINE-GRAINED device memory
 // (tf_ar_alloc): peers' stores and loads bypass the caches; plain device memory is only coherent across GPUs at kernel
-// boundaries.  Every spin is bounded; a timeout sets the error word instead of hanging the GPU.
+// boundaries.  Every spin is bounded (tens of seconds: a peer may legitimately be that late right after start-up); a
+// timeout sets the sticky error word, after which every later call returns immediately instead of waiting again.
 #include "common.h"
 #include <string.h>
 
@@ -63,9 +64,10 @@ __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c,
     ArFlags* mine = c.flags[c.rank];
     if (tid == 0) {
         s_epoch = ar_load(&mine->epoch) + 1u;       // bumped only after every workgroup of this launch has read it
-        s_ok = 1;
+        s_ok = ar_load(&mine->error) == 0u;         // sticky: after one timeout every later call returns at once
     }
     __syncthreads();
+    if (!s_ok) return;                               // (block-uniform) the host reads tf_ar_error and gives up
     const unsigned epoch = s_epoch;
     // ---- READY: my partial was staged by the previous kernel in this stream ----
     if (blockIdx.x == 0 && tid < c.world) ar_store(&c.flags[tid]->ready[c.rank], epoch);
