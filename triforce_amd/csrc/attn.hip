@@ -602,8 +602,12 @@ __device__ __forceinline__ void lds_softmax_pv(AttnState<D, QT>& st, const f32x4
     }
 }
 
+#ifndef TF_BLOCK_TREE_OCC
+#define TF_BLOCK_TREE_OCC 2      // waves per SIMD of the TREE form of the LDS block kernel.  At 2 it spills 46 registers; at 1
+                                 // (512 registers, no spill) the 512-node Sequoia verify is 25 % SLOWER (2 890 -> 3 630 us): kept at 2
+#endif
 template <int D, bool TREE>
-__global__ __launch_bounds__(256, 2) void attn_block_lds_kernel(
+__global__ __launch_bounds__(256, TREE ? TF_BLOCK_TREE_OCC : 2) void attn_block_lds_kernel(
     const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
     int64_t stride_h, int sq, int sk, int H, float scale, int nsplit, float* __restrict__ ws,
     const uint32_t* __restrict__ mask, int mask_words, int mask_row0, int tree_start) {
