@@ -226,3 +226,73 @@ def test_oneshot_allreduce_protocol_on_one_device(world):
     finally:
         for g in group:
             g.close()
+
+
+def _ipc_worker(rank, world, port, q):
+    """One rank of a 2-process group that shares ONE device: gloo carries the handle exchange and the reference
+    collective, hipIpc maps the peers' fine-grained staging / control buffers, the one-shot kernels of the two processes
+    talk to each other through those mappings."""
+    import os
+    import sys
+    import traceback
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from triforce_amd.utils.oneshot_ar import OneShotAllReduce, reference_sum
+        hidden = 4096
+        ar = OneShotAllReduce(rank, world, "cuda:0", 32 * hidden)          # collective: exchanges the IPC handles
+        gen = torch.Generator(device="cuda:0").manual_seed(100 + rank)
+        ok, worst = True, 0.0
+        for it, rows in enumerate([1, 7, 18, 32, 8, 7] * 4):
+            part = torch.randn(rows, hidden, generator=gen, device="cuda:0").to(torch.float16)
+            ring = part.clone()
+            dist.all_reduce(ring, dist.ReduceOp.SUM)                       # gloo: fp16 sum of the two partials
+            st = ar.staging(rows, hidden)
+            st.copy_(part)
+            got = ar.reduce(st, torch.empty_like(part))
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(got, ring)                              # world 2: bit-identical to the collective
+            worst = max(worst, float((got.float() - ring.float()).abs().max()))
+        err = ar.error()
+        dist.barrier()
+        ar.close()
+        q.put((rank, "ok", ok, worst, err))
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_oneshot_allreduce_across_two_processes_through_hipipc():
+    """The part the one-device protocol test cannot reach: two PROCESSES (the production arrangement, one per rank), the
+    staging and control buffers exported with hipIpcGetMemHandle and mapped by the peer, flags and partials crossing the
+    process boundary.  Both ranks sit on this box's single GPU (RCCL refuses two ranks on one device, so gloo carries
+    the handle exchange and the reference all_reduce); results must equal the collective bit for bit and no wait may
+    time out."""
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_ipc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = []
+    try:
+        for _ in range(2):
+            outs.append(q.get(timeout=300))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    for o in outs:
+        assert o[1] == "ok", o[2]
+    for rank, _, ok, worst, err in outs:
+        assert err == 0, f"rank {rank}: a wait timed out (code {err})"
+        assert ok, f"rank {rank}: result differs from the collective by up to {worst}"
