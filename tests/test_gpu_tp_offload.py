@@ -296,3 +296,118 @@ def test_oneshot_allreduce_across_two_processes_through_hipipc():
     for rank, _, ok, worst, err in outs:
         assert err == 0, f"rank {rank}: a wait timed out (code {err})"
         assert ok, f"rank {rank}: result differs from the collective by up to {worst}"
+
+
+def _tp2_worker(rank, world, port, q):
+    """One rank of the tensor-parallel engine at world size 2 with BOTH ranks on this box's single GPU: real kernels on
+    each rank's head / MLP-column shard, the decode-sized all-reduces through the one-shot kernel over hipIpc mappings
+    (the production path), prefill-sized ones and the token broadcast through gloo."""
+    import os
+    import sys
+    import traceback
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK="0")
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from triforce_amd.models.cache import StreamingLLMEvictionCache
+        from triforce_amd.models.config_yarn import LlamaConfig
+        from triforce_amd.models.modeling_llama_68m import LlamaForCausalLM as Draft
+        from triforce_amd.models.TP_llama import DistributedLlama
+        from triforce_amd.utils.decoding import TriForce_Dist
+        out = {}
+        # 1) the four forward stages against the REFERENCE engine's own world-2 logits (tests/golden/tp_world2.pt)
+        g = Hh.load_golden("tp_world2")
+        tcfg = LlamaConfig.from_dict(g["tcfg"])
+        gamma = g["gamma"]
+        llm = DistributedLlama("unused", config=tcfg, device=DEV, local_rank=rank, world_size=world,
+                               prefill=g["prefill"], gen_len=g["gen_len"], temperature=g["temperature"], top_p=g["top_p"],
+                               retrieval_budget=g["budget"], retrieval_chunk_size=g["chunk"], kv_offload=True,
+                               on_chip_layers=tcfg.num_hidden_layers, gamma=gamma)
+        llm.init_parameters(specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g["head_std"]))
+        out["oneshot_stage"] = llm._ar is not None
+        prompt = Hh.prompt_of(g).to(DEV)
+        llm.reset()
+        lp = llm.prefill(prompt[:, :-1])[:, -1]
+        lb = llm.build_retrieval_cache(prompt[:, -1:])
+        S = llm.kv_cache.seq_len
+        vt = torch.tensor([[11, 12, 13] + [100] * (gamma - 2)], device=DEV)
+        ls = llm.retrieval_inference(vt, torch.arange(S, S + gamma + 1, device=DEV).unsqueeze(0))
+        lv = llm.inference(vt)
+        torch.cuda.synchronize()
+        out.update(S=S, stages=[t.float().cpu() for t in (lp, lb, ls, lv)],
+                   ar_error_stage=llm._ar.error() if llm._ar is not None else -1)
+        del llm
+        # 2) the whole decode loop (draft + retrieval verify + target verify, hipGraphs) on the small_gamma6 fixture
+        g = Hh.load_golden("small_gamma6")
+        gamma = g["gamma"]
+        draft = Draft.from_state_dict(LlamaConfig.from_dict(g["dcfg"]),
+                                      specs.random_state_dict(g["dcfg"], g["dseed"], head_std=g["head_std"]), DEV)
+        dcache = StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - gamma, gamma=gamma)
+        tcfg = LlamaConfig.from_dict(g["tcfg"])
+        llm = DistributedLlama("unused", config=tcfg, device=DEV, local_rank=rank, world_size=world,
+                               prefill=g["prefill"], gen_len=g["gen_len"], temperature=g["temperature"], top_p=g["top_p"],
+                               retrieval_budget=g["budget"], kv_offload=True, on_chip_layers=tcfg.num_hidden_layers,
+                               draft=draft, draft_cache=dcache, gamma=gamma)
+        llm.init_parameters(specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g["head_std"]))
+        llm.initialize_graphs()
+        res = TriForce_Dist(Hh.FakeTokenizer(), llm, Hh.prompt_of(g).to(DEV), gamma=gamma, max_len=24, top_k=-1,
+                            top_p=g["top_p"], temperature=g["temperature"], return_details=True)
+        torch.cuda.synchronize()
+        out.update(tokens=res["tokens"], counts=res["counts"], seq_len=llm.kv_cache.seq_len, graph_form=llm.graph_form,
+                   oneshot_decode=llm._ar is not None, ar_error_decode=llm._ar.error() if llm._ar is not None else -1)
+        dist.barrier()
+        q.put((rank, "ok", out))
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_tp_world2_on_one_device_real_kernels_and_oneshot_allreduce():
+    """World size 2 on hardware, as far as a 1-GPU box allows: two processes, each with its own shard of the heads and
+    of the MLP columns, running the real kernels on the same device; every decode-sized all-reduce is the one-shot
+    kernel across the process boundary.  (1) the four forward stages equal the logits the UNMODIFIED reference engine
+    produced as 2 gloo processes (same tolerance as the CPU test of the host logic), bit-identical on both ranks;
+    (2) the graphed decode loop emits the same stream on both ranks and stays on the oracle's greedy path."""
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_tp2_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = {}
+    try:
+        for _ in range(2):
+            o = q.get(timeout=600)
+            outs[o[0]] = o
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    for o in outs.values():
+        assert o[1] == "ok", o[2]
+    a, b = outs[0][2], outs[1][2]
+    g = Hh.load_golden("tp_world2")
+    for r, o in ((0, a), (1, b)):
+        assert o["oneshot_stage"] and o["oneshot_decode"], f"rank {r}: the engine fell back to the ring collective"
+        assert o["ar_error_stage"] == 0 and o["ar_error_decode"] == 0, f"rank {r}: an all-reduce wait timed out"
+        assert o["S"] == g["S"]
+        for name, ours in zip(("prefill_logits", "build_logits", "spec_logits", "verify_logits"), o["stages"]):
+            gap = (ours.reshape(g[name].shape) - g[name].float()).abs().max().item()
+            assert gap < 4e-3, f"rank {r} {name}: {gap:.2e} from the reference's world-2 logits"
+    for x, y in zip(a["stages"], b["stages"]):
+        assert torch.equal(x, y)                                  # every rank holds the same bits after each all-reduce
+    assert a["tokens"] == b["tokens"] and a["counts"] == b["counts"] and a["seq_len"] == b["seq_len"]
+    print(f"[tp2 on one device] graph form {a['graph_form']}, {len(a['tokens'])} tokens, accept counts {a['counts']}")
+    g6 = Hh.load_golden("small_gamma6")
+    gaps = Hh.teacher_forced_gaps(g6, a["tokens"])
+    assert max(gaps) < 8e-3, f"TP stream leaves the oracle's greedy path: gap {max(gaps):.4f}"
+    assert Hh.common_prefix(a["tokens"], g6["ar_tokens"]) >= 12
