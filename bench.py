@@ -78,6 +78,10 @@ def parse(argv=None):
     ap.add_argument("--dry-run", action="store_true",
                     help="tensor-parallel path only: build the process group, the sharded engine and its weights, agree "
                          "across ranks, print the JSON line with dry_run=true and exit (no decode; runs on CPU under gloo)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="tensor-parallel path only: put every rank on cuda:0 (a functional full-size check of world "
+                         "size N on a 1-GPU box: real shards, real kernels, one-shot all-reduce across processes; "
+                         "large collectives over gloo).  NOT a scaling measurement; the line says so")
     ap.add_argument("--eager-comparator", action="store_true",
                     help="also time the same-hardware un-tuned comparator (eager PyTorch-ROCm restatement, ~20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

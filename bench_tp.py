@@ -91,7 +91,11 @@ def run_tp(args, rank, world, local):
             sock.bind(("127.0.0.1", 0))
             port = sock.getsockname()[1]
         os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    distributed_init("nccl" if on_gpu else "gloo")              # gloo: the CPU plumbing test (--dry-run)
+    share = on_gpu and getattr(args, "share_device", False)     # every rank on cuda:0 (functional check on a 1-GPU box):
+    if share:                                                   # RCCL refuses two ranks on one device, so gloo carries
+        local = 0                                               # the large collectives; the decode-sized ones are the
+        torch.cuda.set_device(0)                                # one-shot kernel over hipIpc mappings either way
+    distributed_init("nccl" if on_gpu and not share else "gloo")    # gloo also: the CPU plumbing test (--dry-run)
     device = torch.device("cuda", local) if on_gpu else torch.device("cpu")
     if not on_gpu and not args.dry_run:
         raise SystemExit("bench.py --gpus N needs GPUs (use --dry-run for the CPU plumbing check)")
@@ -180,7 +184,9 @@ def run_tp(args, rank, world, local):
             "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1] shapes, tensor-parallel: {tcfg._name_or_path} TriForce decode, "
                                    f"prefill {args.prefill}, budget {args.budget}, chunk {args.chunk_size}, gamma "
-                                   f"{args.gamma}, T={args.temp}, top_p={args.top_p}, TP={world} over RCCL/xGMI, "
+                                   f"{args.gamma}, T={args.temp}, top_p={args.top_p}, TP={world} "
+                                   + ("with ALL RANKS ON ONE DEVICE (functional check, not a scaling point), "
+                                      if share else "over RCCL/xGMI, ")
                                    + ("KV resident in HBM" if offload is None else
                                       f"KV of {offload['offloaded_layers']} layers in pinned host memory (on_chip "
                                       f"{offload['on_chip_layers']})"),
@@ -193,6 +199,7 @@ def run_tp(args, rank, world, local):
             "kv_seq_len": llm.kv_cache.seq_len, "graph_form": getattr(llm, "graph_form", "eager"),
             "decode_allreduce": "one-shot peer reads (tf_allreduce_oneshot)" if getattr(llm, "_ar", None) is not None
             else ("rccl" if world > 1 else "none (one rank)"),
+            "ranks_share_one_device": bool(share),
             "roofline": roof, "roofline_note": None if roof else "target verify replayed from a hipGraph on this run: "
             "no per-launch HIP events; see profiles/ for the rocprofv3 kernel trace", "cpu_baseline": None}), flush=True)
     dist.barrier()
