@@ -59,6 +59,16 @@ int tf_attn_decode(const void* q, const void* k, const void* v, void* out,
                    int64_t stride_t, int64_t stride_h,
                    int sq, int sk, const int32_t* sk_dev, int H, int D, float scale,
                    int nsplit, float* ws, int64_t ws_floats, void* stream);
+/* The same call as ONE launch (tf_attn_decode is split kernel + merge kernel): the last workgroup of each head to
+ * finish merges that head's splits inside the split kernel — same arithmetic in the same order, bit-identical output.
+ *   tickets  H uint32 words of device memory, ZERO before the first call; every call leaves them zero.  One ticket
+ *            array serves one stream: calls that may run concurrently need separate arrays.
+ * Falls back to the two-launch form when 3 * nsplit * 16*ceil(sq/16) floats do not fit the kernel's 64*(D+1)-float
+ * merge scratch (e.g. D = 128: nsplit > 172 at sq <= 16). */
+int tf_attn_decode_fused(const void* q, const void* k, const void* v, void* out,
+                         int64_t stride_t, int64_t stride_h,
+                         int sq, int sk, const int32_t* sk_dev, int H, int D, float scale,
+                         int nsplit, float* ws, int64_t ws_floats, uint32_t* tickets, void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Block attention: 1 <= sq <= 128 query rows in ONE pass over the keys.

@@ -46,6 +46,7 @@ def test_bad_arguments_are_rejected_without_launching():
     lib = hip.lib()
     null = ctypes.c_void_p(0)
     assert lib.tf_attn_decode(null, null, null, null, 128, 128, 1, 1, null, 1, 128, 1.0, 1, null, 0, null) == -22
+    assert lib.tf_attn_decode_fused(null, null, null, null, 128, 128, 1, 1, null, 1, 128, 1.0, 1, null, 0, null, null) == -22
     assert lib.tf_rmsnorm(null, null, null, null, null, 1, 8, 1e-6, null) == -22
     assert lib.tf_retrieval_topk(null, null, 10, 2, 1, null) == -22
     assert lib.tf_kv_copy_rows(null, 0, 0, 0, null, 0, 0, 0, 0, 0, 0, 1, 1, 8, null) == 0      # n == 0 is a no-op

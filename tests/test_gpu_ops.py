@@ -144,6 +144,40 @@ def test_attn_decode_matches_oracle(sq, sk, H, D, nsplit):
     torch.testing.assert_close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
 
 
+@pytest.mark.parametrize("sq,sk,H,D,nsplit", ATTN_CASES + [(7, 4103, 32, 128, 8), (17, 12305, 16, 128, 48),
+                                                         (1, 130000, 4, 128, 64), (6, 300, 12, 64, None)])
+def test_attn_decode_one_launch_merge_is_bit_identical_to_two_launches(sq, sk, H, D, nsplit, monkeypatch):
+    """tf_attn_decode_fused (the last workgroup of a head merges its splits inside the split kernel) against
+    tf_attn_decode (split kernel + merge kernel): same arithmetic in the same order -> the same bits; repeated
+    launches on one ticket row (the row must come back zero each time), and replayed from a hipGraph."""
+    ops = _ops()
+    scale = R.softmax_scale_for(D)
+    q, k, v, kd, vd = _attn_inputs(sq, sk, H, D, seed=31 + sq + sk)
+    qd = q.to(DEV)
+    monkeypatch.setattr(ops, "ATTN_FUSED_MERGE", False)
+    two = ops.attn_decode(qd, kd, vd, sk, scale, nsplit=nsplit)
+    monkeypatch.setattr(ops, "ATTN_FUSED_MERGE", True)
+    for _ in range(3):
+        one = ops.attn_decode(qd, kd, vd, sk, scale, nsplit=nsplit)
+        assert torch.equal(one, two)
+    row = ops._ticket_row(qd.device, torch.cuda.current_stream().cuda_stream or 0)
+    torch.cuda.synchronize()
+    assert int(row.abs().sum()) == 0
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.attn_decode(qd, kd, vd, sk, scale, nsplit=nsplit)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = ops.attn_decode(qd, kd, vd, sk, scale, nsplit=nsplit)
+    for _ in range(3):
+        captured.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(captured, two)
+
+
 def test_attn_decode_token_major_and_device_seqlen():
     ops = _ops()
     sq, sk, H, D, cap = 7, 777, 4, 128, 1024

@@ -38,9 +38,20 @@
 #ifndef TF_ATTN_QT2_OCC
 #define TF_ATTN_QT2_OCC 2
 #endif
+#define COMBINE_GROUPS 8           // independent accumulation chains of the split merge (fixed: part of the arithmetic)
+#define COMBINE_MAX_SPLITS 128
+#define FUSED_MERGE_MAX_SPLITS 8   // = COMBINE_GROUPS: each split is then one chain, merged in registers by one workgroup
 #ifndef TF_ATTN_DEPTH
 #define TF_ATTN_DEPTH 2        // KV tiles in flight per wave in the split-KV kernel (3 = 24 KiB; A/B in tools/tune.py)
 #endif
+
+// agent-scope relaxed accesses: global_store / global_load ... sc1 (write-through / L2-coherent across XCDs)
+__device__ __forceinline__ void st_agent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <int D, int QT>
 struct AttnState {
@@ -155,7 +166,7 @@ template <int D, int QT>
 __device__ __forceinline__ void attn_split_body(
     const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
     int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
-    float* __restrict__ ws) {
+    float* __restrict__ ws, unsigned* __restrict__ tickets, h16* __restrict__ out) {
     constexpr int NC = D / 32, NT = D / 16, QR = QT * 16;
     const int split = blockIdx.x, h = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -262,22 +273,86 @@ __device__ __forceinline__ void attn_split_body(
             const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
             const float w0 = __expf(m0 - mm), w1 = __expf(m1 - mm), w2 = __expf(m2 - mm), w3 = __expf(m3 - mm);
             const float o = sm_o[0][qq][d] * w0 + sm_o[1][qq][d] * w1 + sm_o[2][qq][d] * w2 + sm_o[3][qq][d] * w3;
-            ws_o[(pbase + qt * 16 + qq) * D + d] = o;
-            if (d == 0) {
-                ws_m[pbase + qt * 16 + qq] = mm;
-                ws_l[pbase + qt * 16 + qq] = sm_l[0][qq] * w0 + sm_l[1][qq] * w1 + sm_l[2][qq] * w2 + sm_l[3][qq] * w3;
+            const float lw = sm_l[0][qq] * w0 + sm_l[1][qq] * w1 + sm_l[2][qq] * w2 + sm_l[3][qq] * w3;
+            if (tickets == nullptr) {
+                ws_o[(pbase + qt * 16 + qq) * D + d] = o;
+                if (d == 0) {
+                    ws_m[pbase + qt * 16 + qq] = mm;
+                    ws_l[pbase + qt * 16 + qq] = lw;
+                }
+            } else {                                   // one-launch form: write-through (sc1) stores, see below
+                st_agent(&ws_o[(pbase + qt * 16 + qq) * D + d], o);
+                if (d == 0) {
+                    st_agent(&ws_m[pbase + qt * 16 + qq], mm);
+                    st_agent(&ws_l[pbase + qt * 16 + qq], lw);
+                }
             }
         }
         __syncthreads();
     }
+    if (tickets == nullptr) return;                    // two-launch form: attn_combine_kernel merges the splits
+
+    // ---- fused merge: the LAST workgroup of this head to finish folds the nsplit partials (same arithmetic, same
+    // order as attn_combine_kernel: bit-identical output) — no second launch, no kernel boundary.  The partials cross
+    // XCDs (one L2 each): they are written with agent-scope write-through stores and read back with agent-scope loads
+    // (sc1), ordered by "own stores landed (vmcnt 0) -> ticket".  An agent-scope release FENCE instead writes the whole
+    // L2 back: measured 21.7 -> 47.9 us on the 7B retrieval-verify shape.
+    __shared__ int s_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0)
+        s_last = __hip_atomic_fetch_add(&tickets[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nsplit - 1);
+    __syncthreads();
+    if (!s_last) return;
+    // nsplit <= FUSED_MERGE_MAX_SPLITS (host-checked): every load of an output element is issued up front — one memory
+    // latency — and each split is its own accumulation chain of attn_combine_kernel
+    const int64_t hbase = (int64_t)h * nsplit * QR;
+    for (int e = tid; e < sq * (D / 4); e += 256) {
+        const int r = e / (D / 4), d4 = e - r * (D / 4);
+        float pm[FUSED_MERGE_MAX_SPLITS], pl[FUSED_MERGE_MAX_SPLITS];
+        f32x4 px[FUSED_MERGE_MAX_SPLITS];
+#pragma unroll
+        for (int s = 0; s < FUSED_MERGE_MAX_SPLITS; ++s) {
+            if (s < nsplit) {
+                const float* xp = ws_o + (hbase + (int64_t)s * QR + r) * D + 4 * d4;
+                px[s] = f32x4{ld_agent(xp), ld_agent(xp + 1), ld_agent(xp + 2), ld_agent(xp + 3)};
+                pm[s] = ld_agent(&ws_m[hbase + (int64_t)s * QR + r]);
+                pl[s] = ld_agent(&ws_l[hbase + (int64_t)s * QR + r]);
+            } else {
+                px[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+                pm[s] = NEG_BIG;
+                pl[s] = 0.f;
+            }
+        }
+        float mm = NEG_BIG;
+#pragma unroll
+        for (int s = 0; s < FUSED_MERGE_MAX_SPLITS; ++s) mm = fmaxf(mm, pm[s]);
+        float l = 0.f;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < FUSED_MERGE_MAX_SPLITS; ++s) {
+            float w = 0.f;
+            if (s < nsplit) {
+                w = __expf(pm[s] - mm);
+                l += pl[s] * w;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += fmaf(px[s][c], w, 0.f);
+        }
+        half4 o4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o4[c] = (h16)(acc[c] / l);
+        *reinterpret_cast<half4*>(out + ((int64_t)r * H + h) * D + 4 * d4) = o4;
+    }
+    if (tid == 0) __hip_atomic_store(&tickets[h], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left zero for the next launch (graph replays included)
 }
 
 template <int D, int QT>
 __global__ ATTN_SPLIT_BOUNDS void attn_split_kernel(
     const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
     int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
-    float* __restrict__ ws) {
-    attn_split_body<D, QT>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws);
+    float* __restrict__ ws, unsigned* __restrict__ tickets, h16* __restrict__ out) {
+    attn_split_body<D, QT>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws, tickets, out);
 }
 
 // The two-q-tile form compiled for TF_ATTN_QT2_OCC waves per SIMD (see the note at the top of the file).
@@ -286,8 +361,8 @@ template <int D>
 __global__ __launch_bounds__(256, TF_ATTN_QT2_OCC) void attn_split_q2_kernel(
     const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
     int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
-    float* __restrict__ ws) {
-    attn_split_body<D, 2>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws);
+    float* __restrict__ ws, unsigned* __restrict__ tickets, h16* __restrict__ out) {
+    attn_split_body<D, 2>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws, tickets, out);
 }
 #endif
 
@@ -746,8 +821,6 @@ static size_t blk_lds_bytes() {
 // Merge of the per-split partials.  grid (H, sq), block (D, CG): thread (d, g) folds the splits s == g (mod CG)
 // with independent loads (the first version walked all splits serially per thread: 29 us at nsplit=32 — a
 // dependent-latency chain, 8% on top of the 331 us split kernel); the CG partial sums meet in LDS.
-#define COMBINE_GROUPS 8
-#define COMBINE_MAX_SPLITS 128
 template <int D>
 __global__ __launch_bounds__(D * COMBINE_GROUPS) void attn_combine_kernel(const float* __restrict__ ws,
                                                                           h16* __restrict__ out, int sq, int H,
@@ -1070,37 +1143,57 @@ extern "C" int tf_attn_decode_pick_nsplit(int H, int sk) {
 template <int D, int QT>
 static int launch_attn(const void* q, const void* k, const void* v, void* out, int64_t stride_t, int64_t stride_h,
                        int sq, int sk, const int32_t* sk_dev, int H, float scale, int nsplit, float* ws,
-                       hipStream_t st) {
+                       unsigned* tickets, hipStream_t st) {
     dim3 grid(nsplit, H), block(256);
+    if (tickets && nsplit > FUSED_MERGE_MAX_SPLITS) tickets = nullptr;    // many splits: the parallel merge kernel wins
 #if TF_ATTN_QT2_OCC > 0
     if constexpr (QT == 2)
         hipLaunchKernelGGL((attn_split_q2_kernel<D>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
-                           stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws);
+                           stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, (h16*)out);
     else
 #endif
         hipLaunchKernelGGL((attn_split_kernel<D, QT>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
-                           stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws);
+                           stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, (h16*)out);
     TF_LAUNCH_CHECK();
+    if (tickets) return TF_OK;
     hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(H, sq), dim3(D, COMBINE_GROUPS), 0, st, (const float*)ws,
                        (h16*)out, sq, H, nsplit, QT * 16);
     TF_LAUNCH_CHECK();
     return TF_OK;
 }
 
-extern "C" int tf_attn_decode(const void* q, const void* k, const void* v, void* out, int64_t stride_t,
-                              int64_t stride_h, int sq, int sk, const int32_t* sk_dev, int H, int D, float scale,
-                              int nsplit, float* ws, int64_t ws_floats, void* stream) {
+static int attn_decode_any(const void* q, const void* k, const void* v, void* out, int64_t stride_t,
+                           int64_t stride_h, int sq, int sk, const int32_t* sk_dev, int H, int D, float scale,
+                           int nsplit, float* ws, int64_t ws_floats, unsigned* tickets, void* stream) {
     if (!q || !k || !v || !out || !ws) return TF_EINVAL;
     if (sq < 1 || sq > 32 || sk < 1 || H < 1 || nsplit < 1 || nsplit > COMBINE_MAX_SPLITS) return TF_EINVAL;
     if ((stride_t % 8) || (stride_h % 8)) return TF_EINVAL;          // 16-B loads
     if (ws_floats < tf_attn_decode_ws_floats(H, sq, D, nsplit)) return TF_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
     const int QT = (sq + 15) / 16;
-    if (D == 128 && QT == 1) return launch_attn<128, 1>(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, st);
-    if (D == 128 && QT == 2) return launch_attn<128, 2>(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, st);
-    if (D == 64 && QT == 1) return launch_attn<64, 1>(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, st);
-    if (D == 64 && QT == 2) return launch_attn<64, 2>(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, st);
+    if (D == 128 && QT == 1) return launch_attn<128, 1>(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, st);
+    if (D == 128 && QT == 2) return launch_attn<128, 2>(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, st);
+    if (D == 64 && QT == 1) return launch_attn<64, 1>(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, st);
+    if (D == 64 && QT == 2) return launch_attn<64, 2>(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, st);
     return TF_EINVAL;
+}
+
+extern "C" int tf_attn_decode(const void* q, const void* k, const void* v, void* out, int64_t stride_t,
+                              int64_t stride_h, int sq, int sk, const int32_t* sk_dev, int H, int D, float scale,
+                              int nsplit, float* ws, int64_t ws_floats, void* stream) {
+    return attn_decode_any(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, D, scale, nsplit, ws, ws_floats, nullptr,
+                           stream);
+}
+
+// The same call as ONE launch: the last workgroup of each head to finish merges that head's splits (bit-identical to
+// the two-launch form).  ``tickets``: H uint32 words of device memory, zero before the first call; every call leaves
+// them zero.  One ticket array serves one stream: two calls that may run concurrently need two arrays.
+extern "C" int tf_attn_decode_fused(const void* q, const void* k, const void* v, void* out, int64_t stride_t,
+                                    int64_t stride_h, int sq, int sk, const int32_t* sk_dev, int H, int D, float scale,
+                                    int nsplit, float* ws, int64_t ws_floats, uint32_t* tickets, void* stream) {
+    if (!tickets) return TF_EINVAL;
+    return attn_decode_any(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, D, scale, nsplit, ws, ws_floats, tickets,
+                           stream);
 }
 
 extern "C" int64_t tf_attn_block_ws_floats(int H, int D, int nsplit) { return (int64_t)H * nsplit * 128 * (D + 2); }

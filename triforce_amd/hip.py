@@ -17,6 +17,8 @@ SIGNATURES = {
     "tf_attn_decode_ws_floats": (_i64, [_i32, _i32, _i32, _i32]),
     "tf_attn_decode_pick_nsplit": (_i32, [_i32, _i32]),
     "tf_attn_decode": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _i32, _f32, _i32, _vp, _i64, _vp]),
+    "tf_attn_decode_fused": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _i32, _f32, _i32, _vp, _i64, _vp,
+                                    _vp]),
     "tf_attn_block_ws_floats": (_i64, [_i32, _i32, _i32]),
     "tf_attn_block_pick_nsplit": (_i32, [_i32, _i32, _i32]),
     "tf_attn_block": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _i64, _vp, _i32,

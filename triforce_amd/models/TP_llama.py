@@ -513,6 +513,14 @@ class DistributedLlama:
                 self._target_caps[q_len] = cap
         self.graph_form = self._verify_cap["form"] if self._verify_cap else "eager"
         self.reset()
+        # the probe replays above ran the one-shot all-reduce inside the captured forwards: if any rank saw a peer
+        # wait time out there, every rank drops to RCCL and captures again — before any real state exists
+        if self._ar is not None and not self._agree(self._ar.error() == 0):
+            if verbose or self.local_rank == 0:
+                print("[TP] one-shot all-reduce timed out inside a captured forward: falling back to RCCL", flush=True)
+            self._ar.close()
+            self._ar = None
+            return self.initialize_graphs(gamma, capture_verify, verbose)
 
     def _inference_captured(self, cap, input_ids, advance=True):
         kvc, S, q_len = self.kv_cache, self.kv_cache.seq_len, input_ids.shape[1]

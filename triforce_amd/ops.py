@@ -243,6 +243,27 @@ def _ws_floats(H, sq, D, nsplit):
     return hip.lib().tf_attn_decode_ws_floats(H, sq, D, nsplit)
 
 
+# Ticket words of the one-launch attention (tf_attn_decode_fused): per device one zeroed block, one 128-word row per
+# stream that has launched attention (calls on one stream are ordered; two streams must not share a row).  Allocated
+# at the first call, never freed; every launch leaves its row zero.
+ATTN_FUSED_MERGE = _os.environ.get("TRIFORCE_ATTN_FUSED_MERGE", "1") != "0"
+_TICKET_ROWS, _TICKET_WORDS = 64, 128
+_tickets = {}
+
+
+def _ticket_row(device, stream):
+    dev = _tickets.get(device)
+    if dev is None:
+        dev = _tickets[device] = (torch.zeros(_TICKET_ROWS, _TICKET_WORDS, dtype=torch.int32, device=device), {})
+    block, rows = dev
+    row = rows.get(stream)
+    if row is None:
+        if len(rows) >= _TICKET_ROWS:
+            return None                               # more streams than rows: the two-launch form is always valid
+        row = rows[stream] = len(rows)
+    return block[row]
+
+
 def attn_decode(q, k_layer, v_layer, sk, scale, sk_dev=None, nsplit=None):
     """flash_attn_with_kvcache(q, k, v, softmax_scale, causal=True) for sq<=32 rows (bottom-right causal).
     q (sq,H,D); returns (sq, H*D) fp16."""
@@ -264,8 +285,15 @@ def attn_decode(q, k_layer, v_layer, sk, scale, sk_dev=None, nsplit=None):
     if timed:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    hip.check(L.tf_attn_decode(_ptr(q), _ptr(k_layer), _ptr(v_layer), _ptr(out), st, sh, sq, int(sk), _ptr(sk_dev),
-                               H, D, float(scale), nsplit, _ptr(ws), ws.numel(), _stream()), "tf_attn_decode")
+    stream = _stream()
+    tickets = _ticket_row(q.device, stream.value or 0) if ATTN_FUSED_MERGE and H <= _TICKET_WORDS else None
+    if tickets is not None:
+        hip.check(L.tf_attn_decode_fused(_ptr(q), _ptr(k_layer), _ptr(v_layer), _ptr(out), st, sh, sq, int(sk),
+                                         _ptr(sk_dev), H, D, float(scale), nsplit, _ptr(ws), ws.numel(), _ptr(tickets),
+                                         stream), "tf_attn_decode_fused")
+    else:
+        hip.check(L.tf_attn_decode(_ptr(q), _ptr(k_layer), _ptr(v_layer), _ptr(out), st, sh, sq, int(sk), _ptr(sk_dev),
+                                   H, D, float(scale), nsplit, _ptr(ws), ws.numel(), stream), "tf_attn_decode")
     if timed:
         ev1.record()
         ATTN_TIMER.append((ev0, ev1, int(sk), H, D))
