@@ -90,6 +90,17 @@ int tf_attn_block(const void* q, const void* k, const void* v, void* out,
                   int nsplit, float* ws, int64_t ws_floats,
                   const uint32_t* mask, int mask_words, int mask_row0, int tree_start, void* stream);
 
+/* Whole-chunk causal prefill: 1 <= sq <= 4096 query rows (bottom-right aligned: row i sees keys [0, sk - sq + i]) in
+ * ONE launch — the chunked prefill's attention (utils/graph_infer.py:30-37 -> models/modeling_llama.py:240 with
+ * q_len = the chunk).  The 128-row blocks of the chunk that read the same key range run together on one XCD and share
+ * its L2, so the KV cache is streamed from HBM about once per chunk instead of once per 128 rows.
+ * (H * nsplit) % 8 must be 0 (tf_attn_prefill_pick_nsplit returns such a value); sk >= sq. */
+int tf_attn_prefill_pick_nsplit(int H, int sq, int sk);
+int64_t tf_attn_prefill_ws_floats(int H, int sq, int D, int nsplit);
+int tf_attn_prefill(const void* q, const void* k, const void* v, void* out,
+                    int64_t stride_t, int64_t stride_h, int sq, int sk, int H, int D, float scale,
+                    int nsplit, float* ws, int64_t ws_floats, void* stream);
+
 /* -------------------------------------------------------------------------------------------
  * Draft (Llama-68M) attention with RoPE applied to the cached keys on read
  * (models/modeling_llama_68m.py:151-190): keys are cached UN-rotated and rotated with

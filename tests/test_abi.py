@@ -46,6 +46,10 @@ def test_bad_arguments_are_rejected_without_launching():
     lib = hip.lib()
     null = ctypes.c_void_p(0)
     assert lib.tf_attn_decode(null, null, null, null, 128, 128, 1, 1, null, 1, 128, 1.0, 1, null, 0, null) == -22
+    assert lib.tf_attn_prefill_pick_nsplit(32, 1024, 124928) == 4          # 1024 / (32 heads x 8 row blocks)
+    assert lib.tf_attn_prefill_pick_nsplit(32, 1024, 1024) == 1            # 16 slabs: no split
+    assert (12 * lib.tf_attn_prefill_pick_nsplit(12, 256, 4096)) % 8 == 0  # pairs are dealt to the 8 XCDs
+    assert lib.tf_attn_prefill_ws_floats(32, 1000, 128, 4) == 8 * 32 * 4 * 128 * 130
     assert lib.tf_attn_decode_fused(null, null, null, null, 128, 128, 1, 1, null, 1, 128, 1.0, 1, null, 0, null, null) == -22
     assert lib.tf_rmsnorm(null, null, null, null, null, 1, 8, 1e-6, null) == -22
     assert lib.tf_retrieval_topk(null, null, 10, 2, 1, null) == -22
@@ -66,6 +70,7 @@ def test_ops_refuse_cpu_tensors():
 
 
 _QUERIES = {"tf_abi_version", "tf_attn_block_pick_nsplit", "tf_attn_block_ws_floats", "tf_attn_decode_pick_nsplit",
+            "tf_attn_prefill_pick_nsplit", "tf_attn_prefill_ws_floats",
             "tf_attn_decode_ws_floats", "tf_ar_flags_bytes", "tf_ar_ipc_handle_bytes"}
 
 

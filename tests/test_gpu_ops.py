@@ -220,6 +220,32 @@ def test_attn_prefill_block_equals_oracle(sq, sk, H, D):
     torch.testing.assert_close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
 
 
+@pytest.mark.parametrize("sq,sk,H,D", [(300, 700, 2, 128), (1024, 1024, 4, 128), (1024, 5000, 8, 128), (1000, 3333, 4, 64),
+                                        (129, 129, 2, 128), (2048, 4096, 4, 128), (640, 70000, 8, 128)])
+def test_attn_prefill_one_launch_equals_oracle_and_block_by_block(sq, sk, H, D, monkeypatch):
+    """tf_attn_prefill (every 128-row block of the chunk in one launch, common key partition, neutral partials past a
+    block's causal edge) against the oracle and against one tf_attn_block launch per block; ragged last block, chunks
+    that ARE the whole cache (sk == sq), more than 8 row blocks, and causality (perturbing the last key moves only the
+    last row)."""
+    ops = _ops()
+    scale = R.softmax_scale_for(D)
+    q, k, v, kd, vd = _attn_inputs(sq, sk, H, D, seed=41 + sq)
+    qd = q.to(DEV)
+    monkeypatch.setattr(ops, "ATTN_PREFILL_ONE_LAUNCH", True)
+    got = ops.attn_prefill(qd, kd, vd, sk, scale)
+    monkeypatch.setattr(ops, "ATTN_PREFILL_ONE_LAUNCH", False)
+    blocks = ops.attn_prefill(qd, kd, vd, sk, scale)
+    torch.testing.assert_close(got.float(), blocks.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+    if sq * sk <= 1024 * 5000:                       # the CPU oracle materialises sq x sk scores per head
+        want = R.attn_kvcache(q, k, v, scale).reshape(sq, H * D)
+        torch.testing.assert_close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+    monkeypatch.setattr(ops, "ATTN_PREFILL_ONE_LAUNCH", True)
+    kd2 = kd.clone()
+    kd2[:, sk - 1] += 1.0
+    moved = (ops.attn_prefill(qd, kd2, vd, sk, scale) != got).any(dim=1)
+    assert not moved[:-1].any()
+
+
 def test_attn_block_splits_agree_and_match_decode_kernel():
     """Same block through 1 / 3 / 16 KV splits and, row slab by row slab, through the <=32-row decode kernel."""
     ops = _ops()

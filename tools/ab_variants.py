@@ -7,7 +7,6 @@ Each knob's shipped value is the measured winner (profiles/r02_nsplit_sweep.json
 variants are the losing sides, kept buildable for re-measurement on new silicon / compilers:
   q2occ1      TF_ATTN_QT2_OCC=0        two-q-tile split-KV kernel at the compiler's own 1 wave per SIMD (298 registers)
   nofunnel    TF_TREE_MASK_FUNNEL=0    128-row tree slabs read the mask bit of every key separately
-  depth3      TF_ATTN_DEPTH=3          three K/V tiles in flight per wave (no gain at any measured shape)
 """
 import json
 import os
@@ -19,7 +18,7 @@ sys.path.insert(0, ROOT)
 from triforce_amd.build import LIB_PATH, build_variant  # noqa: E402
 
 VARIANTS = {"q2occ1": ["TF_ATTN_QT2_OCC=0"],
-            "nofunnel": ["TF_TREE_MASK_FUNNEL=0"], "depth3": ["TF_ATTN_DEPTH=3"]}
+            "nofunnel": ["TF_TREE_MASK_FUNNEL=0"]}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(VARIANTS)

@@ -38,11 +38,23 @@
 #ifndef TF_ATTN_QT2_OCC
 #define TF_ATTN_QT2_OCC 2
 #endif
+// The LDS block kernel is VALU-issue-bound (≈270 non-MFMA instructions per 32 MFMAs before this): the softmax uses the
+// bare v_exp_f32 (libm's exp2f wraps it in a denormal-range fix-up: compare, 2 selects, ldexp) with the score scale
+// folded into one fma.  Results below 2^-126 flush to zero — they are probabilities of keys 2^126 times below the row max.
+#ifndef TF_BLOCK_FAST_EXP
+#define TF_BLOCK_FAST_EXP 1
+#endif
+#ifndef TF_BLOCK_SETPRIO
+#define TF_BLOCK_SETPRIO 0
+#endif
 #define COMBINE_GROUPS 8           // independent accumulation chains of the split merge (fixed: part of the arithmetic)
 #define COMBINE_MAX_SPLITS 128
 #define FUSED_MERGE_MAX_SPLITS 8   // = COMBINE_GROUPS: each split is then one chain, merged in registers by one workgroup
-#ifndef TF_ATTN_DEPTH
-#define TF_ATTN_DEPTH 2        // KV tiles in flight per wave in the split-KV kernel (3 = 24 KiB; A/B in tools/tune.py)
+#ifndef TF_DECODE_PERMLANE
+#define TF_DECODE_PERMLANE 1
+#endif
+#ifndef TF_ATTN_EAGER_TILES
+#define TF_ATTN_EAGER_TILES 16 // splits of up to this many 16-key tiles per wave use the unconditional-prefetch loop
 #endif
 
 // agent-scope relaxed accesses: global_store / global_load ... sc1 (write-through / L2-coherent across XCDs)
@@ -51,6 +63,25 @@ __device__ __forceinline__ void st_agent(float* p, float v) {
 }
 __device__ __forceinline__ float ld_agent(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// max over the 4 lane groups of a wave (lanes i, i^16, i^32, i^48) on the VALU: v_permlane{32,16}_swap + v_max instead of
+// two ds_bpermute round trips through the LDS queue (and their lgkmcnt(0) waits in the middle of the softmax chain).
+__device__ __forceinline__ float vmax_raw(float a, float b) {          // plain v_max_f32: no canonicalising pre-ops
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float group_max4(float v) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = vmax_raw(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return vmax_raw(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
 template <int D, int QT>
@@ -128,8 +159,12 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
             x[r] = s[r] * scale;
             tmax = ok[r] ? fmaxf(tmax, x[r]) : tmax;
         }
+#if TF_DECODE_PERMLANE
+        tmax = group_max4(tmax);
+#else
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+#endif
         const float mnew = fmaxf(st.m[qt], tmax);
         float psum = 0.f;
 #pragma unroll
@@ -210,39 +245,42 @@ __device__ __forceinline__ void attn_split_body(
         if ((T) * 16 + 15 <= sk - sq) attn_tile<D, QT, false, false>(st, KF, VF, sel0, sel1, (T), sk, sq, scale, li, g); \
         else attn_tile<D, QT, false, true>(st, KF, VF, sel0, sel1, (T), sk, sq, scale, li, g);        \
     } while (0)
-#if TF_ATTN_DEPTH == 3
-    // three tiles deep (24 KiB in flight per wave): tile t+8 is requested before tile t goes to the matrix core
-    half8 ka[NC], va_[NC], kb[NC], vb[NC], kc[NC], vc[NC];
+    // Two forms of the same two-tiles-deep loop.  A load under `if (t1 < t_end)` makes the compiler assume the worst
+    // case at the use of the OLDER tile — "no younger load was issued" — so it waits vmcnt(7..0) there, i.e. for the
+    // prefetch it has just issued: the wave runs one tile deep.  Issuing the run-ahead loads unconditionally (past the
+    // last tile they re-read it) gives the intended vmcnt(15..8).  Measured (tools/attn_merge_ab.py): short streams gain
+    // (7B retrieval verify 21.0 -> 20.2 us, 4-head TP shard 14.3 -> 13.6, draft-sized 6.9 -> 6.5) but the 125K-key
+    // streams, already bandwidth-bound with 8 MB in flight chip-wide, LOSE 0.7 % (32 heads) to 4 % (16 heads x 17 rows)
+    // with twice as much in flight — so the form is chosen by the length of the wave's stream.
     int t = t_begin + wave;
-    if (t < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t, sk, li, g, ka, va_);
-    if (t + 4 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t + 4, sk, li, g, kb, vb);
-    while (t < t_end) {
-        if (t + 8 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t + 8, sk, li, g, kc, vc);
-        ATTN_TILE_AUTO(ka, va_, t);
-        if (t + 4 >= t_end) break;
-        if (t + 12 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t + 12, sk, li, g, ka, va_);
-        ATTN_TILE_AUTO(kb, vb, t + 4);
-        if (t + 8 >= t_end) break;
-        if (t + 16 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t + 16, sk, li, g, kb, vb);
-        ATTN_TILE_AUTO(kc, vc, t + 8);
-        t += 12;
+    if (t < t_end) {
+        half8 ka[NC], va_[NC], kb[NC], vb[NC];
+        load_kv_tile<D>(kbase, vbase, stride_t, t, sk, li, g, ka, va_);
+        // (one-q-tile form only: with both loops the two-q-tile form no longer fits its 2-waves-per-SIMD register budget)
+        if (TF_ATTN_EAGER_TILES > 0 && QT == 1 && t_end - t_begin <= 4 * TF_ATTN_EAGER_TILES) {
+            const int tl = t_end - 1;
+            while (true) {
+                load_kv_tile<D>(kbase, vbase, stride_t, min(t + 4, tl), sk, li, g, kb, vb);
+                ATTN_TILE_AUTO(ka, va_, t);
+                if (t + 4 >= t_end) break;
+                load_kv_tile<D>(kbase, vbase, stride_t, min(t + 8, tl), sk, li, g, ka, va_);
+                ATTN_TILE_AUTO(kb, vb, t + 4);
+                if (t + 8 >= t_end) break;
+                t += 8;
+            }
+        } else {
+            while (t < t_end) {
+                const int t1 = t + 4;
+                if (t1 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t1, sk, li, g, kb, vb);
+                ATTN_TILE_AUTO(ka, va_, t);
+                if (t1 >= t_end) break;
+                const int t2 = t1 + 4;
+                if (t2 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t2, sk, li, g, ka, va_);
+                ATTN_TILE_AUTO(kb, vb, t1);
+                t = t2;
+            }
+        }
     }
-#else
-    // two tiles deep: the loads of tile t+4 are in flight while tile t is on the matrix core
-    half8 ka[NC], va_[NC], kb[NC], vb[NC];
-    int t = t_begin + wave;
-    if (t < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t, sk, li, g, ka, va_);
-    while (t < t_end) {
-        const int t1 = t + 4;
-        if (t1 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t1, sk, li, g, kb, vb);
-        ATTN_TILE_AUTO(ka, va_, t);
-        if (t1 >= t_end) break;
-        const int t2 = t1 + 4;
-        if (t2 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t2, sk, li, g, ka, va_);
-        ATTN_TILE_AUTO(kb, vb, t1);
-        t = t2;
-    }
-#endif
 
 #undef ATTN_TILE_AUTO
     // ---- merge the 4 waves of this split through LDS, one q-tile at a time ----
@@ -435,8 +473,7 @@ __device__ __forceinline__ void pair_softmax_pv(AttnState<D, QT>& st, const Pair
             x[r] = (r < 4 ? ps.sa[qt][r] : ps.sb[qt][r - 4]) * scale_log2;
             tmax = v ? fmaxf(tmax, x[r]) : tmax;
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = group_max4(tmax);
         const float mnew = fmaxf(st.m[qt], tmax);
         float psum = 0.f;
         half8 pb;
@@ -599,6 +636,31 @@ __global__ __launch_bounds__(256, TF_BLOCK_OCC) void attn_block_kernel(
 // per slab, which bounded the kernel.  Reads stay one 16-byte access per (d, block).
 #endif
 #define BLK_VSWZ(d) (((d) >> 3) & (BLK_SLAB / 8 - 1))
+// D = 128 (TF_BLOCK_TR_READ): no padding, no transposing store.  Rows of K and V are 256 B = one pass over the 64 banks:
+//   K  16-byte chunk j of slab row r sits at chunk j ^ fK(r), fK(r) = (r & 3) | ((r >> 3) & 3) << 2.  The MFMA A-fragment
+//      read (lane (li, g): row 8 (li >> 2) + (li & 3) [+4], chunk 4c + g) then lands at chunk (4c + g) ^ li: 16 distinct
+//      chunks in each 16-lane service group of ds_read_b128 (the padded layout was 2-way conflicted there);
+//   V  row-major like K, 32-byte unit t (= 16 output columns) of row r at unit t ^ fV(r), fV(r) = (r & 3) | ((r >> 3) & 1) << 2;
+//      the PV A operand V^T[d][8 keys] comes from two ds_read_b64_tr_b16 (hardware 4 x 16 transpose across a 16-lane
+//      group: lane i passes row i >> 2, columns 4 (i & 3)..+3 and receives column i of the 4 rows) — the 8 rows a
+//      half-wave touches hit 8 distinct units.  Replaces 8 two-byte scatter stores per 16 bytes of V.
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the padded + transposed layout on a 1024-row prefill chunk: 0.43.
+#ifndef TF_BLOCK_TR_READ
+#define TF_BLOCK_TR_READ 1
+#endif
+typedef __fp16 tr_fp16x4 __attribute__((vector_size(8)));
+__device__ __forceinline__ half4 lds_read_tr4(const h16* p) {
+    const tr_fp16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_fp16x4*)(p));
+    return __builtin_bit_cast(half4, r);
+}
+template <int D>
+struct BlkLayout {
+    static constexpr bool TR = TF_BLOCK_TR_READ && D == 128;
+    static constexpr int RS = TR ? D : D + 8;                         // K row stride (halfs)
+    static constexpr int VS = BLK_SLAB + 8;                           // V^T row stride (transposed layout only)
+    static constexpr int K_HALFS = BLK_SLAB * RS;
+    static constexpr int V_HALFS = TR ? BLK_SLAB * D : D * VS;
+};
 template <int D, int QT, bool TREE, bool MASKED>
 __device__ __forceinline__ void lds_softmax_pv(AttnState<D, QT>& st, const f32x4 (&sa)[QT], const f32x4 (&sb)[QT],
                                                const h16* __restrict__ svt, int g0, int key0, int sk, int sq,
@@ -641,21 +703,37 @@ __device__ __forceinline__ void lds_softmax_pv(AttnState<D, QT>& st, const f32x4
                 }
             }
             ok[r] = v;
+#if TF_BLOCK_FAST_EXP
+            x[r] = (r < 4 ? sa[qt][r] : sb[qt][r - 4]);                 // raw score: the scale rides in the fma below
+#else
             x[r] = (r < 4 ? sa[qt][r] : sb[qt][r - 4]) * scale_log2;
-            tmax = v ? fmaxf(tmax, x[r]) : tmax;
+#endif
+            if (MASKED) tmax = v ? fmaxf(tmax, x[r]) : tmax;
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        if (!MASKED) tmax = vmax3_raw(vmax3_raw(x[0], x[1], x[2]), vmax3_raw(x[3], x[4], x[5]), vmax_raw(x[6], x[7]));
+        tmax = group_max4(tmax);
+#if TF_BLOCK_FAST_EXP
+        const float mnew = fmaxf(st.m[qt], tmax * scale_log2);          // scale > 0: max commutes with it
+#else
         const float mnew = fmaxf(st.m[qt], tmax);
+#endif
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
+#if TF_BLOCK_FAST_EXP
+            const float p = ok[r] ? __builtin_amdgcn_exp2f(fmaf(x[r], scale_log2, -mnew)) : 0.f;
+#else
             const float p = ok[r] ? exp2f(x[r] - mnew) : 0.f;
+#endif
             psum += p;
             pb[qt][r] = (h16)p;
         }
         if (__builtin_amdgcn_ballot_w64(mnew != st.m[qt])) {
+#if TF_BLOCK_FAST_EXP
+            const float alpha = __builtin_amdgcn_exp2f(st.m[qt] - mnew);
+#else
             const float alpha = exp2f(st.m[qt] - mnew);
+#endif
             st.l[qt] *= alpha;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -667,43 +745,61 @@ __device__ __forceinline__ void lds_softmax_pv(AttnState<D, QT>& st, const f32x4
         st.l[qt] += psum;
     }
     // PV: every V^T fragment is read from LDS once and feeds the MFMAs of all q-tiles of the wave
+#if TF_BLOCK_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+    if constexpr (BlkLayout<D>::TR) {
+        const int fv = (li >> 2) | ((g & 1) << 2);
+        const h16* vrow = svt + (8 * (g0 + g) + (li >> 2)) * D + 4 * (li & 3);       // keys 8(g0+g) + {0..3}; +4 rows below
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int d = 16 * t + li;                                                  // V^T[d][keys 8(g0+g) .. +7]
-        const half8 vt = load_half8(svt + d * VS + 8 * ((g0 + g) ^ BLK_VSWZ(d)));
+        for (int t = 0; t < NT; ++t) {
+            const int pos = (t ^ fv) * 16;
+            const half4 lo = lds_read_tr4(vrow + pos), hi = lds_read_tr4(vrow + 4 * D + pos);
+            const half8 vt = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-            st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vt, pb[qt], st.acc[qt][t], 0, 0, 0);
+            for (int qt = 0; qt < QT; ++qt)
+                st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vt, pb[qt], st.acc[qt][t], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int d = 16 * t + li;                                              // V^T[d][keys 8(g0+g) .. +7]
+            const half8 vt = load_half8(svt + d * VS + 8 * ((g0 + g) ^ BLK_VSWZ(d)));
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+                st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vt, pb[qt], st.acc[qt][t], 0, 0, 0);
+        }
     }
+#if TF_BLOCK_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 #ifndef TF_BLOCK_TREE_OCC
 #define TF_BLOCK_TREE_OCC 2      // waves per SIMD of the TREE form of the LDS block kernel.  At 2 it spills 46 registers; at 1
                                  // (512 registers, no spill) the 512-node Sequoia verify is 25 % SLOWER (2 890 -> 3 630 us): kept at 2
 #endif
+// One workgroup: the 128-row block ``q`` against slabs [s_begin, s_end) of head h; partial (m, l, O) to slot ``split``.
 template <int D, bool TREE>
-__global__ __launch_bounds__(256, TREE ? TF_BLOCK_TREE_OCC : 2) void attn_block_lds_kernel(
+__device__ __forceinline__ void attn_block_lds_body(
     const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
     int64_t stride_h, int sq, int sk, int H, float scale, int nsplit, float* __restrict__ ws,
-    const uint32_t* __restrict__ mask, int mask_words, int mask_row0, int tree_start) {
+    const uint32_t* __restrict__ mask, int mask_words, int mask_row0, int tree_start, int split, int h, int s_begin,
+    int s_end) {
     constexpr int NC = D / 32, NT = D / 16, QT = 2, QR = 128;
     constexpr int SLAB = BLK_SLAB;                          // keys per load step: 64 -> 32 KiB (D=128) in flight per WG
-    constexpr int RS = D + 8;                               // K row stride in LDS (halfs)
-    constexpr int VS = SLAB + 8;                            // V^T row stride in LDS (halfs)
+    constexpr bool TR = BlkLayout<D>::TR;                   // swizzled K, row-major V + transpose reads (see above)
+    constexpr int RS = BlkLayout<D>::RS;                    // K row stride in LDS (halfs)
+    constexpr int VS = BlkLayout<D>::VS;                    // V^T row stride in LDS (halfs)
     constexpr int VPR = D / 8;                              // 16-byte vectors per row
     constexpr int RPP = 256 / VPR;                          // rows covered by one pass of the 256 threads
     constexpr int NPASS = SLAB / RPP;                       // passes per slab (4 for D=128, 2 for D=64)
     extern __shared__ __attribute__((aligned(16))) unsigned char blk_smem[];
     h16* sK = reinterpret_cast<h16*>(blk_smem);             // [2][SLAB * RS]
-    h16* sVt = sK + 2 * SLAB * RS;                          // [2][D * VS]
-    const int split = blockIdx.x, h = blockIdx.y;
+    h16* sVt = sK + 2 * BlkLayout<D>::K_HALFS;              // [2][D * VS]  or  [2][SLAB * D]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     const int qbase = wave * 32;
-    const int nslabs = (sk + SLAB - 1) / SLAB;
-    const int sps = (nslabs + nsplit - 1) / nsplit;
-    const int s_begin = split * sps;
-    const int s_end = min(nslabs, s_begin + sps);
 
     AttnState<D, QT> st;
 #pragma unroll
@@ -741,15 +837,21 @@ __global__ __launch_bounds__(256, TREE ? TF_BLOCK_TREE_OCC : 2) void attn_block_
         }
     };
     auto stash = [&](int buf) {
-        h16* dk = sK + buf * SLAB * RS;
-        h16* dv = sVt + buf * D * VS;
+        h16* dk = sK + buf * BlkLayout<D>::K_HALFS;
+        h16* dv = sVt + buf * BlkLayout<D>::V_HALFS;
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
             const int r = p * RPP + lr;
-            store_half8(dk + r * RS + 8 * lc, gk[p]);
+            if constexpr (TR) {
+                const int fk = (r & 3) | (((r >> 3) & 3) << 2), fv = (r & 3) | (((r >> 3) & 1) << 2);
+                store_half8(dk + r * RS + 8 * (lc ^ fk), gk[p]);
+                store_half8(dv + r * D + 8 * ((((lc >> 1) ^ fv) << 1) | (lc & 1)), gv[p]);
+            } else {
+                store_half8(dk + r * RS + 8 * lc, gk[p]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e)                    // d = 8*lc + e -> swizzle key = lc
-                dv[(8 * lc + e) * VS + ((((r >> 3) ^ (lc & (SLAB / 8 - 1))) << 3) | (r & 7))] = gv[p][e];
+                for (int e = 0; e < 8; ++e)                // d = 8*lc + e -> swizzle key = lc
+                    dv[(8 * lc + e) * VS + ((((r >> 3) ^ (lc & (SLAB / 8 - 1))) << 3) | (r & 7))] = gv[p][e];
+            }
         }
     };
 
@@ -757,12 +859,17 @@ __global__ __launch_bounds__(256, TREE ? TF_BLOCK_TREE_OCC : 2) void attn_block_
         fetch(s_begin);
         stash(0);
     }
+    // Every load issued so far — the Q fragments above all — has landed before the loop: without this the compiler,
+    // which cannot tell the Q loads from the slab prefetch through the in-order vmcnt, waits vmcnt(0) right after issuing
+    // each prefetch (the path that skips the stash above leaves Q pending at the loop header), i.e. serialises the HBM
+    // latency of every slab with its MFMAs.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0), expcnt / lgkmcnt untouched
     __syncthreads();
     for (int sl = s_begin; sl < s_end; ++sl) {
         const int buf = (sl - s_begin) & 1;
-        if (sl + 1 < s_end) fetch(sl + 1);                  // in flight under this slab's MFMAs
-        const h16* bk = sK + buf * SLAB * RS;
-        const h16* bv = sVt + buf * D * VS;
+        fetch(min(sl + 1, s_end - 1));                      // in flight under this slab's MFMAs (unconditional: see attn_split_body)
+        const h16* bk = sK + buf * BlkLayout<D>::K_HALFS;
+        const h16* bv = sVt + buf * BlkLayout<D>::V_HALFS;
 #pragma unroll
         for (int sub = 0; sub < SLAB / 32; ++sub) {
             const int key0 = sl * SLAB + 32 * sub;
@@ -775,8 +882,9 @@ __global__ __launch_bounds__(256, TREE ? TF_BLOCK_TREE_OCC : 2) void attn_block_
             }
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const half8 ka = load_half8(bk + (32 * sub + row_a) * RS + 32 * c + 8 * g);
-                const half8 kb = load_half8(bk + (32 * sub + row_a + 4) * RS + 32 * c + 8 * g);
+                const int kcol = TR ? 8 * ((4 * c + g) ^ li) : 32 * c + 8 * g;
+                const half8 ka = load_half8(bk + (32 * sub + row_a) * RS + kcol);
+                const half8 kb = load_half8(bk + (32 * sub + row_a + 4) * RS + kcol);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
                     sa[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, st.qf[qt][c], sa[qt], 0, 0, 0);
@@ -813,9 +921,53 @@ __global__ __launch_bounds__(256, TREE ? TF_BLOCK_TREE_OCC : 2) void attn_block_
     }
 }
 
+template <int D, bool TREE>
+__global__ __launch_bounds__(256, TREE ? TF_BLOCK_TREE_OCC : 2) void attn_block_lds_kernel(
+    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
+    int64_t stride_h, int sq, int sk, int H, float scale, int nsplit, float* __restrict__ ws,
+    const uint32_t* __restrict__ mask, int mask_words, int mask_row0, int tree_start) {
+    const int split = blockIdx.x, h = blockIdx.y;
+    const int nslabs = (sk + BLK_SLAB - 1) / BLK_SLAB;
+    const int sps = (nslabs + nsplit - 1) / nsplit;
+    const int s_begin = split * sps;
+    attn_block_lds_body<D, TREE>(q, k, v, stride_t, stride_h, sq, sk, H, scale, nsplit, ws, mask, mask_words, mask_row0,
+                                 tree_start, split, h, s_begin, min(nslabs, s_begin + sps));
+}
+
+// A whole causal prefill chunk (sq rows = nrb blocks of 128) in ONE launch.  Block rb sees keys [0, sk - sq + end_rb).
+// Launching the blocks one by one streams the KV cache from HBM once per 128 rows (128 flop per byte: an 800 TF/s
+// ceiling at 6.3 TB/s, and the 125K-token prefill ran at ~490).  Here the row blocks that read the SAME key range run at
+// the same time on the SAME XCD, so all but one of them hit that XCD's L2: workgroup ids are laid out as
+//   id % 8 = XCD (hardware round-robin),  (id / 8) % RBG = row block within a group of RBG <= 8,  id / (8 RBG) = the rest,
+// and a (split, head) pair is pinned to XCD pair % 8.  Every row block uses the key partition of the full sk, so its
+// splits cover the same slabs as its neighbours'; splits past a block's causal edge write a neutral partial.
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(
+    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
+    int64_t stride_h, int sq, int sk, int H, float scale, int nsplit, float* __restrict__ ws, int nrb, int rbg) {
+    const int id = blockIdx.x;
+    const int pairs = H * nsplit;                                     // host guarantees pairs % 8 == 0
+    const int xcd = id & 7, j = id >> 3;
+    const int rb_lo = j % rbg, rest = j / rbg;
+    const int pair = (rest % (pairs >> 3)) * 8 + xcd;
+    const int rb = rb_lo + rbg * (rest / (pairs >> 3));
+    if (rb >= nrb) return;
+    const int h = pair / nsplit, split = pair - h * nsplit;
+    const int r0 = rb * 128;
+    const int rows = min(128, sq - r0);
+    const int sk_eff = sk - (sq - (r0 + rows));                        // keys visible to the last row of this block
+    const int nslabs_all = (sk + BLK_SLAB - 1) / BLK_SLAB;
+    const int nslabs = (sk_eff + BLK_SLAB - 1) / BLK_SLAB;
+    const int sps = (nslabs_all + nsplit - 1) / nsplit;
+    const int s_begin = split * sps;
+    float* ws_rb = ws + (int64_t)rb * H * nsplit * 128 * (D + 2);
+    attn_block_lds_body<D, false>(q + (int64_t)r0 * H * D, k, v, stride_t, stride_h, rows, sk_eff, H, scale, nsplit, ws_rb,
+                                  nullptr, 0, 0, 0, split, h, s_begin, min(nslabs, s_begin + sps));
+}
+
 template <int D>
 static size_t blk_lds_bytes() {
-    return (size_t)2 * (BLK_SLAB * (D + 8) + D * (BLK_SLAB + 8)) * sizeof(h16);
+    return (size_t)2 * (BlkLayout<D>::K_HALFS + BlkLayout<D>::V_HALFS) * sizeof(h16);
 }
 
 // Merge of the per-split partials.  grid (H, sq), block (D, CG): thread (d, g) folds the splits s == g (mod CG)
@@ -870,13 +1022,17 @@ __global__ __launch_bounds__(D * COMBINE_GROUPS) void attn_combine_kernel(const 
 // coalesced loads.
 template <int D>
 __global__ __launch_bounds__(256) void attn_combine_rows_kernel(const float* __restrict__ ws, h16* __restrict__ out,
-                                                                int sq, int H, int nsplit, int QR) {
+                                                                int sq, int H, int nsplit, int QR, int block_rows) {
     constexpr int VPL = D / 64;
     static_assert(COMBINE_MAX_SPLITS <= 128, "two weights per lane");
     const int lane = threadIdx.x & 63;
     const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);           // pair = row * H + head (output order)
     if (pair >= sq * H) return;
-    const int qq = pair / H, h = pair - qq * H;
+    const int row = pair / H, h = pair - row * H;
+    // block_rows > 0 (tf_attn_prefill): rows [rb * block_rows, ...) have their own workspace image
+    const int rb = block_rows > 0 ? row / block_rows : 0;
+    const int qq = row - rb * block_rows;
+    ws += (int64_t)rb * H * nsplit * QR * (D + 2);
     const float* ws_o = ws;
     const float* ws_m = ws + (int64_t)H * nsplit * QR * D;
     const float* ws_l = ws_m + (int64_t)H * nsplit * QR;
@@ -1235,12 +1391,68 @@ static int launch_block(const void* q, const void* k, const void* v, void* out, 
     TF_LAUNCH_CHECK();
     if (sq > 32)
         hipLaunchKernelGGL((attn_combine_rows_kernel<D>), dim3((sq * H + 3) / 4), dim3(256), 0, st, (const float*)ws,
-                           (h16*)out, sq, H, nsplit * (4 / rg), 32 * rg);
+                           (h16*)out, sq, H, nsplit * (4 / rg), 32 * rg, 0);
     else
         hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(H, sq), dim3(D, COMBINE_GROUPS), 0, st, (const float*)ws,
                            (h16*)out, sq, H, nsplit * (4 / rg), 32 * rg);
     TF_LAUNCH_CHECK();
     return TF_OK;
+}
+
+// ---- whole-chunk causal prefill: tf_attn_prefill ---------------------------------------------------------------
+#define PREFILL_MAX_ROWS 4096
+extern "C" int tf_attn_prefill_pick_nsplit(int H, int sq, int sk) {
+    const int nrb = (sq + 127) / 128;
+    const int slabs = (sk + BLK_SLAB - 1) / BLK_SLAB;
+    int n = 1024 / ((H > 0 ? H : 1) * nrb);          // ~4 workgroups per CU over the launch
+    const int by_work = slabs / 16;                   // >= 16 slabs (1024 keys) per workgroup
+    if (n > by_work) n = by_work;
+    if (n > COMBINE_MAX_SPLITS) n = COMBINE_MAX_SPLITS;
+    if (n < 1) n = 1;
+    while ((H * n) % 8) ++n;                          // (split, head) pairs are dealt to the 8 XCDs
+    return n;
+}
+
+extern "C" int64_t tf_attn_prefill_ws_floats(int H, int sq, int D, int nsplit) {
+    return (int64_t)((sq + 127) / 128) * H * nsplit * 128 * (D + 2);
+}
+
+template <int D>
+static int launch_prefill(const void* q, const void* k, const void* v, void* out, int64_t stride_t, int64_t stride_h,
+                          int sq, int sk, int H, float scale, int nsplit, float* ws, hipStream_t st) {
+    static bool attr_set = false;                         // 70 KiB of dynamic LDS: above the 64 KiB default limit
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_prefill_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)blk_lds_bytes<D>());
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int nrb = (sq + 127) / 128, rbg = nrb < 8 ? nrb : 8;
+    const int groups = (nrb + rbg - 1) / rbg;
+    const int64_t blocks = (int64_t)H * nsplit * rbg * groups;
+    hipLaunchKernelGGL((attn_prefill_kernel<D>), dim3((unsigned)blocks), dim3(256), blk_lds_bytes<D>(), st, (const h16*)q,
+                       (const h16*)k, (const h16*)v, stride_t, stride_h, sq, sk, H, scale, nsplit, ws, nrb, rbg);
+    TF_LAUNCH_CHECK();
+    hipLaunchKernelGGL((attn_combine_rows_kernel<D>), dim3((sq * H + 3) / 4), dim3(256), 0, st, (const float*)ws,
+                       (h16*)out, sq, H, nsplit, 128, 128);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}
+
+// Causal attention of a prefill chunk of 129..4096 query rows in one launch (bottom-right aligned: row i sees keys
+// [0, sk - sq + i]); replaces one flash_attn_with_kvcache call per 128-row piece of the chunk.  (H * nsplit) % 8 == 0.
+extern "C" int tf_attn_prefill(const void* q, const void* k, const void* v, void* out, int64_t stride_t,
+                               int64_t stride_h, int sq, int sk, int H, int D, float scale, int nsplit, float* ws,
+                               int64_t ws_floats, void* stream) {
+    if (!q || !k || !v || !out || !ws) return TF_EINVAL;
+    if (sq < 1 || sq > PREFILL_MAX_ROWS || sk < sq || H < 1 || nsplit < 1 || nsplit > COMBINE_MAX_SPLITS) return TF_EINVAL;
+    if ((H * nsplit) % 8) return TF_EINVAL;
+    if ((stride_t % 8) || (stride_h % 8)) return TF_EINVAL;
+    if (ws_floats < tf_attn_prefill_ws_floats(H, sq, D, nsplit)) return TF_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    if (D == 128) return launch_prefill<128>(q, k, v, out, stride_t, stride_h, sq, sk, H, scale, nsplit, ws, st);
+    if (D == 64) return launch_prefill<64>(q, k, v, out, stride_t, stride_h, sq, sk, H, scale, nsplit, ws, st);
+    return TF_EINVAL;
 }
 
 // Attention of a block of 1..128 query rows against the cache, D = 128 or 64.  mask == NULL: bottom-right causal

@@ -21,6 +21,9 @@ SIGNATURES = {
                                     _vp]),
     "tf_attn_block_ws_floats": (_i64, [_i32, _i32, _i32]),
     "tf_attn_block_pick_nsplit": (_i32, [_i32, _i32, _i32]),
+    "tf_attn_prefill_pick_nsplit": (_i32, [_i32, _i32, _i32]),
+    "tf_attn_prefill_ws_floats": (_i64, [_i32, _i32, _i32, _i32]),
+    "tf_attn_prefill": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _i64, _vp]),
     "tf_attn_block": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _i64, _vp, _i32,
                              _i32, _i32, _vp]),
     "tf_attn_rope_on_read": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp]),

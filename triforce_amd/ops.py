@@ -349,20 +349,37 @@ def pack_tree_mask(visible):
     return w.to(torch.int32).contiguous()
 
 
+# 0: a prefill chunk's attention as one tf_attn_block launch per 128 rows (A/B; default: tf_attn_prefill, one launch)
+ATTN_PREFILL_ONE_LAUNCH = _os.environ.get("TRIFORCE_PREFILL_ONE_LAUNCH", "1") != "0"
+
+
 def attn_prefill(q, k_layer, v_layer, sk, scale):
     """Causal attention for a prefill block of any length: <=32 rows use the decode kernel, longer blocks are cut
-    into <=128-row slabs, slab j seeing keys [0, sk - sq + end_j) — each slab is one bottom-right-aligned
-    tf_attn_block call (one pass over the KV cache per 128 rows)."""
+    (up to 4096 rows) go to tf_attn_prefill: the 128-row blocks of the chunk, block j seeing keys
+    [0, sk - sq + end_j), run in one launch and share the KV stream through L2."""
     sq = q.shape[0]
     if sq <= 32:
         return attn_decode(q, k_layer, v_layer, sk, scale)
     if sq <= 128:
         return attn_block(q, k_layer, v_layer, sk, scale)
-    outs = []
-    for r0 in range(0, sq, 128):
-        r1 = min(sq, r0 + 128)
-        outs.append(attn_block(q[r0:r1].contiguous(), k_layer, v_layer, sk - (sq - r1), scale))
-    return torch.cat(outs, dim=0)
+    if not ATTN_PREFILL_ONE_LAUNCH or sq > 4096:
+        outs = []
+        for r0 in range(0, sq, 128):
+            r1 = min(sq, r0 + 128)
+            outs.append(attn_block(q[r0:r1].contiguous(), k_layer, v_layer, sk - (sq - r1), scale))
+        return torch.cat(outs, dim=0)
+    _dev(q, k_layer, v_layer)
+    _, H, D = q.shape
+    assert q.dtype == _HALF and q.is_contiguous()
+    st, sh = _kv(k_layer)
+    assert _kv(v_layer) == (st, sh)
+    L = hip.lib()
+    nsplit = L.tf_attn_prefill_pick_nsplit(H, sq, int(sk))
+    ws = _workspace(q.device, L.tf_attn_prefill_ws_floats(H, sq, D, nsplit))
+    out = torch.empty(sq, H * D, dtype=_HALF, device=q.device)
+    hip.check(L.tf_attn_prefill(_ptr(q), _ptr(k_layer), _ptr(v_layer), _ptr(out), st, sh, sq, int(sk), H, D, float(scale),
+                                nsplit, _ptr(ws), ws.numel(), _stream()), "tf_attn_prefill")
+    return out
 
 
 def attn_rope_on_read(q, k_layer, v_layer, cos, sin, kv_len, scale):
