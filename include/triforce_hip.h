@@ -113,6 +113,48 @@ int tf_attn_rope_on_read(const void* q, const void* k, const void* v, const void
                          int sq, int kv_len, int H, int D, float scale, void* stream);
 
 /* -------------------------------------------------------------------------------------------
+ * The Llama-68M draft forward as one entry point (models/modeling_llama_68m.py:129-190 with the StreamingLLM cache of
+ * models/cache.py:266-330; utils/graph_infer.py:52-57 `draft_run`): n <= 32 token ids -> fp32 logits [n][vocab] and,
+ * when probs_out != NULL, softmax(top_p(logits[n-1] / temperature)) [vocab] (utils/sampling.py:43-60).
+ * Native host code: the call issues the whole launch chain (embedding + positions, per layer RMSNorm + q|k|v + RoPE +
+ * KV append / rope-on-read attention / o_proj + residual / RMSNorm + gate|up + SwiGLU / down_proj + residual, final
+ * RMSNorm + lm_head, top-p) on `stream` through the kernels of the entry points above — bit-identical to calling them
+ * one by one — allocates nothing and is graph-capturable.
+ *   model  device pointers: embed [vocab][hidden] fp16; per layer ln1 / ln2 [hidden], wqkv packed in ROTARY-PAIR row
+ *          order (tf_skinny_qkv_rope), wo / wgate / wup / wdown packed (tf_skinny_gemm); norm, lm_head packed;
+ *          cos / sin [max_pos][head_dim] fp16.  head_dim must be 64 (tf_attn_rope_on_read).
+ *   cache  per layer K / V base pointers, stride convention of the top of this file; keys are stored UN-rotated
+ *   slot0  cache row of ids[0] (the rows [slot0, slot0 + n) are written); kv_len >= slot0 + n keys are attended
+ *   ws     >= tf_draft_forward_ws_bytes(model, n) bytes of device scratch
+ * ------------------------------------------------------------------------------------------- */
+#define TF_DRAFT_MAX_LAYERS 8
+typedef struct TfDraftModel {
+    const void* embed;
+    const void* ln1[TF_DRAFT_MAX_LAYERS];
+    const void* wqkv[TF_DRAFT_MAX_LAYERS];
+    const void* wo[TF_DRAFT_MAX_LAYERS];
+    const void* ln2[TF_DRAFT_MAX_LAYERS];
+    const void* wgate[TF_DRAFT_MAX_LAYERS];
+    const void* wup[TF_DRAFT_MAX_LAYERS];
+    const void* wdown[TF_DRAFT_MAX_LAYERS];
+    const void* norm;
+    const void* lm_head;
+    const void* cos;
+    const void* sin;
+    int32_t layers, hidden, heads, head_dim, inter, vocab;
+    float eps, scale;
+} TfDraftModel;
+typedef struct TfDraftCache {
+    void* k[TF_DRAFT_MAX_LAYERS];
+    void* v[TF_DRAFT_MAX_LAYERS];
+    int64_t stride_t, stride_h;
+} TfDraftCache;
+int64_t tf_draft_forward_ws_bytes(const TfDraftModel* model, int n);
+int tf_draft_forward_68m(const TfDraftModel* model, const TfDraftCache* cache, const int64_t* ids, int n, int slot0,
+                         int kv_len, float* logits_out, float* probs_out, float temperature, float top_p,
+                         void* ws, int64_t ws_bytes, void* stream);
+
+/* -------------------------------------------------------------------------------------------
  * Retrieval-cache build (models/cache.py:146-178 == :517-556): chunk-mean scoring, per-head
  * top-k, chunk gather.
  * tf_retrieval_score : scores[h][c] = fp16( q[h] . fp16(mean_{t in chunk c} K[t][h]) ), un-scaled

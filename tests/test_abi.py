@@ -46,6 +46,11 @@ def test_bad_arguments_are_rejected_without_launching():
     lib = hip.lib()
     null = ctypes.c_void_p(0)
     assert lib.tf_attn_decode(null, null, null, null, 128, 128, 1, 1, null, 1, 128, 1.0, 1, null, 0, null) == -22
+    m = hip.TfDraftModel()
+    m.layers, m.hidden, m.heads, m.head_dim, m.inter, m.vocab = 2, 768, 12, 64, 3072, 32000
+    assert lib.tf_draft_forward_ws_bytes(ctypes.byref(m), 7) == 3 * 10752 + 256 + 43008 + 6144     # 256-byte aligned pieces
+    assert lib.tf_draft_forward_ws_bytes(None, 7) == 0
+    assert lib.tf_draft_forward_68m(ctypes.byref(m), None, null, 7, 0, 7, null, null, 0.6, 0.9, null, 0, null) == -22
     assert lib.tf_attn_prefill_pick_nsplit(32, 1024, 124928) == 4          # 1024 / (32 heads x 8 row blocks)
     assert lib.tf_attn_prefill_pick_nsplit(32, 1024, 1024) == 1            # 16 slabs: no split
     assert (12 * lib.tf_attn_prefill_pick_nsplit(12, 256, 4096)) % 8 == 0  # pairs are dealt to the 8 XCDs
@@ -70,7 +75,7 @@ def test_ops_refuse_cpu_tensors():
 
 
 _QUERIES = {"tf_abi_version", "tf_attn_block_pick_nsplit", "tf_attn_block_ws_floats", "tf_attn_decode_pick_nsplit",
-            "tf_attn_prefill_pick_nsplit", "tf_attn_prefill_ws_floats",
+            "tf_attn_prefill_pick_nsplit", "tf_attn_prefill_ws_floats", "tf_draft_forward_ws_bytes",
             "tf_attn_decode_ws_floats", "tf_ar_flags_bytes", "tf_ar_ipc_handle_bytes"}
 
 
@@ -88,6 +93,8 @@ def test_every_entry_point_rejects_null_buffers(fill):
         for t in argtypes:
             if t is ctypes.c_void_p:
                 args.append(ctypes.c_void_p(0))
+            elif isinstance(t, type) and issubclass(t, ctypes._Pointer):
+                args.append(None)                                       # struct pointers (TfDraftModel*, ...): NULL
             elif t in (ctypes.c_float, ctypes.c_double):
                 args.append(1.0)
             else:

@@ -117,6 +117,62 @@ def test_logits_and_retrieval_stages_match_oracle(name):
     assert (qo - qp).abs().max() < 5e-3, f"draft probs differ by {(qo - qp).abs().max():.3e}"
 
 
+def test_native_draft_forward_is_bit_identical_to_the_op_by_op_chain(monkeypatch):
+    """tf_draft_forward_68m (one C call issuing the whole 68M forward: embedding + positions, 2 x 5 layer launches,
+    lm_head, top-p) against the same forward issued entry point by entry point from Python: decode steps over a warm
+    StreamingLLM cache, every speculative offset, logits, probability rows and the K / V rows written — all bit for bit;
+    and replayed from a hipGraph."""
+    from oracle import specs
+    from triforce_amd.models.cache import StreamingLLMEvictionCache
+    from triforce_amd.models.config_yarn import LlamaConfig
+    from triforce_amd.models.modeling_llama_68m import LlamaForCausalLM as Draft
+    g = Hh.load_golden("small_gamma6")
+    gamma = g["gamma"]
+    dsd = specs.random_state_dict(g["dcfg"], g["dseed"], head_std=g["head_std"])
+    cfg = LlamaConfig.from_dict(g["dcfg"])
+
+    def run(native):
+        monkeypatch.setenv("TRIFORCE_DRAFT_NATIVE", "1" if native else "0")
+        m = Draft.from_state_dict(cfg, dsd, DEV)
+        c = StreamingLLMEvictionCache(m, start_size=16, recent_size=256 - 16 - gamma, gamma=gamma)
+        assert (m._native_model() is not None) == native
+        gen = torch.Generator().manual_seed(5)
+        outs = []
+        for n in (20, 7, 1):                                           # non-speculative appends (<= 32 rows each)
+            ids = torch.randint(3, cfg.vocab_size, (1, n), generator=gen).to(DEV)
+            outs.append(m.forward(ids, c, None, -1).logits)
+        for off in range(gamma + 3):                                   # speculative steps at every offset, with top-p
+            ids = torch.randint(3, cfg.vocab_size, (1, off + 1), generator=gen).to(DEV)
+            o = m.forward(ids, c, c, off, probs=(0.6, 0.9))
+            outs += [o.logits, o.probs]
+        torch.cuda.synchronize()
+        return m, c, outs
+
+    m0, c0, ref = run(False)
+    m1, c1, got = run(True)
+    assert len(ref) == len(got)
+    for a, b in zip(ref, got):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert torch.equal(c0.k, c1.k) and torch.equal(c0.v, c1.v) and c0.seq_len == c1.seq_len
+    # graph replay of the native call
+    ids = torch.randint(3, cfg.vocab_size, (1, 3)).to(DEV)
+    want = m0.forward(ids, c0, c0, 2, probs=(0.6, 0.9))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m1.forward(ids, c1, c1, 2, probs=(0.6, 0.9))
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        cap = m1.forward(ids, c1, c1, 2, probs=(0.6, 0.9))
+    for _ in range(2):
+        cap.logits.zero_()
+        cap.probs.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(cap.logits, want.logits) and torch.equal(cap.probs, want.probs)
+
+
 def test_periodic_retrieval_rebuild_stays_lossless_on_device():
     """--rebuild_every: re-selecting the retrieval chunks inside a target verify changes what the
     middle model drafts from, never what the target accepts — the greedy stream stays on the oracle's argmax path,

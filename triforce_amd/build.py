@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtriforce_hip.so")
-SOURCES = ["attn.hip", "retrieval.hip", "elementwise.hip", "sampling.hip", "offload.hip", "gemv.hip", "allreduce.hip", "abi.hip"]
+SOURCES = ["attn.hip", "retrieval.hip", "elementwise.hip", "sampling.hip", "offload.hip", "gemv.hip", "allreduce.hip", "draft.hip", "abi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-gpu-rdc", "-Wno-unused-result"]
 

@@ -62,6 +62,26 @@ SIGNATURES = {
     "tf_ar_error": (_i32, [_vp]),
 }
 
+TF_DRAFT_MAX_LAYERS = 8
+
+
+class TfDraftModel(_c.Structure):
+    """include/triforce_hip.h: TfDraftModel (device pointers of the 68M draft model's weights)."""
+    _fields_ = ([("embed", _vp)] + [(n, _vp * TF_DRAFT_MAX_LAYERS) for n in
+                                    ("ln1", "wqkv", "wo", "ln2", "wgate", "wup", "wdown")]
+                + [("norm", _vp), ("lm_head", _vp), ("cos", _vp), ("sin", _vp)]
+                + [(n, _i32) for n in ("layers", "hidden", "heads", "head_dim", "inter", "vocab")]
+                + [("eps", _f32), ("scale", _f32)])
+
+
+class TfDraftCache(_c.Structure):
+    _fields_ = [("k", _vp * TF_DRAFT_MAX_LAYERS), ("v", _vp * TF_DRAFT_MAX_LAYERS), ("stride_t", _i64), ("stride_h", _i64)]
+
+
+SIGNATURES["tf_draft_forward_ws_bytes"] = (_i64, [_c.POINTER(TfDraftModel), _i32])
+SIGNATURES["tf_draft_forward_68m"] = (_i32, [_c.POINTER(TfDraftModel), _c.POINTER(TfDraftCache), _vp, _i32, _i32, _i32, _vp,
+                                             _vp, _f32, _f32, _vp, _i64, _vp])
+
 ABI_VERSION = 1
 _lib = None
 

@@ -559,8 +559,9 @@ class DistributedLlama:
                 logits = self.draft(input_ids=input_ids[:, i * 128:(i + 1) * 128], kv_cache=self.draft_cache,
                                     graph_cache=None).logits
         else:
-            logits = self.draft(input_ids=input_ids, kv_cache=self.draft_cache, graph_cache=self.draft_cache,
-                                gamma_offset=gamma_offset).logits
+            out = self.draft.forward(input_ids, self.draft_cache, self.draft_cache, gamma_offset,
+                                     probs=(temperature, top_p) if probs else None)
+            return out.probs if probs else out.logits
         if probs:
             return norm_logits(logits[0, -1:], temperature=temperature, top_k=-1, top_p=top_p)[0]
         return logits

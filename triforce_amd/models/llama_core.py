@@ -60,10 +60,11 @@ def softmax_scale_for(head_dim):
 
 
 class CausalLMOutput:
-    __slots__ = ("logits",)
+    __slots__ = ("logits", "probs")
 
-    def __init__(self, logits):
+    def __init__(self, logits, probs=None):
         self.logits = logits
+        self.probs = probs
 
 
 class LlamaWeights:

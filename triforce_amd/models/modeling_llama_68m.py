@@ -63,12 +63,50 @@ class LlamaForCausalLM:
                  attention_mask=None, storage_ids=None):
         return self.forward(input_ids, kv_cache, graph_cache, gamma_offset)
 
-    def forward(self, input_ids, kv_cache, graph_cache=None, gamma_offset=-1):
+    # ---- native chain (tf_draft_forward_68m): one C call issues the whole forward --------------------------------
+    def _native_model(self):
+        """TfDraftModel over this model's packed weights, or None (CPU tensors / a weight the fused kernels cannot
+        take / TRIFORCE_FUSE != all / TRIFORCE_DRAFT_NATIVE=0).  Built once; the weights are never reallocated
+        (aligned re-calibration rewrites them in place)."""
+        if not hasattr(self, "_native"):
+            import os
+            W = self.weights
+            ok = (self.device.type == "cuda" and ops.FUSE_MODE == "all" and os.environ.get("TRIFORCE_DRAFT_NATIVE", "1") != "0"
+                  and isinstance(W.lm_head, ops.PackedLinear))
+            self._native = ops.draft_model_struct(W.embed, W.ln1, W.wqkv, W.wo, W.ln2, W.wgu, W.wd, W.norm, W.lm_head,
+                                                  self.cos, self.sin, W.H, W.D, W.eps, self.scale) if ok else None
+        return self._native
+
+    def _native_cache(self, c):
+        key = id(c)
+        if getattr(self, "_native_cache_key", None) != key:
+            self._native_cache_struct, self._native_cache_key = ops.draft_cache_struct(c, self.weights.L), key
+            self._native_cache_ref = c                                  # keeps id(c) from being recycled
+        return self._native_cache_struct
+
+    def forward(self, input_ids, kv_cache, graph_cache=None, gamma_offset=-1, probs=None):
+        """``probs`` = (temperature, top_p): also return the top-p probability row of the last token (out.probs)."""
         W = self.weights
         H, D = W.H, W.D
         q_len = input_ids.shape[1]
-        x = W.embed[input_ids.reshape(-1)]
         spec = gamma_offset >= 0
+        native = self._native_model() if q_len <= ops.SKINNY_MAX_ROWS else None
+        if native is not None:
+            if spec:
+                c = graph_cache
+                assert q_len == gamma_offset + 1 and q_len <= c.gamma + 3
+                slot0, kv_len = c.spec_slot, gamma_offset + c.start_size + c.recent_size + 1
+            else:
+                c = kv_cache
+                slot0 = c.seq_len
+                kv_len = slot0 + q_len
+                for i in range(W.L):
+                    c.append_slot(i, q_len)
+            logits, p = ops.draft_forward(native, self._native_cache(c), input_ids.reshape(-1), slot0, kv_len, probs)
+            out = CausalLMOutput(logits.unsqueeze(0))
+            out.probs = p
+            return out
+        x = W.embed[input_ids.reshape(-1)]
         if spec:                                                          # 68m.py:151-162
             c = graph_cache
             assert q_len == gamma_offset + 1 and q_len <= c.gamma + 3
@@ -118,4 +156,8 @@ class LlamaForCausalLM:
         else:
             h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)
             logits = ops.linear(h, W.lm_head, out_f32=True).unsqueeze(0)
-        return CausalLMOutput(logits)
+        out = CausalLMOutput(logits)
+        if probs is not None:
+            from ..utils.sampling import norm_logits
+            out.probs = norm_logits(logits[0, -1:], temperature=probs[0], top_k=-1, top_p=probs[1])[0]
+        return out

@@ -382,6 +382,59 @@ def attn_prefill(q, k_layer, v_layer, sk, scale):
     return out
 
 
+def draft_model_struct(embed, ln1, wqkv, wo, ln2, wgu, wd, norm, lm_head, cos, sin, H, D, eps, scale):
+    """TfDraftModel for tf_draft_forward_68m from the draft's weights (PackedLinear lists); None when a weight is not
+    packed for the fused kernels (CPU tensors, odd shapes).  The struct holds raw pointers: keep the tensors alive."""
+    L = len(wqkv)
+    ws = list(wqkv) + list(wo) + list(wgu) + list(wd) + [lm_head]
+    if L > hip.TF_DRAFT_MAX_LAYERS or D != 64 or not all(isinstance(w, PackedLinear) and w.parts is not None for w in ws):
+        return None
+    if any(w.wp_rope is None for w in wqkv) or any(w.split != 2 for w in wgu) or not embed.is_cuda:
+        return None
+    m = hip.TfDraftModel()
+    m.embed = embed.data_ptr()
+    for i in range(L):
+        m.ln1[i], m.ln2[i] = ln1[i].data_ptr(), ln2[i].data_ptr()
+        m.wqkv[i], m.wo[i], m.wdown[i] = wqkv[i].wp_rope.data_ptr(), wo[i].wp.data_ptr(), wd[i].wp.data_ptr()
+        m.wgate[i], m.wup[i] = wgu[i].parts[0].data_ptr(), wgu[i].parts[1].data_ptr()
+    m.norm, m.lm_head, m.cos, m.sin = norm.data_ptr(), lm_head.wp.data_ptr(), cos.data_ptr(), sin.data_ptr()
+    m.layers, m.hidden, m.heads, m.head_dim = L, embed.shape[1], H, D
+    m.inter, m.vocab, m.eps, m.scale = wgu[0].N // 2, lm_head.N, float(eps), float(scale)
+    return m
+
+
+def draft_cache_struct(cache, L):
+    """TfDraftCache over the per-layer K / V views of a StreamingLLM cache."""
+    c = hip.TfDraftCache()
+    st = sh = None
+    for i in range(L):
+        kl, vl = cache.layer_kv(i)
+        _dev(kl, vl)
+        assert _kv(vl) == _kv(kl) and (st is None or (st, sh) == _kv(kl))
+        st, sh = _kv(kl)
+        c.k[i], c.v[i] = kl.data_ptr(), vl.data_ptr()
+    c.stride_t, c.stride_h = st, sh
+    return c
+
+
+def draft_forward(model, cache, ids, slot0, kv_len, probs=None):
+    """tf_draft_forward_68m: ids (n,) int64 -> fp32 logits (n, vocab) [and the top-p probability row of the last token
+    when ``probs`` = (temperature, top_p)] in one native call."""
+    _dev(ids)
+    n = ids.numel()
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and 1 <= n <= SKINNY_MAX_ROWS
+    L = hip.lib()
+    nbytes = L.tf_draft_forward_ws_bytes(ctypes.byref(model), n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=ids.device)
+    logits = torch.empty(n, model.vocab, dtype=torch.float32, device=ids.device)
+    p = torch.empty(model.vocab, dtype=torch.float32, device=ids.device) if probs is not None else None
+    T, top_p = probs if probs is not None else (1.0, 1.0)
+    hip.check(L.tf_draft_forward_68m(ctypes.byref(model), ctypes.byref(cache), _ptr(ids), n, int(slot0), int(kv_len),
+                                     _ptr(logits), _ptr(p), float(T), float(top_p), _ptr(ws), nbytes, _stream()),
+              "tf_draft_forward_68m")
+    return logits, p
+
+
 def attn_rope_on_read(q, k_layer, v_layer, cos, sin, kv_len, scale):
     """Draft attention: cached keys are un-rotated and rotated on read with positions 0..kv_len-1."""
     _dev(q, k_layer, v_layer, cos, sin)

@@ -62,9 +62,12 @@ class InferenceEngine:
                 logits = self.draft(input_ids=input_ids[:, i * 64:(i + 1) * 64], kv_cache=self.draft_cache,
                                     graph_cache=None).logits
         else:
-            logits = self.draft(input_ids=input_ids, kv_cache=self.draft_cache, graph_cache=self.draft_cache,
-                                gamma_offset=gamma_offset).logits
-        if probs:     # only the last row is used (graph_infer.py:57); rows are independent, so normalise just that one
+            # only the last row is used (graph_infer.py:57); rows are independent, so just that one is normalised —
+            # inside the same native call when the draft runs through tf_draft_forward_68m
+            out = self.draft.forward(input_ids, self.draft_cache, self.draft_cache, gamma_offset,
+                                     probs=(temperature, top_p) if probs else None)
+            return out.probs if probs else out.logits
+        if probs:
             return norm_logits(logits[0, -1:], temperature=temperature, top_k=-1, top_p=top_p)[0]
         return logits
 
