@@ -38,21 +38,13 @@
 #ifndef TF_ATTN_QT2_OCC
 #define TF_ATTN_QT2_OCC 2
 #endif
-// The LDS block kernel is VALU-issue-bound (≈270 non-MFMA instructions per 32 MFMAs before this): the softmax uses the
-// bare v_exp_f32 (libm's exp2f wraps it in a denormal-range fix-up: compare, 2 selects, ldexp) with the score scale
-// folded into one fma.  Results below 2^-126 flush to zero — they are probabilities of keys 2^126 times below the row max.
-#ifndef TF_BLOCK_FAST_EXP
-#define TF_BLOCK_FAST_EXP 1
-#endif
-#ifndef TF_BLOCK_SETPRIO
-#define TF_BLOCK_SETPRIO 0
-#endif
+// The LDS block kernel is VALU-issue-bound (≈270 non-MFMA instructions per 32 MFMAs with libm's exp2f): its softmax uses
+// the bare v_exp_f32 (exp2f wraps it in a denormal-range fix-up: compare, 2 selects, ldexp) with the score scale folded
+// into one fma: 580 -> 628 TF/s on a 1024-row chunk.  Results below 2^-126 flush to zero — probabilities of keys 2^126
+// times below the row max.  (s_setprio around the PV MFMA cluster measured +0.8 %, inside the noise: not kept.)
 #define COMBINE_GROUPS 8           // independent accumulation chains of the split merge (fixed: part of the arithmetic)
 #define COMBINE_MAX_SPLITS 128
 #define FUSED_MERGE_MAX_SPLITS 8   // = COMBINE_GROUPS: each split is then one chain, merged in registers by one workgroup
-#ifndef TF_DECODE_PERMLANE
-#define TF_DECODE_PERMLANE 1
-#endif
 #ifndef TF_ATTN_EAGER_TILES
 #define TF_ATTN_EAGER_TILES 16 // splits of up to this many 16-key tiles per wave use the unconditional-prefetch loop
 #endif
@@ -159,12 +151,7 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
             x[r] = s[r] * scale;
             tmax = ok[r] ? fmaxf(tmax, x[r]) : tmax;
         }
-#if TF_DECODE_PERMLANE
         tmax = group_max4(tmax);
-#else
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-#endif
         const float mnew = fmaxf(st.m[qt], tmax);
         float psum = 0.f;
 #pragma unroll
@@ -636,7 +623,7 @@ __global__ __launch_bounds__(256, TF_BLOCK_OCC) void attn_block_kernel(
 // per slab, which bounded the kernel.  Reads stay one 16-byte access per (d, block).
 #endif
 #define BLK_VSWZ(d) (((d) >> 3) & (BLK_SLAB / 8 - 1))
-// D = 128 (TF_BLOCK_TR_READ): no padding, no transposing store.  Rows of K and V are 256 B = one pass over the 64 banks:
+// D = 128: no padding, no transposing store.  Rows of K and V are 256 B = one pass over the 64 banks:
 //   K  16-byte chunk j of slab row r sits at chunk j ^ fK(r), fK(r) = (r & 3) | ((r >> 3) & 3) << 2.  The MFMA A-fragment
 //      read (lane (li, g): row 8 (li >> 2) + (li & 3) [+4], chunk 4c + g) then lands at chunk (4c + g) ^ li: 16 distinct
 //      chunks in each 16-lane service group of ds_read_b128 (the padded layout was 2-way conflicted there);
@@ -645,9 +632,6 @@ __global__ __launch_bounds__(256, TF_BLOCK_OCC) void attn_block_kernel(
 //      group: lane i passes row i >> 2, columns 4 (i & 3)..+3 and receives column i of the 4 rows) — the 8 rows a
 //      half-wave touches hit 8 distinct units.  Replaces 8 two-byte scatter stores per 16 bytes of V.
 // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the padded + transposed layout on a 1024-row prefill chunk: 0.43.
-#ifndef TF_BLOCK_TR_READ
-#define TF_BLOCK_TR_READ 1
-#endif
 typedef __fp16 tr_fp16x4 __attribute__((vector_size(8)));
 __device__ __forceinline__ half4 lds_read_tr4(const h16* p) {
     const tr_fp16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_fp16x4*)(p));
@@ -655,7 +639,7 @@ __device__ __forceinline__ half4 lds_read_tr4(const h16* p) {
 }
 template <int D>
 struct BlkLayout {
-    static constexpr bool TR = TF_BLOCK_TR_READ && D == 128;
+    static constexpr bool TR = D == 128;
     static constexpr int RS = TR ? D : D + 8;                         // K row stride (halfs)
     static constexpr int VS = BLK_SLAB + 8;                           // V^T row stride (transposed layout only)
     static constexpr int K_HALFS = BLK_SLAB * RS;
@@ -703,37 +687,21 @@ __device__ __forceinline__ void lds_softmax_pv(AttnState<D, QT>& st, const f32x4
                 }
             }
             ok[r] = v;
-#if TF_BLOCK_FAST_EXP
             x[r] = (r < 4 ? sa[qt][r] : sb[qt][r - 4]);                 // raw score: the scale rides in the fma below
-#else
-            x[r] = (r < 4 ? sa[qt][r] : sb[qt][r - 4]) * scale_log2;
-#endif
             if (MASKED) tmax = v ? fmaxf(tmax, x[r]) : tmax;
         }
         if (!MASKED) tmax = vmax3_raw(vmax3_raw(x[0], x[1], x[2]), vmax3_raw(x[3], x[4], x[5]), vmax_raw(x[6], x[7]));
         tmax = group_max4(tmax);
-#if TF_BLOCK_FAST_EXP
         const float mnew = fmaxf(st.m[qt], tmax * scale_log2);          // scale > 0: max commutes with it
-#else
-        const float mnew = fmaxf(st.m[qt], tmax);
-#endif
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-#if TF_BLOCK_FAST_EXP
             const float p = ok[r] ? __builtin_amdgcn_exp2f(fmaf(x[r], scale_log2, -mnew)) : 0.f;
-#else
-            const float p = ok[r] ? exp2f(x[r] - mnew) : 0.f;
-#endif
             psum += p;
             pb[qt][r] = (h16)p;
         }
         if (__builtin_amdgcn_ballot_w64(mnew != st.m[qt])) {
-#if TF_BLOCK_FAST_EXP
             const float alpha = __builtin_amdgcn_exp2f(st.m[qt] - mnew);
-#else
-            const float alpha = exp2f(st.m[qt] - mnew);
-#endif
             st.l[qt] *= alpha;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -745,9 +713,6 @@ __device__ __forceinline__ void lds_softmax_pv(AttnState<D, QT>& st, const f32x4
         st.l[qt] += psum;
     }
     // PV: every V^T fragment is read from LDS once and feeds the MFMAs of all q-tiles of the wave
-#if TF_BLOCK_SETPRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
     if constexpr (BlkLayout<D>::TR) {
         const int fv = (li >> 2) | ((g & 1) << 2);
         const h16* vrow = svt + (8 * (g0 + g) + (li >> 2)) * D + 4 * (li & 3);       // keys 8(g0+g) + {0..3}; +4 rows below
@@ -770,9 +735,6 @@ __device__ __forceinline__ void lds_softmax_pv(AttnState<D, QT>& st, const f32x4
                 st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vt, pb[qt], st.acc[qt][t], 0, 0, 0);
         }
     }
-#if TF_BLOCK_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
 }
 
 #ifndef TF_BLOCK_TREE_OCC
