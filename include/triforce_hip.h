@@ -338,6 +338,11 @@ int tf_allreduce_oneshot(void* const* peer_data, void* const* peer_flags, int ra
  * `out` itself (in-place residual stream), NULL = plain all-reduce. */
 int tf_allreduce_oneshot_add(void* const* peer_data, void* const* peer_flags, int rank, int world, const void* resid,
                              void* out, int64_t n, void* stream);
+/* ... plus the per-panel sums of squares of the result rows (out = [n / hidden][hidden], <= 32 rows):
+ * ss_out[panel * 32 + row], the hand-off tf_skinny_gemm_ex folds as ss_in — the RMSNorm after an all-reduce
+ * (tensor_op.py:52-64 after :179 / :359) then runs in the prologue of the next GEMM without re-reading the rows. */
+int tf_allreduce_oneshot_add_ss(void* const* peer_data, void* const* peer_flags, int rank, int world, const void* resid,
+                                void* out, int64_t n, int hidden, float* ss_out, void* stream);
 int tf_ar_error(const void* flags_local);
 
 #ifdef __cplusplus

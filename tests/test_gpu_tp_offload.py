@@ -220,6 +220,23 @@ def test_oneshot_allreduce_protocol_on_one_device(world):
             torch.cuda.synchronize()
             for r in range(world):
                 assert torch.equal(xs[r], want_x[r]), f"epoch {it}, rank {r}: residual form"
+            # ... and with the sums of squares of the result rows per 16-column panel (the norm hand-off of the fused
+            # tensor-parallel layer): same x, ss[panel][row] = sum of x[row][16 panel .. +15]^2
+            ys = [x.clone() for x in want_x]
+            sss = [torch.full((hidden // 16, 32), -1.0, dtype=torch.float32, device=DEV) for _ in range(world)]
+            want_y = [reference_sum(parts, resid=y) for y in ys]
+            torch.cuda.synchronize()
+            for r in range(world):
+                with torch.cuda.stream(streams[r]):
+                    st = group[r].staging(rows, hidden)
+                    st.copy_(parts[r])
+                    group[r].reduce(st, ys[r], resid=ys[r], ss_out=sss[r])
+            torch.cuda.synchronize()
+            for r in range(world):
+                assert torch.equal(ys[r], want_y[r])
+                want_ss = want_y[r].float().square().view(rows, hidden // 16, 16).sum(-1).t()       # (panels, rows)
+                torch.testing.assert_close(sss[r][:, :rows], want_ss, rtol=1e-5, atol=1e-6)
+                assert (sss[r][:, rows:] == -1.0).all()             # rows beyond the block are not touched
         assert [g.error() for g in group] == [0] * world
         with pytest.raises(AssertionError):
             group[0].reduce(group[0].staging(8, hidden), group[0].staging(8, hidden))     # out must not alias the staging

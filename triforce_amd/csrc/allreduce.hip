@@ -57,7 +57,8 @@ __device__ __forceinline__ bool ar_wait(const unsigned* slot, unsigned epoch) {
     return false;
 }
 
-__global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c, const h16* resid, h16* out, int64_t n_vec8) {
+__global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c, const h16* resid, h16* out, int64_t n_vec8,
+                                                                        float* ss_out, int hidden) {
     __shared__ unsigned s_epoch;
     __shared__ int s_ok;
     const int tid = threadIdx.x;
@@ -102,6 +103,19 @@ __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c,
                 for (int e = 0; e < 8; ++e) o[e] = hadd_rn(rv[e], o[e]);
             }
             *reinterpret_cast<half8*>(out + 8 * i) = o;
+            if (ss_out) {
+                // sum of squares of the 16-column panel this vector is half of -> ss_out[panel][row]: the hand-off the
+                // RMSNorm prologue of the consuming GEMM folds (tf_skinny_gemm_ex ss_in) instead of re-reading the rows.
+                // Vectors 2j and 2j+1 sit in adjacent lanes of one loop trip (n_vec8 and AR_THREADS are even).
+                float sq = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sq = fmaf((float)o[e], (float)o[e], sq);
+                const float other = __shfl_xor(sq, 1, 64);
+                if ((i & 1) == 0) {
+                    const int64_t col0 = (8 * i) % hidden, row = (8 * i) / hidden;
+                    ss_out[(col0 >> 4) * 32 + row] = sq + other;
+                }
+            }
         }
     }
     // ---- DONE: the last workgroup of this launch releases the peers' staging buffers and waits for mine ----
@@ -175,10 +189,11 @@ extern "C" int tf_ar_close_ipc_handle(void* ptr) {
 // tf_allreduce_oneshot_add: out = resid + (sum over ranks), the residual added in fp16 to the rounded sum — the
 // `hidden_states = residual + all_reduce(o)` of tensor_op.py:179-181,359-360 in the same launch.  resid may equal out
 // (in-place residual stream); resid == NULL is the plain all-reduce.
-extern "C" int tf_allreduce_oneshot_add(void* const* peer_data, void* const* peer_flags, int rank, int world,
-                                        const void* resid, void* out, int64_t n, void* stream) {
+static int ar_launch(void* const* peer_data, void* const* peer_flags, int rank, int world, const void* resid, void* out,
+                     int64_t n, float* ss_out, int hidden, void* stream) {
     if (!peer_data || !peer_flags || !out || world < 1 || world > AR_MAX_WORLD || rank < 0 || rank >= world) return TF_EINVAL;
     if (n < 8 || (n % 8)) return TF_EINVAL;
+    if (ss_out && (hidden < 16 || (hidden % 16) || (n % hidden) || n / hidden > 32)) return TF_EINVAL;
     ArComm c;
     for (int r = 0; r < AR_MAX_WORLD; ++r) {
         c.data[r] = (r < world) ? (const h16*)peer_data[r] : nullptr;
@@ -192,9 +207,25 @@ extern "C" int tf_allreduce_oneshot_add(void* const* peer_data, void* const* pee
     int blocks = (int)((n_vec8 + AR_THREADS - 1) / AR_THREADS);
     if (blocks > 64) blocks = 64;                     // <= 64 workgroups: co-resident with anything, latency-bound anyway
     hipLaunchKernelGGL(allreduce_oneshot_kernel, dim3(blocks), dim3(AR_THREADS), 0, (hipStream_t)stream, c,
-                       (const h16*)resid, (h16*)out, n_vec8);
+                       (const h16*)resid, (h16*)out, n_vec8, ss_out, hidden);
     TF_LAUNCH_CHECK();
     return TF_OK;
+}
+
+extern "C" int tf_allreduce_oneshot_add(void* const* peer_data, void* const* peer_flags, int rank, int world,
+                                        const void* resid, void* out, int64_t n, void* stream) {
+    return ar_launch(peer_data, peer_flags, rank, world, resid, out, n, nullptr, 0, stream);
+}
+
+// ... and the sums of squares of the result rows, per 16-column panel: out is [n / hidden][hidden], ss_out[panel * 32 + row]
+// (fp32, hidden / 16 panels x 32 rows — the layout tf_skinny_gemm_ex writes as ss_out and folds as ss_in).  Lets the
+// tensor-parallel decode layer keep the single-GPU engine's fused form: the RMSNorm that follows an all-reduce runs in the
+// prologue of the next GEMM without another pass over the residual stream.  n / hidden <= 32 rows.
+extern "C" int tf_allreduce_oneshot_add_ss(void* const* peer_data, void* const* peer_flags, int rank, int world,
+                                           const void* resid, void* out, int64_t n, int hidden, float* ss_out,
+                                           void* stream) {
+    if (!ss_out) return TF_EINVAL;
+    return ar_launch(peer_data, peer_flags, rank, world, resid, out, n, ss_out, hidden, stream);
 }
 
 extern "C" int tf_allreduce_oneshot(void* const* peer_data, void* const* peer_flags, int rank, int world, void* out,

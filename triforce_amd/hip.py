@@ -59,6 +59,7 @@ SIGNATURES = {
     "tf_ar_close_ipc_handle": (_i32, [_vp]),
     "tf_allreduce_oneshot": (_i32, [_vp, _vp, _i32, _i32, _vp, _i64, _vp]),
     "tf_allreduce_oneshot_add": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i64, _vp]),
+    "tf_allreduce_oneshot_add_ss": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
     "tf_ar_error": (_i32, [_vp]),
 }
 

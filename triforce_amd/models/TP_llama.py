@@ -247,6 +247,67 @@ class DistributedLlama:
                                          out=self._partial_out(q_len)))                                # tensor_op.py:176-179
         return self._reduce(self._mlp_half(i, x, o, out=self._partial_out(q_len)))                     # tensor_op.py:353-359
 
+    # ---- fused decode layer (<= 32 rows): the single-GPU engine's 5-launch layer with an exchange step in it -------
+    # q|k|v GEMM with RMSNorm prologue and RoPE + KV-append epilogue, attention, o_proj, [exchange], gate|up GEMM with
+    # RMSNorm prologue and SwiGLU epilogue, down_proj, [exchange].  The exchange (tf_allreduce_oneshot_add_ss) adds the
+    # summed partials to the residual stream x in place AND leaves the per-panel sums of squares of the new x, so the
+    # norm prologue that follows folds 256 floats per row instead of re-reading x in every workgroup (without that
+    # hand-off this form measured SLOWER than the un-fused one: profiles/r02_tp_shard_fused_path_rejected.jsonl).
+    # 8 launches per layer instead of 11; used for blocks of <= 16 rows.  At world size 1 the residual / sum-of-squares epilogue of the GEMM itself
+    # plays the exchange's part.  TRIFORCE_TP_FUSE=0 keeps the un-fused layer.
+    def _fused_decode(self, q_len, tree=None):
+        # one 16-row MFMA tile: measured per rank with the exchange kernel in the chain (tools/tp_shard_bench.py
+        # --local-exchange, profiles/r02_tp_shard_fused_vs_unfused.jsonl) the fused layer wins at 1 and 7 rows (7B, 8 ranks:
+        # retrieval verify 2 001 -> 1 893 us, autoregressive step 4 021 -> 3 333) and loses 1-2 % at the 17 rows of a
+        # gamma = 16 verify, where every norm prologue works on two row tiles
+        if tree is not None or q_len > 16 or self.device.type != "cuda":
+            return False
+        if ops.FUSE_MODE != "all" or os.environ.get("TRIFORCE_TP_FUSE", "1") == "0":
+            return False
+        if self.world_size > 1 and (self._ar is None or q_len > self.ONESHOT_MAX_ROWS):
+            return False
+        W = self.weights
+        return (all(isinstance(w, ops.PackedLinear) and w.parts is not None for w in (W.wqkv[0], W.wo[0], W.wgu[0], W.wd[0], W.lm_head))
+                and W.wqkv[0].wp_rope is not None and (q_len * self.hidden_size) % 8 == 0)
+
+    def _attn_half_fused(self, i, x, ss, pos, kl, vl, slot, sk, retrieval_build=False, slot_dev=None, sk_dev=None):
+        """Attention block of layer i, fused form: returns this rank's partial o_proj output in the exchange's staging
+        buffer, or None at world size 1 (x and ss already updated by the GEMM's own epilogue)."""
+        W = self.weights
+        Hl, D = W.H_local, W.D
+        q = ops.qkv_rope(x, W.wqkv[i], W.ln1[i], W.eps, self.cos_cache, self.sin_cache, pos, kl, vl, slot, Hl, D,
+                         slot0_dev=slot_dev, ss_in=ss if i > 0 else None)
+        if retrieval_build:                               # tensor_op.py:161-162
+            self.retrieval_cache.init_graph_cache((kl, vl), q, i)
+        a = ops.attn_decode(q, kl, vl, sk, self.scale, sk_dev=sk_dev)
+        if self.world_size == 1:
+            ops.linear(a, W.wo[i], resid=x, out=x, ss_out=ss)
+            return None
+        return ops.linear(a, W.wo[i], out=self._ar.staging(x.shape[0], self.hidden_size))
+
+    def _mlp_half_fused(self, i, x, ss):
+        W = self.weights
+        act = ops.mlp_act(x, W.wgu[i], ln=W.ln2[i], eps=W.eps, ss_in=ss)
+        if self.world_size == 1:
+            ops.linear(act, W.wd[i], resid=x, out=x, ss_out=ss)
+            return None
+        return ops.linear(act, W.wd[i], out=self._ar.staging(x.shape[0], self.hidden_size))
+
+    def _exchange_fused(self, part, x, ss):
+        """x += sum over ranks of ``part`` (tensor_op.py:179-181,359-360) and ss <- panel sums of squares of the new x."""
+        if part is not None:
+            self._ar.reduce(part, x, resid=x, ss_out=ss)
+
+    def _layer_fused(self, i, x, ss, pos, kl, vl, slot, sk, retrieval_build=False):
+        self._exchange_fused(self._attn_half_fused(i, x, ss, pos, kl, vl, slot, sk, retrieval_build), x, ss)
+        self._exchange_fused(self._mlp_half_fused(i, x, ss), x, ss)
+
+    def _finish_fused(self, x, ss):
+        W = self.weights
+        if W.capture is not None:
+            W.capture.append(x.clone())
+        return ops.linear(x, W.lm_head, out_f32=True, ln=W.norm, eps=W.eps, ss_in=ss).unsqueeze(0)
+
     def _finish(self, x, d):
         W = self.weights
         h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)
@@ -284,6 +345,8 @@ class DistributedLlama:
                     ready[idx] = torch.cuda.Event()
                     ready[idx].record(cs)
         d = None
+        fused = self._fused_decode(q_len, tree)
+        ss = ops.ss_buffer(self.hidden_size, self.device) if fused else None
         for idx in range(L):
             if idx < n_on:
                 kl, vl = kvc.layer_kv(idx)
@@ -291,7 +354,10 @@ class DistributedLlama:
                 buf = self.kv_buffer[idx % 2]
                 torch.cuda.current_stream(self.device).wait_event(ready[idx])      # H2D of this layer landed
                 kl, vl = buf.k, buf.v
-            d = self._layer(idx, x, d, pos, kl, vl, S, S + q_len, q_len, retrieval_build=build, tree=tree)
+            if fused:
+                self._layer_fused(idx, x, ss, pos, kl, vl, S, S + q_len, retrieval_build=build)
+            else:
+                d = self._layer(idx, x, d, pos, kl, vl, S, S + q_len, q_len, retrieval_build=build, tree=tree)
             if tail is not None:                          # keep the generated rows on the device for the retrieval tail
                 ops.kv_copy_rows(kl.unsqueeze(0), tail.tail_k[idx:idx + 1], S, S - self.prefill_len, q_len)
                 ops.kv_copy_rows(vl.unsqueeze(0), tail.tail_v[idx:idx + 1], S, S - self.prefill_len, q_len)
@@ -307,7 +373,7 @@ class DistributedLlama:
         if n_on < L:
             torch.cuda.current_stream(self.device).wait_stream(cs)              # write-backs visible before reuse
         kvc.seq_len = S + q_len
-        return self._finish(x, d)
+        return self._finish_fused(x, ss) if fused else self._finish(x, d)
 
     def _tree_mask(self, attention_mask, tree_start, q_len):
         """Tree visibility for the block-attention kernel: (bit rows int32, first row, key index of tree column 0).
@@ -351,7 +417,8 @@ class DistributedLlama:
                     sk=torch.full((1,), q_len, dtype=torch.int32, device=dev),
                     x=torch.zeros(q_len, hid, dtype=torch.float16, device=dev),
                     o=torch.zeros(q_len, hid, dtype=torch.float16, device=dev),
-                    d=torch.zeros(q_len, hid, dtype=torch.float16, device=dev))
+                    d=torch.zeros(q_len, hid, dtype=torch.float16, device=dev),
+                    ss=torch.zeros(hid // 16, 32, dtype=torch.float32, device=dev))
 
     def _stages(self, st, kind):
         """The forward as a list of collective-free stages [(fn, buffer to all-reduce afterwards | None)] on static
@@ -361,6 +428,8 @@ class DistributedLlama:
         rc, kvc = self.retrieval_cache, self.kv_cache
 
         q_len = st["x"].shape[0]
+        if self._fused_decode(q_len):
+            return self._stages_fused(st, kind)
         part_o, part_d = self._partial_out(q_len, st["o"]), self._partial_out(q_len, st["d"])   # staging, or in place
 
         def attn(i):
@@ -393,6 +462,47 @@ class DistributedLlama:
         for i in range(L):
             stages.append((attn(i), lambda: self._reduce(part_o, st["o"])))
             stages.append((mlp(i), lambda: self._reduce(part_d, st["d"])))
+        stages.append((finish, None))
+        return stages
+
+    def _stages_fused(self, st, kind):
+        """``_stages`` for the fused decode layer: the exchange steps update st["x"] / st["ss"] in place."""
+        L = self.num_layers
+        rc, kvc = self.retrieval_cache, self.kv_cache
+        x, ss = st["x"], st["ss"]
+        box = {}                                          # partial handed from a stage to its exchange step
+
+        def attn(i):
+            def run():
+                if i == 0:
+                    x.copy_(self.embed_tokens[st["ids"].reshape(-1)])
+                if kind == "retrieval":
+                    kl, vl = rc.layer_kv(i)
+                    box["p"] = self._attn_half_fused(i, x, ss, st["pos"], kl, vl, rc.spec_slot, rc.real_budget)
+                else:
+                    kl, vl = kvc.layer_kv(i)
+                    box["p"] = self._attn_half_fused(i, x, ss, st["pos"], kl, vl, 0, kvc.max_budget,
+                                                     slot_dev=st["slot"], sk_dev=st["sk"])
+                return x
+            return run
+
+        def mlp(i):
+            def run():
+                box["p"] = self._mlp_half_fused(i, x, ss)
+                return x
+            return run
+
+        def finish():
+            logits = self._finish_fused(x, ss)
+            if kind == "retrieval":
+                return norm_logits(logits[0], temperature=self.temperature, top_k=-1, top_p=self.top_p)
+            return logits
+
+        exchange = (lambda: self._exchange_fused(box["p"], x, ss)) if self.world_size > 1 else None
+        stages = []
+        for i in range(L):
+            stages.append((attn(i), exchange))
+            stages.append((mlp(i), exchange))
         stages.append((finish, None))
         return stages
 
@@ -574,6 +684,12 @@ class DistributedLlama:
         assert q_len == rc.gamma + 1
         pos = position_ids.reshape(-1).contiguous()
         x = self.embed_tokens[input_ids.reshape(-1)]
+        if self._fused_decode(q_len):
+            ss = ops.ss_buffer(self.hidden_size, self.device)
+            for idx in range(self.num_layers):
+                kl, vl = rc.layer_kv(idx)
+                self._layer_fused(idx, x, ss, pos, kl, vl, rc.spec_slot, rc.real_budget)
+            return self._finish_fused(x, ss)
         d = None
         for idx in range(self.num_layers):
             kl, vl = rc.layer_kv(idx)

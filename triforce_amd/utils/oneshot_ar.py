@@ -91,17 +91,26 @@ class OneShotAllReduce:
     def fits(self, t):
         return t.dtype == torch.float16 and t.numel() <= self.max_elems and t.numel() % 8 == 0
 
-    def reduce(self, staged, out, resid=None):
+    def reduce(self, staged, out, resid=None, ss_out=None):
         """out <- [resid +] sum over ranks of their staged partials.  ``staged`` must be (a prefix view of)
-        ``staging()``; ``resid`` (fp16, may be ``out`` itself) is added in fp16 to the rounded sum."""
+        ``staging()``; ``resid`` (fp16, may be ``out`` itself) is added in fp16 to the rounded sum; ``ss_out``
+        (hidden / 16, 32) fp32 receives the per-panel sums of squares of the result rows (ops.ss_buffer)."""
         assert staged.data_ptr() == self.data_ptr and out.dtype == torch.float16 and out.is_contiguous()
         assert out.numel() == staged.numel() and out.data_ptr() != self.data_ptr
         if resid is not None:
             assert resid.dtype == torch.float16 and resid.is_contiguous() and resid.numel() == out.numel()
-        hip.check(hip.lib().tf_allreduce_oneshot_add(self._data, self._flags, self.rank, self.world,
-                                                     ctypes.c_void_p(resid.data_ptr()) if resid is not None else None,
-                                                     ctypes.c_void_p(out.data_ptr()), staged.numel(),
-                                                     ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+        rp = ctypes.c_void_p(resid.data_ptr()) if resid is not None else None
+        st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        if ss_out is not None:
+            hidden = out.shape[-1]
+            assert ss_out.dtype == torch.float32 and ss_out.is_contiguous() and ss_out.shape == (hidden // 16, 32)
+            hip.check(hip.lib().tf_allreduce_oneshot_add_ss(self._data, self._flags, self.rank, self.world, rp,
+                                                            ctypes.c_void_p(out.data_ptr()), staged.numel(), hidden,
+                                                            ctypes.c_void_p(ss_out.data_ptr()), st),
+                      "tf_allreduce_oneshot_add_ss")
+            return out
+        hip.check(hip.lib().tf_allreduce_oneshot_add(self._data, self._flags, self.rank, self.world, rp,
+                                                     ctypes.c_void_p(out.data_ptr()), staged.numel(), st),
                   "tf_allreduce_oneshot_add")
         return out
 
