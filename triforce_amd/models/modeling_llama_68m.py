@@ -66,15 +66,17 @@ class LlamaForCausalLM:
     # ---- native chain (tf_draft_forward_68m): one C call issues the whole forward --------------------------------
     def _native_model(self):
         """TfDraftModel over this model's packed weights, or None (CPU tensors / a weight the fused kernels cannot
-        take / TRIFORCE_FUSE != all / TRIFORCE_DRAFT_NATIVE=0).  Built once; the weights are never reallocated
-        (aligned re-calibration rewrites them in place)."""
-        if not hasattr(self, "_native"):
+        take / TRIFORCE_FUSE != all / TRIFORCE_DRAFT_NATIVE=0).  Rebuilt when the weight tensors are replaced (aligned
+        re-calibration and in-place re-draws keep their storage)."""
+        W = self.weights
+        key = (W.embed.data_ptr(), id(W.lm_head), id(W.wqkv[0]))        # a reloaded state dict brings new tensors
+        if getattr(self, "_native_key", None) != key:
             import os
-            W = self.weights
             ok = (self.device.type == "cuda" and ops.FUSE_MODE == "all" and os.environ.get("TRIFORCE_DRAFT_NATIVE", "1") != "0"
                   and isinstance(W.lm_head, ops.PackedLinear))
             self._native = ops.draft_model_struct(W.embed, W.ln1, W.wqkv, W.wo, W.ln2, W.wgu, W.wd, W.norm, W.lm_head,
                                                   self.cos, self.sin, W.H, W.D, W.eps, self.scale) if ok else None
+            self._native_key = key
         return self._native
 
     def _native_cache(self, c):
