@@ -41,6 +41,23 @@ def test_host_side_helpers():
     assert lib.tf_attn_decode_ws_floats(16, 18, 128, 4) == 16 * 4 * 32 * 130
 
 
+def test_prefill_split_rule_properties():
+    """tf_attn_prefill_pick_nsplit for every head count a TP shard can have: (split, head) pairs divide over the 8 XCDs,
+    the count stays within the merge kernel's limit, short caches are not split, and the workspace query matches the
+    kernel's per-row-block layout."""
+    from triforce_amd import hip
+    lib = hip.lib()
+    for H in list(range(1, 41)) + [64]:
+        for sq in (129, 1024, 2048, 4096):
+            for sk in (sq, 8192, 130048):
+                n = lib.tf_attn_prefill_pick_nsplit(H, sq, sk)
+                assert 1 <= n <= 128 and (H * n) % 8 == 0, (H, sq, sk, n)
+                nrb = (sq + 127) // 128
+                assert lib.tf_attn_prefill_ws_floats(H, sq, 128, n) == nrb * H * n * 128 * 130
+    assert lib.tf_attn_prefill_pick_nsplit(32, 1024, 1024) == 1
+    assert lib.tf_attn_prefill_pick_nsplit(8, 1024, 130048) >= lib.tf_attn_prefill_pick_nsplit(32, 1024, 130048)
+
+
 def test_bad_arguments_are_rejected_without_launching():
     from triforce_amd import hip
     lib = hip.lib()
