@@ -524,8 +524,9 @@ struct ToppShared {
     float red[TOPP_THREADS / 64];
     int red_i[TOPP_THREADS / 64];
     unsigned long long S, tau, nkeep, zk;
+    unsigned long long zpart[TOPP_THREADS / 64];   // per-wave sums of all masses: Z does not come from the histogram
     unsigned ties;
-    int digit;
+    int digit;                                     // >= 0 boundary bin, -1 keep everything, -2 boundary below the candidate cut
 };
 
 __device__ __forceinline__ float block_max_1024(float v, float* sm, int tid) {
@@ -600,10 +601,10 @@ __device__ __forceinline__ void topp_scan(ToppShared* sh, int lane, bool first_r
         const unsigned hi = (unsigned)__shfl_down((int)(unsigned)(inc >> 32), o, 64);
         if (lane + o < 64) inc += ((unsigned long long)hi << 32) | lo;
     }
-    unsigned long long base, tau;
+    unsigned long long base, tau, Z = 0ull;
     if (first_round) {
-        const unsigned zlo = (unsigned)__shfl((int)(unsigned)inc, 0, 64), zhi = (unsigned)__shfl((int)(unsigned)(inc >> 32), 0, 64);
-        const unsigned long long Z = ((unsigned long long)zhi << 32) | zlo;
+#pragma unroll
+        for (int w = 0; w < TOPP_THREADS / 64; ++w) Z += sh->zpart[w];          // exact integers: any order
         const double t = (double)top_p * (double)Z;
         tau = (t >= 18446744073709549568.0) ? ~0ull : __double2ull_rd(t);
         base = 0ull;
@@ -629,7 +630,9 @@ __device__ __forceinline__ void topp_scan(ToppShared* sh, int lane, bool first_r
     }
     const unsigned long long hit = __ballot(found >= 0);
     if (!hit) {
-        if (lane == 0) sh->digit = -1;
+        // nothing crossed: tau >= Z (top_p >= 1: keep everything) — or, first round only, the crossing lies among the
+        // entries the candidate cut left out of the histogram (cannot happen for the cut topp_probs_kernel derives)
+        if (lane == 0) sh->digit = (first_round && tau < Z) ? -2 : -1;
     } else if (found >= 0) {
         sh->digit = 16 * lane + found;
         sh->S = Sf;
@@ -700,7 +703,16 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_probs_kernel(const float* _
     sh->cnt[TOPP_HB(tid)] = 0u;
     mx = block_max_1024(mx, sh->red, tid);
 
-    // ---- round 1: e = exp(x - max) back to LDS; mass histogram over bits 29..20 ----
+    // ---- round 1: e = exp(x - max) back to LDS; mass histogram over bits 29..20 of the CANDIDATES ----
+    // Z is summed in registers from every entry; the histogram (LDS atomics) only takes entries >= cut, with
+    // cut = (1 - top_p) / (2 V) rounded down to a bin edge: the entries below it weigh less than (1 - top_p) / 2 of the
+    // largest entry alone, so the crossing of top_p * Z always lies among the candidates — in a peaked row (what a
+    // language model emits) that is a few hundred of 32 000 entries, and rounds 2 and 3 then visit only those (a bit
+    // per entry in `cand`).  Same Z, tau, boundary and kept set as with the full histogram.
+    unsigned cutpat = 0u;
+    if (top_p < 1.0f) cutpat = __float_as_uint((1.0f - top_p) / (2.0f * (float)V)) & ~((1u << 20) - 1u);
+    unsigned cand = 0u;
+    unsigned long long zacc = 0ull;
 #pragma unroll 1
     for (int s = 0; s < nslab; ++s) {
         f32x4 x = mine[1024 * s];
@@ -710,25 +722,64 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_probs_kernel(const float* _
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const unsigned long long m = topp_fix(x[j]);
-            topp_hist_add(sh, m != 0ull, (int)(__float_as_uint(x[j]) >> 20), m, false);
+            zacc += m;
+            const bool c = m != 0ull && __float_as_uint(x[j]) >= cutpat;
+            cand |= (c ? 1u : 0u) << (4 * s + j);
+            topp_hist_add(sh, c, (int)(__float_as_uint(x[j]) >> 20), m, false);
         }
+    }
+    {
+        const unsigned long long zw = wave_sum_u64(zacc);
+        if (lane == 0) sh->zpart[wave] = zw;
     }
     __syncthreads();
     if (wave == 0) topp_scan(sh, lane, true, false, top_p);
     __syncthreads();
-    const int d1 = sh->digit;
-    unsigned ustar = 0u, ties = 0u;
-    unsigned long long nkeep = 0ull;
-    if (d1 >= 0) {                                               // block-uniform; -1: top_p >= 1 keeps everything
-        // ---- round 2: bits 19..10 of the entries inside the boundary bin ----
+    if (sh->digit == -2) {                                       // block-uniform; unreachable for the cut above (kept as
+        __syncthreads();                                         // the exact fallback): histogram of ALL entries
 #pragma unroll 1
         for (int s = 0; s < nslab; ++s) {
             const f32x4 x = mine[1024 * s];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const unsigned b = __float_as_uint(x[j]);
-                const bool in = (int)(b >> 20) == d1;
-                topp_hist_add(sh, in, (int)((b >> 10) & 1023u), in ? topp_fix(x[j]) : 0ull, false);
+                const unsigned long long m = topp_fix(x[j]);
+                cand |= (m != 0ull ? 1u : 0u) << (4 * s + j);
+                topp_hist_add(sh, m != 0ull, (int)(__float_as_uint(x[j]) >> 20), m, false);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) topp_scan(sh, lane, true, false, top_p);
+        __syncthreads();
+    }
+    const int d1 = sh->digit;
+    unsigned ustar = 0u, ties = 0u;
+    unsigned long long nkeep = 0ull;
+    // a wave whose lanes hold many candidates walks all its entries (unrolled, 16-byte LDS reads); a wave with few walks
+    // only the set bits of `cand`
+    const bool dense = wave_sum_u64((unsigned long long)__popc(cand)) > 4ull * 64ull;
+    if (d1 >= 0) {                                               // block-uniform; -1: top_p >= 1 keeps everything
+        // ---- round 2: bits 19..10 of the entries inside the boundary bin ----
+        if (dense) {
+#pragma unroll 1
+            for (int s = 0; s < nslab; ++s) {
+                const f32x4 x = mine[1024 * s];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned b = __float_as_uint(x[j]);
+                    const bool in = (int)(b >> 20) == d1;
+                    topp_hist_add(sh, in, (int)((b >> 10) & 1023u), in ? topp_fix(x[j]) : 0ull, false);
+                }
+            }
+        } else {
+            unsigned left = cand;
+            while (__ballot(left != 0u)) {
+                const bool has = left != 0u;
+                const int bit = has ? __ffs((int)left) - 1 : 0;
+                left &= left - 1u;
+                const float xv = rowe[4096 * (bit >> 2) + 4 * tid + (bit & 3)];
+                const unsigned b = __float_as_uint(xv);
+                const bool in = has && (int)(b >> 20) == d1;
+                topp_hist_add(sh, in, (int)((b >> 10) & 1023u), in ? topp_fix(xv) : 0ull, false);
             }
         }
         __syncthreads();
@@ -736,14 +787,27 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_probs_kernel(const float* _
         __syncthreads();
         const unsigned pre = ((unsigned)d1 << 10) | (unsigned)sh->digit;
         // ---- round 3: bits 9..0, with tie counts ----
+        if (dense) {
 #pragma unroll 1
-        for (int s = 0; s < nslab; ++s) {
-            const f32x4 x = mine[1024 * s];
+            for (int s = 0; s < nslab; ++s) {
+                const f32x4 x = mine[1024 * s];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned b = __float_as_uint(x[j]);
-                const bool in = (b >> 10) == pre;
-                topp_hist_add(sh, in, (int)(b & 1023u), in ? topp_fix(x[j]) : 0ull, true);
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned b = __float_as_uint(x[j]);
+                    const bool in = (b >> 10) == pre;
+                    topp_hist_add(sh, in, (int)(b & 1023u), in ? topp_fix(x[j]) : 0ull, true);
+                }
+            }
+        } else {
+            unsigned left = cand;
+            while (__ballot(left != 0u)) {
+                const bool has = left != 0u;
+                const int bit = has ? __ffs((int)left) - 1 : 0;
+                left &= left - 1u;
+                const float xv = rowe[4096 * (bit >> 2) + 4 * tid + (bit & 3)];
+                const unsigned b = __float_as_uint(xv);
+                const bool in = has && (b >> 10) == pre;
+                topp_hist_add(sh, in, (int)(b & 1023u), in ? topp_fix(xv) : 0ull, true);
             }
         }
         __syncthreads();
