@@ -249,3 +249,35 @@ def test_tree_walk_limits_and_atomic_grow_map_cache(tmp_path):
     assert files == ["24.json"], files                          # no temp file left behind
     again = T.load_grow_map(24, cache_dir=str(tmp_path))
     assert again["branches"] == small["branches"] and again["size"] == 24
+
+
+def test_topp_candidate_cut_always_contains_the_crossing():
+    """csrc/sampling.hip restricts the top-p histogram to entries >= cut = (1 - top_p) / (2 V), rounded down to a round-1
+    bin edge of the fp32 pattern, and takes Z from ALL entries.  The kernel relies on the crossing of tau = floor(top_p * Z)
+    lying among those candidates.  Restated here in numpy with the kernel's 2^-40 fixed-point masses: random, peaked and
+    adversarial rows (as much mass as possible parked just below the cut), V up to 32768, top_p up to 0.999."""
+    import numpy as np
+
+    def fix(e):                                              # topp_fix: floor(e * 2^40) from the bit pattern
+        return np.floor(e.astype(np.float64) * 2.0 ** 40).astype(np.uint64)
+
+    rng = np.random.default_rng(0)
+    for V in (1000, 32000, 32768):
+        for top_p in (0.5, 0.9, 0.95, 0.99, 0.999):
+            cut = np.float32((np.float32(1.0) - np.float32(top_p)) / np.float32(2.0 * V))
+            cutpat = cut.view(np.uint32) & np.uint32(~((1 << 20) - 1) & 0xFFFFFFFF)
+            cut_edge = cutpat.view(np.float32)
+            rows = [np.exp(rng.normal(0, s, V).astype(np.float32) / np.float32(0.6)) for s in (0.02, 1.0, 3.0)]
+            peaked = np.full(V, 1e-9, dtype=np.float32)
+            peaked[:3] = [1.0, 0.5, 0.2]
+            rows.append(peaked)
+            worst = np.full(V, np.nextafter(cut_edge, np.float32(0)), dtype=np.float32)   # everything just below the cut
+            worst[0] = 1.0
+            rows.append(worst)
+            for e in rows:
+                e = (e / e.max()).astype(np.float32)         # the kernel's e = exp(x - max): the maximum is exactly 1
+                m = fix(e)
+                Z = int(m.sum())
+                tau = int(np.floor(np.float64(np.float32(top_p)) * np.float64(Z)))
+                cand = (m != 0) & (e.view(np.uint32) >= cutpat)
+                assert int(m[cand].sum()) > tau, (V, top_p, int(m[cand].sum()), tau)
