@@ -7,6 +7,7 @@ with 288 GB per MI355X the offloading tier is never needed for these shapes (it 
 by test/offloading_TP.py --on_chip)."""
 import json
 import os
+import sys
 import time
 
 import torch
@@ -74,7 +75,23 @@ def offload_report(llm, args, tcfg, world, device):
     return out
 
 
+def _emit(line):
+    """The one JSON line, on the process's ORIGINAL stdout (see run_tp)."""
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (line + "\n").encode())
+
+
+_REAL_STDOUT = None
+
+
 def run_tp(args, rank, world, local):
+    # stdout must carry exactly one line (rank 0's JSON).  RCCL prints a version banner on the C stdout of every rank when
+    # its first communicator is created (flushed at exit), and the engine logs which exchange / graph form it chose: from
+    # here on file descriptor 1 is stderr, and the JSON line is written to a saved duplicate of the original.
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
     from bench import _Tok, attn_roofline, resolve_weights, target_config
     from triforce_amd.models.aligned import parse_spec
     from triforce_amd import ops
@@ -121,10 +138,10 @@ def run_tp(args, rank, world, local):
         dist.all_gather(got, shard)
         dist.barrier()
         if rank == 0:
-            print(json.dumps({"metric": "decode tokens/sec + avg accepted len, Llama-7B-128K @124K ctx", "dry_run": True,
+            _emit(json.dumps({"metric": "decode tokens/sec + avg accepted len, Llama-7B-128K @124K ctx", "dry_run": True,
                               "n_gpus": world, "world_size_observed": dist.get_world_size(),
                               "backend": dist.get_backend(), "shards": [g.tolist() for g in got],
-                              "config": {"workload": f"{tcfg._name_or_path} TP={world}", "weights": wlabel}}), flush=True)
+                              "config": {"workload": f"{tcfg._name_or_path} TP={world}", "weights": wlabel}}))
         dist.destroy_process_group()
         return
     if not args.no_graphs:
@@ -177,7 +194,7 @@ def run_tp(args, rank, world, local):
     if rank == 0:
         # per-rank roofline: this rank's heads only (H / world), against ONE GPU's HBM peak
         roof = attn_roofline(timer, args.budget + args.gamma + 1, tcfg.num_attention_heads // world, tcfg.head_dim)
-        print(json.dumps({
+        _emit(json.dumps({
             "metric": "decode tokens/sec + avg accepted len, Llama-7B-128K @124K ctx",
             "value": round(tokens / seconds, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(seconds / args.steps * 1e3, 3), "higher_is_better": True,
@@ -201,6 +218,6 @@ def run_tp(args, rank, world, local):
             else ("rccl" if world > 1 else "none (one rank)"),
             "ranks_share_one_device": bool(share),
             "roofline": roof, "roofline_note": None if roof else "target verify replayed from a hipGraph on this run: "
-            "no per-launch HIP events; see profiles/ for the rocprofv3 kernel trace", "cpu_baseline": None}), flush=True)
+            "no per-launch HIP events; see profiles/ for the rocprofv3 kernel trace", "cpu_baseline": None}))
     dist.barrier()
     dist.destroy_process_group()
