@@ -112,7 +112,7 @@ def resolve_weights(args):
         if t and d:
             return "checkpoint", t, d, f"checkpoints {t} + {d}"
         w = "aligned:0.7:0.9"
-    if w.startswith("aligned"):
+    if w == "aligned" or w.startswith("aligned:"):
         return "aligned", w, w, w
     if w.startswith("random"):
         seed = int(w.split(":")[1]) if ":" in w and w.split(":")[1] else args.seed

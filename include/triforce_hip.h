@@ -319,7 +319,8 @@ int tf_kv_d2h_async(void* dst_host, int64_t dst_pitch_elems, const void* src_dev
  * (tf_ar_alloc + tf_ar_get_ipc_handle / tf_ar_open_ipc_handle), exchanges one READY flag, reads all partials and adds
  * them in rank order with fp32 accumulation (bit-identical on every rank), then exchanges one DONE flag so the staging
  * buffer can be reused when the kernel ends.  The epoch lives in the control block: capturable in a hipGraph.  All
- * spins are bounded (tf_ar_error != 0 afterwards = a peer never arrived).
+ * spins are bounded (tf_ar_error != 0 afterwards = a peer never arrived; from then on every call fills `out` with NaN
+ * and returns at once — the host polls tf_ar_error once per decode step).
  *   peer_data / peer_flags : `world` device-visible pointers (own entry included); this rank's partial must already be
  *                            in peer_data[rank], written by an earlier kernel of `stream`; n % 8 == 0 fp16 elements;
  *                            `out` is ordinary device memory, not the staging buffer.
@@ -344,6 +345,8 @@ int tf_allreduce_oneshot_add(void* const* peer_data, void* const* peer_flags, in
 int tf_allreduce_oneshot_add_ss(void* const* peer_data, void* const* peer_flags, int rank, int world, const void* resid,
                                 void* out, int64_t n, int hidden, float* ss_out, void* stream);
 int tf_ar_error(const void* flags_local);
+/* Fault injection for tests: sets (code > 0) or clears (0) the sticky error word of a control block from the host. */
+int tf_ar_inject_error(void* flags_local, int code);
 
 #ifdef __cplusplus
 }

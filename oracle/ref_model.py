@@ -24,7 +24,7 @@ class FullCache:
 
     def __init__(self, cfg, max_budget):
         L, H = cfg["num_hidden_layers"], cfg["num_key_value_heads"]
-        D = cfg["hidden_size"] // cfg["num_attention_heads"]
+        D = R.head_dim_of(cfg)
         self.layers, self.max_budget, self.seq_len = L, max_budget, 0
         self.key_cache = torch.zeros(L, max_budget, H, D, dtype=torch.float16)
         self.value_cache = torch.zeros(L, max_budget, H, D, dtype=torch.float16)
@@ -51,7 +51,7 @@ class RetrievalCacheO:
     def __init__(self, cfg, max_budget, prefill, chunk_size=8, gamma=6):
         assert prefill % chunk_size == 0 and max_budget % chunk_size == 0   # cache.py:126-127
         L, H = cfg["num_hidden_layers"], cfg["num_key_value_heads"]
-        D = cfg["hidden_size"] // cfg["num_attention_heads"]
+        D = R.head_dim_of(cfg)
         self.layers, self.chunk_size, self.prefill, self.gamma = L, chunk_size, prefill, gamma
         self.chunks = prefill // chunk_size
         self.select_sets = max_budget // chunk_size
@@ -105,7 +105,7 @@ class StreamingCacheO:
 
     def __init__(self, cfg, gamma=6, start_size=16, recent_size=496):
         L, H = cfg["num_hidden_layers"], cfg["num_key_value_heads"]
-        D = cfg["hidden_size"] // cfg["num_attention_heads"]
+        D = R.head_dim_of(cfg)
         self.layers, self.gamma, self.start_size, self.recent_size = L, gamma, start_size, recent_size
         self.real_budget = start_size + recent_size + gamma + 3
         self.seq_len = 0
@@ -157,7 +157,7 @@ class _Weights:
         self.cfg = cfg
         self.L = cfg["num_hidden_layers"]
         self.H = cfg["num_attention_heads"]
-        self.D = cfg["hidden_size"] // self.H
+        self.D = R.head_dim_of(cfg)
         self.eps = cfg["rms_norm_eps"]
         self.sd = sd
 

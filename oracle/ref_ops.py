@@ -59,9 +59,16 @@ def rope_tables_yarn(dim, max_pos, factor, orig_max_pos, base=10000.0, beta_fast
     return (emb.cos() * mscale).to(dtype), (emb.sin() * mscale).to(dtype)
 
 
+def head_dim_of(cfg):
+    """hidden_size // num_attention_heads (modeling_llama.py:169), unless the config names ``head_dim`` explicitly: a
+    tensor-parallel SHARD keeps the model's head_dim with fewer heads (TP_layers.py:115-116 computes head_dim from the
+    UNSHARDED head count; oracle.specs.shard_of builds such configs)."""
+    return int(cfg.get("head_dim") or cfg["hidden_size"] // cfg["num_attention_heads"])
+
+
 def rope_tables_for(cfg):
     """Dispatch of modeling_llama.py:181-198 (_init_rope)."""
-    D = cfg["hidden_size"] // cfg["num_attention_heads"]
+    D = head_dim_of(cfg)
     rs = cfg.get("rope_scaling")
     if rs is None:
         return rope_tables_plain(D, cfg["max_position_embeddings"], cfg["rope_theta"])

@@ -87,6 +87,31 @@ def random_state_dict(cfg, seed, std=0.02, head_std=None, dtype=torch.float16, d
     return sd
 
 
+def shard_of(cfg, sd, rank, world):
+    """(config, state dict) of ONE tensor-parallel rank's network, sliced as the reference slices a layer
+    (models/TP_layers.py:126-147: q/k/v/gate/up split on dim 0, o/down on dim 1, `.split(n // world)[rank]`; embedding,
+    norms and lm_head replicated, TP_llama.py:91-94).  With the all-reduces taken out (a one-process group) a rank
+    computes exactly this narrower network — hidden size unchanged, H / world heads of the model's head_dim, I / world
+    MLP columns — which is what the device's shard forward is compared with at the 13B / TP = 8 widths."""
+    H, I, hid = cfg["num_attention_heads"], cfg["intermediate_size"], cfg["hidden_size"]
+    assert H % world == 0 and I % world == 0
+    D = hid // H
+    scfg = dict(cfg, num_attention_heads=H // world, num_key_value_heads=cfg["num_key_value_heads"] // world,
+                intermediate_size=I // world, head_dim=D, _name_or_path=f"{cfg['_name_or_path']}[rank {rank}/{world}]")
+    out = {}
+    for name, w in sd.items():
+        if any(k in name for k in ("q_proj", "k_proj", "v_proj")):
+            w = w.split((H * D) // world, dim=0)[rank]
+        elif "o_proj" in name:
+            w = w.split(hid // world, dim=1)[rank]
+        elif "gate_proj" in name or "up_proj" in name:
+            w = w.split(I // world, dim=0)[rank]
+        elif "down_proj" in name:
+            w = w.split(I // world, dim=1)[rank]
+        out[name] = w.contiguous()
+    return scfg, out
+
+
 def random_prompt(vocab_size, length, seed):
     g = torch.Generator(device="cpu").manual_seed(seed)
     return torch.randint(3, vocab_size, (1, length), generator=g, dtype=torch.long)

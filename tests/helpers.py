@@ -9,6 +9,21 @@ from oracle import specs
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def note(msg):
+    """A measured parity figure: printed (visible with -s / on failure) AND appended to gpurun_out/parity_notes.txt, which
+    tools/gpu_validate.sh copies to profiles/ — so the measured max / mean deviations behind every tolerance are on
+    record, not just the pass / fail bit."""
+    line = f"[parity] {msg}"
+    print(line, flush=True)
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_notes.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
 def load_golden(name):
     return torch.load(os.path.join(GOLDEN, f"{name}.pt"), weights_only=False)
 

@@ -231,17 +231,17 @@ def test_stochastic_triforce_with_injected_uniforms():
         tok_g, steps_g = tok_g + got["n"], steps_g + len(got["counts"])
         d_acc.append(got["accepted"] / max(got["drafted"], 1) - want["accepted"] / max(want["drafted"], 1))
         d_tok.append(got["n"] / len(got["counts"]) - want["n"] / len(want["counts"]))
-    print(f"[parity] stochastic common prefixes (of {max_len}+ tokens, {runs} runs): {sorted(prefixes)}")
+    Hh.note(f"stochastic common prefixes (of {max_len}+ tokens, {runs} runs): {sorted(prefixes)}")
     assert sum(1 for c in prefixes if c >= 1) >= runs - 3, prefixes          # the first draw agrees (near-)always
     assert sum(prefixes) / runs >= 3.0, prefixes
     for what, d in (("acceptance", d_acc), ("tokens per step", d_tok)):
         mean = sum(d) / runs
         se = math.sqrt(sum((x - mean) ** 2 for x in d) / (runs - 1) / runs)
-        print(f"[parity] stochastic {what}: mean paired difference {mean:+.4f} +- {se:.4f} (standard error)")
+        Hh.note(f"stochastic {what}: mean paired difference {mean:+.4f} +- {se:.4f} (standard error)")
         assert abs(mean) <= 4 * se + 1e-9, (what, mean, se)
     p_w, p_g = acc_w / dr_w, acc_g / dr_g
     per_w, per_g = tok_w / steps_w, tok_g / steps_g
-    print(f"[parity] stochastic pooled acceptance device {p_g:.3f} vs oracle {p_w:.3f}; tokens/step {per_g:.2f} vs {per_w:.2f}")
+    Hh.note(f"stochastic pooled acceptance device {p_g:.3f} vs oracle {p_w:.3f}; tokens/step {per_g:.2f} vs {per_w:.2f}")
     assert abs(p_g - p_w) <= 0.2 * max(p_w, 0.05) + 0.02 and abs(per_g - per_w) <= 0.2 * per_w
     assert acc_g > 0
 
@@ -260,7 +260,7 @@ def test_greedy_divergence_from_golden_happens_only_at_near_ties():
         gold, dev = g["triforce"][0]["tokens"], res["tokens"]
         n = min(len(gold), len(dev))
         common = Hh.common_prefix(dev[:n], gold[:n])
-        print(f"[parity] {name}: device greedy stream == golden stream for {common}/{n} tokens")
+        Hh.note(f"{name}: device greedy stream == golden stream for {common}/{n} tokens")
         if common == n:
             continue
         eng, _, _ = Hh.build_oracle(g)

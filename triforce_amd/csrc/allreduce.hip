@@ -17,7 +17,9 @@
 // itself, so a captured launch replays correctly.  Staging and flag buffers must be FINE-GRAINED device memory
 // (tf_ar_alloc): peers' stores and loads bypass the caches; plain device memory is only coherent across GPUs at kernel
 // boundaries.  Every spin is bounded (tens of seconds: a peer may legitimately be that late right after start-up); a
-// timeout sets the sticky error word, after which every later call returns immediately instead of waiting again.
+// timeout sets the sticky error word, after which every later call returns immediately instead of waiting again — and
+// on every error path `out` is filled with NaN, so no token can be computed from a reduction that did not happen; the
+// host polls tf_ar_error once per decode step (utils/decoding.py) and raises.
 #include "common.h"
 #include <string.h>
 
@@ -57,6 +59,15 @@ __device__ __forceinline__ bool ar_wait(const unsigned* slot, unsigned epoch) {
     return false;
 }
 
+// error path: out <- NaN (fp16 0x7e00), so a timed-out reduction can never pass for a result
+__device__ __forceinline__ void ar_poison(h16* out, int64_t n_vec8) {
+    half8 nan8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) nan8[e] = __builtin_bit_cast(h16, (unsigned short)0x7e00);
+    for (int64_t i = (int64_t)blockIdx.x * AR_THREADS + threadIdx.x; i < n_vec8; i += (int64_t)gridDim.x * AR_THREADS)
+        *reinterpret_cast<half8*>(out + 8 * i) = nan8;
+}
+
 __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c, const h16* resid, h16* out, int64_t n_vec8,
                                                                         float* ss_out, int hidden) {
     __shared__ unsigned s_epoch;
@@ -68,7 +79,10 @@ __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c,
         s_ok = ar_load(&mine->error) == 0u;         // sticky: after one timeout every later call returns at once
     }
     __syncthreads();
-    if (!s_ok) return;                               // (block-uniform) the host reads tf_ar_error and gives up
+    if (!s_ok) {                                     // (block-uniform) the host polls tf_ar_error once per decode step;
+        ar_poison(out, n_vec8);                      // until it does, nothing computed from `out` may look plausible
+        return;
+    }
     const unsigned epoch = s_epoch;
     // ---- READY: my partial was staged by the previous kernel in this stream ----
     if (blockIdx.x == 0 && tid < c.world) ar_store(&c.flags[tid]->ready[c.rank], epoch);
@@ -117,6 +131,8 @@ __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c,
                 }
             }
         }
+    } else {
+        ar_poison(out, n_vec8);                      // READY timed out: `out` would otherwise keep whatever it held
     }
     // ---- DONE: the last workgroup of this launch releases the peers' staging buffers and waits for mine ----
     __syncthreads();
@@ -233,7 +249,16 @@ extern "C" int tf_allreduce_oneshot(void* const* peer_data, void* const* peer_fl
     return tf_allreduce_oneshot_add(peer_data, peer_flags, rank, world, nullptr, out, n, stream);
 }
 
-// Error word of a control block (0 = never timed out); host-side read for the self-check.
+// Sets the sticky error word of a control block from the host (0 clears it): fault injection for the tests of the
+// error path (NaN-filled outputs, the per-step host poll, the bench line's "allreduce_error" field).
+extern "C" int tf_ar_inject_error(void* flags_local, int code) {
+    if (!flags_local || code < 0) return TF_EINVAL;
+    const unsigned v = (unsigned)code;
+    hipError_t e = hipMemcpy(&reinterpret_cast<ArFlags*>(flags_local)->error, &v, sizeof(v), hipMemcpyHostToDevice);
+    return e == hipSuccess ? TF_OK : (int)e;
+}
+
+// Error word of a control block (0 = never timed out); host-side read for the self-check and the per-step poll.
 extern "C" int tf_ar_error(const void* flags_local) {
     if (!flags_local) return TF_EINVAL;
     ArFlags f;

@@ -323,7 +323,11 @@ __device__ __forceinline__ void attn_split_body(
     // (sc1), ordered by "own stores landed (vmcnt 0) -> ticket".  An agent-scope release FENCE instead writes the whole
     // L2 back: measured 21.7 -> 47.9 us on the 7B retrieval-verify shape.
     __shared__ int s_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // Every thread drains ITS OWN write-through stores before the barrier that precedes the ticket: a workgroup-scope
+    // release fence emits no s_waitcnt vmcnt(0) on gfx950 (the ISA was store -> s_barrier -> atomic), so the ticket
+    // could overtake the partials and the last arriver — on another XCD — could fold the previous launch's values.
+    // Inline asm: the compiler's waitcnt pass may not drop or move it (MI355X_MICROARCH.md, compiler hazard).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0)
         s_last = __hip_atomic_fetch_add(&tickets[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nsplit - 1);

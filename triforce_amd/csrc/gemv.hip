@@ -61,19 +61,6 @@ struct SgRope {                       // arguments of the RoPE + KV-append epilo
     int slot0, H, D, rotate_k;
 };
 
-// Cross-kernel prefetch: the weight stream of the NEXT skinny GEMM of the forward does not depend on this kernel's
-// result, only its first bytes' arrival does on the launch boundary.  When a descriptor is given, every workgroup —
-// after its own stream has been issued and consumed — pulls the first ``depth`` KiB of each K-split of the next
-// kernel's panels b, b + G, b + 2G, ... (G = this grid; all grids are multiples of 8, so those panels' workgroups
-// will run on this workgroup's XCD and find the lines in its L2) with plain (temporal) loads that nobody waits for
-// until the wave ends.  The next kernel's ramp then starts from L2 hits instead of HBM misses.
-struct SgPrefetch {
-    const half8* base0;               // packed weights of the next GEMM (nullptr: no prefetch)
-    const half8* base1;               // second matrix of a gate|up pair, or nullptr
-    int panels, nchunks;              // next GEMM: N / 16, K / 32
-    int waves, depth;                 // its K-splits per panel and the chunks (KiB) to pull per split
-};
-
 // h = w_ln * fp16(x * inv): the cast precedes the weight multiply (modeling_llama.py:141-143); the fp16 product of
 // two fp16 values rounded once is the native half multiply.
 __device__ __forceinline__ half8 sg_normalise(half8 xv, half8 wv, float inv) {
@@ -91,7 +78,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
                                                                  const h16* resid, int64_t ldr, void* yv, int64_t ldy,
                                                                  int M, int N, int K, SgRope rp,
                                                                  const float* __restrict__ ss_in,
-                                                                 float* __restrict__ ss_out, SgPrefetch pf) {
+                                                                 float* __restrict__ ss_out) {
     constexpr bool GATEUP = MODE == SG_GATEUP;
     const int panel = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -277,28 +264,6 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
         }
     }
 
-    // next kernel's first weight tiles -> this XCD's L2 (see SgPrefetch); consumed by nobody, retired at wave end
-    unsigned pf_sink = 0u;
-    if (pf.base0) {
-        const int per_panel = pf.waves * pf.depth;                        // KiB pieces per next-kernel panel
-        const int cpw_n = (pf.nchunks + pf.waves - 1) / pf.waves;
-        for (int p = panel; p < pf.panels; p += gridDim.x) {
-            for (int e = wave; e < per_panel; e += WAVES) {
-                const int w = e / pf.depth, u = e - w * pf.depth;
-                const int ck = w * cpw_n + u;
-                if (ck < pf.nchunks) {
-                    const int64_t off = ((int64_t)p * pf.nchunks + ck) * 64 + lane;
-                    const half8 v0 = pf.base0[off];
-                    pf_sink ^= (unsigned)(float)v0[0];
-                    if (pf.base1) {
-                        const half8 v1 = pf.base1[off];
-                        pf_sink ^= (unsigned)(float)v1[0];
-                    }
-                }
-            }
-        }
-    }
-
     // split-K merge across the waves; C layout: lane holds D[n = 4g + r][m = li]
 #pragma unroll
     for (int t = 0; t < MT; ++t)
@@ -308,7 +273,6 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
             if (GATEUP) sm[wave][GATEUP ? 1 : 0][t][lane][r] = acc2[t][r];
         }
     __syncthreads();
-    if (pf.base0) asm volatile("" ::"v"(pf_sink));                         // keeps the prefetch loads; waited for only here
     if (wave != 0) return;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -395,25 +359,13 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
     }
 }
 
-// The prefetch descriptor for the NEXT launch, set by tf_skinny_set_next and consumed (cleared) by the launch that
-// follows on the same host thread.  Under hipGraph capture it is baked into the captured kernel arguments.
-static thread_local SgPrefetch g_next_pf = {nullptr, nullptr, 0, 0, 0, 0};
-
-static int sg_waves_for(int mode, int N, int K) {
-    const bool can_wide = mode != SG_GATEUP;
-    const bool wide = can_wide && (N / 16) <= SG_WIDE_MAX_PANELS && (K >> 5) >= 2 * SG_WAVES_WIDE;
-    return wide ? SG_WAVES_WIDE : SG_WAVES;
-}
-
 template <int MT, int MODE, bool NORM, int WAVES>
 static void launch_sg_w(const void* wp, const void* wp_up, const void* x, int64_t ldx, const void* ln_w, float eps,
                         const void* resid, int64_t ldr, void* y, int64_t ldy, int M, int N, int K, const SgRope& rp,
                         const float* ss_in, float* ss_out, hipStream_t st) {
-    const SgPrefetch pf = g_next_pf;
-    g_next_pf.base0 = nullptr;
     hipLaunchKernelGGL((skinny_gemm_kernel<MT, MODE, NORM, WAVES>), dim3(N / 16), dim3(WAVES * 64), 0, st,
                        (const half8*)wp, (const half8*)wp_up, (const h16*)x, ldx, (const h16*)ln_w, eps,
-                       (const h16*)resid, ldr, y, ldy, M, N, K, rp, ss_in, ss_out, pf);
+                       (const h16*)resid, ldr, y, ldy, M, N, K, rp, ss_in, ss_out);
 }
 
 template <int MODE, bool NORM>
@@ -432,24 +384,6 @@ static int launch_sg(const void* wp, const void* wp_up, const void* x, int64_t l
         else launch_sg_w<2, MODE, NORM, SG_WAVES>(wp, wp_up, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, ss_in, ss_out, st);
     }
     TF_LAUNCH_CHECK();
-    return TF_OK;
-}
-
-// Names the skinny GEMM that will FOLLOW the next launch on this thread, so that launch can prefetch its first weight
-// tiles (SgPrefetch).  w0 / w1: packed weights (w1 only for a gate|up pair), N x K its shape, mode_next as the SG_*
-// enum (0 plain / f32-out, 1 gate|up, 3 q|k|v + RoPE), depth = KiB per K-split.  w0 == NULL clears the hint.
-extern "C" int tf_skinny_set_next(const void* w0, const void* w1, int N, int K, int mode_next, int depth) {
-    if (!w0) {
-        g_next_pf.base0 = nullptr;
-        return TF_OK;
-    }
-    if (N < 16 || (N % 16) || K < 32 || (K % 32) || depth < 1 || depth > 16) return TF_EINVAL;
-    g_next_pf.base0 = (const half8*)w0;
-    g_next_pf.base1 = (const half8*)w1;
-    g_next_pf.panels = N / 16;
-    g_next_pf.nchunks = K / 32;
-    g_next_pf.waves = sg_waves_for(mode_next, N, K);
-    g_next_pf.depth = depth;
     return TF_OK;
 }
 

@@ -131,7 +131,13 @@ class DistributedLlama:
         self.cos_cache, self.sin_cache = cos.to(self.device), sin.to(self.device)
         self.embed_tokens, self.lm_head, self.norm_weight = W.embed, W.lm_head, W.norm
         self.norm_variance_epsilon = W.eps
-        if self.world_size > 1 and self.device.type == "cuda" and os.environ.get("TRIFORCE_ONESHOT_AR", "1") != "0":
+        # TRIFORCE_ALLREDUCE = auto (one-shot after its self-check, else RCCL) | oneshot (fail if unavailable) | rccl;
+        # TRIFORCE_ONESHOT_AR=0 is the older spelling of rccl
+        mode = os.environ.get("TRIFORCE_ALLREDUCE", "auto")
+        if mode not in ("auto", "oneshot", "rccl"):
+            raise ValueError(f"TRIFORCE_ALLREDUCE={mode!r}: expected auto, oneshot or rccl")
+        if self.world_size > 1 and self.device.type == "cuda" and mode != "rccl" \
+                and os.environ.get("TRIFORCE_ONESHOT_AR", "1") != "0":
             self.enable_oneshot_allreduce()
 
     # ---------------------------------------------------------------------------------------
@@ -144,34 +150,69 @@ class DistributedLlama:
         dist.all_reduce on random data — every rank must agree that it was exact (world 2) / within one fp16 rounding of
         the ring's result and that no wait timed out — else the engine stays on RCCL."""
         from ..utils.oneshot_ar import OneShotAllReduce
-        ok, ar = True, None
-        try:
-            ar = OneShotAllReduce(self.local_rank, self.world_size, self.device, self.ONESHOT_MAX_ROWS * self.hidden_size)
+        forced = os.environ.get("TRIFORCE_ALLREDUCE", "auto")          # rccl | oneshot | auto (bench.py --allreduce)
+        ar, why = None, []
+
+        def stage(fn, what):
+            """Run one LOCAL stage under try, then let the ranks agree on it: a rank that fails never leaves its peers
+            inside a collective it has skipped (every collective below is entered by all ranks or by none)."""
+            good = True
+            try:
+                fn()
+            except Exception as ex:
+                good = False
+                why.append(f"{what}: {type(ex).__name__}: {ex}")
+            return self._agree(good)
+
+        def alloc():
+            nonlocal ar
+            ar = OneShotAllReduce(self.local_rank, self.world_size, self.device, self.ONESHOT_MAX_ROWS * self.hidden_size,
+                                  connect=False)
+
+        ok = stage(alloc, "allocation")
+        # connect() always reaches its all-gather (a failed export contributes None), and raises afterwards
+        ok = ok and stage(lambda: ar.connect(), "handle exchange")
+        if ok:
+            # self-test: the reference sums come from RCCL first, unconditionally, so the collectives match on every
+            # rank whatever happens to the one-shot launches afterwards
             g = torch.Generator(device=self.device).manual_seed(1234 + self.local_rank)
-            for rows in (1, 7, self.ONESHOT_MAX_ROWS):
-                part = torch.randn(rows, self.hidden_size, generator=g, device=self.device).to(torch.float16)
-                want = part.clone()
-                dist.all_reduce(want, dist.ReduceOp.SUM)
-                stage = ar.staging(rows, self.hidden_size)
-                stage.copy_(part)
-                got = ar.reduce(stage, torch.empty_like(part))
-                torch.cuda.synchronize(self.device)
-                err = (got.float() - want.float()).abs()
-                tol = 0.0 if self.world_size == 2 else 2.0 ** -8 * float(want.float().abs().max())
-                ok = ok and bool(torch.isfinite(got).all()) and float(err.max()) <= tol
-            ok = ok and ar.error() == 0
-        except Exception as ex:
-            ok = False
-            if verbose or self.local_rank == 0:
-                print(f"[TP] one-shot all-reduce unavailable, staying on RCCL: {type(ex).__name__}: {ex}", flush=True)
-        ok = self._agree(ok)
+            parts = [torch.randn(rows, self.hidden_size, generator=g, device=self.device).to(torch.float16)
+                     for rows in (1, 7, self.ONESHOT_MAX_ROWS)]
+            wants = [p.clone() for p in parts]
+            for w in wants:
+                dist.all_reduce(w, dist.ReduceOp.SUM)
+
+            def selftest():
+                for part, want in zip(parts, wants):
+                    st = ar.staging(part.shape[0], self.hidden_size)
+                    st.copy_(part)
+                    got = ar.reduce(st, torch.empty_like(part))
+                    torch.cuda.synchronize(self.device)
+                    err = (got.float() - want.float()).abs()
+                    tol = 0.0 if self.world_size == 2 else 2.0 ** -8 * float(want.float().abs().max())
+                    if not bool(torch.isfinite(got).all()) or float(err.max()) > tol:
+                        raise RuntimeError(f"self-test mismatch at {part.shape[0]} rows: max err {float(err.max())}")
+                ar.check("self-test")
+
+            ok = stage(selftest, "self-test")
         if ok:
             self._ar = ar
         elif ar is not None:
             ar.close()
+        self.allreduce_note = "; ".join(why)
         if verbose or self.local_rank == 0:
-            print(f"[TP] decode all-reduce: {'one-shot peer reads (xGMI)' if ok else 'RCCL'}", flush=True)
+            print(f"[TP] decode all-reduce: {'one-shot peer reads (xGMI)' if ok else 'RCCL'}"
+                  + (f" ({self.allreduce_note})" if why else ""), flush=True)
+        if not ok and forced == "oneshot":
+            raise RuntimeError("TRIFORCE_ALLREDUCE=oneshot but the one-shot all-reduce is unavailable: "
+                               + (self.allreduce_note or "a peer rank failed its stage"))
         return ok
+
+    def check_exchange(self, where=""):
+        """Raise if the one-shot all-reduce ever timed out (its outputs are NaN-filled from then on).  Called once per
+        decode step by the loops in utils/decoding.py, after the step's host read."""
+        if self._ar is not None:
+            self._ar.check(where)
 
     def reset(self):
         self.kv_cache.reset()

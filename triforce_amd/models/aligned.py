@@ -53,8 +53,8 @@ class AlignedSpec:
 
 def parse_spec(s):
     """``aligned[:draft_acc[:retrieval_acc[:seed]]]`` -> AlignedSpec, anything else -> None."""
-    if not isinstance(s, str) or not s.startswith("aligned"):
-        return None
+    if not isinstance(s, str) or not (s == "aligned" or s.startswith("aligned:")):
+        return None                     # exactly the spec grammar: a checkpoint directory named aligned* is a path
     parts = s.split(":")[1:]
     spec = AlignedSpec()
     if len(parts) > 0 and parts[0]:

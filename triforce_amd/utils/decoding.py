@@ -262,6 +262,9 @@ class TriForceRunner:
         # sync_record: optional callable applied to each device decision record before it is read (TP: broadcast
         #              from rank 0, the role of sample_dist / the r broadcast, decoding.py:230-239,345-346)
         self.inclusive_accept, self.sync_record = inclusive_accept, sync_record
+        # health: optional callable run once per outer step right after the step's host read (TP: raises when the
+        #              one-shot all-reduce has timed out — its outputs are NaN-filled from then on, csrc/allreduce.hip)
+        self.health = None
         self.tokenizer, self.ge, self.eng = tokenizer, graph_engine, graph_engine.engine
         self.gamma, self.top_k, self.top_p, self.temperature, self.verbose = gamma, top_k, top_p, temperature, verbose
         self.device = self.eng.model.device
@@ -342,6 +345,8 @@ class TriForceRunner:
         if self.sync_record is not None:
             self.sync_record(rec.tensor)
         count, pred, reason, consumed = rec.read(4)                      # the one host read of the outer step
+        if self.health is not None:
+            self.health()
         if self.inclusive_accept and reason == 1 and generated[g2 - 1] == self.eos:
             # TP loop only: an eos accepted as the LAST drafted token ends the loop before the bonus sample
             # (decoding.py:357-360,382-383); the on-chip loop — and tf_accept_chain — go on to the bonus token (:127)
@@ -468,6 +473,11 @@ class _DistEngine:
     def update_graph_cache(self):
         self.llm.retrieval_cache.update_graph_cache(self.llm.kv_cache)
 
+    def health(self):
+        check = getattr(self.llm, "check_exchange", None)
+        if check is not None:
+            check("decode step")
+
 
 @torch.inference_mode()
 def Baseline_Dist(tokenizer, graph_engine, input_ids, max_len=256, top_k=-1, top_p=0.9, temperature=0.6, verbose=False,
@@ -480,6 +490,7 @@ def Baseline_Dist(tokenizer, graph_engine, input_ids, max_len=256, top_k=-1, top
     next_token = sample_dist(norm_logits(logits[:, -1, :], temperature=temperature, top_k=top_k, top_p=top_p), rng)
     gen_tokens = torch.zeros((input_ids.size(0), max_len), dtype=torch.long, device=input_ids.device)
     n = 0
+    check = getattr(llm, "check_exchange", None)
     _sync(llm.device)
     time1 = time.time()
     while n < max_len:
@@ -487,8 +498,12 @@ def Baseline_Dist(tokenizer, graph_engine, input_ids, max_len=256, top_k=-1, top
         next_token = sample_dist(norm_logits(logits[:, -1, :], temperature=temperature, top_k=top_k, top_p=top_p), rng)
         gen_tokens[:, n] = next_token.squeeze()
         n += 1
+        if check is not None and n % 32 == 0:          # a timed-out exchange NaN-fills its outputs: stop, don't emit
+            check("autoregressive step")
     _sync(llm.device)
     time2 = time.time()
+    if check is not None:
+        check("autoregressive loop")
     return 1000 * (time2 - time1) / n, gen_tokens
 
 
@@ -507,6 +522,7 @@ def TriForce_Dist(tokenizer, llm, input_ids, gamma=4, max_len=256, top_k=-1, top
     rng = rng or UniformSource(llm.device, seed=1)          # same seed on every rank: identical uniform streams
     run = TriForceRunner(tokenizer, ge, gamma, top_k, top_p, temperature, verbose, rng, inclusive_accept=True,
                          sync_record=_bcast_record)
+    run.health = ge.health
     llm.reset()
     if input_ids.shape[1] != llm.prefill_len:
         # the retrieval cache's chunk grid and the device mirror of the generated rows are laid out for exactly this

@@ -33,23 +33,36 @@ def reference_sum(partials, resid=None):
 
 
 class OneShotAllReduce:
-    def __init__(self, rank, world, device, max_elems, peer_data=None, peer_flags=None, own=None):
+    def __init__(self, rank, world, device, max_elems, peer_data=None, peer_flags=None, own=None, connect=True):
         """Collective constructor (every rank of the default process group calls it) unless ``peer_data`` /
-        ``peer_flags`` are given (single-process groups of virtual ranks: tests)."""
+        ``peer_flags`` are given (single-process groups of virtual ranks: tests).  ``connect=False`` only allocates this
+        rank's buffers — no collective — and leaves the handle exchange to ``connect()``, so a caller can let the ranks
+        agree that every allocation succeeded before any of them enters the exchange (DistributedLlama does)."""
         self.rank, self.world, self.device, self.max_elems = rank, world, torch.device(device), int(max_elems)
         L = hip.lib()
         self._opened = []
+        self._data = self._flags = None
         if own is None:
             own = (self._alloc(self.max_elems * 2), self._alloc(L.tf_ar_flags_bytes()))
             self._owned = own
         else:
             self._owned = ()
         self.data_ptr, self.flags_ptr = own
-        if peer_data is None:
-            peer_data, peer_flags = self._exchange()
-        self._data = (ctypes.c_void_p * world)(*peer_data)
-        self._flags = (ctypes.c_void_p * world)(*peer_flags)
         self._stage = torch.as_tensor(_RawBuffer(self.data_ptr, (self.max_elems,), "<f2"), device=self.device)
+        if peer_data is not None:
+            self._set_peers(peer_data, peer_flags)
+        elif connect:
+            self.connect()
+
+    def _set_peers(self, peer_data, peer_flags):
+        self._data = (ctypes.c_void_p * self.world)(*peer_data)
+        self._flags = (ctypes.c_void_p * self.world)(*peer_flags)
+
+    def connect(self):
+        """The collective half of construction: export this rank's buffers, all-gather the handles, map the peers'.
+        EVERY rank reaches the all-gather even when its own export failed (it contributes None), so the ranks cannot
+        end up in different collectives; the failure is raised afterwards, on every rank that saw it."""
+        self._set_peers(*self._exchange())
 
     @staticmethod
     def _alloc(nbytes):
@@ -61,13 +74,21 @@ class OneShotAllReduce:
         import torch.distributed as dist
         L = hip.lib()
         n = L.tf_ar_ipc_handle_bytes()
-        mine = []
-        for ptr in (self.data_ptr, self.flags_ptr):
-            buf = ctypes.create_string_buffer(n)
-            hip.check(L.tf_ar_get_ipc_handle(ctypes.c_void_p(ptr), buf), "tf_ar_get_ipc_handle")
-            mine.append(bytes(buf.raw))
+        mine, failure = [], None
+        try:
+            for ptr in (self.data_ptr, self.flags_ptr):
+                buf = ctypes.create_string_buffer(n)
+                hip.check(L.tf_ar_get_ipc_handle(ctypes.c_void_p(ptr), buf), "tf_ar_get_ipc_handle")
+                mine.append(bytes(buf.raw))
+        except Exception as ex:                       # still take part in the all-gather below
+            mine, failure = None, ex
         everyone = [None] * self.world
         dist.all_gather_object(everyone, mine)
+        if failure is not None:
+            raise failure
+        if any(e is None for e in everyone):
+            raise RuntimeError(f"rank(s) {[r for r, e in enumerate(everyone) if e is None]} could not export their "
+                               "one-shot all-reduce buffers")
         data, flags = [], []
         for r, (hd, hf) in enumerate(everyone):
             if r == self.rank:
@@ -95,6 +116,7 @@ class OneShotAllReduce:
         """out <- [resid +] sum over ranks of their staged partials.  ``staged`` must be (a prefix view of)
         ``staging()``; ``resid`` (fp16, may be ``out`` itself) is added in fp16 to the rounded sum; ``ss_out``
         (hidden / 16, 32) fp32 receives the per-panel sums of squares of the result rows (ops.ss_buffer)."""
+        assert self._data is not None, "OneShotAllReduce.connect() has not run"
         assert staged.data_ptr() == self.data_ptr and out.dtype == torch.float16 and out.is_contiguous()
         assert out.numel() == staged.numel() and out.data_ptr() != self.data_ptr
         if resid is not None:
@@ -115,8 +137,17 @@ class OneShotAllReduce:
         return out
 
     def error(self):
-        """0, or which wait timed out (1 READY, 2 DONE) at some point since creation."""
+        """0, or which wait timed out (1 READY, 2 DONE) at some point since creation.  Sticky: after a timeout every
+        later reduce returns at once and fills ``out`` with NaN (csrc/allreduce.hip) — callers poll this once per
+        decode step (``check()``) and stop instead of emitting tokens computed from a reduction that never happened."""
         return hip.lib().tf_ar_error(ctypes.c_void_p(self.flags_ptr))
+
+    def check(self, where=""):
+        e = self.error()
+        if e:
+            raise RuntimeError(f"rank {self.rank}: one-shot all-reduce timed out waiting for a peer's "
+                               f"{'READY' if e == 1 else 'DONE' if e == 2 else e} flag{(' (' + where + ')') if where else ''}; "
+                               "its outputs since then are NaN-filled. Restart with TRIFORCE_ONESHOT_AR=0 (RCCL).")
 
     def close(self):
         L = hip.lib()
