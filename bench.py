@@ -82,6 +82,13 @@ def parse(argv=None):
                     help="tensor-parallel path only: put every rank on cuda:0 (a functional full-size check of world "
                          "size N on a 1-GPU box: real shards, real kernels, one-shot all-reduce across processes; "
                          "large collectives over gloo).  NOT a scaling measurement; the line says so")
+    ap.add_argument("--allreduce", default="auto", choices=["auto", "oneshot", "rccl"],
+                    help="tensor-parallel path: decode-sized all-reduces through the one-shot peer-read kernel after its "
+                         "collective self-check (auto: falls back to RCCL if the check fails; oneshot: fail instead of "
+                         "falling back) or through RCCL — for A/B on a multi-GPU node")
+    ap.add_argument("--require-graph-form", default=None, choices=["whole", "segments", "eager"],
+                    help="tensor-parallel path: fail (rc != 0, JSON field 'failed') unless the decode forwards were "
+                         "captured in this form")
     ap.add_argument("--eager-comparator", action="store_true",
                     help="also time the same-hardware un-tuned comparator (eager PyTorch-ROCm restatement, ~20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -378,6 +385,76 @@ def eager_comparator(ge, args, inner_per_step, tokens_per_step, device):
             "triforce_step_ms_est": round(step_ms, 2), "triforce_tokens_per_s_est": round(tokens_per_step / step_ms * 1e3, 2)}
 
 
+def baseline_config_label(target, prefill, budget, gamma, on_chip, layers, world):
+    """Which BASELINE.json config the PARAMETERS of this run are (the label on the JSON line must name what ran)."""
+    offload = 0 <= on_chip < layers
+    if (prefill, budget, gamma) == (124928, 4096, 6) and not offload:
+        if target == "llama-7B-128K":
+            return "BASELINE configs[1]" + ("" if world == 1 else f" shapes sharded TP={world}")
+        if target == "lwm-128K":
+            return "BASELINE configs[2]" + ("" if world == 1 else f" shapes sharded TP={world}")
+    if (prefill, budget, gamma) == (130048, 12288, 16):
+        if target == "llama-7B-128K":
+            return "BASELINE configs[3]" + (" (offloading_TP, TP=2)" if world == 2 else
+                                            f" parameters at world size {world}" + (" (offloading tier)" if offload else ""))
+        if target == "llama-13B-128K":
+            return "BASELINE configs[4]" + ("" if world == 8 else f" parameters at world size {world}")
+    return "custom (not a BASELINE.json config)"
+
+
+def forward_bytes(tcfg, keys, world=1):
+    """Algorithmic HBM bytes of ONE decode-sized forward of this rank: every layer's weight shard once
+    + the K and V rows it attends over + the replicated lm_head."""
+    hid, I, L, V = tcfg.hidden_size, tcfg.intermediate_size, tcfg.num_hidden_layers, tcfg.vocab_size
+    H, D = tcfg.num_attention_heads // world, tcfg.head_dim
+    w_layer = (3 * H * D * hid + H * D * hid + 3 * (I // world) * hid) * 2
+    kv_layer = 2 * keys * H * D * 2
+    return L * (w_layer + kv_layer) + V * hid * 2, w_layer, kv_layer
+
+
+def _stage_row(stage, byts, us, how):
+    gbps = byts / (us * 1e-6) / 1e9
+    return {"stage": stage, "bound": "hbm", "algorithmic_bytes": int(byts), "us": round(us, 1), "achieved": round(gbps, 1),
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "measured": how}
+
+
+def retrieval_build_rooflines(ge, args, device):
+    """Chunk scoring / top-k / gather of ONE layer's retrieval build at the run's shapes, each kernel timed with HIP
+    events on the launch stream over different layers of the real KV cache (cold L2 / Infinity Cache) — north_star's
+    'achieved HBM GB/s on the retrieval gather'."""
+    from triforce_amd import ops
+    eng = ge.engine
+    kv, gc = eng.kv_cache, eng.graph_cache
+    H, D = kv.num_heads, kv.head_dim
+    L = kv.layers
+    q = torch.randn(H, D, device=device, dtype=torch.float16)
+    chunks, chunk, sets = gc.chunks, gc.chunk_size, gc.select_sets
+    lay = [0]
+
+    def nxt():
+        lay[0] = (lay[0] + 5) % L
+        return kv.layer_kv(lay[0])
+
+    scores = ops.retrieval_score(nxt()[0], q, chunks, chunk)
+    idx = ops.retrieval_topk(scores, sets)
+    dk, dv = torch.empty(H, sets * chunk, D, device=device, dtype=torch.float16), \
+        torch.empty(H, sets * chunk, D, device=device, dtype=torch.float16)
+    t_score = _timed(lambda: ops.retrieval_score(nxt()[0], q, chunks, chunk), 6)
+    t_topk = _timed(lambda: ops.retrieval_topk(scores, sets), 6)
+
+    def gather():
+        kl, vl = nxt()
+        ops.retrieval_gather(kl, vl, idx, dk, dv, chunk)
+    t_gather = _timed(gather, 6)
+    P = chunks * chunk
+    rows = [_stage_row("retrieval_score (chunk means + q.k per chunk, one layer)", P * H * D * 2, t_score, "HIP events, 6 launches over distinct layers"),
+            _stage_row("retrieval_gather (selected chunks K and V -> retrieval cache, one layer)", 4 * sets * chunk * H * D * 2,
+                       t_gather, "HIP events, 6 launches over distinct layers")]
+    rows.append({"stage": "retrieval_topk (radix select per head, one layer)", "bound": "latency", "us": round(t_topk, 1),
+                 "measured": "HIP events, 6 launches"})
+    return rows
+
+
 def pmc_traffic(alg_bytes, H, D):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, KiB units, FETCH_SIZE doubled for gfx950 — MI355X_MICROARCH.md §HBM).
@@ -507,6 +584,24 @@ def main():
     roof = attn_roofline(m["timer"], args.budget + args.gamma + 1, tcfg.num_attention_heads, tcfg.head_dim)
 
     stages = stage_latencies(ge, args, device)
+    label = baseline_config_label(args.target, args.prefill, args.budget, args.gamma, -1, tcfg.num_hidden_layers, 1)
+    S_now = ge.engine.kv_cache.seq_len
+    rv_bytes, w_layer, rv_kv = forward_bytes(tcfg, args.budget + args.gamma + 1)
+    tv_bytes, _, tv_kv = forward_bytes(tcfg, S_now + args.gamma + 2)
+    dcfg = target_config(args.target)[1]
+    d_bytes = (dcfg.num_hidden_layers * (4 * dcfg.hidden_size ** 2 + 3 * dcfg.intermediate_size * dcfg.hidden_size)
+               + dcfg.vocab_size * dcfg.hidden_size) * 2
+    how = "HIP events around hipGraph replays on the launch stream (stage_latency_us)"
+    roofline_stages = [
+        _stage_row(f"retrieval_verify forward ({args.gamma + 1} rows: {tcfg.num_hidden_layers} x ({w_layer / 1e6:.1f} MB weights + "
+                   f"{rv_kv / 1e6:.1f} MB retrieval KV) + lm_head)", rv_bytes, stages["retrieval_verify_us"], how),
+        _stage_row(f"target_verify forward ({args.gamma + 2} rows: {tcfg.num_hidden_layers} x ({w_layer / 1e6:.1f} MB weights + "
+                   f"{tv_kv / 1e6:.1f} MB KV) + lm_head)", tv_bytes, stages["target_verify_us"], how),
+        _stage_row("draft step (68M forward, weights once)", d_bytes, stages["draft_step_us"], how)]
+    try:
+        roofline_stages += retrieval_build_rooflines(ge, args, device)
+    except Exception as ex:                                        # a probe must never cost the bench line
+        roofline_stages.append({"stage": "retrieval build", "failed": f"{type(ex).__name__}: {ex}"[:300]})
     ar_tps = autoregressive_baseline(ge, args, run.next_token)
     inner_per_step = m["inner"] / max(args.steps, 1)
     cal = (target.weights.aligned or {}).get("calibration") if kind == "aligned" else None
@@ -515,7 +610,7 @@ def main():
         "value": round(value, 3), "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(seconds / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: {tcfg._name_or_path} on-chip TriForce decode, prefill "
+        "config": {"workload": f"{label}: {tcfg._name_or_path} on-chip TriForce decode, prefill "
                                f"{args.prefill}, budget {args.budget}, chunk {args.chunk_size}, gamma {args.gamma}, "
                                f"T={args.temp}, top_p={args.top_p}, 1xMI355X",
                    "prefill_mode": args.prefill_mode, "weights": wlabel, "weights_kind": kind,
@@ -535,7 +630,7 @@ def main():
                                                 "source": "reference README.md:49-55"},
         "prefill_seconds": round(t_prefill, 2), "setup_seconds": round(t0 - t_setup, 2),
         "kv_seq_len": ge.engine.kv_cache.seq_len,
-        "roofline": roof,
+        "roofline": roof, "roofline_stages": roofline_stages,
     }
     if cal is not None:
         result["aligned_calibration"] = cal

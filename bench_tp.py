@@ -92,7 +92,8 @@ def run_tp(args, rank, world, local):
         sys.stdout.flush()
         _REAL_STDOUT = os.dup(1)
         os.dup2(2, 1)
-    from bench import _Tok, attn_roofline, resolve_weights, target_config
+    from bench import (_Tok, attn_roofline, baseline_config_label, cpu_baseline, forward_bytes, resolve_weights,
+                       target_config, _stage_row, _timed)
     from triforce_amd.models.aligned import parse_spec
     from triforce_amd import ops
     from triforce_amd.models.cache import StreamingLLMEvictionCache
@@ -102,6 +103,7 @@ def run_tp(args, rank, world, local):
     from triforce_amd.utils.sampling import UniformSource
 
     on_gpu = torch.cuda.is_available()
+    os.environ["TRIFORCE_ALLREDUCE"] = getattr(args, "allreduce", "auto")     # read by DistributedLlama.init_parameters
     if "RANK" not in os.environ:                                # one process, no launcher (--engine tp / --on-chip at N=1)
         import socket
         with socket.socket() as sock:
@@ -152,6 +154,7 @@ def run_tp(args, rank, world, local):
     ge = _DistEngine(llm)
     run = TriForceRunner(_Tok(), ge, args.gamma, top_k=-1, top_p=args.top_p, temperature=args.temp,
                          rng=UniformSource(device, seed=args.seed), inclusive_accept=True, sync_record=_bcast_record)
+    run.health = ge.health                                      # a timed-out exchange raises instead of emitting tokens
     t0 = time.time()
     llm.reset()
     if args.prefill_mode == "real":
@@ -171,20 +174,46 @@ def run_tp(args, rank, world, local):
     for _ in range(args.warmup):
         run.step()
     n0, acc0, dr0 = run.n, run.accepted_count, run.draft_count
+    inject = int(os.environ.get("TRIFORCE_BENCH_INJECT_AR_ERROR", "0"))
+    if inject and getattr(llm, "_ar", None) is not None:        # fault injection (tests): as if a peer had timed out
+        torch.cuda.synchronize()
+        llm._ar.inject_error(inject)
     if rank == 0:
         ops.ATTN_TIMER = []                                     # rank 0 samples its attention launches (HIP events)
+    # every --roofline-every-th target verify runs eagerly on EVERY rank (same exchanges, same order as the captured
+    # forward) so that rank 0 can bracket attention launches with HIP events inside the timed region, like bench.py
+    graphed_target = bool(getattr(llm, "_target_caps", None))
+    run.eager_every = args.roofline_every if (graphed_target and args.roofline_every > 0) else 0
+    in0 = run.inner_iters
     dist.barrier()
     torch.cuda.synchronize()
     t1 = time.time()
-    for _ in range(args.steps):
-        run.step()
+    failure = None
+    try:
+        for _ in range(args.steps):
+            run.step()
+    except RuntimeError as ex:                                  # one-shot all-reduce timeout surfaced by run.health
+        failure = f"{type(ex).__name__}: {ex}"
     torch.cuda.synchronize()
-    dist.barrier()
+    if failure is None:
+        dist.barrier()
     t2 = time.time()
+    run.eager_every = 0
     timer, ops.ATTN_TIMER = ops.ATTN_TIMER, None
-    if getattr(llm, "_ar", None) is not None and llm._ar.error():
-        raise SystemExit(f"rank {rank}: one-shot all-reduce timed out waiting for a peer (code {llm._ar.error()}); "
-                         "results invalid — rerun with TRIFORCE_ONESHOT_AR=0")
+    ar_err = llm._ar.error() if getattr(llm, "_ar", None) is not None else 0
+    if failure is None and ar_err:
+        failure = f"one-shot all-reduce error word {ar_err} after the timed region"
+    want_form = getattr(args, "require_graph_form", None)
+    if failure is None and want_form and getattr(llm, "graph_form", "eager") != want_form:
+        failure = f"graph_form {getattr(llm, 'graph_form', 'eager')!r} != required {want_form!r}"
+    if failure is None and getattr(args, "allreduce", "auto") == "oneshot" and world > 1 and getattr(llm, "_ar", None) is None:
+        failure = "--allreduce oneshot but the engine is on RCCL"
+    if failure is not None:                                     # fail LOUDLY: a JSON line that says so, and rc != 0
+        _emit(json.dumps({"metric": "decode tokens/sec + avg accepted len, Llama-7B-128K @124K ctx", "value": None,
+                          "failed": failure, "rank": rank, "n_gpus": world, "allreduce_error": int(ar_err),
+                          "world_size_observed": dist.get_world_size(), "graph_form": getattr(llm, "graph_form", "eager"),
+                          "decode_allreduce": "oneshot" if getattr(llm, "_ar", None) is not None else "rccl"}))
+        os._exit(3)
     offload = offload_report(llm, args, tcfg, world, device) if llm.on_chip_layers < tcfg.num_hidden_layers else None
     elapsed = torch.tensor([t2 - t1], dtype=torch.float64, device=device)
     dist.all_reduce(elapsed, dist.ReduceOp.MAX)                 # slowest rank defines the job time
@@ -194,12 +223,46 @@ def run_tp(args, rank, world, local):
     if rank == 0:
         # per-rank roofline: this rank's heads only (H / world), against ONE GPU's HBM peak
         roof = attn_roofline(timer, args.budget + args.gamma + 1, tcfg.num_attention_heads // world, tcfg.head_dim)
+        if roof is not None:
+            roof["kernel"] = ("attn_split_q2_kernel<128>" if args.gamma + 2 > 16 else "attn_split_kernel<128,1>") + \
+                f" via tf_attn_decode[_fused], {tcfg.num_attention_heads // world} heads of this rank"
+        inner_per_step = (run.inner_iters - in0) / max(args.steps, 1)
+        label = baseline_config_label(args.target, args.prefill, args.budget, args.gamma, args.on_chip,
+                                      tcfg.num_hidden_layers, world)
+        # stage rooflines of THIS rank's shard (graph replays, HIP events), after the timed region
+        stages, stage_rows = None, None
+        if offload is None:
+            S_now = llm.kv_cache.seq_len
+            g = args.gamma
+            ids = torch.full((1, g + 2), 100, dtype=torch.long, device=device)
+            pos = torch.arange(S_now, S_now + g + 1, device=device).unsqueeze(0)
+            solo = world == 1                                   # other ranks are past their timed loop: only a one-rank
+            if solo:                                            # engine can run extra forwards without its peers
+
+                def tv():
+                    llm.inference(input_ids=ids)
+                    llm.kv_cache.seq_len = S_now
+                stages = {"draft_step_us": round(_timed(lambda: llm.draft_run(ids[:, :3], gamma_offset=2), 5), 1),
+                          "retrieval_verify_us": round(_timed(lambda: llm.retrieval_verify(ids[:, :g + 1], pos, args.temp, args.top_p), 5), 1),
+                          "target_verify_us": round(_timed(tv, 3), 1)}
+                rvb, wl, rkv = forward_bytes(tcfg, args.budget + g + 1, world)
+                tvb, _, tkv = forward_bytes(tcfg, S_now + g + 2, world)
+                how = "HIP events around the engine's forwards (hipGraph replays where captured)"
+                stage_rows = [_stage_row("retrieval_verify forward (this rank's shard)", rvb, stages["retrieval_verify_us"], how),
+                              _stage_row("target_verify forward (this rank's shard)", tvb, stages["target_verify_us"], how)]
+        cpu = None
+        if not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline(args, tokens / args.steps, inner_per_step)
+            except Exception as ex:
+                cpu = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+                       "sample": f"failed: {type(ex).__name__}: {ex}"}
         _emit(json.dumps({
             "metric": "decode tokens/sec + avg accepted len, Llama-7B-128K @124K ctx",
             "value": round(tokens / seconds, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(seconds / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1] shapes, tensor-parallel: {tcfg._name_or_path} TriForce decode, "
+            "config": {"workload": f"{label}, tensor-parallel engine: {tcfg._name_or_path} TriForce decode, "
                                    f"prefill {args.prefill}, budget {args.budget}, chunk {args.chunk_size}, gamma "
                                    f"{args.gamma}, T={args.temp}, top_p={args.top_p}, TP={world} "
                                    + ("with ALL RANKS ON ONE DEVICE (functional check, not a scaling point), "
@@ -216,8 +279,12 @@ def run_tp(args, rank, world, local):
             "kv_seq_len": llm.kv_cache.seq_len, "graph_form": getattr(llm, "graph_form", "eager"),
             "decode_allreduce": "one-shot peer reads (tf_allreduce_oneshot)" if getattr(llm, "_ar", None) is not None
             else ("rccl" if world > 1 else "none (one rank)"),
-            "ranks_share_one_device": bool(share),
-            "roofline": roof, "roofline_note": None if roof else "target verify replayed from a hipGraph on this run: "
-            "no per-launch HIP events; see profiles/ for the rocprofv3 kernel trace", "cpu_baseline": None}))
+            "ranks_share_one_device": bool(share), "allreduce_error": int(ar_err),
+            "allreduce_requested": getattr(args, "allreduce", "auto"),
+            "allreduce_note": getattr(llm, "allreduce_note", "") or None,
+            "inner_iterations_per_step": round(inner_per_step, 3), "stage_latency_us": stages,
+            "roofline": roof, "roofline_stages": stage_rows,
+            "roofline_note": None if roof else "no eager target verify was sampled (--roofline-every 0, or no target "
+            "graph): no per-launch HIP events on this run", "cpu_baseline": cpu}))
     dist.barrier()
     dist.destroy_process_group()

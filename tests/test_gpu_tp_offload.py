@@ -428,3 +428,68 @@ def test_tp_world2_on_one_device_real_kernels_and_oneshot_allreduce():
     gaps = Hh.teacher_forced_gaps(g6, a["tokens"])
     assert max(gaps) < 8e-3, f"TP stream leaves the oracle's greedy path: gap {max(gaps):.4f}"
     assert Hh.common_prefix(a["tokens"], g6["ar_tokens"]) >= 12
+
+
+def test_oneshot_allreduce_error_path_poisons_output_and_raises():
+    """A timed-out exchange must never pass for a result: with the sticky error word set (fault injection — what a
+    READY / DONE timeout leaves behind) every later reduce returns at once with `out` NaN-filled, `check()` raises, and
+    after the word is cleared the same group reduces correctly again."""
+    from triforce_amd.utils.oneshot_ar import OneShotAllReduce
+    hidden = 512
+    ar = OneShotAllReduce.local_group(1, DEV, 32 * hidden)[0]
+    part = torch.randn(7, hidden, device=DEV).to(torch.float16)
+    st = ar.staging(7, hidden)
+    st.copy_(part)
+    out = ar.reduce(st, torch.zeros_like(part))
+    torch.cuda.synchronize()
+    assert torch.equal(out, part) and ar.error() == 0
+    ar.check()
+    ar.inject_error(1)
+    out = ar.reduce(st, torch.zeros_like(part))
+    resid = torch.ones_like(part)
+    ss = torch.zeros(hidden // 16, 32, dtype=torch.float32, device=DEV)
+    out2 = ar.reduce(st, resid, resid=resid, ss_out=ss)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out).all()) and bool(torch.isnan(out2).all()), "error path left plausible values in out"
+    assert ar.error() == 1
+    with pytest.raises(RuntimeError, match="timed out"):
+        ar.check("unit test")
+    ar.inject_error(0)
+    st.copy_(part)
+    out = ar.reduce(st, torch.zeros_like(part))
+    torch.cuda.synchronize()
+    assert torch.equal(out, part) and ar.error() == 0
+    ar.close()
+
+
+def _bench_tp2(extra_env, extra_args=()):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--target", "tiny", "--prefill",
+           "2048", "--budget", "256", "--gamma", "4", "--steps", "4", "--warmup", "1", "--weights", "random",
+           "--no-cpu-baseline", "--roofline-every", "2", *extra_args]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, lines, p.stderr[-2000:]
+
+
+def test_bench_tp_line_reports_allreduce_state_and_fails_loudly_on_a_timeout():
+    """bench.py --gpus 2 (two ranks sharing this box's one GPU; gloo carries the large collectives, the decode-sized ones
+    are the one-shot kernel across the process boundary).  Healthy run: rc 0, the line says which exchange and which
+    graph form ran, allreduce_error 0, and carries a roofline from the eagerly sampled target verifies.  With a timeout
+    injected on every rank after warm-up: rc != 0 and a JSON line with `failed` and the error word — never tokens/s."""
+    rc, lines, err = _bench_tp2({}, ("--allreduce", "oneshot", "--require-graph-form", "whole"))
+    assert rc == 0 and len(lines) == 1, err
+    j = lines[0]
+    assert j["allreduce_error"] == 0 and j["decode_allreduce"].startswith("one-shot") and j["graph_form"] == "whole"
+    assert j["config"]["world_size_observed"] == 2 and j["value"] > 0
+    assert j["roofline"] is not None and j["roofline"]["launches"] >= 1, "no eager target verify was sampled"
+    assert j["config"]["workload"].startswith("custom")
+    rc, lines, err = _bench_tp2({"TRIFORCE_BENCH_INJECT_AR_ERROR": "1"}, ("--allreduce", "oneshot"))
+    assert rc != 0, "a timed-out all-reduce must fail the bench"
+    bad = [ln for ln in lines if ln.get("failed")]
+    assert bad and all(ln["value"] is None and ln["allreduce_error"] == 1 for ln in bad), (lines, err)
+    assert not any(ln.get("value") for ln in lines)

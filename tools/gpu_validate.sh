@@ -1,21 +1,59 @@
 #!/bin/bash
-# One gpurun call that reproduces the round's evidence: GPU tests, smoke, the driver-form bench line, and the
-# rocprofv3 kernel-trace summary of the same command.  Outputs under gpurun_out/validate/.
-#   gpurun --timeout 1500 -- 'bash tools/gpu_validate.sh'
+# One gpurun call that reproduces the round's evidence.  Outputs under gpurun_out/validate/.
+#   gpurun --timeout 1500 -- 'bash tools/gpu_validate.sh'          GPU tests, smoke, driver-form bench, rocprof summary +
+#                                                                   by-stage split, PMC traffic + MFMA utilisation
+#   gpurun --timeout 2400 -- 'bash tools/gpu_validate.sh all'      + the other full-size configs and the acceptance sweep
+#   bash tools/gpu_validate.sh tp N                                 on an N-GPU node: the tensor-parallel path, both
+#                                                                   exchanges A/B, FAILS (rc != 0) on any silent fallback
 O=gpurun_out/validate; mkdir -p $O
-python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest.log; grep "\[parity\]" $O/pytest.log
+R=${GRAFT_REPO_ROOT:-$PWD}
+if [ "$1" = "tp" ]; then
+  N=${2:-8}; rc=0
+  # (1) one-shot exchange REQUIRED (no silent RCCL fallback), whole-forward hipGraphs REQUIRED, world size checked
+  python bench.py --gpus $N --steps 20 --warmup 5 --allreduce oneshot --require-graph-form whole > $O/bench_tp${N}_oneshot.json 2> $O/bench_tp${N}_oneshot.err || rc=1
+  # (2) the same run over RCCL, for the A/B
+  python bench.py --gpus $N --steps 20 --warmup 5 --allreduce rccl > $O/bench_tp${N}_rccl.json 2> $O/bench_tp${N}_rccl.err || rc=1
+  python - "$N" $O/bench_tp${N}_oneshot.json $O/bench_tp${N}_rccl.json <<'PY' || rc=1
+import json, sys
+n, bad = int(sys.argv[1]), []
+for path, want in ((sys.argv[2], "one-shot"), (sys.argv[3], "rccl")):
+    try:
+        j = json.loads([l for l in open(path) if l.startswith("{")][-1])
+    except Exception as e:
+        bad.append(f"{path}: no JSON line ({e})"); continue
+    if j.get("failed"): bad.append(f"{path}: {j['failed']}")
+    if j.get("config", {}).get("world_size_observed") != n: bad.append(f"{path}: RCCL saw world {j.get('config', {}).get('world_size_observed')} != {n}")
+    if not str(j.get("decode_allreduce", "")).startswith(want): bad.append(f"{path}: decode_allreduce = {j.get('decode_allreduce')!r}, wanted {want}")
+    if j.get("allreduce_error"): bad.append(f"{path}: allreduce_error {j['allreduce_error']}")
+    if want == "one-shot" and j.get("graph_form") != "whole": bad.append(f"{path}: graph_form {j.get('graph_form')}")
+    print(path, {k: j.get(k) for k in ("value", "ms_per_step", "graph_form", "decode_allreduce", "allreduce_error", "acceptance_rate")})
+print(json.dumps({"tp_validate_ok": not bad, "problems": bad}))
+sys.exit(1 if bad else 0)
+PY
+  echo "tp validate rc=$rc"; exit $rc
+fi
+rm -f gpurun_out/parity_notes.txt
+python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest.log
+cp gpurun_out/parity_notes.txt $O/parity_notes.txt 2>/dev/null; grep -c "" $O/parity_notes.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 800 $O/bench.json
-R=${GRAFT_REPO_ROOT:-$PWD}; cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --random-steps 0 > $R/$O/bench_prof.json 2> $R/$O/bench_prof.err; echo "rocprof rc=$?"
+# target-verify / retrieval-verify launches of the split-KV kernel separated by duration cluster + priced (tracked copy -> profiles/)
+T=$(ls -S $R/$O/prof/*/*kernel_trace.csv | head -1)
+python $R/tools/attn_by_grid.py $T $R/$O/kernels_by_stage.json "rocprofv3 --kernel-trace of python bench.py --steps 20 --warmup 5 --no-cpu-baseline --random-steps 0 (tools/gpu_validate.sh)" > $R/$O/kernels_by_stage.log 2>&1; echo "by-stage rc=$?"
 # HBM traffic of the roofline kernel (two separate --pmc passes, kernel-trace only) -> the figure bench.py quotes as roofline.traffic
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_fetch -- python $R/tools/pmc_attn.py > $R/$O/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_write -- python $R/tools/pmc_attn.py > $R/$O/pmc_write.log 2>&1; echo "pmc write rc=$?"
+# MFMA-pipe utilisation of the same kernel (own pass: SQ + GRBM counters only)
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $R/$O/pmc_mfma -- python $R/tools/pmc_attn.py > $R/$O/pmc_mfma.log 2>&1; echo "pmc mfma rc=$?"
 cd $R; python tools/pmc_reduce.py $O/pmc_fetch $O/pmc_write $O/pmc_attn_target_verify.json "tools/gpu_validate.sh"
-find $O/prof $O/pmc_fetch $O/pmc_write -name "*kernel_trace.csv" -size +20M -delete
+python tools/pmc_mfma.py $O/pmc_mfma $O/pmc_mfma_attn_target_verify.json "tools/gpu_validate.sh"
+find $O/prof $O/pmc_fetch $O/pmc_write $O/pmc_mfma -name "*kernel_trace.csv" -size +20M -delete
 # the other full-size configs (BASELINE configs[2], and configs[3] at world size 1: offloading tier), only with "all"
 if [ "$1" = "all" ]; then
   python bench.py --target lwm-128K --steps 20 --warmup 5 --no-cpu-baseline --random-steps 0 > $O/bench_lwm.json 2> $O/bench_lwm.err; echo "lwm rc=$?"; tail -c 300 $O/bench_lwm.json
   TRIFORCE_PREFILL_CHUNK=2048 python bench.py --prefill 130048 --budget 12288 --gamma 16 --on-chip 9 --steps 8 --warmup 2 --no-cpu-baseline --random-steps 0 > $O/bench_offload.json 2> $O/bench_offload.err; echo "offload rc=$?"; tail -c 300 $O/bench_offload.json
+  python tools/acceptance_sweep.py $O/acceptance_sweep.json > $O/acceptance_sweep.log 2>&1; echo "sweep rc=$?"; tail -3 $O/acceptance_sweep.log
   python tools/verify_bench.py final > $O/verify_bench.json 2> $O/verify_bench.err; echo "verify_bench rc=$?"; tail -c 400 $O/verify_bench.json
 fi

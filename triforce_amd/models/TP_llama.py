@@ -357,8 +357,10 @@ class DistributedLlama:
         return ops.linear(h, W.lm_head, out_f32=True).unsqueeze(0)
 
     @torch.inference_mode()
-    def inference(self, input_ids, position_ids=None, attention_mask=None, retrieval_cache=None):
-        """Target forward over the full KV cache (TP_llama.py:200-243)."""
+    def inference(self, input_ids, position_ids=None, attention_mask=None, retrieval_cache=None, eager=False):
+        """Target forward over the full KV cache (TP_llama.py:200-243).  ``eager=True`` skips the captured forward (every
+        rank must pass the same value: the eager and the captured forward issue the same exchanges in the same order) —
+        bench_tp.py runs every N-th target verify that way so its attention launches can be bracketed by HIP events."""
         W, kvc = self.weights, self.kv_cache
         q_len = input_ids.shape[1]
         S = kvc.seq_len
@@ -366,7 +368,7 @@ class DistributedLlama:
         if S + q_len > kvc.max_budget:
             raise IndexError(f"KV cache overflow: {S}+{q_len} > {kvc.max_budget}")
         cap = getattr(self, "_target_caps", {}).get(q_len)
-        if cap is not None and position_ids is None and attention_mask is None and retrieval_cache is None:
+        if cap is not None and position_ids is None and attention_mask is None and retrieval_cache is None and not eager:
             return self._inference_captured(cap, input_ids)
         if position_ids is None:
             position_ids = (S + torch.arange(q_len, dtype=torch.long, device=self.device)).unsqueeze(0)

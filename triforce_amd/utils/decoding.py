@@ -173,7 +173,8 @@ def _buffers(graph_engine, gamma, vocab, device, mailbox=False):
 
 
 @torch.inference_mode()
-def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, buffers=None, sync_record=None):
+def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, buffers=None, sync_record=None,
+                health=None):
     """Inner loop: the 68M drafts one token at a time for the retrieval-cache model (decoding.py:163-223).
     Returns (ids [next, t1..t_g2], rows = device (g2, V) view of the retrieval-model prob rows, acceptance)."""
     eng = graph_engine.engine
@@ -207,6 +208,8 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
             if n + 1 < flat.numel():
                 flat[n + 1:n + 3].copy_(_mid_tokens(rec.tensor, n, gamma, flat))
         acc, b, d = rec.read(3)                                               # the one host read of this step
+        if health is not None:                # TP: a timed-out exchange NaN-filled p — stop before its tokens are used
+            health()
         rng.advance(3)
         drafted += 1
         g = len(ids) - 1                                                      # == n: verify_tokens holds exactly ids
@@ -320,7 +323,7 @@ class TriForceRunner:
         next_token = self.next_token
         n0 = self.n
         ids, spec_rows, acc_mid = Middle_Spec(next_token, ge, gamma, False, tokenizer, rng=rng, buffers=bufs,
-                                              sync_record=self.sync_record)
+                                              sync_record=self.sync_record, health=self.health)
         self.acc_rate_middle_list.append(acc_mid)
         generated = ids[1:]
         g2 = len(generated)
@@ -336,7 +339,7 @@ class TriForceRunner:
             probs = ge.verify_probs(verify_tokens, self.temperature, self.top_p, rebuild_retrieval=rebuild, eager=eager)
         else:
             logits = ge.inference(input_ids=verify_tokens, rebuild_retrieval=True) if rebuild \
-                else ge.inference(input_ids=verify_tokens)
+                else (ge.inference(input_ids=verify_tokens, eager=True) if eager else ge.inference(input_ids=verify_tokens))
             probs = norm_logits(logits[0], temperature=self.temperature, top_k=self.top_k, top_p=self.top_p)
         rec = bufs.chain_out
         rec.arm(4)
@@ -467,8 +470,8 @@ class _DistEngine:
         return self.llm.retrieval_verify(input_ids=input_ids, position_ids=position_ids,
                                          temperature=self.llm.temperature, top_p=self.llm.top_p)
 
-    def inference(self, input_ids):
-        return self.llm.inference(input_ids=input_ids)
+    def inference(self, input_ids, eager=False):
+        return self.llm.inference(input_ids=input_ids, eager=eager)
 
     def update_graph_cache(self):
         self.llm.retrieval_cache.update_graph_cache(self.llm.kv_cache)

@@ -142,6 +142,10 @@ class OneShotAllReduce:
         decode step (``check()``) and stop instead of emitting tokens computed from a reduction that never happened."""
         return hip.lib().tf_ar_error(ctypes.c_void_p(self.flags_ptr))
 
+    def inject_error(self, code):
+        """Fault injection (tests, bench.py TRIFORCE_BENCH_INJECT_AR_ERROR): set / clear the sticky error word."""
+        hip.check(hip.lib().tf_ar_inject_error(ctypes.c_void_p(self.flags_ptr), int(code)), "tf_ar_inject_error")
+
     def check(self, where=""):
         e = self.error()
         if e:
