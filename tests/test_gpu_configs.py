@@ -98,6 +98,42 @@ def test_lwm_plain_rope_theta1e7_layer_logits_match_oracle():
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# configs[1] at FULL cache size: one layer's target verify, model forward vs oracle
+# ---------------------------------------------------------------------------------------------------------------
+def test_full_size_cfg2_single_layer_target_verify_matches_oracle():
+    """BASELINE configs[1] shapes for ONE layer through the MODEL forward (not op by op): 8 verify rows appended behind
+    124 928 cached keys (32 heads x 128, YaRN positions 124 928...), fused q|k|v + RoPE + append, split-KV attention over
+    124 936 keys, o_proj, MLP, lm_head — against the oracle's forward over the same cache.  (The 32-layer engine at this
+    size is checked on the device for losslessness in tests/test_gpu_e2e.py; the oracle cannot run 32 layers x 125K keys
+    on a CPU in test time, one layer it can.)"""
+    from triforce_amd.models.cache import FlashSimpleCache
+    from triforce_amd.models.config_yarn import LlamaConfig
+    from triforce_amd.models.modeling_llama import LlamaForCausalLM
+    cfg = specs.llama2_7b_128k_config()
+    cfg["num_hidden_layers"] = 1
+    sd = specs.random_state_dict(cfg, 61)
+    S, rows = 124928, 8
+    ot = M.OracleTarget(cfg, sd)
+    model = LlamaForCausalLM.from_state_dict(LlamaConfig.from_dict(cfg), sd, DEV)
+    okv, pkv = M.FullCache(cfg, S + 16), FlashSimpleCache(model, S + 16)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    pkv.k[0, :, :S].normal_(generator=g)                      # (H, S, D) on the device; the oracle gets the same bits
+    pkv.v[0, :, :S].normal_(generator=g)
+    okv.key_cache[0, :S] = pkv.k[0, :, :S].permute(1, 0, 2).cpu()
+    okv.value_cache[0, :S] = pkv.v[0, :, :S].permute(1, 0, 2).cpu()
+    okv.seq_len = pkv.seq_len = S
+    ids = torch.randint(3, 32000, (1, rows), generator=torch.Generator().manual_seed(10))
+    want = ot.forward(ids, okv, None)
+    got = model(input_ids=ids.to(DEV), kv_cache=pkv, graph_cache=None).logits.cpu()
+    _deviation(f"configs[1] full-size single layer: {rows} rows over {S + rows} keys x 32 heads", got, want)
+    _logit_check("full-size cfg2 layer, target verify", got, want)
+    dk = (pkv.k[0, :, S:S + rows].permute(1, 0, 2).cpu().float() - okv.key_cache[0, S:S + rows].float()).abs()
+    assert float(dk.max()) < 2e-2 and float(dk.mean()) < 2e-4, "appended K rows (RoPE at positions >= 124 928) differ"
+    trail = want.max(-1).values - want.gather(-1, got.argmax(-1, keepdim=True))[..., 0]
+    assert float(trail.max()) < GAP_TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # configs[4]: 13B, one rank of TP = 8
 # ---------------------------------------------------------------------------------------------------------------
 def _one_process_group():

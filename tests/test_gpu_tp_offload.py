@@ -467,7 +467,8 @@ def _bench_tp2(extra_env, extra_args=()):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    # the tiny target has 2 layers: time EVERY eager attention launch (the default samples every 8th of 32 per verify)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TRIFORCE_ATTN_TIMER_EVERY="1", **extra_env)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--target", "tiny", "--prefill",
            "2048", "--budget", "256", "--gamma", "4", "--steps", "4", "--warmup", "1", "--weights", "random",
            "--no-cpu-baseline", "--roofline-every", "2", *extra_args]

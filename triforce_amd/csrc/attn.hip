@@ -49,6 +49,26 @@
 #define TF_ATTN_EAGER_TILES 16 // splits of up to this many 16-key tiles per wave use the unconditional-prefetch loop
 #endif
 
+// Short streams (the retrieval verify: 4 103 keys = 8-9 tiles per wave) are LATENCY-bound in the two-tiles-deep loop: a
+// wave walks its 8 tiles as 4 dependent round trips of ~2 us each.  The deep form (attn_split_deep_kernel, one wave per
+// SIMD = 512 registers) issues the loads of up to TF_ATTN_DEEP_TILES tiles (8 KiB each) before the first MFMA and
+// consumes them in order — same tiles, same order, same arithmetic per tile: bit-identical partials.  Chosen by the host
+// when a wave owns at most 2 * TF_ATTN_DEEP_TILES tiles.  0 disables it.
+#ifndef TF_ATTN_DEEP_TILES
+#define TF_ATTN_DEEP_TILES 0
+#endif
+// Long streams: a RING of N tiles in flight per wave instead of the two-deep ping-pong — every load unconditional (past
+// the end it re-reads the last tile), slot s refilled right after tile s is consumed, so the waitcnt pass keeps
+// vmcnt(8 (N - 1)) in front of every tile.  The workgroup-per-CU split rule leaves one wave per SIMD, i.e. 512
+// registers: room for 4 tiles (32 registers each) even in the two-q-tile form, whose conditional-prefetch loop ran ONE
+// tile deep ("a compiler trap").  Same tiles, same order per wave: bit-identical partials.  0 = off.
+#ifndef TF_ATTN_RING_Q1
+#define TF_ATTN_RING_Q1 0
+#endif
+#ifndef TF_ATTN_RING_Q2
+#define TF_ATTN_RING_Q2 0
+#endif
+
 // agent-scope relaxed accesses: global_store / global_load ... sc1 (write-through / L2-coherent across XCDs)
 __device__ __forceinline__ void st_agent(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -76,12 +96,26 @@ __device__ __forceinline__ float group_max4(float v) {
     return vmax_raw(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
+// P = exp(S - m) goes to the PV MFMA as fp16.  Rounded ONCE (flash-attn's choice, TF_ATTN_P_SPLIT 0) that costs the
+// attention output ~0.6 fp16 ulp (37 % of the outputs of a 4 103-key retrieval verify differ from the exactly
+// accumulated result, and the layer's logits end up 1.4x further from it than the CPU oracle's: tests/test_gpu_configs.py,
+// fp64 truth).  The split forms feed P as hi + lo — two fp16 operands, 8 more MFMAs per tile on a matrix core that is
+// ~9 % busy: 1 = lo as a (possibly subnormal) fp16 into the same accumulator; 2 = lo scaled by 2^11 into its own
+// accumulator (no subnormal operands), folded in when the wave's partial is written.
+#ifndef TF_ATTN_P_SPLIT
+#define TF_ATTN_P_SPLIT 0
+#endif
+#define ATTN_P_LO_SCALE 2048.0f
+
 template <int D, int QT>
 struct AttnState {
     static constexpr int NC = D / 32;
     static constexpr int NT = D / 16;
     half8 qf[QT][NC];
     f32x4 acc[QT][NT];
+#if TF_ATTN_P_SPLIT == 2
+    f32x4 acc_lo[QT][NT];
+#endif
     float m[QT];
     float l[QT];
 };
@@ -122,6 +156,9 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
         va[t] = half4{(h16)r[0], (h16)r[1], (h16)r[2], (h16)r[3]};
     }
     half4 pb[QT];
+#if TF_ATTN_P_SPLIT > 0
+    half4 pl[QT];
+#endif
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -159,6 +196,11 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
             const float p = ok[r] ? __expf(x[r] - mnew) : 0.f;
             psum += p;
             pb[qt][r] = (h16)p;
+#if TF_ATTN_P_SPLIT == 1
+            pl[qt][r] = (h16)(p - (float)pb[qt][r]);
+#elif TF_ATTN_P_SPLIT == 2
+            pl[qt][r] = (h16)((p - (float)pb[qt][r]) * ATTN_P_LO_SCALE);
+#endif
         }
         // The running maximum settles after the first tiles of a stream; rescaling the 32 accumulator registers
         // (alpha == 1 exactly when no query column of the wave raised its maximum) is skipped wave-uniformly then.
@@ -169,6 +211,10 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
             for (int t = 0; t < NT; ++t) {
                 st.acc[qt][t][0] *= alpha; st.acc[qt][t][1] *= alpha;
                 st.acc[qt][t][2] *= alpha; st.acc[qt][t][3] *= alpha;
+#if TF_ATTN_P_SPLIT == 2
+                st.acc_lo[qt][t][0] *= alpha; st.acc_lo[qt][t][1] *= alpha;
+                st.acc_lo[qt][t][2] *= alpha; st.acc_lo[qt][t][3] *= alpha;
+#endif
             }
             st.m[qt] = mnew;
         }
@@ -178,13 +224,33 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
+        for (int qt = 0; qt < QT; ++qt) {
             st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(va[t], pb[qt], st.acc[qt][t], 0, 0, 0);
+#if TF_ATTN_P_SPLIT == 1
+            st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(va[t], pl[qt], st.acc[qt][t], 0, 0, 0);
+#elif TF_ATTN_P_SPLIT == 2
+            st.acc_lo[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(va[t], pl[qt], st.acc_lo[qt][t], 0, 0, 0);
+#endif
+        }
+}
+
+// fold the scaled low-order accumulator into the main one (TF_ATTN_P_SPLIT == 2): once per wave, before its partial
+// leaves the registers
+template <int D, int QT>
+__device__ __forceinline__ void attn_fold_lo(AttnState<D, QT>& st) {
+#if TF_ATTN_P_SPLIT == 2
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int t = 0; t < D / 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st.acc[qt][t][r] += st.acc_lo[qt][t][r] * (1.0f / ATTN_P_LO_SCALE);
+#endif
 }
 
 
 // ws layout: o[H][nsplit][QR][D] | m[H][nsplit][QR] | l[H][nsplit][QR],  QR = QT*16
-template <int D, int QT>
+template <int D, int QT, int DEEP = 0>
 __device__ __forceinline__ void attn_split_body(
     const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
     int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
@@ -212,7 +278,12 @@ __device__ __forceinline__ void attn_split_body(
             st.qf[qt][c] = (row < sq) ? load_half8(q + ((int64_t)row * H + h) * D + 32 * c + 8 * g) : z;
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) st.acc[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NT; ++t) {
+            st.acc[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if TF_ATTN_P_SPLIT == 2
+            st.acc_lo[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+        }
         st.m[qt] = NEG_BIG;
         st.l[qt] = 0.f;
     }
@@ -240,7 +311,46 @@ __device__ __forceinline__ void attn_split_body(
     // streams, already bandwidth-bound with 8 MB in flight chip-wide, LOSE 0.7 % (32 heads) to 4 % (16 heads x 17 rows)
     // with twice as much in flight — so the form is chosen by the length of the wave's stream.
     int t = t_begin + wave;
-    if (t < t_end) {
+    if constexpr (DEEP > 0) {
+        // rounds of N tiles: all N loads issued (tiles past the end re-read the last one: no conditional load, so the
+        // waitcnt pass keeps vmcnt(8 (N - 1 - i)) in front of tile i), then consumed in order
+#define ATTN_DEEP_ROUND(N)                                                                                   \
+    do {                                                                                                       \
+        half8 kd[N][NC], vd[N][NC];                                                                            \
+        const int tl = t_end - 1;                                                                              \
+        _Pragma("unroll") for (int i = 0; i < (N); ++i)                                                        \
+            load_kv_tile<D>(kbase, vbase, stride_t, min(t + 4 * i, tl), sk, li, g, kd[i], vd[i]);              \
+        _Pragma("unroll") for (int i = 0; i < (N); ++i) {                                                      \
+            const int ti = t + 4 * i;                                                                          \
+            if (ti < t_end) ATTN_TILE_AUTO(kd[i], vd[i], ti);                                                  \
+        }                                                                                                      \
+        t += 4 * (N);                                                                                          \
+    } while (0)
+        while (t < t_end) {
+            const int left = (t_end - t + 3) >> 2;               // tiles this wave still owns (wave-uniform)
+            if (left > DEEP / 2) ATTN_DEEP_ROUND(DEEP);
+            else if (left > 1) ATTN_DEEP_ROUND(DEEP / 2);
+            else ATTN_DEEP_ROUND(1);
+        }
+#undef ATTN_DEEP_ROUND
+    } else if constexpr ((QT == 1 ? TF_ATTN_RING_Q1 : TF_ATTN_RING_Q2) > 0) {
+        constexpr int RING = QT == 1 ? TF_ATTN_RING_Q1 : TF_ATTN_RING_Q2;
+        if (t < t_end) {
+            half8 kr[RING][NC], vr[RING][NC];
+            const int tl = t_end - 1;
+#pragma unroll
+            for (int s = 0; s < RING; ++s) load_kv_tile<D>(kbase, vbase, stride_t, min(t + 4 * s, tl), sk, li, g, kr[s], vr[s]);
+            while (t < t_end) {
+#pragma unroll
+                for (int s = 0; s < RING; ++s) {
+                    const int ti = t + 4 * s;
+                    if (ti < t_end) ATTN_TILE_AUTO(kr[s], vr[s], ti);
+                    load_kv_tile<D>(kbase, vbase, stride_t, min(ti + 4 * RING, tl), sk, li, g, kr[s], vr[s]);
+                }
+                t += 4 * RING;
+            }
+        }
+    } else if (t < t_end) {
         half8 ka[NC], va_[NC], kb[NC], vb[NC];
         load_kv_tile<D>(kbase, vbase, stride_t, t, sk, li, g, ka, va_);
         // (one-q-tile form only: with both loops the two-q-tile form no longer fits its 2-waves-per-SIMD register budget)
@@ -270,6 +380,7 @@ __device__ __forceinline__ void attn_split_body(
     }
 
 #undef ATTN_TILE_AUTO
+    attn_fold_lo<D, QT>(st);
     // ---- merge the 4 waves of this split through LDS, one q-tile at a time ----
     __shared__ float sm_o[4][16][D + 1];
     __shared__ float sm_m[4][16];
@@ -383,6 +494,18 @@ __global__ ATTN_SPLIT_BOUNDS void attn_split_kernel(
     float* __restrict__ ws, unsigned* __restrict__ tickets, h16* __restrict__ out) {
     attn_split_body<D, QT>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws, tickets, out);
 }
+
+// The deep-prefetch form for short streams (one q-tile; see TF_ATTN_DEEP_TILES): one wave per SIMD, 512 registers.
+#if TF_ATTN_DEEP_TILES > 0
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_split_deep_kernel(
+    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
+    int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
+    float* __restrict__ ws, unsigned* __restrict__ tickets, h16* __restrict__ out) {
+    attn_split_body<D, 1, TF_ATTN_DEEP_TILES>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws, tickets,
+                                              out);
+}
+#endif
 
 // The two-q-tile form compiled for TF_ATTN_QT2_OCC waves per SIMD (see the note at the top of the file).
 #if TF_ATTN_QT2_OCC > 0
@@ -1268,12 +1391,25 @@ static int launch_attn(const void* q, const void* k, const void* v, void* out, i
                        unsigned* tickets, hipStream_t st) {
     dim3 grid(nsplit, H), block(256);
     if (tickets && nsplit > FUSED_MERGE_MAX_SPLITS) tickets = nullptr;    // many splits: the parallel merge kernel wins
+    bool launched = false;
+#if TF_ATTN_DEEP_TILES > 0
+    if constexpr (QT == 1) {
+        // tiles one wave owns at the HOST key count (a device-side count can only be smaller)
+        const int ntiles = (sk + 15) / 16, tps = (ntiles + nsplit - 1) / nsplit, per_wave = (tps + 3) / 4;
+        if (per_wave <= 2 * TF_ATTN_DEEP_TILES && (int64_t)nsplit * H <= 320) {      // short streams, <= ~1 workgroup per CU
+            hipLaunchKernelGGL((attn_split_deep_kernel<D>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
+                               stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, (h16*)out);
+            launched = true;
+        }
+    }
+#endif
 #if TF_ATTN_QT2_OCC > 0
     if constexpr (QT == 2)
         hipLaunchKernelGGL((attn_split_q2_kernel<D>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
                            stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, (h16*)out);
     else
 #endif
+    if (!launched)
         hipLaunchKernelGGL((attn_split_kernel<D, QT>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
                            stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, (h16*)out);
     TF_LAUNCH_CHECK();

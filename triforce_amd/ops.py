@@ -229,7 +229,7 @@ def _workspace(device, floats):
 # timed: an event record is a queue packet of its own (~3 us of gap on each side of the kernel), so bracketing all
 # 32 launches of a target verify would cost the step ~0.4 ms of the very time being measured.
 ATTN_TIMER = None
-ATTN_TIMER_EVERY = 8
+ATTN_TIMER_EVERY = max(1, int(_os.environ.get("TRIFORCE_ATTN_TIMER_EVERY", "8")))
 _attn_calls = 0
 
 
