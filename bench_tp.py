@@ -183,7 +183,9 @@ def run_tp(args, rank, world, local):
     # every --roofline-every-th target verify runs eagerly on EVERY rank (same exchanges, same order as the captured
     # forward) so that rank 0 can bracket attention launches with HIP events inside the timed region, like bench.py
     graphed_target = bool(getattr(llm, "_target_caps", None))
-    run.eager_every = args.roofline_every if (graphed_target and args.roofline_every > 0) else 0
+    # (world > 1: every 2N-th step — a rank's eager forward is ~10 short kernels + 2 exchanges per layer, closer to the
+    # host's launch rate than the one-GPU forward, so it is sampled half as often)
+    run.eager_every = args.roofline_every * (2 if world > 1 else 1) if (graphed_target and args.roofline_every > 0) else 0
     in0 = run.inner_iters
     dist.barrier()
     torch.cuda.synchronize()

@@ -240,7 +240,7 @@ def test_attn_decode_default_split_rule_at_13b_head_counts(sq, sk, H):
     d = (got.float().cpu() - want.float()).abs()
     Hh.note(f"attention {sq} rows x {sk} keys x {H} heads, default nsplit {nsplit}: max |d| {float(d.max()):.2e}, "
             f"mean {float(d.mean()):.2e}")
-    torch.testing.assert_close(got.float().cpu(), want.float(), atol=2e-3, rtol=2e-3)
+    torch.testing.assert_close(got.float().cpu(), want.float(), atol=2e-5, rtol=1.5e-3)      # tests/test_gpu_ops.py DECODE_*
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -292,7 +292,12 @@ def test_device_is_as_close_to_fp64_truth_as_the_cpu_oracle():
     spacings at the largest logit, arguing that the CPU path's own fp32 accumulation order is that far from exact.
     Here that argument is measured at 7B widths: device, CPU oracle and an fp64-accumulating restatement (same fp16
     rounding points) of one layer over a 4 103-slot retrieval cache.  The device must be no further from the fp64 result
-    than the CPU oracle is (max within one fp16 spacing more, mean within 15 %)."""
+    than the CPU oracle is (max within one fp16 spacing more, mean within 15 %).
+    Measured (profiles/r03*_parity_notes.txt): with P rounded once to fp16 before the PV MFMA (round 2) the device's mean
+    distance to the fp64 result was 7.9e-4 against the oracle's 5.7e-4 — 37 % of the attention outputs were one ulp
+    off; with P fed as hi + lo (csrc/attn.hip TF_ATTN_P_SPLIT) it is 5.5e-4 / max one fp16 spacing: level with the oracle.
+    Both differ from the exactly accumulated logits at ~2/3 of the positions — a one-ulp flip in a hidden state moves
+    every logit of the row by a fraction of a spacing — which is what the resolution-aware bar of _logit_check rests on."""
     from triforce_amd.models.cache import FlashSimpleCache, RetrievalCache
     from triforce_amd.models.config_yarn import LlamaConfig
     from triforce_amd.models.modeling_llama import LlamaForCausalLM

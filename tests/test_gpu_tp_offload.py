@@ -471,7 +471,7 @@ def _bench_tp2(extra_env, extra_args=()):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TRIFORCE_ATTN_TIMER_EVERY="1", **extra_env)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--target", "tiny", "--prefill",
            "2048", "--budget", "256", "--gamma", "4", "--steps", "4", "--warmup", "1", "--weights", "random",
-           "--no-cpu-baseline", "--roofline-every", "2", *extra_args]
+           "--no-cpu-baseline", "--roofline-every", "1", *extra_args]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
     return p.returncode, lines, p.stderr[-2000:]

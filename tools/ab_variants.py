@@ -19,16 +19,12 @@ from triforce_amd.build import LIB_PATH, build_variant  # noqa: E402
 
 VARIANTS = {"q2occ1": ["TF_ATTN_QT2_OCC=0"],
             "nofunnel": ["TF_TREE_MASK_FUNNEL=0"],
-            # round 3: split-KV attention load pipelines (tools/attn_variants_ab.py)
-            "nodeep": ["TF_ATTN_DEEP_TILES=0", "TF_ATTN_RING_Q1=0", "TF_ATTN_RING_Q2=0", "TF_ATTN_QT2_OCC=2"],
-            "deep8": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_RING_Q1=0", "TF_ATTN_RING_Q2=0", "TF_ATTN_QT2_OCC=2"],
-            "ring4q2": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_RING_Q1=0", "TF_ATTN_RING_Q2=4", "TF_ATTN_QT2_OCC=1"],
-            "ring4": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_RING_Q1=4", "TF_ATTN_RING_Q2=4", "TF_ATTN_QT2_OCC=1"],
-            "ps1": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_RING_Q1=0", "TF_ATTN_RING_Q2=0", "TF_ATTN_QT2_OCC=2", "TF_ATTN_P_SPLIT=1"],
-            "ps2": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_RING_Q1=0", "TF_ATTN_RING_Q2=0", "TF_ATTN_QT2_OCC=1", "TF_ATTN_P_SPLIT=2"],
-            "ring4ps1": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_RING_Q1=4", "TF_ATTN_RING_Q2=4", "TF_ATTN_QT2_OCC=1", "TF_ATTN_P_SPLIT=1"],
-            "ring4ps2": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_RING_Q1=4", "TF_ATTN_RING_Q2=4", "TF_ATTN_QT2_OCC=1", "TF_ATTN_P_SPLIT=2"],
-            "ring3": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_RING_Q1=3", "TF_ATTN_RING_Q2=3", "TF_ATTN_QT2_OCC=1"]}
+            # round 3: split-KV attention load pipelines and the precision of P (tools/attn_variants_ab.py;
+            # profiles/r03_attn_pipeline_ab.jsonl).  "ps0" = round 2's kernel: P rounded once to fp16.
+            "ps0": ["TF_ATTN_P_SPLIT=0"],
+            "deep8": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_P_SPLIT=0"],
+            "ring4": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_RING_Q1=4", "TF_ATTN_RING_Q2=4", "TF_ATTN_QT2_OCC=1", "TF_ATTN_P_SPLIT=0"],
+            "ring4ps1": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_RING_Q1=4", "TF_ATTN_RING_Q2=4", "TF_ATTN_QT2_OCC=1", "TF_ATTN_P_SPLIT=1"]}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(VARIANTS)

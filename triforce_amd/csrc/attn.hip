@@ -49,19 +49,20 @@
 #define TF_ATTN_EAGER_TILES 16 // splits of up to this many 16-key tiles per wave use the unconditional-prefetch loop
 #endif
 
-// Short streams (the retrieval verify: 4 103 keys = 8-9 tiles per wave) are LATENCY-bound in the two-tiles-deep loop: a
-// wave walks its 8 tiles as 4 dependent round trips of ~2 us each.  The deep form (attn_split_deep_kernel, one wave per
-// SIMD = 512 registers) issues the loads of up to TF_ATTN_DEEP_TILES tiles (8 KiB each) before the first MFMA and
-// consumes them in order — same tiles, same order, same arithmetic per tile: bit-identical partials.  Chosen by the host
-// when a wave owns at most 2 * TF_ATTN_DEEP_TILES tiles.  0 disables it.
+// Two deeper load pipelines, MEASURED AND REJECTED in round 3 (profiles/r03_attn_pipeline_ab.jsonl; cold-cache hipGraph
+// chains, tools/attn_variants_ab.py) — both compile-time off, kept buildable (tools/ab_variants.py "deep8" / "ring4"):
+//   TF_ATTN_DEEP_TILES = N   short streams (a wave owns <= 2 N tiles): attn_split_deep_kernel issues the loads of N
+//       tiles (8 KiB each; one wave per SIMD = 512 registers) before the first MFMA and consumes them in order.  The
+//       hypothesis — the 4 103-key retrieval verify is latency-bound in the two-deep loop, 4 dependent round trips per
+//       wave — is wrong: N = 8 takes it from 20.8 to 25.4 us per launch, the draft-sized stream from 6.5 to 7.5.
+//   TF_ATTN_RING_Q1 / _Q2 = N   long streams: a ring of N tiles in flight per wave, every load unconditional (so the
+//       waitcnt pass keeps vmcnt(8 (N - 1)) in front of each tile — the two-q-tile form's conditional prefetch runs one
+//       tile deep).  N = 4: 32 heads x 125K keys 346.9 -> 347.6 us, 16 heads x 17 rows x 130K keys 195.2 -> 204.3 us,
+//       32 heads x 18 rows 370.0 -> 376.2 us.  More bytes in flight than the shipped loops keep buys nothing here.
+// Both forms walk the same tiles in the same order per wave: bit-identical partials.
 #ifndef TF_ATTN_DEEP_TILES
 #define TF_ATTN_DEEP_TILES 0
 #endif
-// Long streams: a RING of N tiles in flight per wave instead of the two-deep ping-pong — every load unconditional (past
-// the end it re-reads the last tile), slot s refilled right after tile s is consumed, so the waitcnt pass keeps
-// vmcnt(8 (N - 1)) in front of every tile.  The workgroup-per-CU split rule leaves one wave per SIMD, i.e. 512
-// registers: room for 4 tiles (32 registers each) even in the two-q-tile form, whose conditional-prefetch loop ran ONE
-// tile deep ("a compiler trap").  Same tiles, same order per wave: bit-identical partials.  0 = off.
 #ifndef TF_ATTN_RING_Q1
 #define TF_ATTN_RING_Q1 0
 #endif
@@ -96,16 +97,16 @@ __device__ __forceinline__ float group_max4(float v) {
     return vmax_raw(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
-// P = exp(S - m) goes to the PV MFMA as fp16.  Rounded ONCE (flash-attn's choice, TF_ATTN_P_SPLIT 0) that costs the
-// attention output ~0.6 fp16 ulp (37 % of the outputs of a 4 103-key retrieval verify differ from the exactly
-// accumulated result, and the layer's logits end up 1.4x further from it than the CPU oracle's: tests/test_gpu_configs.py,
-// fp64 truth).  The split forms feed P as hi + lo — two fp16 operands, 8 more MFMAs per tile on a matrix core that is
-// ~9 % busy: 1 = lo as a (possibly subnormal) fp16 into the same accumulator; 2 = lo scaled by 2^11 into its own
-// accumulator (no subnormal operands), folded in when the wave's partial is written.
+// P = exp(S - m) goes to the PV MFMA as fp16.  Rounded ONCE (flash-attn's choice; TF_ATTN_P_SPLIT 0) that costs the
+// attention output ~1 fp16 ulp on average: 36 % of the outputs of a 7 x 4 103-key retrieval verify differ from the
+// exactly accumulated result, and a 7B-width layer's logits end up 1.4x further from it than the CPU oracle's (fp32 P)
+// are (tests/test_gpu_configs.py, fp64 truth; profiles/r03_attn_pipeline_ab.jsonl).  With TF_ATTN_P_SPLIT 1 (default) P
+// is fed as hi + lo — lo = fp16(p - hi), a possibly subnormal fp16 the matrix core takes at full precision — into the
+// same accumulator: 8 more MFMAs per tile and q-tile on a matrix core that is ~9 % busy.  0.16 % of the outputs then
+// differ from exact (mean error 0.25 ulp = the final rounding alone) for +0.9 % on the 125K-key stream.
 #ifndef TF_ATTN_P_SPLIT
-#define TF_ATTN_P_SPLIT 0
+#define TF_ATTN_P_SPLIT 1
 #endif
-#define ATTN_P_LO_SCALE 2048.0f
 
 template <int D, int QT>
 struct AttnState {
@@ -113,9 +114,6 @@ struct AttnState {
     static constexpr int NT = D / 16;
     half8 qf[QT][NC];
     f32x4 acc[QT][NT];
-#if TF_ATTN_P_SPLIT == 2
-    f32x4 acc_lo[QT][NT];
-#endif
     float m[QT];
     float l[QT];
 };
@@ -196,10 +194,8 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
             const float p = ok[r] ? __expf(x[r] - mnew) : 0.f;
             psum += p;
             pb[qt][r] = (h16)p;
-#if TF_ATTN_P_SPLIT == 1
+#if TF_ATTN_P_SPLIT > 0
             pl[qt][r] = (h16)(p - (float)pb[qt][r]);
-#elif TF_ATTN_P_SPLIT == 2
-            pl[qt][r] = (h16)((p - (float)pb[qt][r]) * ATTN_P_LO_SCALE);
 #endif
         }
         // The running maximum settles after the first tiles of a stream; rescaling the 32 accumulator registers
@@ -211,10 +207,6 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
             for (int t = 0; t < NT; ++t) {
                 st.acc[qt][t][0] *= alpha; st.acc[qt][t][1] *= alpha;
                 st.acc[qt][t][2] *= alpha; st.acc[qt][t][3] *= alpha;
-#if TF_ATTN_P_SPLIT == 2
-                st.acc_lo[qt][t][0] *= alpha; st.acc_lo[qt][t][1] *= alpha;
-                st.acc_lo[qt][t][2] *= alpha; st.acc_lo[qt][t][3] *= alpha;
-#endif
             }
             st.m[qt] = mnew;
         }
@@ -226,26 +218,10 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(va[t], pb[qt], st.acc[qt][t], 0, 0, 0);
-#if TF_ATTN_P_SPLIT == 1
+#if TF_ATTN_P_SPLIT > 0
             st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(va[t], pl[qt], st.acc[qt][t], 0, 0, 0);
-#elif TF_ATTN_P_SPLIT == 2
-            st.acc_lo[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(va[t], pl[qt], st.acc_lo[qt][t], 0, 0, 0);
 #endif
         }
-}
-
-// fold the scaled low-order accumulator into the main one (TF_ATTN_P_SPLIT == 2): once per wave, before its partial
-// leaves the registers
-template <int D, int QT>
-__device__ __forceinline__ void attn_fold_lo(AttnState<D, QT>& st) {
-#if TF_ATTN_P_SPLIT == 2
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-        for (int t = 0; t < D / 16; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) st.acc[qt][t][r] += st.acc_lo[qt][t][r] * (1.0f / ATTN_P_LO_SCALE);
-#endif
 }
 
 
@@ -278,12 +254,7 @@ __device__ __forceinline__ void attn_split_body(
             st.qf[qt][c] = (row < sq) ? load_half8(q + ((int64_t)row * H + h) * D + 32 * c + 8 * g) : z;
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            st.acc[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if TF_ATTN_P_SPLIT == 2
-            st.acc_lo[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
-        }
+        for (int t = 0; t < NT; ++t) st.acc[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         st.m[qt] = NEG_BIG;
         st.l[qt] = 0.f;
     }
@@ -380,7 +351,6 @@ __device__ __forceinline__ void attn_split_body(
     }
 
 #undef ATTN_TILE_AUTO
-    attn_fold_lo<D, QT>(st);
     // ---- merge the 4 waves of this split through LDS, one q-tile at a time ----
     __shared__ float sm_o[4][16][D + 1];
     __shared__ float sm_m[4][16];
