@@ -453,3 +453,43 @@ def test_aligned_weights_set_the_acceptance_on_device(spec_str, lo_mid, hi_mid, 
     # (no acceptance claim here: at this toy size N(0, 0.02) weights give both models near-uniform distributions over
     # the 4096 tokens, which overlap; the 7B / 32000-token collapse to ~0.01 is bench.py's ``random_weights`` line)
     assert target.weights.aligned is None and run2.n >= 12 and all(0 <= t < V for t in run2.emitted)
+
+
+def test_static_verify_rows_equal_per_step_copies_and_lifetime_is_guarded():
+    """The decode loop hands the retrieval-verify graph's STATIC output to the outer accept test instead of copying a
+    probability row out per inner step (row i of the last replay is bit-identical to the row an earlier replay produced
+    when position i was decided).  Checked here: Middle_Spec with static rows == Middle_Spec with per-step copies, bit for
+    bit, on the same uniforms (stochastic settings, several drafted positions); and the lifetime guard trips when the
+    verify graph replays before the rows are consumed."""
+    from triforce_amd.utils.decoding import Middle_Spec, TriForceRunner
+    from triforce_amd.utils.sampling import UniformSource
+    g = Hh.load_golden("small_gamma6")
+    ge = Hh.build_product(g, DEV, temperature=0.8, top_p=0.95, graphs=True)
+    assert ge.static_outputs and ge.verify_generation() is not None
+    vals = Hh.fixed_uniforms(seed=123)
+    run = TriForceRunner(Hh.FakeTokenizer(), ge, g["gamma"], top_k=-1, top_p=0.95, temperature=0.8,
+                         rng=UniformSource(DEV, values=vals))
+    run.prefill(Hh.prompt_of(g).to(DEV))
+    tok = run.next_token
+    out = {}
+    for static in (True, False, True):
+        ge.static_outputs = static
+        rng = UniformSource(DEV, values=vals)
+        rng.advance(7)
+        ids, rows, acc = Middle_Spec(tok, ge, g["gamma"], False, Hh.FakeTokenizer(), rng=rng)
+        out.setdefault(static, []).append((list(ids), rows.clone(), acc))
+    ge.static_outputs = True
+    (ids_s, rows_s, acc_s), (ids_s2, rows_s2, _) = out[True]
+    ids_c, rows_c, acc_c = out[False][0]
+    assert ids_s == ids_c == ids_s2 and acc_s == acc_c
+    assert torch.equal(rows_s, rows_c), "static retrieval-verify rows differ from the per-step copies"
+    assert torch.equal(rows_s, rows_s2), "re-running the same inner loop is not bitwise deterministic"
+    Hh.note(f"static verify rows == per-step copies over {len(ids_s) - 1} drafted positions (acceptance {acc_s:.2f})")
+    # lifetime guard: a stray replay of the verify graph between Middle_Spec and the accept test must be caught
+    run.step()                                             # a normal step passes the guard
+    bufs = run.bufs
+    gen0 = ge.verify_generation()
+    Middle_Spec(run.next_token, ge, g["gamma"], False, Hh.FakeTokenizer(), rng=run.rng, buffers=bufs)
+    assert bufs.rows_generation == ge.verify_generation() > gen0
+    ge.graph_verify(bufs.verify_tokens, bufs.positions, clone=False)           # the stray replay
+    assert ge.verify_generation() != bufs.rows_generation   # ... is what TriForceRunner.step's assert compares

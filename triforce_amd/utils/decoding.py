@@ -138,6 +138,7 @@ class _SpecBuffers:
             self.verify_tokens = torch.full((1, gamma + 1), PAD_TOKEN, dtype=torch.long, device=device)
             self.positions = torch.zeros((1, gamma + 1), dtype=torch.long, device=device)
         self.spec_rows = torch.empty(gamma + 2, vocab, dtype=torch.float32, device=device)
+        self.rows_generation = None                # lifetime token of static (un-copied) retrieval-verify rows
         mailbox = bool(mailbox) and _mailbox_supported(device)
         self.mid_out = _Record(device, 4, mailbox)
         self.chain_out = _Record(device, 4, mailbox)
@@ -232,8 +233,12 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
     if noclone:
         # Static verify output: row i of the LAST replay is the retrieval model's distribution after tokens 0..i —
         # the very row an earlier replay produced when position i was decided (same graph, same tokens <= i, same
-        # cache; the kernels are deterministic), so the rows need not be copied out step by step.
+        # cache; the kernels are deterministic), so the rows need not be copied out step by step.  The rows stay valid
+        # only until the verify graph replays again: the caller checks ``rows_generation`` before consuming them.
+        gen = getattr(graph_engine, "verify_generation", None)
+        buffers.rows_generation = gen() if gen is not None else None
         return ids, p[:len(ids) - 1], accepted / drafted
+    buffers.rows_generation = None
     return ids, buffers.spec_rows[:len(ids) - 1], accepted / drafted
 
 
@@ -341,6 +346,10 @@ class TriForceRunner:
             logits = ge.inference(input_ids=verify_tokens, rebuild_retrieval=True) if rebuild \
                 else (ge.inference(input_ids=verify_tokens, eager=True) if eager else ge.inference(input_ids=verify_tokens))
             probs = norm_logits(logits[0], temperature=self.temperature, top_k=self.top_k, top_p=self.top_p)
+        if getattr(bufs, "rows_generation", None) is not None:
+            # spec_rows is a view of the retrieval-verify graph's static output: nothing may have replayed that graph
+            # between Middle_Spec's return and this read (the target verify above is a different graph)
+            assert ge.verify_generation() == bufs.rows_generation, "retrieval-verify graph replayed before its rows were consumed"
         rec = bufs.chain_out
         rec.arm(4)
         ops.accept_chain(probs, spec_rows, verify_tokens.view(-1)[1:], rng.take(g2 + 1), g2, self.inclusive_accept,

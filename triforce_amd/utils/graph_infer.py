@@ -143,15 +143,18 @@ class _GraphedCall:
 
     def __init__(self, fn, static_inputs, mempool, n_warmups):
         self.inputs = static_inputs
-        self.graph, self.output = _capture(fn, static_inputs, mempool, n_warmups)
+        self.generation = 0                        # replays so far: a static output handed out at generation g is valid
+        self.graph, self.output = _capture(fn, static_inputs, mempool, n_warmups)   # only while generation == g
 
     def __call__(self, *live, clone=True):
         for buf, value in zip(self.inputs, live):
             if not (value.data_ptr() == buf.data_ptr() and value.shape == buf.shape and value.stride() == buf.stride()):
                 buf.copy_(value)                   # the caller may also write the static input buffer directly
         self.graph.replay()
+        self.generation += 1
         # clone=False hands out the static output buffer itself: valid until THIS graph is replayed again (the decode
-        # loops consume a draft / verify result before they ask for the next one)
+        # loops consume a draft / verify result before they ask for the next one; TriForceRunner.step asserts it through
+        # ``generation``)
         return self.output.clone() if clone else self.output
 
 
@@ -322,6 +325,12 @@ class GraphInferenceEngine:
     def graph_verify(self, input_ids: torch.LongTensor, position_ids: torch.LongTensor, clone=True):
         fn = self.callable_model_verify
         return fn(input_ids, position_ids, clone=clone) if isinstance(fn, _GraphedCall) else fn(input_ids, position_ids)
+
+    def verify_generation(self):
+        """Replay count of the retrieval-verify graph (None when it is not a captured graph): the lifetime token of the
+        static probability rows ``graph_verify(..., clone=False)`` hands out."""
+        fn = self.callable_model_verify
+        return fn.generation if isinstance(fn, _GraphedCall) else None
 
     def init_graph_cache(self):
         self.engine.graph_cache.init_graph_cache(kv_cache=self.engine.kv_cache)
