@@ -834,6 +834,105 @@ __device__ __forceinline__ void lds_softmax_pv(AttnState<D, QT>& st, const f32x4
     }
 }
 
+// ---- the fully visible slab, software-pipelined (TF_BLOCK_PIPE) -----------------------------------------------------
+// A 64-key slab all of whose keys every row of the wave may see (all slabs of a long prefix but the last one or two) is
+// walked as  QK(0) QK(1) | softmax(0) | PV(0) | softmax(1) | PV(1)  instead of  QK softmax PV  twice: the QK^T MFMAs of
+// sub-step 1 and the softmax VALU work of sub-step 0 are independent and sit in one basic block, as do the PV MFMAs of
+// sub-step 0 and the softmax of sub-step 1 — the scheduler can overlap matrix-core and VALU work of ONE wave, which the
+// strictly alternating form cannot (the body is VALU-issue-bound: ~170 VALU instructions per 32 MFMAs).
+#ifndef TF_BLOCK_PIPE
+#define TF_BLOCK_PIPE 0
+#endif
+template <int D, int QT>
+__device__ __forceinline__ void lds_softmax_clear(AttnState<D, QT>& st, const f32x4 (&sa)[QT], const f32x4 (&sb)[QT],
+                                                  float scale_log2, half8 (&pb)[QT]) {
+    constexpr int NT = D / 16;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float x[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = (r < 4 ? sa[qt][r] : sb[qt][r - 4]);
+        float tmax = vmax3_raw(vmax3_raw(x[0], x[1], x[2]), vmax3_raw(x[3], x[4], x[5]), vmax_raw(x[6], x[7]));
+        tmax = group_max4(tmax);
+        const float mnew = fmaxf(st.m[qt], tmax * scale_log2);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(x[r], scale_log2, -mnew));
+            psum += p;
+            pb[qt][r] = (h16)p;
+        }
+        if (__builtin_amdgcn_ballot_w64(mnew != st.m[qt])) {
+            const float alpha = __builtin_amdgcn_exp2f(st.m[qt] - mnew);
+            st.l[qt] *= alpha;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                st.acc[qt][t][0] *= alpha; st.acc[qt][t][1] *= alpha;
+                st.acc[qt][t][2] *= alpha; st.acc[qt][t][3] *= alpha;
+            }
+            st.m[qt] = mnew;
+        }
+        st.l[qt] += psum;
+    }
+}
+// TF_BLOCK_PIPE == 2: ONE running-max update (and at most one accumulator rescale) per 64-key slab: both sub-steps'
+// probabilities are taken against max(m, slab max) — the same softmax, half the max / ballot / rescale bookkeeping, and
+// the matrix core sees QK(0) QK(1) | exps | PV(0) PV(1): two long MFMA runs instead of four short ones.
+template <int D, int QT>
+__device__ __forceinline__ void lds_softmax_clear2(AttnState<D, QT>& st, const f32x4 (&s0a)[QT], const f32x4 (&s0b)[QT],
+                                                   const f32x4 (&s1a)[QT], const f32x4 (&s1b)[QT], float scale_log2,
+                                                   half8 (&p0)[QT], half8 (&p1)[QT]) {
+    constexpr int NT = D / 16;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float x[16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            x[r] = s0a[qt][r]; x[4 + r] = s0b[qt][r]; x[8 + r] = s1a[qt][r]; x[12 + r] = s1b[qt][r];
+        }
+        float tmax = vmax3_raw(vmax3_raw(x[0], x[1], x[2]), vmax3_raw(x[3], x[4], x[5]), vmax_raw(x[6], x[7]));
+        tmax = vmax3_raw(tmax, vmax3_raw(x[8], x[9], x[10]), vmax3_raw(x[11], x[12], x[13]));
+        tmax = vmax3_raw(tmax, x[14], x[15]);
+        tmax = group_max4(tmax);
+        const float mnew = fmaxf(st.m[qt], tmax * scale_log2);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(x[r], scale_log2, -mnew));
+            psum += p;
+            if (r < 8) p0[qt][r] = (h16)p;
+            else p1[qt][r - 8] = (h16)p;
+        }
+        if (__builtin_amdgcn_ballot_w64(mnew != st.m[qt])) {
+            const float alpha = __builtin_amdgcn_exp2f(st.m[qt] - mnew);
+            st.l[qt] *= alpha;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                st.acc[qt][t][0] *= alpha; st.acc[qt][t][1] *= alpha;
+                st.acc[qt][t][2] *= alpha; st.acc[qt][t][3] *= alpha;
+            }
+            st.m[qt] = mnew;
+        }
+        st.l[qt] += psum;
+    }
+}
+template <int D, int QT>
+__device__ __forceinline__ void lds_pv_tr(AttnState<D, QT>& st, const half8 (&pb)[QT], const h16* __restrict__ svt, int g0,
+                                          int li, int g) {
+    constexpr int NT = D / 16;
+    const int fv = (li >> 2) | ((g & 1) << 2);
+    const h16* vrow = svt + (8 * (g0 + g) + (li >> 2)) * D + 4 * (li & 3);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int pos = (t ^ fv) * 16;
+        const half4 lo = lds_read_tr4(vrow + pos), hi = lds_read_tr4(vrow + 4 * D + pos);
+        const half8 vt = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+            st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vt, pb[qt], st.acc[qt][t], 0, 0, 0);
+    }
+}
+
 #ifndef TF_BLOCK_TREE_OCC
 #define TF_BLOCK_TREE_OCC 2      // waves per SIMD of the TREE form of the LDS block kernel.  At 2 it spills 46 registers; at 1
                                  // (512 registers, no spill) the 512-node Sequoia verify is 25 % SLOWER (2 890 -> 3 630 us): kept at 2
@@ -929,8 +1028,54 @@ __device__ __forceinline__ void attn_block_lds_body(
         fetch(min(sl + 1, s_end - 1));                      // in flight under this slab's MFMAs (unconditional: see attn_split_body)
         const h16* bk = sK + buf * BlkLayout<D>::K_HALFS;
         const h16* bv = sVt + buf * BlkLayout<D>::V_HALFS;
+        bool piped = false;
+        if constexpr (TF_BLOCK_PIPE && TR && !TREE && SLAB == 64) {
+            const int last = sl * SLAB + SLAB - 1;
+            if (last < sk && last <= sk - sq + qbase) {              // wave-uniform: both sub-steps fully visible
+                piped = true;
+                f32x4 s0a[QT], s0b[QT], s1a[QT], s1b[QT];
 #pragma unroll
-        for (int sub = 0; sub < SLAB / 32; ++sub) {
+                for (int qt = 0; qt < QT; ++qt) {
+                    s0a[qt] = f32x4{0.f, 0.f, 0.f, 0.f}; s0b[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    s1a[qt] = f32x4{0.f, 0.f, 0.f, 0.f}; s1b[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const int kcol = 8 * ((4 * c + g) ^ li);
+                    const half8 ka = load_half8(bk + row_a * RS + kcol);
+                    const half8 kb = load_half8(bk + (row_a + 4) * RS + kcol);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        s0a[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, st.qf[qt][c], s0a[qt], 0, 0, 0);
+                        s0b[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kb, st.qf[qt][c], s0b[qt], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const int kcol = 8 * ((4 * c + g) ^ li);
+                    const half8 ka = load_half8(bk + (32 + row_a) * RS + kcol);
+                    const half8 kb = load_half8(bk + (32 + row_a + 4) * RS + kcol);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        s1a[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, st.qf[qt][c], s1a[qt], 0, 0, 0);
+                        s1b[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kb, st.qf[qt][c], s1b[qt], 0, 0, 0);
+                    }
+                }
+                half8 p0[QT], p1[QT];
+                if constexpr (TF_BLOCK_PIPE == 2) {
+                    lds_softmax_clear2<D, QT>(st, s0a, s0b, s1a, s1b, scale_log2, p0, p1);
+                    lds_pv_tr<D, QT>(st, p0, bv, 0, li, g);
+                    lds_pv_tr<D, QT>(st, p1, bv, 4, li, g);
+                } else {
+                    lds_softmax_clear<D, QT>(st, s0a, s0b, scale_log2, p0);
+                    lds_pv_tr<D, QT>(st, p0, bv, 0, li, g);
+                    lds_softmax_clear<D, QT>(st, s1a, s1b, scale_log2, p1);
+                    lds_pv_tr<D, QT>(st, p1, bv, 4, li, g);
+                }
+            }
+        }
+#pragma unroll
+        for (int sub = 0; sub < (piped ? 0 : SLAB / 32); ++sub) {
             const int key0 = sl * SLAB + 32 * sub;
             if (key0 >= sk) break;
             f32x4 sa[QT], sb[QT];

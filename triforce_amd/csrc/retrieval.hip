@@ -170,35 +170,24 @@ __global__ __launch_bounds__(1024) void retrieval_topk_select_kernel(const uint1
 }
 
 // ---- gather ---------------------------------------------------------------------------------
-// One workgroup per (GATHER_SLOTS consecutive slots, head): threads [0,128) move K, [128,256) move V.  A thread owns one
-// 16-byte vector position (row, d) of a chunk and walks the slots: all GATHER_SLOTS chunk ids are read first (scalar
-// loads), then all its loads are issued, then all its stores — 8 independent 16-byte loads in flight per lane instead
-// of the first form's one (a 128-thread workgroup per single 2-KiB chunk: idx -> load -> store, three dependent round
-// trips per workgroup, 32 768 workgroups at cfg2; 24.9 us = 5.4 TB/s for the 134 MB of a layer, round-3 bench line).
-#define GATHER_SLOTS 8
-__global__ __launch_bounds__(256) void retrieval_gather_kernel(
+// One 128-thread workgroup per (slot, head, K | V): a 2-KiB chunk, one 16-byte vector per thread.  In situ 24.9 us for the
+// 134 MB (67 read + 67 written) of a cfg2 layer = 5.4 TB/s.  A coarser form — one workgroup per 8 slots, all chunk ids
+// read first, 8 loads in flight per lane before the 8 stores — measured 26.0 us (round 3, bench.py roofline_stages on two
+// boxes): the copy is bound by the mixed read / write stream, not by loads in flight; the simple form stays.
+__global__ __launch_bounds__(128) void retrieval_gather_kernel(
     const h16* __restrict__ k_src, const h16* __restrict__ v_src, int64_t sst, int64_t ssh,
     const int32_t* __restrict__ idx, h16* __restrict__ k_dst, h16* __restrict__ v_dst, int64_t dst_t, int64_t dsh,
     int sets, int chunk, int D) {
-    const int slot0 = blockIdx.x * GATHER_SLOTS, h = blockIdx.y;
-    const int half = blockDim.x >> 1;
-    const bool is_v = (int)threadIdx.x >= half;
-    const int t = is_v ? threadIdx.x - half : threadIdx.x;
+    const int slot = blockIdx.x, h = blockIdx.y;
+    const bool is_v = blockIdx.z != 0;
     const h16* src = (is_v ? v_src : k_src) + (int64_t)h * ssh;
     h16* dst = (is_v ? v_dst : k_dst) + (int64_t)h * dsh;
-    const int vec_per_row = D / 8, vecs = chunk * vec_per_row;
-    int c[GATHER_SLOTS];
-#pragma unroll
-    for (int i = 0; i < GATHER_SLOTS; ++i) c[i] = (slot0 + i < sets) ? idx[(int64_t)h * sets + slot0 + i] : -1;
-    for (int e = t; e < vecs; e += half) {                       // one trip when chunk * D / 8 <= 128 (chunk 8, D 128)
+    const int c = idx[(int64_t)h * sets + slot];
+    const int vec_per_row = D / 8;
+    for (int e = threadIdx.x; e < chunk * vec_per_row; e += blockDim.x) {
         const int r = e / vec_per_row, dv = e - r * vec_per_row;
-        half8 x[GATHER_SLOTS];
-#pragma unroll
-        for (int i = 0; i < GATHER_SLOTS; ++i)                    // unconditional (a slot past the end re-reads slot0's chunk)
-            x[i] = load_half8_stream(src + ((int64_t)(c[i] >= 0 ? c[i] : c[0]) * chunk + r) * sst + 8 * dv);
-#pragma unroll
-        for (int i = 0; i < GATHER_SLOTS; ++i)
-            if (c[i] >= 0) store_half8(dst + ((int64_t)(slot0 + i) * chunk + r) * dst_t + 8 * dv, x[i]);
+        const half8 x = load_half8(src + ((int64_t)c * chunk + r) * sst + 8 * dv);
+        store_half8(dst + ((int64_t)slot * chunk + r) * dst_t + 8 * dv, x);
     }
 }
 
@@ -305,7 +294,7 @@ extern "C" int tf_retrieval_gather(const void* k_src, const void* v_src, int64_t
                                    int64_t dst_stride_h, int sets, int chunk, int H, int D, void* stream) {
     if (!k_src || !v_src || !idx || !k_dst || !v_dst || sets < 1 || chunk < 1 || H < 1 || (D % 8)) return TF_EINVAL;
     if ((src_stride_t % 8) || (src_stride_h % 8) || (dst_stride_t % 8) || (dst_stride_h % 8)) return TF_EINVAL;
-    hipLaunchKernelGGL(retrieval_gather_kernel, dim3((sets + GATHER_SLOTS - 1) / GATHER_SLOTS, H), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(retrieval_gather_kernel, dim3(sets, H, 2), dim3(128), 0, (hipStream_t)stream,
                        (const h16*)k_src, (const h16*)v_src, src_stride_t, src_stride_h, idx, (h16*)k_dst, (h16*)v_dst,
                        dst_stride_t, dst_stride_h, sets, chunk, D);
     TF_LAUNCH_CHECK();
