@@ -632,6 +632,15 @@ def main():
         "kv_seq_len": ge.engine.kv_cache.seq_len,
         "roofline": roof, "roofline_stages": roofline_stages,
     }
+    if kind == "aligned":
+        # the headline is CONDITIONAL on a dial: say so next to it (trained checkpoints are not available offline)
+        result["value_note"] = (f"configured-acceptance scenario: synthetic weights {wlabel} SET the draft->retrieval and "
+                                "retrieval->target acceptance rates (models/aligned.py); tokens/s and avg_accepted_len follow "
+                                "from that dial — stage_latency_us, roofline* and random_weights do not depend on it; other "
+                                "operating points: profiles/r03_acceptance_sweep.json; not comparable to the reference's "
+                                "trained-weights 2.2x")
+    elif kind == "random":
+        result["value_note"] = "random-init weights: acceptance ~0, the loop's worst case (gamma inner iterations per token)"
     if cal is not None:
         result["aligned_calibration"] = cal
     # what a step costs beyond its model calls (accept kernels, cache fix-ups, host round trips); the eager verifies

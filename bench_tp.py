@@ -274,6 +274,8 @@ def run_tp(args, rank, world, local):
                                       f"{offload['on_chip_layers']})"),
                        "parallelism": f"tp{world}", "world_size_observed": dist.get_world_size(),
                        "prefill_mode": args.prefill_mode, "weights": wlabel, "weights_kind": kind},
+            "value_note": ("configured-acceptance scenario: the synthetic weights SET both acceptance rates (models/aligned.py); "
+                           "tokens/s and avg_accepted_len follow from that dial" if kind == "aligned" else None),
             "aligned_calibration": cal, "offload": offload,
             "avg_accepted_len": round(accepted / max(drafted, 1) * args.gamma, 4),
             "acceptance_rate": round(accepted / max(drafted, 1), 4), "tokens": tokens,

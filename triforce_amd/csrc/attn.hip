@@ -90,6 +90,16 @@ __device__ __forceinline__ float vmax3_raw(float a, float b, float c) {
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// The asm max helpers above are invisible to the compiler's hazard recogniser: it inserts the wait states an MFMA result
+// needs before a VALU instruction reads it (11 for an 8-pass v_mfma_f32_16x16x32_f16) in front of ITS OWN instructions,
+// not in front of inline asm — in one build of the prefill slab the scheduler put a v_max3_f32 directly behind the MFMA
+// that produced its operand, and the row maxima were garbage (NaN outputs).  Scores that come straight out of MFMAs pass
+// through this block first: the values become outputs of an asm that waits 12 cycles, so the MFMAs are issued before it
+// and every later reader — asm or not — sees settled registers.  12 cycles per (q-tile, sub-step).
+__device__ __forceinline__ void mfma_settle8(float (&x)[8]) {
+    asm volatile("s_nop 7\n\ts_nop 3"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+}
 __device__ __forceinline__ float group_max4(float v) {
     const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = vmax_raw(__uint_as_float(a[0]), __uint_as_float(a[1]));
@@ -787,7 +797,10 @@ __device__ __forceinline__ void lds_softmax_pv(AttnState<D, QT>& st, const f32x4
             x[r] = (r < 4 ? sa[qt][r] : sb[qt][r - 4]);                 // raw score: the scale rides in the fma below
             if (MASKED) tmax = v ? fmaxf(tmax, x[r]) : tmax;
         }
-        if (!MASKED) tmax = vmax3_raw(vmax3_raw(x[0], x[1], x[2]), vmax3_raw(x[3], x[4], x[5]), vmax_raw(x[6], x[7]));
+        if (!MASKED) {
+            mfma_settle8(x);
+            tmax = vmax3_raw(vmax3_raw(x[0], x[1], x[2]), vmax3_raw(x[3], x[4], x[5]), vmax_raw(x[6], x[7]));
+        }
         tmax = group_max4(tmax);
         const float mnew = fmaxf(st.m[qt], tmax * scale_log2);          // scale > 0: max commutes with it
         float psum = 0.f;
@@ -834,14 +847,20 @@ __device__ __forceinline__ void lds_softmax_pv(AttnState<D, QT>& st, const f32x4
     }
 }
 
-// ---- the fully visible slab, software-pipelined (TF_BLOCK_PIPE) -----------------------------------------------------
-// A 64-key slab all of whose keys every row of the wave may see (all slabs of a long prefix but the last one or two) is
-// walked as  QK(0) QK(1) | softmax(0) | PV(0) | softmax(1) | PV(1)  instead of  QK softmax PV  twice: the QK^T MFMAs of
-// sub-step 1 and the softmax VALU work of sub-step 0 are independent and sit in one basic block, as do the PV MFMAs of
-// sub-step 0 and the softmax of sub-step 1 — the scheduler can overlap matrix-core and VALU work of ONE wave, which the
-// strictly alternating form cannot (the body is VALU-issue-bound: ~170 VALU instructions per 32 MFMAs).
+// ---- the fully visible slab (TF_BLOCK_PIPE) --------------------------------------------------------------------------
+// A 64-key slab all of whose keys every row of the wave may see — every slab of a long prefix but the last one or two — is
+// walked as ONE softmax step instead of two:  QK(0) QK(1) | max, exps | PV(0) PV(1).
+//   1  both QK^T runs first, then the two sub-steps' softmax / PV as before (bit-identical to the alternating form):
+//      1024-row chunk over 124 928 keys 722 -> 754 TF/s;
+//   2  (default) ONE running-max update — and at most one accumulator rescale — per slab: both sub-steps' probabilities are
+//      taken against max(m, slab max).  The same softmax (m only ever has to dominate the scores seen so far), half the
+//      max / ballot / rescale bookkeeping, two long MFMA runs instead of four short ones: 722 -> 799 TF/s
+//      (profiles/r03_prefill_slab_ab.jsonl; error against attention accumulated in fp64 unchanged: max 1.64e-5, mean
+//      2.03e-6 on outputs of magnitude ~0.01).  Its max chain is plain fmaxf — measured equal to the asm v_max3 chain, and
+//      the compiler's hazard recogniser then sees every reader of the MFMA results (see mfma_settle8).
+//   0  the alternating form (also what masked slabs, the TREE form and D = 64 use).
 #ifndef TF_BLOCK_PIPE
-#define TF_BLOCK_PIPE 0
+#define TF_BLOCK_PIPE 2
 #endif
 template <int D, int QT>
 __device__ __forceinline__ void lds_softmax_clear(AttnState<D, QT>& st, const f32x4 (&sa)[QT], const f32x4 (&sb)[QT],
@@ -852,6 +871,7 @@ __device__ __forceinline__ void lds_softmax_clear(AttnState<D, QT>& st, const f3
         float x[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) x[r] = (r < 4 ? sa[qt][r] : sb[qt][r - 4]);
+        mfma_settle8(x);
         float tmax = vmax3_raw(vmax3_raw(x[0], x[1], x[2]), vmax3_raw(x[3], x[4], x[5]), vmax_raw(x[6], x[7]));
         tmax = group_max4(tmax);
         const float mnew = fmaxf(st.m[qt], tmax * scale_log2);
@@ -875,9 +895,6 @@ __device__ __forceinline__ void lds_softmax_clear(AttnState<D, QT>& st, const f3
         st.l[qt] += psum;
     }
 }
-// TF_BLOCK_PIPE == 2: ONE running-max update (and at most one accumulator rescale) per 64-key slab: both sub-steps'
-// probabilities are taken against max(m, slab max) — the same softmax, half the max / ballot / rescale bookkeeping, and
-// the matrix core sees QK(0) QK(1) | exps | PV(0) PV(1): two long MFMA runs instead of four short ones.
 template <int D, int QT>
 __device__ __forceinline__ void lds_softmax_clear2(AttnState<D, QT>& st, const f32x4 (&s0a)[QT], const f32x4 (&s0b)[QT],
                                                    const f32x4 (&s1a)[QT], const f32x4 (&s1b)[QT], float scale_log2,
@@ -890,9 +907,9 @@ __device__ __forceinline__ void lds_softmax_clear2(AttnState<D, QT>& st, const f
         for (int r = 0; r < 4; ++r) {
             x[r] = s0a[qt][r]; x[4 + r] = s0b[qt][r]; x[8 + r] = s1a[qt][r]; x[12 + r] = s1b[qt][r];
         }
-        float tmax = vmax3_raw(vmax3_raw(x[0], x[1], x[2]), vmax3_raw(x[3], x[4], x[5]), vmax_raw(x[6], x[7]));
-        tmax = vmax3_raw(tmax, vmax3_raw(x[8], x[9], x[10]), vmax3_raw(x[11], x[12], x[13]));
-        tmax = vmax3_raw(tmax, x[14], x[15]);
+        float tmax = x[0];                               // plain fmaxf: every reader of the MFMA results is compiler-visible
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, x[r]);
         tmax = group_max4(tmax);
         const float mnew = fmaxf(st.m[qt], tmax * scale_log2);
         float psum = 0.f;
@@ -1062,7 +1079,7 @@ __device__ __forceinline__ void attn_block_lds_body(
                     }
                 }
                 half8 p0[QT], p1[QT];
-                if constexpr (TF_BLOCK_PIPE == 2) {
+                if constexpr (TF_BLOCK_PIPE >= 2) {
                     lds_softmax_clear2<D, QT>(st, s0a, s0b, s1a, s1b, scale_log2, p0, p1);
                     lds_pv_tr<D, QT>(st, p0, bv, 0, li, g);
                     lds_pv_tr<D, QT>(st, p1, bv, 4, li, g);
