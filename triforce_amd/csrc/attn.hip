@@ -1155,6 +1155,167 @@ __global__ __launch_bounds__(256, TREE ? TF_BLOCK_TREE_OCC : 2) void attn_block_
                                  tree_start, split, h, s_begin, min(nslabs, s_begin + sps));
 }
 
+// ---- prefill body with the NEXT slab's QK^T issued ahead and K / V brought in by LDS-DMA (TF_PREFILL_AHEAD) -----------------
+// The dependency chain of a slab is QK^T -> softmax -> PV: matrix core, VALU, matrix core.  K[s] is dead as soon as
+// QK^T(s) has run, so with the SAME two K and two V buffers the loop can hold K one slab ahead of V: iteration s runs
+// QK^T(s + 1) (from the K buffer this iteration's PV does not touch), then the softmax of slab s on scores computed one
+// iteration earlier, then PV(s).  One barrier per slab as before: iteration s brings K[s + 2] in over K[s] (dead since the
+// previous barrier) and V[s + 1] over V[s - 1].  The second set of score registers does not fit next to the 32 staging
+// registers of the register-staged loads (256 per lane at two waves per SIMD: that build spills 34 registers and runs at
+// 424 TF/s), so K and V come in by LDS-DMA — `global_load_lds_dwordx4`: one instruction of a wave moves 64 x 16 B straight
+// into 1 KiB of LDS, lane-linear, no staging registers and no ds_write; the XOR swizzle of the layout is applied on the
+// SOURCE side (the lane that fills slot j of row r loads chunk j ^ f(r): the swizzles are involutions).
+// 1024-row chunk x 124 928 keys x 32 heads, same box (profiles/r03_prefill_slab_ab.jsonl): 792.7 -> 848.4 TF/s (+7 %; +10.5 %
+// on a slower box).  Splitting the softmax so that the compiler interleaves the next slab's QK^T MFMAs with this slab's exps
+// INSIDE one wave measured slower (820.5): what overlaps the matrix core with the VALU here is the other wave of the SIMD.
+// D = 128, chain (non-tree) form only; 0 = the shared body (attn_block_lds_body).
+#ifndef TF_PREFILL_AHEAD
+#define TF_PREFILL_AHEAD 1
+#endif
+template <int D>
+__device__ __forceinline__ void attn_prefill_ahead_body(
+    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
+    int64_t stride_h, int sq, int sk, int H, float scale, int nsplit, float* __restrict__ ws, int split, int h,
+    int s_begin, int s_end) {
+    static_assert(BlkLayout<D>::TR && BLK_SLAB == 64, "swizzled-K / transpose-read layout, 64-key slabs");
+    constexpr int NC = D / 32, NT = D / 16, QT = 2, QR = 128, SLAB = BLK_SLAB, RS = BlkLayout<D>::RS;
+    constexpr int VPR = D / 8, RPP = 256 / VPR, NPASS = SLAB / RPP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char blk_smem[];
+    h16* sK = reinterpret_cast<h16*>(blk_smem);             // [2][SLAB * RS]
+    h16* sVt = sK + 2 * BlkLayout<D>::K_HALFS;              // [2][SLAB * D]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int qbase = wave * 32;
+
+    AttnState<D, QT> st;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int row = qbase + qt * 16 + li;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            st.qf[qt][c] = (row < sq) ? load_half8(q + ((int64_t)row * H + h) * D + 32 * c + 8 * g) : z;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) st.acc[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        st.m[qt] = NEG_BIG;
+        st.l[qt] = 0.f;
+    }
+    const h16* kbase = k + (int64_t)h * stride_h;
+    const h16* vbase = v + (int64_t)h * stride_h;
+    const TreeMask tm{nullptr, 0, 0, 0};
+    const float scale_log2 = scale * 1.4426950408889634f;
+    const int lr = tid / VPR, lc = tid % VPR;
+    const int row_a = 8 * (li >> 2) + (li & 3);
+
+    // one slab (64 rows x 256 B) = 4 passes; pass p, wave w fills rows 16 p + 4 w .. + 3 (1 KiB, lane-linear)
+    auto dma_slab = [&](const h16* base, h16* dst_buf, int slab, bool is_v) {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int r = p * RPP + lr;                                   // lr = tid / 16: row within the pass
+            int key = slab * SLAB + r;
+            key = key < sk ? key : sk - 1;
+            int c;
+            if (!is_v) {
+                const int fk = (r & 3) | (((r >> 3) & 3) << 2);
+                c = lc ^ fk;
+            } else {
+                const int fv = (r & 3) | (((r >> 3) & 1) << 2);
+                c = (((lc >> 1) ^ fv) << 1) | (lc & 1);
+            }
+            const h16* src = base + (int64_t)key * stride_t + 8 * c;
+            h16* dst = dst_buf + (p * RPP + 4 * wave) * D;                // wave-uniform 1-KiB destination of this pass
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    auto fetch_k = [&](int slab, int buf) { dma_slab(kbase, sK + buf * BlkLayout<D>::K_HALFS, slab, false); };
+    auto fetch_v = [&](int slab, int buf) { dma_slab(vbase, sVt + buf * BlkLayout<D>::V_HALFS, slab, true); };
+    // both 32-key sub-steps of one slab: scores S^T[key][q] of tiles A / B (keys 4g..4g+3 of either half) per q-tile
+    auto qk_slab = [&](const h16* bk, f32x4 (&a0)[QT], f32x4 (&b0)[QT], f32x4 (&a1)[QT], f32x4 (&b1)[QT]) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            a0[qt] = f32x4{0.f, 0.f, 0.f, 0.f}; b0[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            a1[qt] = f32x4{0.f, 0.f, 0.f, 0.f}; b1[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int kcol = 8 * ((4 * c + g) ^ li);
+                const half8 ka = load_half8(bk + (32 * sub + row_a) * RS + kcol);
+                const half8 kb = load_half8(bk + (32 * sub + row_a + 4) * RS + kcol);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    if (sub == 0) {
+                        a0[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, st.qf[qt][c], a0[qt], 0, 0, 0);
+                        b0[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kb, st.qf[qt][c], b0[qt], 0, 0, 0);
+                    } else {
+                        a1[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, st.qf[qt][c], a1[qt], 0, 0, 0);
+                        b1[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kb, st.qf[qt][c], b1[qt], 0, 0, 0);
+                    }
+                }
+            }
+    };
+
+    if (s_begin < s_end) {
+        f32x4 c0a[QT], c0b[QT], c1a[QT], c1b[QT];            // scores of the CURRENT slab
+        fetch_k(s_begin, 0);
+        fetch_v(s_begin, 0);
+        fetch_k(min(s_begin + 1, s_end - 1), 1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): Q fragments and the prologue slabs have landed
+        __syncthreads();
+        qk_slab(sK, c0a, c0b, c1a, c1b);
+        __syncthreads();                                     // every wave is done with K[s_begin] before iteration 0 overwrites it
+        for (int sl = s_begin; sl < s_end; ++sl) {
+            const int i = sl - s_begin;
+            fetch_k(min(sl + 2, s_end - 1), i & 1);          // K[sl + 2] over K[sl] (dead since the previous barrier), V[sl + 1]
+            fetch_v(min(sl + 1, s_end - 1), (i + 1) & 1);    // over V[sl - 1]; unconditional: in flight under the MFMAs
+            const h16* bk_next = sK + ((i + 1) & 1) * BlkLayout<D>::K_HALFS;
+            const h16* bv = sVt + (i & 1) * BlkLayout<D>::V_HALFS;
+            f32x4 n0a[QT], n0b[QT], n1a[QT], n1b[QT];
+            const int last = sl * SLAB + SLAB - 1;
+            if (last < sk && last <= sk - sq + qbase) {      // wave-uniform: the whole slab is visible to every row of the wave
+                half8 p0[QT], p1[QT];
+                qk_slab(bk_next, n0a, n0b, n1a, n1b);        // next slab's QK^T (past the end: finite garbage, never used)
+                lds_softmax_clear2<D, QT>(st, c0a, c0b, c1a, c1b, scale_log2, p0, p1);
+                lds_pv_tr<D, QT>(st, p0, bv, 0, li, g);
+                lds_pv_tr<D, QT>(st, p1, bv, 4, li, g);
+            } else {
+                qk_slab(bk_next, n0a, n0b, n1a, n1b);
+                const int key0 = sl * SLAB;
+                lds_softmax_pv<D, QT, false, true>(st, c0a, c0b, bv, 0, key0, sk, sq, scale_log2, li, g, qbase, tm);
+                if (key0 + 32 < sk)
+                    lds_softmax_pv<D, QT, false, true>(st, c1a, c1b, bv, 4, key0 + 32, sk, sq, scale_log2, li, g, qbase, tm);
+            }
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                c0a[qt] = n0a[qt]; c0b[qt] = n0b[qt]; c1a[qt] = n1a[qt]; c1b[qt] = n1b[qt];
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): this wave's DMA writes are in LDS before the barrier
+            __syncthreads();
+        }
+    }
+
+    float* ws_o = ws;
+    float* ws_m = ws + (int64_t)H * nsplit * QR * D;
+    float* ws_l = ws_m + (int64_t)H * nsplit * QR;
+    const int64_t pbase = ((int64_t)h * nsplit + split) * QR;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float lsum = st.l[qt];
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        const int64_t row = pbase + qbase + qt * 16 + li;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) *reinterpret_cast<f32x4*>(ws_o + row * D + 16 * tt + 4 * g) = st.acc[qt][tt];
+        if (g == 0) {
+            ws_m[row] = st.m[qt] * 0.6931471805599453f;
+            ws_l[row] = lsum;
+        }
+    }
+}
+
 // A whole causal prefill chunk (sq rows = nrb blocks of 128) in ONE launch.  Block rb sees keys [0, sk - sq + end_rb).
 // Launching the blocks one by one streams the KV cache from HBM once per 128 rows (128 flop per byte: an 800 TF/s
 // ceiling at 6.3 TB/s, and the 125K-token prefill ran at ~490).  Here the row blocks that read the SAME key range run at
@@ -1182,8 +1343,12 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(
     const int sps = (nslabs_all + nsplit - 1) / nsplit;
     const int s_begin = split * sps;
     float* ws_rb = ws + (int64_t)rb * H * nsplit * 128 * (D + 2);
-    attn_block_lds_body<D, false>(q + (int64_t)r0 * H * D, k, v, stride_t, stride_h, rows, sk_eff, H, scale, nsplit, ws_rb,
-                                  nullptr, 0, 0, 0, split, h, s_begin, min(nslabs, s_begin + sps));
+    if constexpr (TF_PREFILL_AHEAD && BlkLayout<D>::TR)
+        attn_prefill_ahead_body<D>(q + (int64_t)r0 * H * D, k, v, stride_t, stride_h, rows, sk_eff, H, scale, nsplit, ws_rb,
+                                   split, h, s_begin, min(nslabs, s_begin + sps));
+    else
+        attn_block_lds_body<D, false>(q + (int64_t)r0 * H * D, k, v, stride_t, stride_h, rows, sk_eff, H, scale, nsplit, ws_rb,
+                                      nullptr, 0, 0, 0, split, h, s_begin, min(nslabs, s_begin + sps));
 }
 
 template <int D>
