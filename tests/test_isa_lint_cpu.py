@@ -27,7 +27,7 @@ _Zkernel:
     assert isa_lint.lint_asm(ok) == []
 
 
-@pytest.mark.parametrize("defines", [(), ("TF_BLOCK_PIPE=0",), ("TF_BLOCK_PIPE=1",), ("TF_ATTN_P_SPLIT=0",), ("TF_PREFILL_AHEAD=0",)])
+@pytest.mark.parametrize("defines", [(), ("TF_BLOCK_PIPE=0",), ("TF_BLOCK_PIPE=1",), ("TF_ATTN_P_SPLIT=0",), ("TF_PREFILL_AHEAD=0",), ("TF_BLOCK_DMA=0",)])
 def test_attention_kernels_have_no_unguarded_asm_read_of_an_mfma_result(defines):
     text = isa_lint.compile_to_asm(os.path.join(CSRC, "attn.hip"), defines)
     findings = isa_lint.lint_asm(text)

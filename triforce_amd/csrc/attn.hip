@@ -950,6 +950,13 @@ __device__ __forceinline__ void lds_pv_tr(AttnState<D, QT>& st, const half8 (&pb
     }
 }
 
+// K / V slab loads of the LDS block kernel by LDS-DMA instead of through 32 staging registers per lane (swizzled layout,
+// D = 128): 1 = TREE form only, 2 = chain form too (default), 0 = register-staged.  The TREE form spilled 24 registers at
+// its 2 waves per SIMD; without the staging registers it spills 2: 512-node Sequoia verify over a 124 928-token prefix
+// 2 298 -> 1 905 us, 128-row chain block 465 -> 422 us, outputs bit-identical (profiles/r03_block_dma_ab.jsonl).
+#ifndef TF_BLOCK_DMA
+#define TF_BLOCK_DMA 2
+#endif
 #ifndef TF_BLOCK_TREE_OCC
 #define TF_BLOCK_TREE_OCC 2      // waves per SIMD of the TREE form of the LDS block kernel.  At 2 it spills 46 registers; at 1
                                  // (512 registers, no spill) the 512-node Sequoia verify is 25 % SLOWER (2 890 -> 3 630 us): kept at 2
@@ -1001,21 +1008,40 @@ __device__ __forceinline__ void attn_block_lds_body(
     const int lr = tid / VPR, lc = tid % VPR;               // this thread's (row, 16-byte column) in a load pass
     const int row_a = 8 * (li >> 2) + (li & 3);             // slab row behind MFMA row li of tile A (tile B: +4)
 
-    half8 gk[NPASS], gv[NPASS];
-    auto fetch = [&](int slab) {
+    // K / V slabs reach LDS either through staging registers (fetch -> stash: 32 registers per lane live across a slab's
+    // MFMAs) or — TF_BLOCK_DMA, swizzled layout only — by LDS-DMA straight into the buffer the NEXT iteration reads (free
+    // since the previous barrier), the XOR swizzle applied on the source side (see attn_prefill_ahead_body).
+    constexpr bool DMA = TF_BLOCK_DMA && TR && (TREE || TF_BLOCK_DMA > 1);
+    half8 gk[DMA ? 1 : NPASS], gv[DMA ? 1 : NPASS];
+    auto fetch = [&](int slab, int buf) {
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
             int key = slab * SLAB + p * RPP + lr;
             key = key < sk ? key : sk - 1;                  // clamp: masked below, but must stay in-bounds
-            gk[p] = load_half8_stream(kbase + (int64_t)key * stride_t + 8 * lc);
-            gv[p] = load_half8_stream(vbase + (int64_t)key * stride_t + 8 * lc);
+            if constexpr (DMA) {
+                const int r = p * RPP + lr;
+                const int fk = (r & 3) | (((r >> 3) & 3) << 2), fv = (r & 3) | (((r >> 3) & 1) << 2);
+                h16* dk = sK + buf * BlkLayout<D>::K_HALFS + (p * RPP + 4 * wave) * D;      // wave-uniform 1 KiB of this pass
+                h16* dv = sVt + buf * BlkLayout<D>::V_HALFS + (p * RPP + 4 * wave) * D;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(kbase + (int64_t)key * stride_t + 8 * (lc ^ fk)),
+                    (__attribute__((address_space(3))) void*)dk, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(vbase + (int64_t)key * stride_t +
+                                                                     8 * ((((lc >> 1) ^ fv) << 1) | (lc & 1))),
+                    (__attribute__((address_space(3))) void*)dv, 16, 0, 0);
+            } else {
+                gk[p] = load_half8_stream(kbase + (int64_t)key * stride_t + 8 * lc);
+                gv[p] = load_half8_stream(vbase + (int64_t)key * stride_t + 8 * lc);
+            }
         }
     };
     auto stash = [&](int buf) {
+        if constexpr (DMA) return;
         h16* dk = sK + buf * BlkLayout<D>::K_HALFS;
         h16* dv = sVt + buf * BlkLayout<D>::V_HALFS;
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
+        for (int p = 0; p < (DMA ? 0 : NPASS); ++p) {
             const int r = p * RPP + lr;
             if constexpr (TR) {
                 const int fk = (r & 3) | (((r >> 3) & 3) << 2), fv = (r & 3) | (((r >> 3) & 1) << 2);
@@ -1031,7 +1057,7 @@ __device__ __forceinline__ void attn_block_lds_body(
     };
 
     if (s_begin < s_end) {
-        fetch(s_begin);
+        fetch(s_begin, 0);
         stash(0);
     }
     // Every load issued so far — the Q fragments above all — has landed before the loop: without this the compiler,
@@ -1042,7 +1068,7 @@ __device__ __forceinline__ void attn_block_lds_body(
     __syncthreads();
     for (int sl = s_begin; sl < s_end; ++sl) {
         const int buf = (sl - s_begin) & 1;
-        fetch(min(sl + 1, s_end - 1));                      // in flight under this slab's MFMAs (unconditional: see attn_split_body)
+        fetch(min(sl + 1, s_end - 1), buf ^ 1);             // in flight under this slab's MFMAs (unconditional: see attn_split_body)
         const h16* bk = sK + buf * BlkLayout<D>::K_HALFS;
         const h16* bv = sVt + buf * BlkLayout<D>::V_HALFS;
         bool piped = false;
@@ -1120,6 +1146,7 @@ __device__ __forceinline__ void attn_block_lds_body(
                 lds_softmax_pv<D, QT, TREE, true>(st, sa, sb, bv, 4 * sub, key0, sk, sq, scale_log2, li, g, qbase, tm);
         }
         if (sl + 1 < s_end) stash(buf ^ 1);
+        if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA writes are in LDS before the barrier
         __syncthreads();
     }
 
