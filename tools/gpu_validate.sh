@@ -54,7 +54,7 @@ find $O/prof $O/pmc_fetch $O/pmc_write $O/pmc_mfma -name "*kernel_trace.csv" -si
 # the other full-size configs (BASELINE configs[2], and configs[3] at world size 1: offloading tier), only with "all"
 if [ "$1" = "all" ]; then
   python bench.py --target lwm-128K --steps 20 --warmup 5 --no-cpu-baseline --random-steps 0 > $O/bench_lwm.json 2> $O/bench_lwm.err; echo "lwm rc=$?"; tail -c 300 $O/bench_lwm.json
-  TRIFORCE_PREFILL_CHUNK=2048 python bench.py --prefill 130048 --budget 12288 --gamma 16 --on-chip 9 --steps 8 --warmup 2 --no-cpu-baseline --random-steps 0 > $O/bench_offload.json 2> $O/bench_offload.err; echo "offload rc=$?"; tail -c 300 $O/bench_offload.json
+  python bench.py --prefill 130048 --budget 12288 --gamma 16 --on-chip 9 --steps 8 --warmup 2 --no-cpu-baseline --random-steps 0 > $O/bench_offload.json 2> $O/bench_offload.err; echo "offload rc=$?"; tail -c 300 $O/bench_offload.json
   python tools/acceptance_sweep.py $O/acceptance_sweep.json > $O/acceptance_sweep.log 2>&1; echo "sweep rc=$?"; tail -3 $O/acceptance_sweep.log
   python tools/verify_bench.py final > $O/verify_bench.json 2> $O/verify_bench.err; echo "verify_bench rc=$?"; tail -c 400 $O/verify_bench.json
 fi

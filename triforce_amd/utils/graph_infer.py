@@ -17,11 +17,12 @@ from .sampling import norm_logits
 
 # Target prefill: the reference feeds 128 tokens per forward (graph_infer.py:30-37, TP_llama.py:246-250), which at
 # 128 rows leaves every GEMM bound by re-streaming the 13 GB of weights (976 times for a 125K prompt).  On the device
-# the chunk is 1024 rows — same causal attention (tf_attn_block takes it as 128-row slabs), an eighth of the weight
-# traffic, and under KV offloading an eighth of the host->device re-streams (125K prompt, 7B: 15.4 s at 128 rows,
-# 12.6 s at 512, 11.75 s at 1024 and at 2048).  The returned logits keep the
+# the chunk is 4096 rows — the most tf_attn_prefill takes in one launch; same causal attention, 1/32 of the weight
+# traffic, and under KV offloading 1/32 of the host->device re-streams (125K prompt, 7B, target model only: round 1
+# 15.4 s at 128 rows, 12.6 s at 512, 11.75 s at 1024; round 3, with the faster prefill attention, 6.69 s at 1024, 6.63 s
+# at 2048, 6.38 s at 4096: profiles/r03_prefill_chunk.jsonl).  The returned logits keep the
 # reference's shape (the rows of ITS last 128-token chunk).  CPU (oracle-backed tests) keeps 128.
-PREFILL_CHUNK = int(os.environ.get("TRIFORCE_PREFILL_CHUNK", "1024"))
+PREFILL_CHUNK = int(os.environ.get("TRIFORCE_PREFILL_CHUNK", "4096"))
 assert PREFILL_CHUNK % 128 == 0 and PREFILL_CHUNK > 0
 
 
