@@ -1,19 +1,34 @@
-"""Idle-gap analysis of a rocprofv3 --kernel-trace CSV: for the last N seconds of the run (the timed decode steps of
-bench.py) report GPU busy time, idle time and the largest sources of idle (which kernel follows the gap).
-Usage: python tools/gap_analysis.py <kernel_trace.csv> [tail_ms]"""
+"""Idle-gap analysis of a rocprofv3 --kernel-trace CSV: GPU busy time, idle time and the largest sources of idle (which
+kernel follows the gap) over a window of the run.
+Usage: python tools/gap_analysis.py <kernel_trace.csv> [tail_ms]            the last tail_ms milliseconds of the run
+       python tools/gap_analysis.py <kernel_trace.csv> --steps N [--skip M]  exactly N outer TriForce steps: the window runs
+           from the end of one accept_chain_kernel (the last kernel decision of an outer step) to the end of the N-th one
+           after it, counted back from the LAST accept_chain_kernel of the run minus M (bench.py's timed steps are followed
+           by probes without accept_chain launches, so M = 0 selects the last N timed steps)"""
 import csv
 import sys
 from collections import defaultdict
 
 path = sys.argv[1]
-tail_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 300.0
 rows = []
 with open(path) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-t_end = rows[-1][1]
-rows = [r for r in rows if r[0] >= t_end - tail_ms * 1e6]
+if "--steps" in sys.argv:
+    n = int(sys.argv[sys.argv.index("--steps") + 1])
+    skip = int(sys.argv[sys.argv.index("--skip") + 1]) if "--skip" in sys.argv else 0
+    marks = [e for s, e, name in rows if "accept_chain_kernel" in name]
+    if len(marks) < n + skip + 1:
+        raise SystemExit(f"only {len(marks)} accept_chain_kernel launches in the trace")
+    hi = marks[len(marks) - 1 - skip]
+    lo = marks[len(marks) - 1 - skip - n]
+    rows = [r for r in rows if r[0] >= lo and r[1] <= hi]
+    print(f"window = {n} outer steps (between accept_chain_kernel launches)")
+else:
+    tail_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 300.0
+    t_end = rows[-1][1]
+    rows = [r for r in rows if r[0] >= t_end - tail_ms * 1e6]
 busy = sum(e - s for s, e, _ in rows)
 span = rows[-1][1] - rows[0][0]
 gaps = defaultdict(lambda: [0, 0])

@@ -42,7 +42,7 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -
 # target-verify / retrieval-verify launches of the split-KV kernel separated by duration cluster + priced (tracked copy -> profiles/)
 T=$(ls -S $R/$O/prof/*/*kernel_trace.csv | head -1)
 python $R/tools/attn_by_grid.py $T $R/$O/kernels_by_stage.json "rocprofv3 --kernel-trace of python bench.py --steps 20 --warmup 5 --no-cpu-baseline --random-steps 0 (tools/gpu_validate.sh)" > $R/$O/kernels_by_stage.log 2>&1; echo "by-stage rc=$?"
-python $R/tools/gap_analysis.py $T 560 > $R/$O/gap_analysis_decode_steps.txt 2>&1; head -3 $R/$O/gap_analysis_decode_steps.txt
+python $R/tools/gap_analysis.py $T --steps 19 > $R/$O/gap_analysis_decode_steps.txt 2>&1; head -3 $R/$O/gap_analysis_decode_steps.txt
 # HBM traffic of the roofline kernel (two separate --pmc passes, kernel-trace only) -> the figure bench.py quotes as roofline.traffic
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_fetch -- python $R/tools/pmc_attn.py > $R/$O/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_write -- python $R/tools/pmc_attn.py > $R/$O/pmc_write.log 2>&1; echo "pmc write rc=$?"
