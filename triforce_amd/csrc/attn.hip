@@ -236,7 +236,7 @@ __device__ __forceinline__ void attn_tile(AttnState<D, QT>& st, const half8 (&kf
 
 
 // ws layout: o[H][nsplit][QR][D] | m[H][nsplit][QR] | l[H][nsplit][QR],  QR = QT*16
-template <int D, int QT, int DEEP = 0>
+template <int D, int QT, int DEEP = 0, int NW = 4>
 __device__ __forceinline__ void attn_split_body(
     const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
     int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
@@ -291,6 +291,7 @@ __device__ __forceinline__ void attn_split_body(
     // (7B retrieval verify 21.0 -> 20.2 us, 4-head TP shard 14.3 -> 13.6, draft-sized 6.9 -> 6.5) but the 125K-key
     // streams, already bandwidth-bound with 8 MB in flight chip-wide, LOSE 0.7 % (32 heads) to 4 % (16 heads x 17 rows)
     // with twice as much in flight — so the form is chosen by the length of the wave's stream.
+    static_assert(NW == 4 || (DEEP == 0 && (QT == 1 ? TF_ATTN_RING_Q1 : TF_ATTN_RING_Q2) == 0), "deep / ring forms: 4 waves");
     int t = t_begin + wave;
     if constexpr (DEEP > 0) {
         // rounds of N tiles: all N loads issued (tiles past the end re-read the last one: no conditional load, so the
@@ -335,24 +336,24 @@ __device__ __forceinline__ void attn_split_body(
         half8 ka[NC], va_[NC], kb[NC], vb[NC];
         load_kv_tile<D>(kbase, vbase, stride_t, t, sk, li, g, ka, va_);
         // (one-q-tile form only: with both loops the two-q-tile form no longer fits its 2-waves-per-SIMD register budget)
-        if (TF_ATTN_EAGER_TILES > 0 && QT == 1 && t_end - t_begin <= 4 * TF_ATTN_EAGER_TILES) {
+        if (TF_ATTN_EAGER_TILES > 0 && QT == 1 && t_end - t_begin <= NW * TF_ATTN_EAGER_TILES) {
             const int tl = t_end - 1;
             while (true) {
-                load_kv_tile<D>(kbase, vbase, stride_t, min(t + 4, tl), sk, li, g, kb, vb);
+                load_kv_tile<D>(kbase, vbase, stride_t, min(t + NW, tl), sk, li, g, kb, vb);
                 ATTN_TILE_AUTO(ka, va_, t);
-                if (t + 4 >= t_end) break;
-                load_kv_tile<D>(kbase, vbase, stride_t, min(t + 8, tl), sk, li, g, ka, va_);
-                ATTN_TILE_AUTO(kb, vb, t + 4);
-                if (t + 8 >= t_end) break;
-                t += 8;
+                if (t + NW >= t_end) break;
+                load_kv_tile<D>(kbase, vbase, stride_t, min(t + 2 * NW, tl), sk, li, g, ka, va_);
+                ATTN_TILE_AUTO(kb, vb, t + NW);
+                if (t + 2 * NW >= t_end) break;
+                t += 2 * NW;
             }
         } else {
             while (t < t_end) {
-                const int t1 = t + 4;
+                const int t1 = t + NW;
                 if (t1 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t1, sk, li, g, kb, vb);
                 ATTN_TILE_AUTO(ka, va_, t);
                 if (t1 >= t_end) break;
-                const int t2 = t1 + 4;
+                const int t2 = t1 + NW;
                 if (t2 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t2, sk, li, g, ka, va_);
                 ATTN_TILE_AUTO(kb, vb, t1);
                 t = t2;
@@ -361,10 +362,12 @@ __device__ __forceinline__ void attn_split_body(
     }
 
 #undef ATTN_TILE_AUTO
-    // ---- merge the 4 waves of this split through LDS, one q-tile at a time ----
-    __shared__ float sm_o[4][16][D + 1];
-    __shared__ float sm_m[4][16];
-    __shared__ float sm_l[4][16];
+    // ---- merge the NW waves of this split through LDS, one q-tile at a time (8 waves: one half of D at a time, so the
+    // staging stays under the 64 KiB static limit) ----
+    constexpr int HALVES = NW > 4 ? 2 : 1, DH = D / HALVES, NTH = NT / HALVES;
+    __shared__ float sm_o[NW][16][DH + 1];
+    __shared__ float sm_m[NW][16];
+    __shared__ float sm_l[NW][16];
     float* ws_o = ws;
     float* ws_m = ws + (int64_t)H * nsplit * QR * D;
     float* ws_l = ws_m + (int64_t)H * nsplit * QR;
@@ -375,36 +378,45 @@ __device__ __forceinline__ void attn_split_body(
         lsum += __shfl_xor(lsum, 16, 64);
         lsum += __shfl_xor(lsum, 32, 64);
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
+        for (int hv = 0; hv < HALVES; ++hv) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sm_o[wave][li][16 * tt + 4 * g + r] = st.acc[qt][tt][r];
-        if (g == 0) {
-            sm_m[wave][li] = st.m[qt];
-            sm_l[wave][li] = lsum;
-        }
-        __syncthreads();
-        for (int e = tid; e < 16 * D; e += 256) {
-            const int qq = e / D, d = e - qq * D;
-            const float m0 = sm_m[0][qq], m1 = sm_m[1][qq], m2 = sm_m[2][qq], m3 = sm_m[3][qq];
-            const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-            const float w0 = __expf(m0 - mm), w1 = __expf(m1 - mm), w2 = __expf(m2 - mm), w3 = __expf(m3 - mm);
-            const float o = sm_o[0][qq][d] * w0 + sm_o[1][qq][d] * w1 + sm_o[2][qq][d] * w2 + sm_o[3][qq][d] * w3;
-            const float lw = sm_l[0][qq] * w0 + sm_l[1][qq] * w1 + sm_l[2][qq] * w2 + sm_l[3][qq] * w3;
-            if (tickets == nullptr) {
-                ws_o[(pbase + qt * 16 + qq) * D + d] = o;
-                if (d == 0) {
-                    ws_m[pbase + qt * 16 + qq] = mm;
-                    ws_l[pbase + qt * 16 + qq] = lw;
+            for (int tt = 0; tt < NTH; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sm_o[wave][li][16 * tt + 4 * g + r] = st.acc[qt][hv * NTH + tt][r];
+            if (g == 0) {
+                sm_m[wave][li] = st.m[qt];
+                sm_l[wave][li] = lsum;
+            }
+            __syncthreads();
+            for (int e = tid; e < 16 * DH; e += 64 * NW) {
+                const int qq = e / DH, dl = e - qq * DH, d = hv * DH + dl;
+                float mm = sm_m[0][qq];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) mm = fmaxf(mm, sm_m[w][qq]);
+                // sum over the waves in wave order (for NW = 4 the very expression of round 2: ((a0 w0 + a1 w1) + a2 w2) + a3 w3)
+                float o = 0.f, lw = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const float ww = __expf(sm_m[w][qq] - mm);
+                    o = (w == 0) ? sm_o[w][qq][dl] * ww : o + sm_o[w][qq][dl] * ww;
+                    lw = (w == 0) ? sm_l[w][qq] * ww : lw + sm_l[w][qq] * ww;
                 }
-            } else {                                   // one-launch form: write-through (sc1) stores, see below
-                st_agent(&ws_o[(pbase + qt * 16 + qq) * D + d], o);
-                if (d == 0) {
-                    st_agent(&ws_m[pbase + qt * 16 + qq], mm);
-                    st_agent(&ws_l[pbase + qt * 16 + qq], lw);
+                if (tickets == nullptr) {
+                    ws_o[(pbase + qt * 16 + qq) * D + d] = o;
+                    if (d == 0) {
+                        ws_m[pbase + qt * 16 + qq] = mm;
+                        ws_l[pbase + qt * 16 + qq] = lw;
+                    }
+                } else {                                   // one-launch form: write-through (sc1) stores, see below
+                    st_agent(&ws_o[(pbase + qt * 16 + qq) * D + d], o);
+                    if (d == 0) {
+                        st_agent(&ws_m[pbase + qt * 16 + qq], mm);
+                        st_agent(&ws_l[pbase + qt * 16 + qq], lw);
+                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (tickets == nullptr) return;                    // two-launch form: attn_combine_kernel merges the splits
 
@@ -427,7 +439,7 @@ __device__ __forceinline__ void attn_split_body(
     // nsplit <= FUSED_MERGE_MAX_SPLITS (host-checked): every load of an output element is issued up front — one memory
     // latency — and each split is its own accumulation chain of attn_combine_kernel
     const int64_t hbase = (int64_t)h * nsplit * QR;
-    for (int e = tid; e < sq * (D / 4); e += 256) {
+    for (int e = tid; e < sq * (D / 4); e += 64 * NW) {
         const int r = e / (D / 4), d4 = e - r * (D / 4);
         float pm[FUSED_MERGE_MAX_SPLITS], pl[FUSED_MERGE_MAX_SPLITS];
         f32x4 px[FUSED_MERGE_MAX_SPLITS];
@@ -488,13 +500,18 @@ __global__ __launch_bounds__(256, 1) void attn_split_deep_kernel(
 #endif
 
 // The two-q-tile form compiled for TF_ATTN_QT2_OCC waves per SIMD (see the note at the top of the file).
+// TF_ATTN_Q2_WAVES: waves per workgroup of the two-q-tile form (4 = round 2; 8 = two waves per SIMD at the one-workgroup-
+// per-CU grid, so one wave's softmax / MFMA work runs under the other's loads)
+#ifndef TF_ATTN_Q2_WAVES
+#define TF_ATTN_Q2_WAVES 4
+#endif
 #if TF_ATTN_QT2_OCC > 0
 template <int D>
-__global__ __launch_bounds__(256, TF_ATTN_QT2_OCC) void attn_split_q2_kernel(
+__global__ __launch_bounds__(64 * TF_ATTN_Q2_WAVES, TF_ATTN_Q2_WAVES == 8 ? 2 : TF_ATTN_QT2_OCC) void attn_split_q2_kernel(
     const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
     int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
     float* __restrict__ ws, unsigned* __restrict__ tickets, h16* __restrict__ out) {
-    attn_split_body<D, 2>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws, tickets, out);
+    attn_split_body<D, 2, 0, TF_ATTN_Q2_WAVES>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws, tickets, out);
 }
 #endif
 
@@ -1729,7 +1746,7 @@ static int launch_attn(const void* q, const void* k, const void* v, void* out, i
 #endif
 #if TF_ATTN_QT2_OCC > 0
     if constexpr (QT == 2)
-        hipLaunchKernelGGL((attn_split_q2_kernel<D>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
+        hipLaunchKernelGGL((attn_split_q2_kernel<D>), grid, dim3(64 * TF_ATTN_Q2_WAVES), 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
                            stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, (h16*)out);
     else
 #endif
