@@ -493,3 +493,29 @@ def test_static_verify_rows_equal_per_step_copies_and_lifetime_is_guarded():
     assert bufs.rows_generation == ge.verify_generation() > gen0
     ge.graph_verify(bufs.verify_tokens, bufs.positions, clone=False)           # the stray replay
     assert ge.verify_generation() != bufs.rows_generation   # ... is what TriForceRunner.step's assert compares
+
+
+def test_draft_prefill_graph_equals_eager(monkeypatch):
+    """The 68M draft's prompt pass replays ONE captured steady-state step (shift the StreamingLLM window by 64 rows, run 64
+    rows) per full chunk once the window is full; the result must equal the all-eager pass bit for bit: returned logits,
+    draft cache contents, cache length — including a ragged last chunk and a second prompt through the cached graph."""
+    g = Hh.load_golden("cfg1_greedy")
+    ge = Hh.build_product(g, DEV, graphs=False)
+    eng = ge.engine
+    prompt = Hh.prompt_of(g).to(DEV)
+    vocab = g["dcfg"]["vocab_size"]
+    other = torch.randint(3, vocab, (1, 1500 + 37), generator=torch.Generator().manual_seed(4)).to(DEV)
+    results = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TRIFORCE_DRAFT_PREFILL_GRAPH", mode)
+        outs = []
+        for ids in (prompt, other, prompt[:, :1000]):                 # 1000 = 15 full chunks + 40: below the graph threshold
+            eng.draft_cache.reset()
+            eng.draft_cache.seq_len = 0
+            lg = ge.graph_draft_prefill(input_ids=ids)
+            torch.cuda.synchronize()
+            outs.append((lg.clone(), eng.draft_cache.k.clone(), eng.draft_cache.v.clone(), eng.draft_cache.seq_len))
+        results[mode] = outs
+    assert getattr(eng, "_dpf_graph", None) is not None and eng._dpf_graph[1] is not None, "the steady step was not captured"
+    for (la, ka, va, sa), (lb, kb, vb, sb) in zip(results["0"], results["1"]):
+        assert sa == sb and torch.equal(la, lb) and torch.equal(ka, kb) and torch.equal(va, vb)

@@ -729,3 +729,37 @@ def test_row_copy_wrappers_refuse_out_of_range_rows():
         ops.kv_gather_rows(src, src.clone(), 10, idx, max_index=6)   # source row 16 does not exist
     with pytest.raises(IndexError):
         ops.kv_gather_rows(src, src.clone(), 14, idx)                # destination rows 14..16
+
+
+def test_attn_fused_merge_never_folds_stale_partials_under_uneven_load(monkeypatch):
+    """The one-launch split merge hands partials from 8 workgroups (on 8 XCDs) to the last arriver through write-through
+    stores, a drained store queue (s_waitcnt vmcnt(0)) and a ticket.  Round 2 shipped it without the drain — a narrow
+    window in which the last arriver could fold the PREVIOUS launch's partials.  Stress: 600 back-to-back launches whose
+    query changes every launch (stale partials would show), with a bandwidth hog running on a second stream so that the
+    workgroups of a head finish at uneven times; every output must equal the two-launch form bit for bit."""
+    ops = _ops()
+    sq, sk, H, D = 7, 4103, 32, 128
+    scale = R.softmax_scale_for(D)
+    g = torch.Generator(device=DEV).manual_seed(77)
+    k = torch.randn(H, sk, D, generator=g, device=DEV, dtype=torch.float16)
+    v = torch.randn(H, sk, D, generator=g, device=DEV, dtype=torch.float16)
+    qs = torch.randn(12, sq, H, D, generator=g, device=DEV, dtype=torch.float16)
+    monkeypatch.setattr(ops, "ATTN_FUSED_MERGE", False)
+    want = [ops.attn_decode(qs[i], k, v, sk, scale).clone() for i in range(qs.shape[0])]
+    monkeypatch.setattr(ops, "ATTN_FUSED_MERGE", True)
+    hog_src = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+    hog_dst = torch.empty_like(hog_src)
+    side = torch.cuda.Stream()
+    outs = []
+    for it in range(600):
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                hog_dst.copy_(hog_src)                      # 512 MB of HBM traffic overlapping the next launches
+        outs.append(ops.attn_decode(qs[it % qs.shape[0]], k, v, sk, scale))
+        if len(outs) == 60:
+            torch.cuda.synchronize()
+            for j, o in enumerate(outs):
+                i = (it - 59 + j) % qs.shape[0]
+                assert torch.equal(o, want[i]), f"launch {it - 59 + j}: one-launch merge differs from the two-launch form"
+            outs = []
+    torch.cuda.synchronize()

@@ -58,10 +58,7 @@ class InferenceEngine:
     def draft_run(self, input_ids: torch.LongTensor, gamma_offset: int = 0, probs=False, temperature=0.6, top_p=0.9):
         n = input_ids.shape[-1]
         if n > 64:                                 # draft prefill, 64 tokens per forward with eviction (:44-52)
-            for i in range(math.ceil(n / 64)):
-                self.draft_cache.evict_prefill(64)
-                logits = self.draft(input_ids=input_ids[:, i * 64:(i + 1) * 64], kv_cache=self.draft_cache,
-                                    graph_cache=None).logits
+            logits = self._draft_prefill(input_ids)
         else:
             # only the last row is used (graph_infer.py:57); rows are independent, so just that one is normalised —
             # inside the same native call when the draft runs through tf_draft_forward_68m
@@ -71,6 +68,62 @@ class InferenceEngine:
         if probs:
             return norm_logits(logits[0, -1:], temperature=temperature, top_k=-1, top_p=top_p)[0]
         return logits
+
+    def _draft_prefill(self, input_ids):
+        """The 68M draft over the whole prompt, 64 tokens per forward with StreamingLLM eviction in front of each (reference
+        graph_infer.py:44-52).  Once the window is full every full chunk is the SAME launch sequence — shift the window down
+        by 64 rows, run 64 rows at slot start + recent - 64 — so on the device that step is captured once as a hipGraph and
+        replayed (a 124 928-token prompt is 1 952 chunks of ~25 short launches each; eager they are host-bound).  The
+        warm-up / capture passes run on a snapshot of the (1.6 MB) draft cache, which is restored afterwards; the ragged
+        last chunk and the chunks that fill the window run eagerly.  TRIFORCE_DRAFT_PREFILL_GRAPH=0: all eager."""
+        dc, n = self.draft_cache, input_ids.shape[-1]
+        cap = dc.start_size + dc.recent_size
+        chunks, full = math.ceil(n / 64), n // 64
+        use_graph = (input_ids.is_cuda and full >= 16 and os.environ.get("TRIFORCE_DRAFT_PREFILL_GRAPH", "1") != "0"
+                     and not torch.cuda.is_current_stream_capturing())
+        logits = None
+        for i in range(chunks):
+            ids = input_ids[:, i * 64:(i + 1) * 64]
+            if use_graph and ids.shape[-1] == 64 and dc.seq_len == cap:
+                g = self._draft_prefill_graph(ids)
+                if g is not None:
+                    graph, ids_buf, logits = g
+                    ids_buf.copy_(ids)
+                    graph.replay()
+                    dc.seq_len = cap               # what evict_prefill + the forward leave behind on the host side
+                    continue
+                use_graph = False
+            dc.evict_prefill(64)
+            logits = self.draft(input_ids=ids, kv_cache=dc, graph_cache=None).logits
+        return logits
+
+    def _draft_prefill_graph(self, ids):
+        """(graph, static 64-token input, static logits) of one steady-state draft-prefill step over the CURRENT draft
+        cache and draft weights; captured at the first use, None if capture fails (the caller falls back to eager)."""
+        dc = self.draft_cache
+        key = (id(dc), dc.k.data_ptr(), id(self.draft))
+        cached = getattr(self, "_dpf_graph", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        cap = dc.start_size + dc.recent_size
+        snap = (dc.k.clone(), dc.v.clone(), dc.seq_len)
+        ids_buf = ids.clone()
+
+        def step():
+            dc.seq_len = cap                       # host-side state at the entry of every steady step
+            dc.evict_prefill(64)
+            return self.draft(input_ids=ids_buf, kv_cache=dc, graph_cache=None).logits
+
+        try:
+            graph, logits = _capture(step, (), None, 1)
+            out = (graph, ids_buf, logits)
+        except Exception:                          # capture unsupported for some op in this build: stay eager
+            out = None
+        dc.k.copy_(snap[0])
+        dc.v.copy_(snap[1])
+        dc.seq_len = snap[2]
+        self._dpf_graph = (key, out)
+        return out
 
     @torch.inference_mode()
     def model_verify(self, input_ids: torch.LongTensor, position_ids: Optional[torch.LongTensor] = None, probs=False,
