@@ -1,12 +1,13 @@
 """Generate tests/golden/*.pt by running the UNMODIFIED reference (/root/reference) on CPU.
 
 TEST INFRASTRUCTURE ONLY.  Run in the build container (the reference tree is absent on the
-GPU box):   python -m oracle.gen_golden [sequoia | sequoia2 | cli | tp | tp2 | offloading]      (no argument = everything)
+GPU box):   python -m oracle.gen_golden [sequoia | sequoia2 | cli | tp | tp2 | shards | offloading]   (no argument = everything)
 
   (default)   rope_tables, forward_small, cfg1_greedy, cfg1_stochastic, small_gamma6   on-chip path (test/on_chip.py)
   sequoia     sequoia_tree512, sequoia_small            SpecTree + TP_llama_tree (test/offloading_seqouia.py)
   tp          tp_chain                                  TP_llama + TriForce_Dist at world size 1 (test/offloading_TP.py)
   tp2         tp_world2, tp_world4                      the same engine as 2 / 4 gloo processes: shards + all-reduces
+  shards      tp_shards                                 TP_layers' own weight slicing for every rank of a 4- / 8-way split
   sequoia2    sequoia_world2                            the Sequoia loop as TWO gloo processes
   offloading  offloading_small                          OffloadingFlashSimpleCache (test/offloading.py)
   cli         cli_flags                                 the four scripts' command lines
@@ -807,6 +808,45 @@ def main():
                   temperature=1.0, top_p=1e-9, repeats=1)
 
 
+def shards_case(name="tp_shards"):
+    """The reference's own weight slicing (models/TP_layers.py:126-147, DistributedLlamaLayer.init_parameters) for EVERY
+    rank of a 4-way and an 8-way split of one seeded layer, next to oracle.specs.shard_of — the helper the 13B / TP = 8
+    shard-width GPU parity test builds its oracle from.  Recorded: per (world, rank) the seven shard tensors of the
+    reference as (shape, sha256 of the fp16 bytes) — the tensors are functions of (config, seed) and are rebuilt by the test.
+    Checked here: shard_of returns exactly those tensors."""
+    ref = _refshim.load_reference_tp()
+    TPL = ref.tp_layers if hasattr(ref, "tp_layers") else __import__("models.TP_layers", fromlist=["x"])
+    # 13B-like proportions, scaled down: 40 heads (D = 16), hidden 640, intermediate 1728 = 8 * 216
+    cfg = specs.llama_config(640, 1728, 1, 40, vocab_size=256, max_position_embeddings=4096,
+                             rope_scaling=dict(type="yarn", factor=8.0, original_max_position_embeddings=512),
+                             name="tiny-13b-proportions")
+    sd = specs.random_state_dict(cfg, 77)
+    hf = build_reference_model(ref, cfg, sd)
+    out = dict(cfg=cfg, seed=77, cases=[])
+    for world in (4, 8):
+        for rank in range(world):
+            dcfg = TPL.DistributedOffloadingConfig(hf.config, local_rank=rank, world_size=world)
+            layer = TPL.DistributedLlamaLayer(0, dcfg)
+            layer.init_parameters(hf.model.layers[0])
+            theirs = dict(q=layer.wq, k=layer.wk, v=layer.wv, o=layer.wo, gate=layer.gate_proj, up=layer.up_proj,
+                          down=layer.down_proj)
+            scfg, ssd = specs.shard_of(cfg, sd, rank, world)
+            pre = "model.layers.0."
+            ours = dict(q=ssd[pre + "self_attn.q_proj.weight"], k=ssd[pre + "self_attn.k_proj.weight"],
+                        v=ssd[pre + "self_attn.v_proj.weight"], o=ssd[pre + "self_attn.o_proj.weight"],
+                        gate=ssd[pre + "mlp.gate_proj.weight"], up=ssd[pre + "mlp.up_proj.weight"],
+                        down=ssd[pre + "mlp.down_proj.weight"])
+            for kname in theirs:
+                assert torch.equal(theirs[kname].cpu(), ours[kname]), (world, rank, kname)
+            assert scfg["num_attention_heads"] == 40 // world and scfg["intermediate_size"] == 1728 // world
+            out["cases"].append(dict(world=world, rank=rank,
+                                     shards={k: dict(shape=list(v.shape), sha256=specs.tensor_digest(v)) for k, v in theirs.items()}))
+    import json
+    with open(os.path.join(GOLDEN, f"{name}.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(f"[golden] {name}: {len(out['cases'])} (world, rank) shard sets written (digests); shard_of == reference slicing")
+
+
 def cli_case(name="cli_flags"):
     """The command lines of the reference's four entry scripts (flag -> type name, default), read from their
     `add_argument` calls with `ast` (the scripts cannot be imported: they run their benchmark at import time)."""
@@ -860,6 +900,8 @@ if __name__ == "__main__":
         torch.set_num_threads(8)
         tp_chain_case()
         tp_chain_case("tp_chain_gamma16", gamma=16, with_baselines=False)     # offloading_TP.py's README command
+    elif len(sys.argv) > 1 and sys.argv[1] == "shards":
+        shards_case()
     elif len(sys.argv) > 1 and sys.argv[1] == "tp2":
         os.makedirs(GOLDEN, exist_ok=True)
         tp_world2_case()

@@ -112,6 +112,12 @@ def shard_of(cfg, sd, rank, world):
     return scfg, out
 
 
+def tensor_digest(t):
+    """sha256 of a tensor's contiguous bytes (fixtures that pin large seeded tensors without storing them)."""
+    import hashlib
+    return hashlib.sha256(t.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
+
+
 def random_prompt(vocab_size, length, seed):
     g = torch.Generator(device="cpu").manual_seed(seed)
     return torch.randint(3, vocab_size, (1, length), generator=g, dtype=torch.long)

@@ -1,6 +1,8 @@
 """The CPU oracle (oracle/ref_ops.py, oracle/ref_model.py) against the golden fixtures that
 oracle/gen_golden.py recorded from the UNMODIFIED reference (tests/golden/*.pt).  This is what pins
 the oracle: the reference itself ships no golden vectors for this path."""
+import os
+
 import pytest
 import torch
 
@@ -131,3 +133,26 @@ def test_accept_chain_edge_cases():
     assert (c, nxt, reason, used) == (2, 2, 2, 2)                       # accepted eos stops the chain, no resample
     c, nxt, reason, used = R.accept_and_correct(p, q, [1, 3, 2], [0.1, 0.1, 0.1, 0.5], eos_token_id=2)
     assert (c, reason, used) == (3, 1, 4)                               # eos as the LAST token: bonus path still runs
+
+
+def test_shard_of_matches_the_reference_slicing_for_every_rank():
+    """tests/golden/tp_shards.json: digests of the shards the UNMODIFIED reference cut (TP_layers.py:126-147,
+    DistributedLlamaLayer.init_parameters) for every rank of a 4-way and an 8-way split of one seeded layer with the 13B's
+    proportions (40 heads, intermediate 1728 = 8 x 216).  oracle.specs.shard_of — the oracle side of the 13B / TP = 8
+    shard-width GPU parity test — must cut the very same tensors."""
+    import json
+    g = json.load(open(os.path.join(Hh.GOLDEN, "tp_shards.json")))
+    cfg = g["cfg"]
+    sd = specs.random_state_dict(cfg, g["seed"])
+    pre = "model.layers.0."
+    names = dict(q="self_attn.q_proj", k="self_attn.k_proj", v="self_attn.v_proj", o="self_attn.o_proj", gate="mlp.gate_proj",
+                 up="mlp.up_proj", down="mlp.down_proj")
+    assert len(g["cases"]) == 12
+    for case in g["cases"]:
+        scfg, ssd = specs.shard_of(cfg, sd, case["rank"], case["world"])
+        assert scfg["head_dim"] == cfg["hidden_size"] // cfg["num_attention_heads"]
+        for short, full in names.items():
+            t = ssd[pre + full + ".weight"]
+            want = case["shards"][short]
+            assert list(t.shape) == want["shape"], (case["world"], case["rank"], short)
+            assert specs.tensor_digest(t) == want["sha256"], (case["world"], case["rank"], short)
