@@ -461,8 +461,13 @@ def pmc_traffic(alg_bytes, H, D):
     PMC counters cannot be read from inside this process; the latest profiles/*pmc_attn*.json is used when it
     was measured on the same shape (H, D, key count within 0.1%), else traffic stays null."""
     import glob
+    import re
+
+    def order(path):        # r03a < r03b < ... < r03 (the un-suffixed file is the final measurement of a round)
+        m = re.match(r"r(\d+)([a-z]?)_", os.path.basename(path))
+        return (int(m.group(1)), m.group(2) or "~") if m else (-1, "")
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_attn*.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_attn*.json")), key=order):
         try:
             j = json.load(open(f))
         except Exception:
