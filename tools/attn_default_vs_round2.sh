@@ -1,5 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r3c; mkdir -p $O
+O=gpurun_out/attn_vs_r2; mkdir -p $O
 rm -f gpurun_out/parity_notes.txt
 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -5 $O/pytest.log
 cp gpurun_out/parity_notes.txt $O/parity_notes.txt

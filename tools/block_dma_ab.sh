@@ -1,6 +1,6 @@
 #!/bin/bash
-O=gpurun_out/r3h; mkdir -p $O
-for L in default dma1 dma2; do
+O=gpurun_out/block_dma; mkdir -p $O
+for L in default dma1 dma0; do
   LIB=$PWD/triforce_amd/lib/libtriforce_hip.so; [ $L != default ] && LIB=$PWD/triforce_amd/lib/libtriforce_hip_$L.so
   TRIFORCE_HIP_LIB=$LIB python - "$L" <<'PY'
 import json, os, sys, torch
@@ -35,4 +35,4 @@ res["block_checksum"] = float(ops.attn_block(q128, kvs[0][0], kvs[0][1], P, 0.08
 print(json.dumps(res), flush=True)
 PY
 done > $O/block_dma_ab.jsonl 2> $O/block_dma_ab.err; cat $O/block_dma_ab.jsonl; tail -2 $O/block_dma_ab.err
-TRIFORCE_HIP_LIB=$PWD/triforce_amd/lib/libtriforce_hip_dma2.so python -m pytest tests/test_gpu_ops.py tests/test_gpu_sequoia.py -q -k "prefill or block or tree or sequoia or Sequoia" > $O/pytest_dma2.log 2>&1; echo "pytest dma2 rc=$?"; tail -3 $O/pytest_dma2.log
+TRIFORCE_HIP_LIB=$PWD/triforce_amd/lib/libtriforce_hip_dma0.so python -m pytest tests/test_gpu_ops.py tests/test_gpu_sequoia.py -q -k "prefill or block or tree or sequoia or Sequoia" > $O/pytest_dma0.log 2>&1; echo "pytest dma0 rc=$?"; tail -3 $O/pytest_dma0.log
