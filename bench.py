@@ -492,7 +492,8 @@ def attn_roofline(timer, retrieval_rows, H, D):
     dur = sum(d for d, _ in full) / len(full)
     byts = sum(2 * sk * H * D * 2 for _, sk in full) / len(full)
     achieved = byts / dur / 1e9
-    roof = {"bound": "hbm", "kernel": "attn_split_kernel<128,1> (split merge inside the launch) via tf_attn_decode_fused",
+    roof = {"bound": "hbm", "kernel": "attn_split_kernel<128,1> / attn_split_q2_kernel<128> above 16 rows (split merge inside "
+                                      "the launch) via tf_attn_decode_fused",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
             "launches": len(full), "launches_sampled_every": ops.ATTN_TIMER_EVERY,
