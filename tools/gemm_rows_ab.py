@@ -39,7 +39,7 @@ for model, hid, inter in (("7B", 4096, 11008), ("13B", 5120, 13824)):
         copies = max(2, int(700e6 // (N * K * 2)) + 1)
         pls = [ops.PackedLinear(torch.randn(N, K, device=DEV, dtype=torch.float16) * 0.02, split=split) for _ in range(copies)]
         row = {"model": model, "gemm": name, "N": N, "K": K, "MB": round(N * K * 2 / 1e6, 1)}
-        for M in (8, 17, 32):
+        for M in ([1, 4, 8, 16] if os.environ.get("GEMM_ROWS_SMALL") else [8, 17, 32]):
             x = torch.randn(M, K, device=DEV, dtype=torch.float16)
             if split == 2:
                 us = timeit([(lambda p=p: ops.mlp_act(x, p)) for p in pls])
