@@ -1,0 +1,64 @@
+"""The measurement tools that turn a rocprofv3 kernel trace into the tracked evidence (profiles/*by_stage*.json,
+*gap_analysis*.txt) on synthetic traces: the duration clustering must separate the split-KV kernel's target-verify and
+retrieval-verify launches (same name, same grid) and price them with the SURVEY 8(d) bytes; the gap analysis must window
+exactly N outer steps."""
+import csv
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIELDS = ["Kernel_Name", "Grid_Size_X", "Grid_Size_Y", "Start_Timestamp", "End_Timestamp"]
+
+
+def _write(path, rows):
+    with open(path, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=FIELDS)
+        w.writeheader()
+        for r in rows:
+            w.writerow(dict(zip(FIELDS, r)))
+
+
+def test_attn_by_grid_separates_and_prices_the_two_verify_stages(tmp_path):
+    name = "_Z17attn_split_kernelILi128ELi1EEvPKDF16_S1_S1_lliiPKiifiPfPjPDF16_"
+    rows, t = [], 0
+    for i in range(64):                                   # 64 target-verify launches ~340 us, 256 retrieval ~20 us
+        rows.append((name, 2048, 32, t, t + 340_000 + 1000 * (i % 7)))
+        t += 400_000
+        for j in range(4):
+            rows.append((name, 2048, 32, t, t + 20_000 + 200 * j))
+            t += 30_000
+    rows.append((name, 2048, 32, t, t + 7_000))            # a lone short probe launch: merged into its neighbour cluster
+    rows.append(("_Z18skinny_gemm_kernelILi1ELi1ELb1ELi4EE", 176128, 1, t + 10_000, t + 42_000))
+    trace, out = tmp_path / "trace.csv", tmp_path / "out.json"
+    _write(trace, rows)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "attn_by_grid.py"), str(trace), str(out), "synthetic",
+                    "--keys-target", "124936", "--keys-retrieval", "4103"], check=True, capture_output=True)
+    res = json.load(open(out))
+    stages = {r["stage"]: r for r in res["rows"] if "stage" in r}
+    tv = stages["target verify / autoregressive step (full KV)"]
+    rv = stages["retrieval verify (retrieval cache)"]
+    assert tv["calls"] == 64 and rv["calls"] == 257
+    assert tv["algorithmic_bytes_per_launch"] == 2 * 124936 * 32 * 128 * 2
+    assert abs(tv["achieved_GBps"] - tv["algorithmic_bytes_per_launch"] / (tv["avg_us"] * 1e-6) / 1e9) < 0.1
+    assert 0.70 < tv["frac_of_hbm_peak"] < 0.78 and 0.38 < rv["frac_of_hbm_peak"] < 0.45
+
+
+def test_gap_analysis_windows_exactly_n_outer_steps(tmp_path):
+    rows, t = [], 0
+    for step in range(6):                                  # each outer step: busy 10 ms, one 50 us idle gap, then the accept
+        rows.append(("verify_kernel", 1, 1, t, t + 10_000_000))
+        t += 10_000_000 + 50_000
+        rows.append(("accept_chain_kernel(float const*)", 1, 1, t, t + 10_000))
+        t += 10_000
+    rows.append(("probe_kernel", 1, 1, t + 5_000_000, t + 6_000_000))   # trailing probes without accept_chain launches
+    trace = tmp_path / "trace.csv"
+    _write(trace, rows)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gap_analysis.py"), str(trace), "--steps", "4"],
+                         check=True, capture_output=True, text=True).stdout
+    assert "window = 4 outer steps" in out
+    first = [ln for ln in out.splitlines() if ln.startswith("window ") and "ms:" in ln][0]
+    span_ms = float(first.split()[1])
+    assert abs(span_ms - 4 * 10.06) < 0.05, first          # 4 x (10 ms + 50 us + 10 us), the trailing probe excluded
+    assert "idle 0.20 ms" in first, first
