@@ -281,7 +281,9 @@ def run_tp(args, rank, world, local):
             "acceptance_rate": round(accepted / max(drafted, 1), 4), "tokens": tokens,
             "tokens_per_step": round(tokens / args.steps, 3), "prefill_seconds": round(t_prefill, 2),
             "kv_seq_len": llm.kv_cache.seq_len, "graph_form": getattr(llm, "graph_form", "eager"),
-            "decode_allreduce": "one-shot peer reads (tf_allreduce_oneshot)" if getattr(llm, "_ar", None) is not None
+            "decode_allreduce": ("one-shot peer reads (tf_allreduce_oneshot_alt, alternating staging halves)"
+                                 if getattr(getattr(llm, "_ar", None), "alternate", False) else
+                                 "one-shot peer reads (tf_allreduce_oneshot)") if getattr(llm, "_ar", None) is not None
             else ("rccl" if world > 1 else "none (one rank)"),
             "ranks_share_one_device": bool(share), "allreduce_error": int(ar_err),
             "allreduce_requested": getattr(args, "allreduce", "auto"),

@@ -344,6 +344,15 @@ int tf_allreduce_oneshot_add(void* const* peer_data, void* const* peer_flags, in
  * (tensor_op.py:52-64 after :179 / :359) then runs in the prologue of the next GEMM without re-reading the rows. */
 int tf_allreduce_oneshot_add_ss(void* const* peer_data, void* const* peer_flags, int rank, int world, const void* resid,
                                 void* out, int64_t n, int hidden, float* ss_out, void* stream);
+/* Alternating form: every staging buffer holds 2 * half_elems values and exchange e (the control block's epoch, 1 for
+ * the first exchange after tf_ar_alloc) uses the half e & 1, which removes the closing DONE handshake: a rank cannot
+ * overwrite a half before every peer has signalled READY for the exchange in between (csrc/allreduce.hip header).
+ * `expect_half` = the half this rank's producer wrote; if the epoch selects the other one the call fills `out` with NaN
+ * and sets the sticky error 3.  resid and ss_out may be NULL (hidden is read only with ss_out).  One form per control
+ * block for its lifetime, the same on every rank. */
+int tf_allreduce_oneshot_alt(void* const* peer_data, void* const* peer_flags, int rank, int world, const void* resid,
+                             void* out, int64_t n, int hidden, float* ss_out, int64_t half_elems, int expect_half,
+                             void* stream);
 int tf_ar_error(const void* flags_local);
 /* Fault injection for tests: sets (code > 0) or clears (0) the sticky error word of a control block from the host. */
 int tf_ar_inject_error(void* flags_local, int code);

@@ -180,8 +180,23 @@ def test_single_gpu_offloading_cache_equals_resident_cache():
     assert ar_off == ar_res
 
 
+_RANK_STREAMS = []
+
+
+def _rank_streams(world):
+    """One stream per virtual rank, the SAME ones for every test of this process.  The kernels of the virtual ranks wait
+    for each other, so they must be resident together, which needs their streams on different hardware queues; the
+    runtime multiplexes streams over a handful of those, and a second pair of fresh streams has been seen to share one
+    (rank 1's kernel then starts only after rank 0's READY wait has timed out).  An artefact of several ranks on one
+    device — a production rank has its device to itself."""
+    while len(_RANK_STREAMS) < world:
+        _RANK_STREAMS.append(torch.cuda.Stream(device=DEV))
+    return _RANK_STREAMS[:world]
+
+
+@pytest.mark.parametrize("alternate", [False, True], ids=["done-handshake", "alternating-halves"])
 @pytest.mark.parametrize("world", [2, 4])      # one device runs 4 streams concurrently (hardware queues); 8 would serialise
-def test_oneshot_allreduce_protocol_on_one_device(world):
+def test_oneshot_allreduce_protocol_on_one_device(world, alternate):
     """tf_allreduce_oneshot with `world` virtual ranks inside this process — each rank's kernel on its own stream, real
     READY / DONE flag exchange between concurrently running kernels, fine-grained staging buffers — against the
     arithmetic it promises: fp32 accumulation in rank order, one rounding, bit-identical on every rank (at world 2 that
@@ -189,11 +204,11 @@ def test_oneshot_allreduce_protocol_on_one_device(world):
     no wait may ever time out."""
     from triforce_amd.utils.oneshot_ar import OneShotAllReduce, reference_sum
     hidden, max_rows = 4096, 32
-    group = OneShotAllReduce.local_group(world, DEV, max_rows * hidden)
-    streams = [torch.cuda.Stream(device=DEV) for _ in range(world)]
+    group = OneShotAllReduce.local_group(world, DEV, max_rows * hidden, alternate=alternate)
+    streams = _rank_streams(world)
     gen = torch.Generator(device=DEV).manual_seed(world)
     try:
-        for it, rows in enumerate([1, 7, 8, 17, 18, 32, 7, 7, 18, 1] * 3):
+        for it, rows in enumerate([1, 7, 8, 17, 18, 32, 7, 7, 18, 1] * 3):      # three exchanges per trip: odd and even epochs
             parts = [torch.randn(rows, hidden, generator=gen, device=DEV).to(torch.float16) for _ in range(world)]
             outs = [torch.empty(rows, hidden, dtype=torch.float16, device=DEV) for _ in range(world)]
             torch.cuda.synchronize()
@@ -205,7 +220,9 @@ def test_oneshot_allreduce_protocol_on_one_device(world):
             torch.cuda.synchronize()
             want = reference_sum(parts)
             for r in range(world):
-                assert torch.equal(outs[r], want), f"epoch {it}, rank {r}: max err {(outs[r].float() - want.float()).abs().max()}"
+                assert torch.equal(outs[r], want), (f"epoch {it}, rank {r}: max err "
+                                                    f"{(outs[r].float() - want.float()).abs().max()}, error words "
+                                                    f"{[g.error() for g in group]}")
             if world == 2:
                 assert torch.equal(want, parts[0] + parts[1])       # one correctly rounded fp16 addition == the ring's
             # residual form: x = x + all_reduce(partials) in the same launch, x updated in place on every rank
@@ -245,7 +262,52 @@ def test_oneshot_allreduce_protocol_on_one_device(world):
             g.close()
 
 
-def _ipc_worker(rank, world, port, q):
+@pytest.mark.parametrize("world", [2, 4])
+def test_oneshot_allreduce_alternating_halves_back_to_back_with_skewed_ranks(world):
+    """What the alternating form must survive without its DONE handshake: exchanges issued back to back with no host
+    synchronisation in between, fresh data every time, and the ranks out of step — each trip delays a different rank's
+    stream before its producer, so the others run ahead as far as the protocol lets them (one exchange).  A rank that
+    overwrote a half a slower peer was still reading would show up as a wrong sum on that peer."""
+    from triforce_amd.utils.oneshot_ar import OneShotAllReduce, reference_sum
+    hidden, rows, trips = 4096, 18, 120
+    group = OneShotAllReduce.local_group(world, DEV, 32 * hidden, alternate=True)
+    streams = _rank_streams(world)
+    gen = torch.Generator(device=DEV).manual_seed(7 * world)
+    parts = torch.randn(trips, world, rows, hidden, generator=gen, device=DEV).to(torch.float16)
+    outs = torch.zeros(trips, world, rows, hidden, dtype=torch.float16, device=DEV)
+    torch.cuda.synchronize()
+    try:
+        for t in range(trips):
+            for r in range(world):
+                with torch.cuda.stream(streams[r]):
+                    if t % world == r and t % 3 != 2:
+                        torch.cuda._sleep(200_000)                   # ~0.1 ms: this rank falls behind its peers
+                    st = group[r].staging(rows, hidden)
+                    st.copy_(parts[t, r])
+                    group[r].reduce(st, outs[t, r])
+        torch.cuda.synchronize()
+        assert [g.error() for g in group] == [0] * world
+        for t in range(trips):
+            want = reference_sum([parts[t, r] for r in range(world)])
+            for r in range(world):
+                assert torch.equal(outs[t, r], want), f"trip {t}, rank {r}"
+        # the guard: a producer that staged into the other half than the epoch selects is an error, never a silent race
+        g0 = group[0]
+        g0._issued += 1                                              # host count out of step with the device epoch
+        out = torch.zeros(rows, hidden, dtype=torch.float16, device=DEV)
+        st = g0.staging(rows, hidden)
+        st.copy_(parts[0, 0])
+        g0.reduce(st, out)
+        torch.cuda.synchronize()
+        assert g0.error() == 3 and bool(torch.isnan(out).all())
+        with pytest.raises(RuntimeError, match="staging half"):
+            g0.check("test")
+    finally:
+        for g in group:
+            g.close()
+
+
+def _ipc_worker(rank, world, port, q, alternate=False):
     """One rank of a 2-process group that shares ONE device: gloo carries the handle exchange and the reference
     collective, hipIpc maps the peers' fine-grained staging / control buffers, the one-shot kernels of the two processes
     talk to each other through those mappings."""
@@ -261,7 +323,7 @@ def _ipc_worker(rank, world, port, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from triforce_amd.utils.oneshot_ar import OneShotAllReduce, reference_sum
         hidden = 4096
-        ar = OneShotAllReduce(rank, world, "cuda:0", 32 * hidden)          # collective: exchanges the IPC handles
+        ar = OneShotAllReduce(rank, world, "cuda:0", 32 * hidden, alternate=alternate)   # collective: exchanges the IPC handles
         gen = torch.Generator(device="cuda:0").manual_seed(100 + rank)
         ok, worst = True, 0.0
         for it, rows in enumerate([1, 7, 18, 32, 8, 7] * 4):
@@ -283,7 +345,8 @@ def _ipc_worker(rank, world, port, q):
         q.put((rank, "error", traceback.format_exc()))
 
 
-def test_oneshot_allreduce_across_two_processes_through_hipipc():
+@pytest.mark.parametrize("alternate", [False, True], ids=["done-handshake", "alternating-halves"])
+def test_oneshot_allreduce_across_two_processes_through_hipipc(alternate):
     """The part the one-device protocol test cannot reach: two PROCESSES (the production arrangement, one per rank), the
     staging and control buffers exported with hipIpcGetMemHandle and mapped by the peer, flags and partials crossing the
     process boundary.  Both ranks sit on this box's single GPU (RCCL refuses two ranks on one device, so gloo carries
@@ -296,7 +359,7 @@ def test_oneshot_allreduce_across_two_processes_through_hipipc():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = [ctx.Process(target=_ipc_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_ipc_worker, args=(r, 2, port, q, alternate)) for r in range(2)]
     for p in procs:
         p.start()
     outs = []
@@ -315,7 +378,7 @@ def test_oneshot_allreduce_across_two_processes_through_hipipc():
         assert ok, f"rank {rank}: result differs from the collective by up to {worst}"
 
 
-def _tp2_worker(rank, world, port, q):
+def _tp2_worker(rank, world, port, q, alternate=False):
     """One rank of the tensor-parallel engine at world size 2 with BOTH ranks on this box's single GPU: real kernels on
     each rank's head / MLP-column shard, the decode-sized all-reduces through the one-shot kernel over hipIpc mappings
     (the production path), prefill-sized ones and the token broadcast through gloo."""
@@ -326,7 +389,7 @@ def _tp2_worker(rank, world, port, q):
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         sys.path.insert(0, root)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                          LOCAL_RANK="0")
+                          LOCAL_RANK="0", TRIFORCE_AR_ALTERNATE="1" if alternate else "0")
         import torch.distributed as dist
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -345,7 +408,7 @@ def _tp2_worker(rank, world, port, q):
                                retrieval_budget=g["budget"], retrieval_chunk_size=g["chunk"], kv_offload=True,
                                on_chip_layers=tcfg.num_hidden_layers, gamma=gamma)
         llm.init_parameters(specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g["head_std"]))
-        out["oneshot_stage"] = llm._ar is not None
+        out["oneshot_stage"] = llm._ar is not None and llm._ar.alternate == alternate
         prompt = Hh.prompt_of(g).to(DEV)
         llm.reset()
         lp = llm.prefill(prompt[:, :-1])[:, -1]
@@ -383,7 +446,8 @@ def _tp2_worker(rank, world, port, q):
         q.put((rank, "error", traceback.format_exc()))
 
 
-def test_tp_world2_on_one_device_real_kernels_and_oneshot_allreduce():
+@pytest.mark.parametrize("alternate", [False, True], ids=["done-handshake", "alternating-halves"])
+def test_tp_world2_on_one_device_real_kernels_and_oneshot_allreduce(alternate):
     """World size 2 on hardware, as far as a 1-GPU box allows: two processes, each with its own shard of the heads and
     of the MLP columns, running the real kernels on the same device; every decode-sized all-reduce is the one-shot
     kernel across the process boundary.  (1) the four forward stages equal the logits the UNMODIFIED reference engine
@@ -396,7 +460,7 @@ def test_tp_world2_on_one_device_real_kernels_and_oneshot_allreduce():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = [ctx.Process(target=_tp2_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_tp2_worker, args=(r, 2, port, q, alternate)) for r in range(2)]
     for p in procs:
         p.start()
     outs = {}

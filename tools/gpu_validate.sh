@@ -13,10 +13,12 @@ if [ "$1" = "tp" ]; then
   python bench.py --gpus $N --steps 20 --warmup 5 --allreduce oneshot --require-graph-form whole > $O/bench_tp${N}_oneshot.json 2> $O/bench_tp${N}_oneshot.err || rc=1
   # (2) the same run over RCCL, for the A/B
   python bench.py --gpus $N --steps 20 --warmup 5 --allreduce rccl > $O/bench_tp${N}_rccl.json 2> $O/bench_tp${N}_rccl.err || rc=1
-  python - "$N" $O/bench_tp${N}_oneshot.json $O/bench_tp${N}_rccl.json <<'PY' || rc=1
+  # (3) the one-shot exchange with alternating staging halves (no DONE handshake) — opt-in until it has a multi-GPU number
+  TRIFORCE_AR_ALTERNATE=1 python bench.py --gpus $N --steps 20 --warmup 5 --allreduce oneshot --require-graph-form whole > $O/bench_tp${N}_oneshot_alt.json 2> $O/bench_tp${N}_oneshot_alt.err || rc=1
+  python - "$N" $O/bench_tp${N}_oneshot.json $O/bench_tp${N}_rccl.json $O/bench_tp${N}_oneshot_alt.json <<'PY' || rc=1
 import json, sys
 n, bad = int(sys.argv[1]), []
-for path, want in ((sys.argv[2], "one-shot"), (sys.argv[3], "rccl")):
+for path, want in ((sys.argv[2], "one-shot"), (sys.argv[3], "rccl"), (sys.argv[4], "one-shot")):
     try:
         j = json.loads([l for l in open(path) if l.startswith("{")][-1])
     except Exception as e:

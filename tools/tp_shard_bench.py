@@ -44,6 +44,8 @@ def main():
                          "exchange step is launched like on a W-rank job and the fused decode layer (which needs it for "
                          "the sum-of-squares hand-off) is the one measured; without it exchanges are no-ops and the "
                          "layer is the un-fused one")
+    ap.add_argument("--alternate", action="store_true",
+                    help="with --local-exchange: the alternating-halves form of the exchange (tf_allreduce_oneshot_alt)")
     args = ap.parse_args()
     from triforce_amd.models import zoo
     from triforce_amd.models.cache import StreamingLLMEvictionCache
@@ -66,7 +68,8 @@ def main():
     llm.init_parameters("random:1")
     if args.local_exchange and W > 1:
         from triforce_amd.utils.oneshot_ar import OneShotAllReduce
-        llm._ar = OneShotAllReduce.local_group(1, dev, llm.ONESHOT_MAX_ROWS * llm.hidden_size)[0]
+        llm._ar = OneShotAllReduce.local_group(1, dev, llm.ONESHOT_MAX_ROWS * llm.hidden_size,
+                                               alternate=args.alternate)[0]
     llm.initialize_graphs(g)
     gen = torch.Generator(device=dev).manual_seed(3)
     for t in (llm.kv_cache.k, llm.kv_cache.v, llm.retrieval_cache.k, llm.retrieval_cache.v, dcache.k, dcache.v):
@@ -86,7 +89,8 @@ def main():
         llm.kv_cache.seq_len = S
     Hl, D, L = tcfg.num_attention_heads // W, tcfg.head_dim, tcfg.num_hidden_layers
     out = {"target": args.target, "emulated_world": W, "heads_per_rank": Hl, "layers": L, "prefill": S, "budget": args.budget,
-           "gamma": g, "graph_form": llm.graph_form, "exchange": "one-rank one-shot kernel" if llm._ar is not None else "no-op",
+           "gamma": g, "graph_form": llm.graph_form, "exchange": ("one-rank one-shot kernel" + (", alternating halves" if args.alternate else ""))
+           if llm._ar is not None else "no-op",
            "decode_layer": "fused (8 launches)" if llm._fused_decode(g + 1) else "un-fused (11 launches)",
            "draft_step_us": round(timed(lambda: llm.draft_run(ids[:, :3], gamma_offset=2)), 1),
            "retrieval_verify_us": round(timed(lambda: llm.retrieval_verify(ids[:, :g + 1], pos)), 1),

@@ -11,6 +11,14 @@
 //   phase DONE     -> the last workgroup tells every peer "I have read your partial", waits for all peers' DONE:
 //                     when the kernel ends the staging buffer may be overwritten by the next producer
 //
+// Alternating form (tf_allreduce_oneshot_alt, half_elems > 0): the staging buffer has two halves and exchange e uses
+// half e & 1, which makes DONE unnecessary.  Rank B overwrites half e & 1 next when it produces the partial of exchange
+// e + 2, i.e. after its kernel e + 1 ended; that kernel got past READY only once every peer A had signalled e + 1, which A
+// does at the start of ITS kernel e + 1 — stream-ordered after A's kernel e, whose reads of B's half e & 1 are therefore
+// over.  No rank can run more than one exchange ahead of another, so two halves suffice.  The half is taken from the
+// device epoch (replays of a captured launch stay correct); the host, which had to point the producer at that half,
+// passes the half it assumed and a disagreement is a sticky error (3) with NaN output, never a silent race.
+//
 // Every rank adds the same values in the same order, so all ranks hold bit-identical results (the reference's NCCL
 // ring gives each rank the same bits too, with a different — sequential fp16 — rounding order; at world size 2 the two
 // are identical: one correctly rounded fp16 addition).  The epoch lives in device memory and is advanced by the kernel
@@ -33,7 +41,8 @@ struct ArFlags {
     unsigned done[AR_MAX_WORLD];      // done[p]  = last epoch whose reads of MY staging peer p finished (written by p)
     unsigned epoch;                   // completed all-reduces on this rank (owner only)
     unsigned ticket;                  // workgroups of the running launch that finished reducing (owner only)
-    unsigned error;                   // sticky: 1 = READY wait timed out, 2 = DONE wait timed out
+    unsigned error;                   // sticky: 1 = READY wait timed out, 2 = DONE wait timed out, 3 = the producer
+                                      //         staged into the other half than the epoch selects (alternating form)
     unsigned pad[13];
 };
 
@@ -69,7 +78,8 @@ __device__ __forceinline__ void ar_poison(h16* out, int64_t n_vec8) {
 }
 
 __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c, const h16* resid, h16* out, int64_t n_vec8,
-                                                                        float* ss_out, int hidden) {
+                                                                        float* ss_out, int hidden, int64_t half_elems,
+                                                                        int expect_half) {
     __shared__ unsigned s_epoch;
     __shared__ int s_ok;
     const int tid = threadIdx.x;
@@ -84,6 +94,12 @@ __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c,
         return;
     }
     const unsigned epoch = s_epoch;
+    const int64_t base = half_elems * (int64_t)(epoch & 1u);       // alternating form: exchange e lives in half e & 1
+    if (half_elems > 0 && (int)(epoch & 1u) != expect_half) {      // (block-uniform) the producer wrote the other half
+        if (tid == 0) ar_store(&mine->error, 3u);
+        ar_poison(out, n_vec8);
+        return;
+    }
     // ---- READY: my partial was staged by the previous kernel in this stream ----
     if (blockIdx.x == 0 && tid < c.world) ar_store(&c.flags[tid]->ready[c.rank], epoch);
     if (tid < c.world && !ar_wait(&mine->ready[tid], epoch)) {
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c,
             half8 v[AR_MAX_WORLD];
 #pragma unroll
             for (int r = 0; r < AR_MAX_WORLD; ++r)
-                if (r < c.world) v[r] = *reinterpret_cast<const half8*>(c.data[r] + 8 * i);
+                if (r < c.world) v[r] = *reinterpret_cast<const half8*>(c.data[r] + base + 8 * i);
 #pragma unroll
             for (int r = 0; r < AR_MAX_WORLD; ++r)
                 if (r < c.world) {
@@ -144,9 +160,11 @@ __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c,
     }
     __syncthreads();
     if (!s_last) return;
-    if (tid < c.world) ar_store(&c.flags[tid]->done[c.rank], epoch);
-    if (tid < c.world && !ar_wait(&mine->done[tid], epoch)) ar_store(&mine->error, 2u);
-    __syncthreads();
+    if (half_elems == 0) {                           // single staging buffer: nobody may leave before every peer has read
+        if (tid < c.world) ar_store(&c.flags[tid]->done[c.rank], epoch);
+        if (tid < c.world && !ar_wait(&mine->done[tid], epoch)) ar_store(&mine->error, 2u);
+        __syncthreads();
+    }
     if (tid == 0) {
         __hip_atomic_store(&mine->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ar_store(&mine->epoch, epoch);               // next launch (stream-ordered after this one) sees epoch + 1
@@ -206,7 +224,7 @@ extern "C" int tf_ar_close_ipc_handle(void* ptr) {
 // `hidden_states = residual + all_reduce(o)` of tensor_op.py:179-181,359-360 in the same launch.  resid may equal out
 // (in-place residual stream); resid == NULL is the plain all-reduce.
 static int ar_launch(void* const* peer_data, void* const* peer_flags, int rank, int world, const void* resid, void* out,
-                     int64_t n, float* ss_out, int hidden, void* stream) {
+                     int64_t n, float* ss_out, int hidden, void* stream, int64_t half_elems = 0, int expect_half = 0) {
     if (!peer_data || !peer_flags || !out || world < 1 || world > AR_MAX_WORLD || rank < 0 || rank >= world) return TF_EINVAL;
     if (n < 8 || (n % 8)) return TF_EINVAL;
     if (ss_out && (hidden < 16 || (hidden % 16) || (n % hidden) || n / hidden > 32)) return TF_EINVAL;
@@ -217,13 +235,16 @@ static int ar_launch(void* const* peer_data, void* const* peer_flags, int rank, 
         if (r < world && (!c.data[r] || !c.flags[r])) return TF_EINVAL;
     }
     if ((const h16*)out == c.data[rank] || (const h16*)resid == c.data[rank]) return TF_EINVAL;
+    if (half_elems < 0 || (half_elems % 8) || (half_elems > 0 && (n > half_elems || (expect_half & ~1)))) return TF_EINVAL;
+    if (half_elems > 0 && ((const h16*)out == c.data[rank] + half_elems || (const h16*)resid == c.data[rank] + half_elems))
+        return TF_EINVAL;
     c.rank = rank;
     c.world = world;
     const int64_t n_vec8 = n / 8;
     int blocks = (int)((n_vec8 + AR_THREADS - 1) / AR_THREADS);
     if (blocks > 64) blocks = 64;                     // <= 64 workgroups: co-resident with anything, latency-bound anyway
     hipLaunchKernelGGL(allreduce_oneshot_kernel, dim3(blocks), dim3(AR_THREADS), 0, (hipStream_t)stream, c,
-                       (const h16*)resid, (h16*)out, n_vec8, ss_out, hidden);
+                       (const h16*)resid, (h16*)out, n_vec8, ss_out, hidden, half_elems, expect_half);
     TF_LAUNCH_CHECK();
     return TF_OK;
 }
@@ -242,6 +263,17 @@ extern "C" int tf_allreduce_oneshot_add_ss(void* const* peer_data, void* const* 
                                            void* stream) {
     if (!ss_out) return TF_EINVAL;
     return ar_launch(peer_data, peer_flags, rank, world, resid, out, n, ss_out, hidden, stream);
+}
+
+// Alternating form (see the header comment): every rank's staging buffer holds 2 * half_elems values and exchange e uses
+// the half e & 1 — no DONE phase.  `expect_half` is the half this rank's producer wrote (the caller counts its exchanges:
+// the first one after allocation uses half 1); resid and ss_out may be NULL.  All ranks must use the same form for
+// the lifetime of a control block.
+extern "C" int tf_allreduce_oneshot_alt(void* const* peer_data, void* const* peer_flags, int rank, int world,
+                                        const void* resid, void* out, int64_t n, int hidden, float* ss_out,
+                                        int64_t half_elems, int expect_half, void* stream) {
+    if (half_elems < 8) return TF_EINVAL;
+    return ar_launch(peer_data, peer_flags, rank, world, resid, out, n, ss_out, hidden, stream, half_elems, expect_half);
 }
 
 extern "C" int tf_allreduce_oneshot(void* const* peer_data, void* const* peer_flags, int rank, int world, void* out,

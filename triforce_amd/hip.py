@@ -60,6 +60,7 @@ SIGNATURES = {
     "tf_allreduce_oneshot": (_i32, [_vp, _vp, _i32, _i32, _vp, _i64, _vp]),
     "tf_allreduce_oneshot_add": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i64, _vp]),
     "tf_allreduce_oneshot_add_ss": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "tf_allreduce_oneshot_alt": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp]),
     "tf_ar_error": (_i32, [_vp]),
     "tf_ar_inject_error": (_i32, [_vp, _i32]),
 }

@@ -166,8 +166,10 @@ class DistributedLlama:
 
         def alloc():
             nonlocal ar
+            # TRIFORCE_AR_ALTERNATE=1: two staging halves used in turn, no DONE handshake (csrc/allreduce.hip); every
+            # forward of this engine issues an even number of exchanges (two per layer), which that form relies on
             ar = OneShotAllReduce(self.local_rank, self.world_size, self.device, self.ONESHOT_MAX_ROWS * self.hidden_size,
-                                  connect=False)
+                                  connect=False, alternate=os.environ.get("TRIFORCE_AR_ALTERNATE", "0") == "1")
 
         ok = stage(alloc, "allocation")
         # connect() always reaches its all-gather (a failed export contributes None), and raises afterwards
@@ -201,7 +203,8 @@ class DistributedLlama:
             ar.close()
         self.allreduce_note = "; ".join(why)
         if verbose or self.local_rank == 0:
-            print(f"[TP] decode all-reduce: {'one-shot peer reads (xGMI)' if ok else 'RCCL'}"
+            form = "one-shot peer reads (xGMI)" + (", alternating staging halves" if ok and ar.alternate else "")
+            print(f"[TP] decode all-reduce: {form if ok else 'RCCL'}"
                   + (f" ({self.allreduce_note})" if why else ""), flush=True)
         if not ok and forced == "oneshot":
             raise RuntimeError("TRIFORCE_ALLREDUCE=oneshot but the one-shot all-reduce is unavailable: "
@@ -242,7 +245,7 @@ class DistributedLlama:
                 dst.copy_(partial)
                 return dst
             return partial
-        if self._ar is not None and partial.data_ptr() == self._ar.data_ptr:
+        if self._ar is not None and self._ar.is_staged(partial):
             return self._ar.reduce(partial, torch.empty_like(partial) if dst is None else dst)
         self._all_reduce(partial)
         if dst is not None and dst.data_ptr() != partial.data_ptr():

@@ -6,6 +6,12 @@ Per rank: one fine-grained staging buffer + one control block, exported to the p
 through torch.distributed) and mapped once.  The producer GEMM writes this rank's partial straight into ``staging()``;
 ``reduce(staged, out)`` then runs the READY / reduce / DONE kernel on the current stream.  Results are bit-identical on
 every rank (same values, same order, fp32 accumulation, one rounding).
+
+``alternate=True`` (TRIFORCE_AR_ALTERNATE=1 through DistributedLlama) allocates two staging halves and uses them in
+turn (tf_allreduce_oneshot_alt): the closing DONE handshake — one more cross-device round trip per exchange — is not
+needed then.  ``staging()`` hands the producer the half the NEXT exchange will read; the kernel takes the half from
+its device-side epoch and a disagreement with the half passed here is a sticky error (3), so a captured forward must
+hold an even number of exchanges (the decode layer's two per layer do).
 """
 import ctypes
 
@@ -33,22 +39,26 @@ def reference_sum(partials, resid=None):
 
 
 class OneShotAllReduce:
-    def __init__(self, rank, world, device, max_elems, peer_data=None, peer_flags=None, own=None, connect=True):
+    def __init__(self, rank, world, device, max_elems, peer_data=None, peer_flags=None, own=None, connect=True,
+                 alternate=False):
         """Collective constructor (every rank of the default process group calls it) unless ``peer_data`` /
         ``peer_flags`` are given (single-process groups of virtual ranks: tests).  ``connect=False`` only allocates this
         rank's buffers — no collective — and leaves the handle exchange to ``connect()``, so a caller can let the ranks
         agree that every allocation succeeded before any of them enters the exchange (DistributedLlama does)."""
         self.rank, self.world, self.device, self.max_elems = rank, world, torch.device(device), int(max_elems)
+        assert self.max_elems % 8 == 0
+        self.alternate, self._issued = bool(alternate), 0          # _issued: exchanges launched or captured so far
         L = hip.lib()
         self._opened = []
         self._data = self._flags = None
         if own is None:
-            own = (self._alloc(self.max_elems * 2), self._alloc(L.tf_ar_flags_bytes()))
+            own = (self._alloc(self.max_elems * 2 * (2 if self.alternate else 1)), self._alloc(L.tf_ar_flags_bytes()))
             self._owned = own
         else:
             self._owned = ()
         self.data_ptr, self.flags_ptr = own
-        self._stage = torch.as_tensor(_RawBuffer(self.data_ptr, (self.max_elems,), "<f2"), device=self.device)
+        self._stage = torch.as_tensor(_RawBuffer(self.data_ptr, (self.max_elems * (2 if self.alternate else 1),), "<f2"),
+                                      device=self.device)
         if peer_data is not None:
             self._set_peers(peer_data, peer_flags)
         elif connect:
@@ -104,10 +114,20 @@ class OneShotAllReduce:
         return data, flags
 
     # ------------------------------------------------------------------------------------------------------
+    def _half(self):
+        """Half of the staging buffer the next exchange reads: its epoch (exchanges so far + 1) & 1; 0 without
+        alternation."""
+        return (self._issued + 1) & 1 if self.alternate else 0
+
     def staging(self, rows, cols):
         """(rows, cols) fp16 view of this rank's staging buffer: the producer kernel's output tensor."""
         assert rows * cols <= self.max_elems and (rows * cols) % 8 == 0
-        return self._stage[:rows * cols].view(rows, cols)
+        lo = self._half() * self.max_elems
+        return self._stage[lo:lo + rows * cols].view(rows, cols)
+
+    def is_staged(self, t):
+        """True when ``t`` starts where the next exchange will read this rank's partial."""
+        return t.data_ptr() == self.data_ptr + 2 * self.max_elems * self._half()
 
     def fits(self, t):
         return t.dtype == torch.float16 and t.numel() <= self.max_elems and t.numel() % 8 == 0
@@ -117,15 +137,24 @@ class OneShotAllReduce:
         ``staging()``; ``resid`` (fp16, may be ``out`` itself) is added in fp16 to the rounded sum; ``ss_out``
         (hidden / 16, 32) fp32 receives the per-panel sums of squares of the result rows (ops.ss_buffer)."""
         assert self._data is not None, "OneShotAllReduce.connect() has not run"
-        assert staged.data_ptr() == self.data_ptr and out.dtype == torch.float16 and out.is_contiguous()
-        assert out.numel() == staged.numel() and out.data_ptr() != self.data_ptr
+        assert self.is_staged(staged) and out.dtype == torch.float16 and out.is_contiguous()
+        assert out.numel() == staged.numel() and out.data_ptr() != staged.data_ptr()
         if resid is not None:
             assert resid.dtype == torch.float16 and resid.is_contiguous() and resid.numel() == out.numel()
         rp = ctypes.c_void_p(resid.data_ptr()) if resid is not None else None
         st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        hidden = out.shape[-1]
         if ss_out is not None:
-            hidden = out.shape[-1]
             assert ss_out.dtype == torch.float32 and ss_out.is_contiguous() and ss_out.shape == (hidden // 16, 32)
+        if self.alternate:
+            half = self._half()
+            self._issued += 1
+            hip.check(hip.lib().tf_allreduce_oneshot_alt(self._data, self._flags, self.rank, self.world, rp,
+                                                         ctypes.c_void_p(out.data_ptr()), staged.numel(), hidden,
+                                                         ctypes.c_void_p(ss_out.data_ptr()) if ss_out is not None else None,
+                                                         self.max_elems, half, st), "tf_allreduce_oneshot_alt")
+            return out
+        if ss_out is not None:
             hip.check(hip.lib().tf_allreduce_oneshot_add_ss(self._data, self._flags, self.rank, self.world, rp,
                                                             ctypes.c_void_p(out.data_ptr()), staged.numel(), hidden,
                                                             ctypes.c_void_p(ss_out.data_ptr()), st),
@@ -137,7 +166,8 @@ class OneShotAllReduce:
         return out
 
     def error(self):
-        """0, or which wait timed out (1 READY, 2 DONE) at some point since creation.  Sticky: after a timeout every
+        """0, or which wait timed out (1 READY, 2 DONE) at some point since creation (3: the alternating form found the
+        partial staged in the other half than its epoch selects — an odd number of exchanges in a captured forward).  Sticky: after a timeout every
         later reduce returns at once and fills ``out`` with NaN (csrc/allreduce.hip) — callers poll this once per
         decode step (``check()``) and stop instead of emitting tokens computed from a reduction that never happened."""
         return hip.lib().tf_ar_error(ctypes.c_void_p(self.flags_ptr))
@@ -149,9 +179,11 @@ class OneShotAllReduce:
     def check(self, where=""):
         e = self.error()
         if e:
-            raise RuntimeError(f"rank {self.rank}: one-shot all-reduce timed out waiting for a peer's "
-                               f"{'READY' if e == 1 else 'DONE' if e == 2 else e} flag{(' (' + where + ')') if where else ''}; "
-                               "its outputs since then are NaN-filled. Restart with TRIFORCE_ONESHOT_AR=0 (RCCL).")
+            what = ("read the staging half its producer did not write (exchanges out of step with the device epoch)"
+                    if e == 3 else
+                    f"timed out waiting for a peer's {'READY' if e == 1 else 'DONE' if e == 2 else e} flag")
+            raise RuntimeError(f"rank {self.rank}: one-shot all-reduce {what}{(' (' + where + ')') if where else ''}; "
+                               "its outputs since then are NaN-filled. Restart with TRIFORCE_ALLREDUCE=rccl.")
 
     def close(self):
         L = hip.lib()
@@ -163,13 +195,15 @@ class OneShotAllReduce:
 
     # ------------------------------------------------------------------------------------------------------
     @classmethod
-    def local_group(cls, world, device, max_elems):
+    def local_group(cls, world, device, max_elems, alternate=False):
         """``world`` virtual ranks inside ONE process on ONE device (their kernels must run on different streams):
         exercises the flag protocol and the arithmetic without peer mappings."""
         L = hip.lib()
-        owned = [(cls._alloc(max_elems * 2), cls._alloc(L.tf_ar_flags_bytes())) for _ in range(world)]
+        owned = [(cls._alloc(max_elems * 2 * (2 if alternate else 1)), cls._alloc(L.tf_ar_flags_bytes()))
+                 for _ in range(world)]
         data, flags = [o[0] for o in owned], [o[1] for o in owned]
-        group = [cls(r, world, device, max_elems, peer_data=data, peer_flags=flags, own=owned[r]) for r in range(world)]
+        group = [cls(r, world, device, max_elems, peer_data=data, peer_flags=flags, own=owned[r], alternate=alternate)
+                 for r in range(world)]
         for g, o in zip(group, owned):
             g._owned = o
         return group
