@@ -24,7 +24,8 @@
 // are identical: one correctly rounded fp16 addition).  The epoch lives in device memory and is advanced by the kernel
 // itself, so a captured launch replays correctly.  Staging and flag buffers must be FINE-GRAINED device memory
 // (tf_ar_alloc): peers' stores and loads bypass the caches; plain device memory is only coherent across GPUs at kernel
-// boundaries.  Every spin is bounded (tens of seconds: a peer may legitimately be that late right after start-up); a
+// boundaries.  Every spin is bounded (about 25 s; a peer may legitimately be
+// seconds late right after start-up, when the ranks leave graph capture at different times); a
 // timeout sets the sticky error word, after which every later call returns immediately instead of waiting again — and
 // on every error path `out` is filled with NaN, so no token can be computed from a reduction that did not happen; the
 // host polls tf_ar_error once per decode step (utils/decoding.py) and raises.
@@ -33,7 +34,7 @@
 
 #define AR_MAX_WORLD 8
 #define AR_THREADS 256
-#define AR_SPIN_LIMIT (1u << 24)
+#define AR_SPIN_LIMIT (1u << 27)            // ~0.2 us per poll: 3 s measured at 1 << 24 -> about 25 s
 
 // One rank's control block (fine-grained memory, mapped by every peer)
 struct ArFlags {
