@@ -455,6 +455,24 @@ def retrieval_build_rooflines(ge, args, device):
     return rows
 
 
+def pmc_layer_traffic(tcfg, slots, rows):
+    """HBM traffic / algorithmic bytes of every kernel of one retrieval-verify decoder layer from the committed
+    rocprofv3 --pmc passes over tools/pmc_layer.py (same counters and corrections as pmc_traffic), when that file was
+    measured at this run's widths; else None."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_retrieval_verify_layer*.json")), reverse=True):
+        try:
+            j = json.load(open(f))
+            sh = j["shape"]
+            if (sh["hidden"], sh["inter"], sh["heads"], sh["head_dim"], sh["slots"], sh["rows"]) == \
+                    (tcfg.hidden_size, tcfg.intermediate_size, tcfg.num_attention_heads, tcfg.head_dim, slots, rows):
+                return {"traffic_over_algorithmic": {k["kernel"]: k["traffic_over_algorithmic"] for k in j["kernels"]},
+                        "traffic_source": os.path.relpath(f, ROOT)}
+        except Exception:
+            continue
+    return None
+
+
 def pmc_traffic(alg_bytes, H, D):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, KiB units, FETCH_SIZE doubled for gfx950 — MI355X_MICROARCH.md §HBM).
@@ -604,6 +622,9 @@ def main():
         _stage_row(f"target_verify forward ({args.gamma + 2} rows: {tcfg.num_hidden_layers} x ({w_layer / 1e6:.1f} MB weights + "
                    f"{tv_kv / 1e6:.1f} MB KV) + lm_head)", tv_bytes, stages["target_verify_us"], how),
         _stage_row("draft step (68M forward, weights once)", d_bytes, stages["draft_step_us"], how)]
+    layer_pmc = pmc_layer_traffic(tcfg, ge.engine.graph_cache.real_budget, args.gamma + 1)
+    if layer_pmc:                                                  # per-kernel PMC traffic of that stage's layer
+        roofline_stages[0].update(layer_pmc)
     try:
         roofline_stages += retrieval_build_rooflines(ge, args, device)
     except Exception as ex:                                        # a probe must never cost the bench line

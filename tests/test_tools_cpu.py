@@ -8,6 +8,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIELDS = ["Kernel_Name", "Grid_Size_X", "Grid_Size_Y", "Start_Timestamp", "End_Timestamp"]
 
@@ -62,3 +64,35 @@ def test_gap_analysis_windows_exactly_n_outer_steps(tmp_path):
     span_ms = float(first.split()[1])
     assert abs(span_ms - 4 * 10.06) < 0.05, first          # 4 x (10 ms + 50 us + 10 us), the trailing probe excluded
     assert "idle 0.20 ms" in first, first
+
+
+def test_pmc_layer_reduce_matches_dispatches_to_the_launch_list(tmp_path):
+    """tools/pmc_layer_reduce.py on a synthetic pair of counter files: per-XCC rows are summed per dispatch, kernels that
+    are not part of the layer are ignored, the first launch per label is dropped, FETCH_SIZE is doubled, and a dispatch
+    order that disagrees with the launch list is an error rather than a wrong table."""
+    import csv
+    from tools import pmc_layer_reduce as R
+    launches = [{"label": "a", "kernel": "skinny_gemm", "algorithmic_bytes": 2048 * 1024}] * 3 \
+        + [{"label": "b", "kernel": "attn_split", "algorithmic_bytes": 1024 * 1024}] * 2
+    meta = {"rows": 7, "hidden": 4096, "inter": 11008, "heads": 32, "head_dim": 128, "slots": 4103, "launches": launches}
+
+    def write(sub, counter, val, names):
+        d = tmp_path / sub / "x"
+        d.mkdir(parents=True)
+        with open(d / "1_counter_collection.csv", "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
+            for i, name in enumerate(names):
+                w.writerow([i + 1, name, counter, val / 2])
+                w.writerow([i + 1, name, counter, val / 2])
+            w.writerow([99, "some_other_kernel", counter, 5])
+        return str(tmp_path / sub)
+    names = ["skinny_gemm_kernel<1>"] * 3 + ["attn_split_kernel<128>"] * 2
+    out = R.reduce(write("f", "FETCH_SIZE", 1024.0, names), write("w", "WRITE_SIZE", 8.0, names), meta)
+    a, b = out["kernels"]
+    assert a["launches_counted"] == 2 and a["hbm_read_bytes_per_launch_corrected"] == 2 * 1024 * 1024
+    assert a["traffic_over_algorithmic"] == round((2 * 1024 * 1024 + 8192) / (2048 * 1024), 4)
+    assert b["launches_counted"] == 1 and b["traffic_over_algorithmic"] == round((2 * 1024 * 1024 + 8192) / (1024 * 1024), 4)
+    bad = write("f2", "FETCH_SIZE", 1024.0, names[::-1])
+    with pytest.raises(SystemExit):
+        R.reduce(bad, str(tmp_path / "w"), meta)

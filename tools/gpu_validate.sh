@@ -50,9 +50,13 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_write -- python $R/tools/pmc_attn.py > $R/$O/pmc_write.log 2>&1; echo "pmc write rc=$?"
 # MFMA-pipe utilisation of the same kernel (own pass: SQ + GRBM counters only)
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $R/$O/pmc_mfma -- python $R/tools/pmc_attn.py > $R/$O/pmc_mfma.log 2>&1; echo "pmc mfma rc=$?"
+# ... and of every kernel of one retrieval-verify decoder layer (GEMMs + retrieval attention), same two-pass recipe
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_layer_fetch -- python $R/tools/pmc_layer.py > $R/$O/pmc_layer_fetch.log 2>&1; echo "pmc layer fetch rc=$?"
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_layer_write -- python $R/tools/pmc_layer.py > $R/$O/pmc_layer_write.log 2>&1; echo "pmc layer write rc=$?"
 cd $R; python tools/pmc_reduce.py $O/pmc_fetch $O/pmc_write $O/pmc_attn_target_verify.json "tools/gpu_validate.sh"
+python tools/pmc_layer_reduce.py $O/pmc_layer_fetch $O/pmc_layer_write gpurun_out/pmc_layer_meta.json $O/pmc_retrieval_verify_layer.json "tools/gpu_validate.sh"
 python tools/pmc_mfma.py $O/pmc_mfma $O/pmc_mfma_attn_target_verify.json "tools/gpu_validate.sh"
-find $O/prof $O/pmc_fetch $O/pmc_write $O/pmc_mfma -name "*kernel_trace.csv" -size +20M -delete
+find $O/prof $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/pmc_layer_fetch $O/pmc_layer_write -name "*kernel_trace.csv" -size +20M -delete
 # the other full-size configs (BASELINE configs[2], and configs[3] at world size 1: offloading tier), only with "all"
 if [ "$1" = "all" ]; then
   python bench.py --target lwm-128K --steps 20 --warmup 5 --no-cpu-baseline --random-steps 0 > $O/bench_lwm.json 2> $O/bench_lwm.err; echo "lwm rc=$?"; tail -c 300 $O/bench_lwm.json
