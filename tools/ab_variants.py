@@ -29,6 +29,7 @@ VARIANTS = {"q2occ1": ["TF_ATTN_QT2_OCC=0"],
             "noahead": ["TF_PREFILL_AHEAD=0"],
             "sgu8": ["SG_U=8"], "sgu2": ["SG_U=2"], "sgw8": ["SG_WAVES=8"],
             "q2w8": ["TF_ATTN_Q2_WAVES=8"],
+            "reslate": ["TF_SG_RES_EARLY=0"],        # residual operands loaded at the GEMM's tail (tools/gemm_resid_ab.py)
             "dma0": ["TF_BLOCK_DMA=0"], "dma1": ["TF_BLOCK_DMA=1"],
             "ring4ps1": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_RING_Q1=4", "TF_ATTN_RING_Q2=4", "TF_ATTN_QT2_OCC=1", "TF_ATTN_P_SPLIT=1"]}
 

@@ -46,6 +46,9 @@
 #ifndef SG_U
 #define SG_U 4              // k-chunks (KiB of weights) in flight per wave
 #endif
+#ifndef TF_SG_RES_EARLY
+#define TF_SG_RES_EARLY 1   // residual epilogue operands fetched before the weight loop (0: at the tail, round 2's form)
+#endif
 
 enum { SG_PLAIN = 0, SG_GATEUP = 1, SG_F32 = 2, SG_QKV = 3 };
 
@@ -225,6 +228,21 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
         }
     }
 
+    // residual epilogue operands (wave 0 only): this lane's 4 residual values per row tile, fetched now — at the tail
+    // they would be one more exposed memory round trip between the split-K merge and the store.  (resid may alias y:
+    // every element is read and written by the same lane only.)
+    half4 res_pre[MT];
+    const bool res_early = TF_SG_RES_EARLY && MODE == SG_PLAIN && resid != nullptr && wave == 0 && (ldr % 4) == 0 &&
+                           (reinterpret_cast<uintptr_t>(resid) % 8) == 0;
+    if (res_early) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int m = t * 16 + li;
+            res_pre[t] = half4{0, 0, 0, 0};
+            if (m < M) res_pre[t] = *reinterpret_cast<const half4*>(resid + (int64_t)m * ldr + panel * 16 + 4 * g);
+        }
+    }
+
     int c = c0;
     for (; c + U <= c1; c += U) {
         half8 a[U], a2[U], b[U][MT];
@@ -345,7 +363,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
                 ((float*)yv)[(int64_t)m * ldy + n] = (float)(h16)s[r];          // logits.float(): fp16 GEMM, then cast
             } else {
                 h16 o = (h16)s[r];
-                if (resid) o = hadd_rn(resid[(int64_t)m * ldr + n], o);           // residual + hidden, fp16 add
+                if (resid) o = hadd_rn(res_early ? res_pre[t][r] : resid[(int64_t)m * ldr + n], o);   // residual + hidden, fp16 add
                 ((h16*)yv)[(int64_t)m * ldy + n] = o;
                 s2[r] = (float)o;
             }
