@@ -183,15 +183,47 @@ def test_single_gpu_offloading_cache_equals_resident_cache():
 _RANK_STREAMS = []
 
 
+def _run_concurrently(streams):
+    """True when a kernel on each of ``streams`` gets to run while kernels on all the others are still busy (they sit
+    on different hardware queues): every stream in turn launches a trivial kernel while the rest spin for ~20 ms."""
+    import time
+    flag = torch.zeros(1, device=DEV)
+    for i, s in enumerate(streams):
+        torch.cuda.synchronize()
+        for j, o in enumerate(streams):
+            if j != i:
+                with torch.cuda.stream(o):
+                    torch.cuda._sleep(40_000_000)                    # ~20 ms of s_sleep on one wave
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(s):
+            flag.add_(1.0)
+            ev.record()
+        t0 = time.time()
+        while not ev.query() and time.time() - t0 < 0.008:
+            pass
+        ok = ev.query()
+        torch.cuda.synchronize()
+        if not ok:
+            return False
+    return True
+
+
 def _rank_streams(world):
     """One stream per virtual rank, the SAME ones for every test of this process.  The kernels of the virtual ranks wait
     for each other, so they must be resident together, which needs their streams on different hardware queues; the
     runtime multiplexes streams over a handful of those, and a second pair of fresh streams has been seen to share one
-    (rank 1's kernel then starts only after rank 0's READY wait has timed out).  An artefact of several ranks on one
+    (rank 1's kernel then starts only after rank 0's READY wait has timed out).  A candidate set is therefore probed
+    first (``_run_concurrently``) and replaced by fresh streams until one passes.  An artefact of several ranks on one
     device — a production rank has its device to itself."""
-    while len(_RANK_STREAMS) < world:
-        _RANK_STREAMS.append(torch.cuda.Stream(device=DEV))
-    return _RANK_STREAMS[:world]
+    if len(_RANK_STREAMS) >= world and _run_concurrently(_RANK_STREAMS[:world]):
+        return _RANK_STREAMS[:world]
+    for _ in range(8):
+        cand = [torch.cuda.Stream(device=DEV) for _ in range(world)]
+        if _run_concurrently(cand):
+            _RANK_STREAMS[:] = cand
+            return cand
+    pytest.skip(f"no {world} streams of this process run concurrently on this device: the virtual-rank protocol tests "
+                "need that (the two-process tests below cover the protocol without it)")
 
 
 @pytest.mark.parametrize("alternate", [False, True], ids=["done-handshake", "alternating-halves"])
