@@ -96,3 +96,44 @@ def test_pmc_layer_reduce_matches_dispatches_to_the_launch_list(tmp_path):
     bad = write("f2", "FETCH_SIZE", 1024.0, names[::-1])
     with pytest.raises(SystemExit):
         R.reduce(bad, str(tmp_path / "w"), meta)
+
+
+def test_oneshot_allreduce_alternating_halves_host_bookkeeping():
+    """The host side of tf_allreduce_oneshot_alt without a device: exchange e (1-based) must be staged in half e & 1,
+    `staging()` must hand out that half, `is_staged()` must accept only it, and a reduce advances the count — the
+    invariant the kernel's epoch / half guard (sticky error 3) checks on the device."""
+    import ctypes
+    import torch
+    from triforce_amd.utils import oneshot_ar as M
+
+    calls = []
+
+    class Lib:
+        def tf_allreduce_oneshot_alt(self, *a):
+            calls.append(a)
+            return 0
+
+    ar = object.__new__(M.OneShotAllReduce)
+    ar.rank, ar.world, ar.device, ar.max_elems = 0, 1, torch.device("cpu"), 64
+    ar.alternate, ar._issued = True, 0
+    ar._stage = torch.zeros(128, dtype=torch.float16)
+    ar.data_ptr, ar.flags_ptr = ar._stage.data_ptr(), 0
+    ar._data = (ctypes.c_void_p * 1)(ar.data_ptr)
+    ar._flags = (ctypes.c_void_p * 1)(0)
+    old_lib, old_stream = M.hip.lib, torch.cuda.current_stream
+    M.hip.lib = lambda: Lib()
+    torch.cuda.current_stream = lambda device=None: type("S", (), {"cuda_stream": 0})()
+    try:
+        halves = []
+        for e in range(1, 6):
+            st = ar.staging(2, 8)
+            assert ar.is_staged(st) and st.data_ptr() == ar.data_ptr + 2 * 64 * (e & 1)
+            other = ar._stage[64 * ((e + 1) & 1):][:16].view(2, 8)
+            assert not ar.is_staged(other)
+            out = torch.zeros(2, 8, dtype=torch.float16)
+            ar.reduce(st, out)
+            halves.append(calls[-1][-2])                       # expect_half as passed to the C entry
+            assert calls[-1][-3] == 64 and ar._issued == e     # half_elems, exchanges counted
+        assert halves == [1, 0, 1, 0, 1]
+    finally:
+        M.hip.lib, torch.cuda.current_stream = old_lib, old_stream
