@@ -69,6 +69,11 @@ int tf_attn_decode_fused(const void* q, const void* k, const void* v, void* out,
                          int64_t stride_t, int64_t stride_h,
                          int sq, int sk, const int32_t* sk_dev, int H, int D, float scale,
                          int nsplit, float* ws, int64_t ws_floats, uint32_t* tickets, void* stream);
+/* tf_attn_decode / tf_attn_decode_fused (tickets != NULL) with the OUTPUT in an explicit activation layout: element (row,
+ * column c = h * D + d) at out[row * out_sm + (c / 8) * out_sk + c % 8] (see tf_skinny_gemm_act; row-major = H * D, 8). */
+int tf_attn_decode_act(const void* q, const void* k, const void* v, void* out, int64_t out_sm, int64_t out_sk,
+                       int64_t stride_t, int64_t stride_h, int sq, int sk, const int32_t* sk_dev, int H, int D,
+                       float scale, int nsplit, float* ws, int64_t ws_floats, uint32_t* tickets, void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Block attention: 1 <= sq <= 128 query rows in ONE pass over the keys.
@@ -211,6 +216,11 @@ int tf_rope_append(const void* qkv, int64_t qkv_row_stride, const void* cos, con
                    int64_t stride_t, int64_t stride_h, int slot0, const int32_t* slot0_dev,
                    int rows, int H, int D, int rotate_k, void* stream);
 int tf_silu_mul(const void* gate_up, void* out, int rows, int I, void* stream);
+/* tf_embed_rows: x = embed_tokens(input_ids) (models/modeling_llama.py:342, TP_llama.py:206) for the n <= 32 rows of a
+ * decode forward, written in an explicit activation layout (see tf_skinny_gemm_act): element (m, k) at
+ * out[m * out_sm + (k / 8) * out_sk + k % 8].  embed [vocab][hidden] fp16, ids [n] int64 (clamped to the vocabulary). */
+int tf_embed_rows(const void* embed, const int64_t* ids, void* out, int64_t out_sm, int64_t out_sk, int n, int hidden,
+                  int vocab, void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Skinny (decode) GEMMs — nn.Linear / F.linear with M <= 32 activation rows (models/modeling_llama.py:
@@ -250,6 +260,29 @@ int tf_skinny_qkv_rope(const void* wqkv_packed, const void* x, int64_t ldx, cons
                        const float* ss_in, const void* cos, const void* sin, const int64_t* positions, void* q_out,
                        void* k_cache, void* v_cache, int64_t stride_t, int64_t stride_h, int slot0,
                        const int32_t* slot0_dev, int M, int H, int D, int K, int rotate_k, void* stream);
+
+/* The same three kernels with an explicit ACTIVATION LAYOUT per operand (round 4).  Element (m, k) of an activation
+ * block lives at base[m * s_m + (k / 8) * s_k + (k % 8)]  (element strides, multiples of 8):
+ *   row-major [M][ld] (the reference's tensors)            : s_m = ld, s_k = 8        — what the entry points above pass;
+ *   k-octet-major, R >= M rows (triforce_amd.ops.ActBlock) : s_m = 8,  s_k = 8 * R    — the 16-byte pieces of one
+ *     k-octet of all rows are contiguous, so the B operand of a 16-row MFMA tile is 4 runs of 256 B instead of 16 row
+ *     fragments of 64 B.  The decode layer keeps its residual stream, attention output and SwiGLU output in this form
+ *     when a block has more than 16 rows (the gamma = 16 verifies of offloading_TP.py: tensor_op.py:276-328,346-360).
+ * The fp32 logits of out_f32 != 0 stay row-major (ys_m = row stride, ys_k ignored); q_out of the q|k|v form stays
+ * [M][H][D].  tf_sg_tune: A/B knobs of the launch rule (key 0: rows from which a wave multiplies TWO weight panels
+ * against one B operand, 33 = never; key 1: waves per workgroup of that form, 4 or 8; key 2: smallest halved grid,
+ * panels / 2, that takes it); returns the previous value, -1 for an unknown key. */
+int tf_skinny_gemm_act(const void* w_packed, const void* x, int64_t xs_m, int64_t xs_k, const void* ln_w, float eps,
+                       const float* ss_in, const void* resid, int64_t rs_m, int64_t rs_k, float* ss_out, void* y,
+                       int64_t ys_m, int64_t ys_k, int M, int N, int K, int out_f32, void* stream);
+int tf_skinny_gemm_swiglu_act(const void* gate_packed, const void* up_packed, const void* x, int64_t xs_m,
+                              int64_t xs_k, const void* ln_w, float eps, const float* ss_in, void* act, int64_t ys_m,
+                              int64_t ys_k, int M, int I, int K, void* stream);
+int tf_skinny_qkv_rope_act(const void* wqkv_packed, const void* x, int64_t xs_m, int64_t xs_k, const void* ln_w,
+                           float eps, const float* ss_in, const void* cos, const void* sin, const int64_t* positions,
+                           void* q_out, void* k_cache, void* v_cache, int64_t stride_t, int64_t stride_h, int slot0,
+                           const int32_t* slot0_dev, int M, int H, int D, int K, int rotate_k, void* stream);
+int tf_sg_tune(int key, int value);
 
 /* -------------------------------------------------------------------------------------------
  * Sampling / accept-rollback (utils/sampling.py:63-75, utils/decoding.py:97-134,190-220).
@@ -353,7 +386,20 @@ int tf_allreduce_oneshot_add_ss(void* const* peer_data, void* const* peer_flags,
 int tf_allreduce_oneshot_alt(void* const* peer_data, void* const* peer_flags, int rank, int world, const void* resid,
                              void* out, int64_t n, int hidden, float* ss_out, int64_t half_elems, int expect_half,
                              void* stream);
+/* tf_allreduce_oneshot_add_ss / _alt for a residual stream kept k-octet-major (tf_skinny_gemm_act): n = pack_rows *
+ * hidden elements, piece i = (k-octet i / pack_rows, row i % pack_rows); ss_out[panel * 32 + row] as above (required).
+ * half_elems == 0: the READY / reduce / DONE form; > 0: alternating halves with expect_half. */
+int tf_allreduce_oneshot_act(void* const* peer_data, void* const* peer_flags, int rank, int world, const void* resid,
+                             void* out, int64_t n, int hidden, int pack_rows, float* ss_out, int64_t half_elems,
+                             int expect_half, void* stream);
 int tf_ar_error(const void* flags_local);
+/* completed exchanges of this control block (device-side epoch), blocking host read: lets a caller that counts its
+ * exchanges (expect_half) resynchronise after a failed launch / capture; TF_EINVAL for NULL, -(hip error) on failure */
+int64_t tf_ar_epoch(const void* flags_local);
+/* host_word: pinned, device-mapped host memory (4 bytes) that receives every error code the kernels set from now on (and
+ * the current one at once) — the per-step health poll then reads host memory instead of copying the control block;
+ * NULL removes the mirror.  The word must outlive the control block. */
+int tf_ar_set_error_mirror(void* flags_local, void* host_word);
 /* Fault injection for tests: sets (code > 0) or clears (0) the sticky error word of a control block from the host. */
 int tf_ar_inject_error(void* flags_local, int code);
 

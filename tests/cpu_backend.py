@@ -35,7 +35,8 @@ def silu_mul(gate_up):
     return R.silu_mul(gate_up[:, :I], gate_up[:, I:])
 
 
-def attn_decode(q, k_layer, v_layer, sk, scale, sk_dev=None, nsplit=None):
+def attn_decode(q, k_layer, v_layer, sk, scale, sk_dev=None, nsplit=None, packed=False):
+    assert not packed, "k-octet-major activations exist only on the device path"
     sq, H, D = q.shape
     k = k_layer[:, :sk].permute(1, 0, 2)
     v = v_layer[:, :sk].permute(1, 0, 2)

@@ -44,8 +44,15 @@ struct ArFlags {
     unsigned ticket;                  // workgroups of the running launch that finished reducing (owner only)
     unsigned error;                   // sticky: 1 = READY wait timed out, 2 = DONE wait timed out, 3 = the producer
                                       //         staged into the other half than the epoch selects (alternating form)
-    unsigned pad[13];
+    unsigned pad0;
+    unsigned long long mirror;        // 0, or the address of a pinned HOST word that receives every error code as well
+                                      // (tf_ar_set_error_mirror): the host then polls the error without a copy
+    unsigned pad[10];
 };
+static_assert(sizeof(ArFlags) == 128, "control block layout");
+
+// error <- code, also into the host mirror when one is registered (owner only)
+__device__ __forceinline__ void ar_set_error(ArFlags* mine, unsigned code);
 
 struct ArComm {
     const h16* data[AR_MAX_WORLD];    // staging buffer of every rank (own entry = local pointer)
@@ -58,6 +65,12 @@ __device__ __forceinline__ unsigned ar_load(const unsigned* p) {
 }
 __device__ __forceinline__ void ar_store(unsigned* p, unsigned v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__device__ __forceinline__ void ar_set_error(ArFlags* mine, unsigned code) {
+    ar_store(&mine->error, code);
+    unsigned* m = reinterpret_cast<unsigned*>(mine->mirror);
+    if (m) ar_store(m, code);
 }
 
 // lane p < world waits until *slot(p) reaches `epoch` (epochs only grow; wrap-safe compare); false on timeout
@@ -78,9 +91,36 @@ __device__ __forceinline__ void ar_poison(h16* out, int64_t n_vec8) {
         *reinterpret_cast<half8*>(out + 8 * i) = nan8;
 }
 
+// out[piece i] = [resid +] fp16( sum over ranks, rank order, fp32 ) of the staged pieces i; returns what was stored
+__device__ __forceinline__ half8 ar_reduce_piece(const ArComm& c, int64_t base, int64_t i, const h16* resid, h16* out) {
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    half8 v[AR_MAX_WORLD];
+#pragma unroll
+    for (int r = 0; r < AR_MAX_WORLD; ++r)
+        if (r < c.world) v[r] = *reinterpret_cast<const half8*>(c.data[r] + base + 8 * i);
+#pragma unroll
+    for (int r = 0; r < AR_MAX_WORLD; ++r)
+        if (r < c.world) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)v[r][e];
+        }
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (h16)acc[e];
+    if (resid) {                                      // hidden = residual + all_reduce(partial): fp16 add of the
+        const half8 rv = *reinterpret_cast<const half8*>(resid + 8 * i);   // ROUNDED sum (tensor_op.py:179-181)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = hadd_rn(rv[e], o[e]);
+    }
+    *reinterpret_cast<half8*>(out + 8 * i) = o;
+    return o;
+}
+
 __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c, const h16* resid, h16* out, int64_t n_vec8,
                                                                         float* ss_out, int hidden, int64_t half_elems,
-                                                                        int expect_half) {
+                                                                        int expect_half, int pack_rows) {
     __shared__ unsigned s_epoch;
     __shared__ int s_ok;
     const int tid = threadIdx.x;
@@ -97,43 +137,41 @@ __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c,
     const unsigned epoch = s_epoch;
     const int64_t base = half_elems * (int64_t)(epoch & 1u);       // alternating form: exchange e lives in half e & 1
     if (half_elems > 0 && (int)(epoch & 1u) != expect_half) {      // (block-uniform) the producer wrote the other half
-        if (tid == 0) ar_store(&mine->error, 3u);
+        if (tid == 0) ar_set_error(mine, 3u);
         ar_poison(out, n_vec8);
         return;
     }
     // ---- READY: my partial was staged by the previous kernel in this stream ----
     if (blockIdx.x == 0 && tid < c.world) ar_store(&c.flags[tid]->ready[c.rank], epoch);
     if (tid < c.world && !ar_wait(&mine->ready[tid], epoch)) {
-        ar_store(&mine->error, 1u);
+        ar_set_error(mine, 1u);
         s_ok = 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");    // system scope: nothing read below may predate the flags
     __syncthreads();
     // ---- reduce: 16-byte vectors, fixed rank order, fp32 accumulation, one rounding ----
-    if (s_ok) {
-        for (int64_t i = (int64_t)blockIdx.x * AR_THREADS + tid; i < n_vec8; i += (int64_t)gridDim.x * AR_THREADS) {
-            float acc[8];
+    if (s_ok && ss_out && pack_rows > 0) {
+        // k-octet-major block (ops.Act, R = pack_rows rows): piece i = (k-octet i / R, row i % R).  A thread reduces the
+        // TWO pieces of one (16-column panel, row) — i0 = 2 p R + m and i0 + R — and owns that entry of the hand-off.
+        const int R = pack_rows;
+        const int64_t pairs = n_vec8 >> 1;
+        for (int64_t j = (int64_t)blockIdx.x * AR_THREADS + tid; j < pairs; j += (int64_t)gridDim.x * AR_THREADS) {
+            const int64_t pnl = j / R;
+            const int m = (int)(j - pnl * R);
+            const int64_t i0 = 2 * pnl * R + m;
+            float sq = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-            half8 v[AR_MAX_WORLD];
+            for (int hpiece = 0; hpiece < 2; ++hpiece) {
+                const int64_t i = i0 + (int64_t)hpiece * R;
+                const half8 o = ar_reduce_piece(c, base, i, resid, out);
 #pragma unroll
-            for (int r = 0; r < AR_MAX_WORLD; ++r)
-                if (r < c.world) v[r] = *reinterpret_cast<const half8*>(c.data[r] + base + 8 * i);
-#pragma unroll
-            for (int r = 0; r < AR_MAX_WORLD; ++r)
-                if (r < c.world) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] += (float)v[r][e];
-                }
-            half8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (h16)acc[e];
-            if (resid) {                                      // hidden = residual + all_reduce(partial): fp16 add of the
-                const half8 rv = *reinterpret_cast<const half8*>(resid + 8 * i);   // ROUNDED sum (tensor_op.py:179-181)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = hadd_rn(rv[e], o[e]);
+                for (int e = 0; e < 8; ++e) sq = fmaf((float)o[e], (float)o[e], sq);
             }
-            *reinterpret_cast<half8*>(out + 8 * i) = o;
+            ss_out[pnl * 32 + m] = sq;
+        }
+    } else if (s_ok) {
+        for (int64_t i = (int64_t)blockIdx.x * AR_THREADS + tid; i < n_vec8; i += (int64_t)gridDim.x * AR_THREADS) {
+            const half8 o = ar_reduce_piece(c, base, i, resid, out);
             if (ss_out) {
                 // sum of squares of the 16-column panel this vector is half of -> ss_out[panel][row]: the hand-off the
                 // RMSNorm prologue of the consuming GEMM folds (tf_skinny_gemm_ex ss_in) instead of re-reading the rows.
@@ -163,7 +201,7 @@ __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(ArComm c,
     if (!s_last) return;
     if (half_elems == 0) {                           // single staging buffer: nobody may leave before every peer has read
         if (tid < c.world) ar_store(&c.flags[tid]->done[c.rank], epoch);
-        if (tid < c.world && !ar_wait(&mine->done[tid], epoch)) ar_store(&mine->error, 2u);
+        if (tid < c.world && !ar_wait(&mine->done[tid], epoch)) ar_set_error(mine, 2u);
         __syncthreads();
     }
     if (tid == 0) {
@@ -225,10 +263,12 @@ extern "C" int tf_ar_close_ipc_handle(void* ptr) {
 // `hidden_states = residual + all_reduce(o)` of tensor_op.py:179-181,359-360 in the same launch.  resid may equal out
 // (in-place residual stream); resid == NULL is the plain all-reduce.
 static int ar_launch(void* const* peer_data, void* const* peer_flags, int rank, int world, const void* resid, void* out,
-                     int64_t n, float* ss_out, int hidden, void* stream, int64_t half_elems = 0, int expect_half = 0) {
+                     int64_t n, float* ss_out, int hidden, void* stream, int64_t half_elems = 0, int expect_half = 0,
+                     int pack_rows = 0) {
     if (!peer_data || !peer_flags || !out || world < 1 || world > AR_MAX_WORLD || rank < 0 || rank >= world) return TF_EINVAL;
     if (n < 8 || (n % 8)) return TF_EINVAL;
     if (ss_out && (hidden < 16 || (hidden % 16) || (n % hidden) || n / hidden > 32)) return TF_EINVAL;
+    if (pack_rows < 0 || (pack_rows > 0 && (!ss_out || (int64_t)pack_rows * hidden != n))) return TF_EINVAL;
     ArComm c;
     for (int r = 0; r < AR_MAX_WORLD; ++r) {
         c.data[r] = (r < world) ? (const h16*)peer_data[r] : nullptr;
@@ -245,7 +285,7 @@ static int ar_launch(void* const* peer_data, void* const* peer_flags, int rank, 
     int blocks = (int)((n_vec8 + AR_THREADS - 1) / AR_THREADS);
     if (blocks > 64) blocks = 64;                     // <= 64 workgroups: co-resident with anything, latency-bound anyway
     hipLaunchKernelGGL(allreduce_oneshot_kernel, dim3(blocks), dim3(AR_THREADS), 0, (hipStream_t)stream, c,
-                       (const h16*)resid, (h16*)out, n_vec8, ss_out, hidden, half_elems, expect_half);
+                       (const h16*)resid, (h16*)out, n_vec8, ss_out, hidden, half_elems, expect_half, pack_rows);
     TF_LAUNCH_CHECK();
     return TF_OK;
 }
@@ -277,6 +317,18 @@ extern "C" int tf_allreduce_oneshot_alt(void* const* peer_data, void* const* pee
     return ar_launch(peer_data, peer_flags, rank, world, resid, out, n, ss_out, hidden, stream, half_elems, expect_half);
 }
 
+// Either form (half_elems == 0: READY / reduce / DONE; > 0: alternating halves) for a residual stream kept K-OCTET-MAJOR
+// (include/triforce_hip.h, tf_skinny_gemm_act; pack_rows = R rows, n = R * hidden): the sum itself is layout-blind, the
+// sum-of-squares hand-off needs to know which pieces make up (panel, row).  ss_out is required (without it the plain
+// entry points serve any layout).
+extern "C" int tf_allreduce_oneshot_act(void* const* peer_data, void* const* peer_flags, int rank, int world,
+                                        const void* resid, void* out, int64_t n, int hidden, int pack_rows, float* ss_out,
+                                        int64_t half_elems, int expect_half, void* stream) {
+    if (pack_rows < 1 || !ss_out) return TF_EINVAL;
+    return ar_launch(peer_data, peer_flags, rank, world, resid, out, n, ss_out, hidden, stream, half_elems, expect_half,
+                     pack_rows);
+}
+
 extern "C" int tf_allreduce_oneshot(void* const* peer_data, void* const* peer_flags, int rank, int world, void* out,
                                     int64_t n, void* stream) {
     return tf_allreduce_oneshot_add(peer_data, peer_flags, rank, world, nullptr, out, n, stream);
@@ -288,6 +340,26 @@ extern "C" int tf_ar_inject_error(void* flags_local, int code) {
     if (!flags_local || code < 0) return TF_EINVAL;
     const unsigned v = (unsigned)code;
     hipError_t e = hipMemcpy(&reinterpret_cast<ArFlags*>(flags_local)->error, &v, sizeof(v), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return (int)e;
+    unsigned long long m = 0;
+    e = hipMemcpy(&m, &reinterpret_cast<ArFlags*>(flags_local)->mirror, sizeof(m), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
+    if (m) *reinterpret_cast<volatile unsigned*>(m) = v;       // the mirror is host memory
+    return TF_OK;
+}
+
+// Registers (or with NULL removes) a pinned, device-mapped HOST word that every error code is also written to, so the
+// decode loop's per-step health poll is a plain host read instead of a blocking copy of the control block.  The word must
+// stay allocated for the lifetime of the control block; it is set to the block's current error value here.
+extern "C" int tf_ar_set_error_mirror(void* flags_local, void* host_word) {
+    if (!flags_local) return TF_EINVAL;
+    ArFlags* f = reinterpret_cast<ArFlags*>(flags_local);
+    unsigned cur = 0;
+    hipError_t e = hipMemcpy(&cur, &f->error, sizeof(cur), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
+    if (host_word) *reinterpret_cast<volatile unsigned*>(host_word) = cur;
+    const unsigned long long m = (unsigned long long)(uintptr_t)host_word;
+    e = hipMemcpy(&f->mirror, &m, sizeof(m), hipMemcpyHostToDevice);
     return e == hipSuccess ? TF_OK : (int)e;
 }
 
@@ -298,4 +370,15 @@ extern "C" int tf_ar_error(const void* flags_local) {
     hipError_t e = hipMemcpy(&f, flags_local, sizeof(f), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return (int)e;
     return (int)f.error;
+}
+
+// Completed exchanges of this rank's control block (the device-side epoch): a blocking host read, for the caller that
+// counts its exchanges (the alternating form's `expect_half`) to resynchronise after a launch or capture it issued failed.
+// Call it with the stream idle.  Negative: -(hip error).
+extern "C" int64_t tf_ar_epoch(const void* flags_local) {
+    if (!flags_local) return TF_EINVAL;
+    ArFlags f;
+    hipError_t e = hipMemcpy(&f, flags_local, sizeof(f), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return -(int64_t)e;
+    return (int64_t)f.epoch;
 }

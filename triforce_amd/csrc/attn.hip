@@ -240,7 +240,7 @@ template <int D, int QT, int DEEP = 0, int NW = 4>
 __device__ __forceinline__ void attn_split_body(
     const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
     int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
-    float* __restrict__ ws, unsigned* __restrict__ tickets, h16* __restrict__ out) {
+    float* __restrict__ ws, unsigned* __restrict__ tickets, h16* __restrict__ out, int64_t osm, int64_t osk) {
     constexpr int NC = D / 32, NT = D / 16, QR = QT * 16;
     const int split = blockIdx.x, h = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -474,7 +474,9 @@ __device__ __forceinline__ void attn_split_body(
         half4 o4;
 #pragma unroll
         for (int c = 0; c < 4; ++c) o4[c] = (h16)(acc[c] / l);
-        *reinterpret_cast<half4*>(out + ((int64_t)r * H + h) * D + 4 * d4) = o4;
+        // output element (row r, column h * D + 4 d4 ...) in the caller's activation layout (see tf_attn_decode_act):
+        // row-major rows of H * D (osm = H * D, osk = 8) or k-octet-major (osm = 8, osk = 8 * R)
+        *reinterpret_cast<half4*>(out + (int64_t)r * osm + (int64_t)((h * D + 4 * d4) >> 3) * osk + ((4 * d4) & 7)) = o4;
     }
     if (tid == 0) __hip_atomic_store(&tickets[h], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left zero for the next launch (graph replays included)
 }
@@ -483,8 +485,8 @@ template <int D, int QT>
 __global__ ATTN_SPLIT_BOUNDS void attn_split_kernel(
     const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
     int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
-    float* __restrict__ ws, unsigned* __restrict__ tickets, h16* __restrict__ out) {
-    attn_split_body<D, QT>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws, tickets, out);
+    float* __restrict__ ws, unsigned* __restrict__ tickets, h16* __restrict__ out, int64_t osm, int64_t osk) {
+    attn_split_body<D, QT>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws, tickets, out, osm, osk);
 }
 
 // The deep-prefetch form for short streams (one q-tile; see TF_ATTN_DEEP_TILES): one wave per SIMD, 512 registers.
@@ -493,9 +495,9 @@ template <int D>
 __global__ __launch_bounds__(256, 1) void attn_split_deep_kernel(
     const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
     int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
-    float* __restrict__ ws, unsigned* __restrict__ tickets, h16* __restrict__ out) {
+    float* __restrict__ ws, unsigned* __restrict__ tickets, h16* __restrict__ out, int64_t osm, int64_t osk) {
     attn_split_body<D, 1, TF_ATTN_DEEP_TILES>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws, tickets,
-                                              out);
+                                              out, osm, osk);
 }
 #endif
 
@@ -510,8 +512,8 @@ template <int D>
 __global__ __launch_bounds__(64 * TF_ATTN_Q2_WAVES, TF_ATTN_Q2_WAVES == 8 ? 2 : TF_ATTN_QT2_OCC) void attn_split_q2_kernel(
     const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
     int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
-    float* __restrict__ ws, unsigned* __restrict__ tickets, h16* __restrict__ out) {
-    attn_split_body<D, 2, 0, TF_ATTN_Q2_WAVES>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws, tickets, out);
+    float* __restrict__ ws, unsigned* __restrict__ tickets, h16* __restrict__ out, int64_t osm, int64_t osk) {
+    attn_split_body<D, 2, 0, TF_ATTN_Q2_WAVES>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws, tickets, out, osm, osk);
 }
 #endif
 
@@ -1406,7 +1408,7 @@ static size_t blk_lds_bytes() {
 template <int D>
 __global__ __launch_bounds__(D * COMBINE_GROUPS) void attn_combine_kernel(const float* __restrict__ ws,
                                                                           h16* __restrict__ out, int sq, int H,
-                                                                          int nsplit, int QR) {
+                                                                          int nsplit, int QR, int64_t osm, int64_t osk) {
     __shared__ float sm_w[COMBINE_MAX_SPLITS];
     __shared__ float sm_l[COMBINE_MAX_SPLITS];
     __shared__ float sm_o[COMBINE_GROUPS][D];
@@ -1441,7 +1443,7 @@ __global__ __launch_bounds__(D * COMBINE_GROUPS) void attn_combine_kernel(const 
         float acc = 0.f;
 #pragma unroll
         for (int gg = 0; gg < COMBINE_GROUPS; ++gg) acc += sm_o[gg][d];
-        out[((int64_t)qq * H + h) * D + d] = (h16)(acc / l);
+        out[(int64_t)qq * osm + (int64_t)((h * D + d) >> 3) * osk + (d & 7)] = (h16)(acc / l);
     }
 }
 
@@ -1718,7 +1720,13 @@ extern "C" int64_t tf_attn_decode_ws_floats(int H, int sq, int D, int nsplit) {
 // on the TP-shard shapes: 16 heads x 130K keys 237 vs 206 us, 32 heads x 12 305 keys 66 vs 54 us.)
 extern "C" int tf_attn_decode_pick_nsplit(int H, int sk) {
     const int tiles = (sk + 15) / 16;
-    int by_grid = 256 / (H > 0 ? H : 1);
+    if (H < 1) H = 1;
+    int by_grid = 256 / H;
+    // Head counts that leave >= 16 CUs without a workgroup at one workgroup per CU (40 and 20 heads: 240 of 256) take TWO
+    // workgroups per CU when the stream is long: 13B / 130K keys / 18 rows 513 -> 484 us at 12 splits; at 12 305 keys the
+    // 6-split one-launch merge stays ahead, 61.4 vs 63.4 us; 7, 8 or 13 splits — a second workgroup on SOME CUs — cost
+    // 30-50 %: a CU's stream rate, not the chip's, bounds this kernel (profiles/r04_attn_nsplit_g16.jsonl)
+    if (by_grid >= 1 && 256 - by_grid * H >= 16 && 512 / H >= 2 * by_grid && tiles / (512 / H) >= 256) by_grid = 512 / H;
     int by_work = tiles / 8;
     int n = by_work < by_grid ? by_work : by_grid;
     if (n < 1) n = 1;
@@ -1727,9 +1735,9 @@ extern "C" int tf_attn_decode_pick_nsplit(int H, int sk) {
 }
 
 template <int D, int QT>
-static int launch_attn(const void* q, const void* k, const void* v, void* out, int64_t stride_t, int64_t stride_h,
-                       int sq, int sk, const int32_t* sk_dev, int H, float scale, int nsplit, float* ws,
-                       unsigned* tickets, hipStream_t st) {
+static int launch_attn(const void* q, const void* k, const void* v, void* out, int64_t osm, int64_t osk,
+                       int64_t stride_t, int64_t stride_h, int sq, int sk, const int32_t* sk_dev, int H, float scale,
+                       int nsplit, float* ws, unsigned* tickets, hipStream_t st) {
     dim3 grid(nsplit, H), block(256);
     if (tickets && nsplit > FUSED_MERGE_MAX_SPLITS) tickets = nullptr;    // many splits: the parallel merge kernel wins
     bool launched = false;
@@ -1739,7 +1747,7 @@ static int launch_attn(const void* q, const void* k, const void* v, void* out, i
         const int ntiles = (sk + 15) / 16, tps = (ntiles + nsplit - 1) / nsplit, per_wave = (tps + 3) / 4;
         if (per_wave <= 2 * TF_ATTN_DEEP_TILES && (int64_t)nsplit * H <= 320) {      // short streams, <= ~1 workgroup per CU
             hipLaunchKernelGGL((attn_split_deep_kernel<D>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
-                               stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, (h16*)out);
+                               stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, (h16*)out, osm, osk);
             launched = true;
         }
     }
@@ -1747,41 +1755,42 @@ static int launch_attn(const void* q, const void* k, const void* v, void* out, i
 #if TF_ATTN_QT2_OCC > 0
     if constexpr (QT == 2)
         hipLaunchKernelGGL((attn_split_q2_kernel<D>), grid, dim3(64 * TF_ATTN_Q2_WAVES), 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
-                           stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, (h16*)out);
+                           stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, (h16*)out, osm, osk);
     else
 #endif
     if (!launched)
         hipLaunchKernelGGL((attn_split_kernel<D, QT>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
-                           stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, (h16*)out);
+                           stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, (h16*)out, osm, osk);
     TF_LAUNCH_CHECK();
     if (tickets) return TF_OK;
     hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(H, sq), dim3(D, COMBINE_GROUPS), 0, st, (const float*)ws,
-                       (h16*)out, sq, H, nsplit, QT * 16);
+                       (h16*)out, sq, H, nsplit, QT * 16, osm, osk);
     TF_LAUNCH_CHECK();
     return TF_OK;
 }
 
-static int attn_decode_any(const void* q, const void* k, const void* v, void* out, int64_t stride_t,
-                           int64_t stride_h, int sq, int sk, const int32_t* sk_dev, int H, int D, float scale,
-                           int nsplit, float* ws, int64_t ws_floats, unsigned* tickets, void* stream) {
+static int attn_decode_any(const void* q, const void* k, const void* v, void* out, int64_t osm, int64_t osk,
+                           int64_t stride_t, int64_t stride_h, int sq, int sk, const int32_t* sk_dev, int H, int D,
+                           float scale, int nsplit, float* ws, int64_t ws_floats, unsigned* tickets, void* stream) {
     if (!q || !k || !v || !out || !ws) return TF_EINVAL;
     if (sq < 1 || sq > 32 || sk < 1 || H < 1 || nsplit < 1 || nsplit > COMBINE_MAX_SPLITS) return TF_EINVAL;
     if ((stride_t % 8) || (stride_h % 8)) return TF_EINVAL;          // 16-B loads
+    if (osm < 8 || osk < 8 || (osm % 4) || (osk % 4)) return TF_EINVAL;   // 8-byte output stores
     if (ws_floats < tf_attn_decode_ws_floats(H, sq, D, nsplit)) return TF_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
     const int QT = (sq + 15) / 16;
-    if (D == 128 && QT == 1) return launch_attn<128, 1>(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, st);
-    if (D == 128 && QT == 2) return launch_attn<128, 2>(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, st);
-    if (D == 64 && QT == 1) return launch_attn<64, 1>(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, st);
-    if (D == 64 && QT == 2) return launch_attn<64, 2>(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, st);
+    if (D == 128 && QT == 1) return launch_attn<128, 1>(q, k, v, out, osm, osk, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, st);
+    if (D == 128 && QT == 2) return launch_attn<128, 2>(q, k, v, out, osm, osk, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, st);
+    if (D == 64 && QT == 1) return launch_attn<64, 1>(q, k, v, out, osm, osk, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, st);
+    if (D == 64 && QT == 2) return launch_attn<64, 2>(q, k, v, out, osm, osk, stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, st);
     return TF_EINVAL;
 }
 
 extern "C" int tf_attn_decode(const void* q, const void* k, const void* v, void* out, int64_t stride_t,
                               int64_t stride_h, int sq, int sk, const int32_t* sk_dev, int H, int D, float scale,
                               int nsplit, float* ws, int64_t ws_floats, void* stream) {
-    return attn_decode_any(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, D, scale, nsplit, ws, ws_floats, nullptr,
-                           stream);
+    return attn_decode_any(q, k, v, out, (int64_t)H * D, 8, stride_t, stride_h, sq, sk, sk_dev, H, D, scale, nsplit, ws,
+                           ws_floats, nullptr, stream);
 }
 
 // The same call as ONE launch: the last workgroup of each head to finish merges that head's splits (bit-identical to
@@ -1791,8 +1800,18 @@ extern "C" int tf_attn_decode_fused(const void* q, const void* k, const void* v,
                                     int64_t stride_h, int sq, int sk, const int32_t* sk_dev, int H, int D, float scale,
                                     int nsplit, float* ws, int64_t ws_floats, uint32_t* tickets, void* stream) {
     if (!tickets) return TF_EINVAL;
-    return attn_decode_any(q, k, v, out, stride_t, stride_h, sq, sk, sk_dev, H, D, scale, nsplit, ws, ws_floats, tickets,
-                           stream);
+    return attn_decode_any(q, k, v, out, (int64_t)H * D, 8, stride_t, stride_h, sq, sk, sk_dev, H, D, scale, nsplit, ws,
+                           ws_floats, tickets, stream);
+}
+
+// Either form with the OUTPUT in an explicit activation layout (include/triforce_hip.h, tf_skinny_gemm_act): element
+// (row, column c = h * D + d) at out[row * out_sm + (c / 8) * out_sk + c % 8] — the o_proj GEMM that consumes it then
+// reads its B operand in k-octet-major form.  tickets == NULL: two launches; else the one-launch merge.
+extern "C" int tf_attn_decode_act(const void* q, const void* k, const void* v, void* out, int64_t out_sm, int64_t out_sk,
+                                  int64_t stride_t, int64_t stride_h, int sq, int sk, const int32_t* sk_dev, int H, int D,
+                                  float scale, int nsplit, float* ws, int64_t ws_floats, uint32_t* tickets, void* stream) {
+    return attn_decode_any(q, k, v, out, out_sm, out_sk, stride_t, stride_h, sq, sk, sk_dev, H, D, scale, nsplit, ws,
+                           ws_floats, tickets, stream);
 }
 
 extern "C" int64_t tf_attn_block_ws_floats(int H, int D, int nsplit) { return (int64_t)H * nsplit * 128 * (D + 2); }
@@ -1837,7 +1856,7 @@ static int launch_block(const void* q, const void* k, const void* v, void* out, 
                            (h16*)out, sq, H, nsplit * (4 / rg), 32 * rg, 0);
     else
         hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(H, sq), dim3(D, COMBINE_GROUPS), 0, st, (const float*)ws,
-                           (h16*)out, sq, H, nsplit * (4 / rg), 32 * rg);
+                           (h16*)out, sq, H, nsplit * (4 / rg), 32 * rg, (int64_t)H * D, (int64_t)8);
     TF_LAUNCH_CHECK();
     return TF_OK;
 }

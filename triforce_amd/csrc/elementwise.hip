@@ -143,3 +143,34 @@ extern "C" int tf_silu_mul(const void* gate_up, void* out, int rows, int I, void
     TF_LAUNCH_CHECK();
     return TF_OK;
 }
+
+// ---- embedding rows -> activation block in an explicit layout (tf_skinny_gemm_act) -------------------------------------
+// x = embed_tokens(input_ids) (models/modeling_llama.py:342, TP_llama.py:206) for the <= 32 rows of a decode forward,
+// written straight in the layout the decode layer's GEMMs read: element (m, k) at out[m * sm + (k / 8) * sk + k % 8].
+// Thread p handles the 16-byte piece (m = p % n, k8 = p / n): in the k-octet-major form consecutive threads write
+// consecutive pieces.  Out-of-range ids are clamped (the reference's index op would fault).
+__global__ __launch_bounds__(256) void embed_rows_kernel(const h16* __restrict__ embed, const int64_t* __restrict__ ids,
+                                                         h16* __restrict__ out, int64_t sm, int64_t sk, int n, int hidden,
+                                                         int vocab) {
+    const int64_t total = (int64_t)n * (hidden / 8);
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (int64_t)gridDim.x * 256) {
+        const int m = (int)(p % n);
+        const int64_t k8 = p / n;
+        int64_t id = ids[m];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        store_half8(out + (int64_t)m * sm + k8 * sk, load_half8(embed + id * hidden + 8 * k8));
+    }
+}
+
+extern "C" int tf_embed_rows(const void* embed, const int64_t* ids, void* out, int64_t out_sm, int64_t out_sk, int n,
+                             int hidden, int vocab, void* stream) {
+    if (!embed || !ids || !out || n < 1 || n > 32 || hidden < 8 || (hidden % 8) || vocab < 1) return TF_EINVAL;
+    if (out_sm < 8 || out_sk < 8 || (out_sm % 8) || (out_sk % 8)) return TF_EINVAL;
+    const int64_t total = (int64_t)n * (hidden / 8);
+    int64_t gx = (total + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, (const h16*)embed, ids,
+                       (h16*)out, out_sm, out_sk, n, hidden, vocab);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}

@@ -52,6 +52,30 @@
 
 enum { SG_PLAIN = 0, SG_GATEUP = 1, SG_F32 = 2, SG_QKV = 3 };
 
+// Activation layout (round 4).  Every activation operand is addressed through two element strides,
+//     element (m, k) at base[m * sm + (k / 8) * sk + (k % 8)],
+// so one kernel serves the reference's row-major [M][ld] blocks (sm = ld, sk = 8) and the k-octet-major form
+// (sm = 8, sk = 8 * R, R >= M): the 16-byte pieces of one k-octet of all rows are contiguous, a 32-wide k-chunk of an
+// M-row block is ONE contiguous run of 4 * R pieces.  The B operand of a 16-row tile is then 4 runs of 256 B instead of
+// 16 row fragments of 64 B (twice the cache lines per load instruction), which is what bounded the 17...32-row GEMMs of the
+// gamma = 16 verifies (profiles/r03_gemm_rows_ab.jsonl).
+struct SgAct {
+    int64_t sm, sk;
+};
+
+// P = panels per wave: a wave that multiplies P weight panels against ONE B operand reads x once per P KiB of weights
+// (x traffic through L2 -> L1 is panels * M * K * 2 bytes: as large as the weight stream itself at 17 rows with P = 1).
+// Measured (profiles/r04_gemm_layout_ab.jsonl, k-octet-major x): P = 2 pays when the halved grid still puts two
+// workgroups on most CUs — 13B q|k|v (480 groups) 32.0 -> 27.6 us at 17 rows, 26.9 -> 25.2 at 8; 13B gate|up (432)
+// 49.8 -> 47.5 / 48.4 -> 44.7 — and LOSES below that: 7B q|k|v (384 groups) 20.5 -> 23.4, 7B gate|up (344) 32.2 -> 35.4.
+// With 4 waves per workgroup it is bit-identical to the P = 1 form (same K ranges per wave, same merge order).
+#ifndef SG_P_WIDE_MIN_GROUPS
+#define SG_P_WIDE_MIN_GROUPS 420
+#endif
+static int g_sg_p2_rows = 1;       // P = 2 from this many rows (tf_sg_tune key 0; 33 = never)
+static int g_sg_p2_waves = 4;      // waves per workgroup of the P = 2 form (key 1)
+static int g_sg_p2_groups = SG_P_WIDE_MIN_GROUPS;   // ... while panels / 2 >= this (key 2)
+
 struct SgRope {                       // arguments of the RoPE + KV-append epilogue (SG_QKV)
     const h16* cosb;                  // [max_pos][D] fp16
     const h16* sinb;
@@ -73,54 +97,61 @@ __device__ __forceinline__ half8 sg_normalise(half8 xv, half8 wv, float inv) {
     return o;
 }
 
-template <int MT, int MODE, bool NORM, int WAVES>
+template <int MT, int MODE, bool NORM, int WAVES, int P>
 __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __restrict__ wp,
                                                                  const half8* __restrict__ wp_up,
-                                                                 const h16* __restrict__ x, int64_t ldx,
+                                                                 const h16* __restrict__ x, SgAct xa,
                                                                  const h16* __restrict__ ln_w, float eps,
-                                                                 const h16* resid, int64_t ldr, void* yv, int64_t ldy,
+                                                                 const h16* resid, SgAct ra, void* yv, SgAct ya,
                                                                  int M, int N, int K, SgRope rp,
                                                                  const float* __restrict__ ss_in,
                                                                  float* __restrict__ ss_out) {
     constexpr bool GATEUP = MODE == SG_GATEUP;
-    const int panel = blockIdx.x;
+    constexpr int NA = GATEUP ? 2 : 1;                       // weight streams (accumulator sets) per panel
+    constexpr int U = (P * NA >= 2) ? (8 / (P * NA)) : SG_U;  // k-chunks in flight per wave: 8 KiB of weights (4 for P = NA = 1)
+    static_assert(P <= WAVES && U >= 1, "one epilogue wave per panel");
+    const int panel0 = blockIdx.x * P;                       // this workgroup's P consecutive panels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     const int nchunks = K >> 5;
     const int cpw = (nchunks + WAVES - 1) / WAVES;
     const int c0 = wave * cpw, c1 = min(nchunks, c0 + cpw);
 
-    __shared__ float sm[WAVES][GATEUP ? 2 : 1][MT][64][4];
+    __shared__ float sm[WAVES][P * NA][MT][64][4];
     __shared__ float sm_ss[NORM ? WAVES : 1][MT][16];
 
-    f32x4 acc[MT], acc2[MT];
+    f32x4 acc[P][NA][MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const half8* wa = wp + ((int64_t)panel * nchunks) * 64 + lane;
-    const half8* wu = GATEUP ? (wp_up + ((int64_t)panel * nchunks) * 64 + lane) : nullptr;
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[j][a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t pstride = (int64_t)nchunks * 64;           // half8 pieces per panel
+    const half8* wa = wp + (int64_t)panel0 * pstride + lane;
+    const half8* wu = GATEUP ? (wp_up + (int64_t)panel0 * pstride + lane) : nullptr;
+    const int64_t xcs = 4 * xa.sk;                           // elements per 32-wide k-chunk step of the B operand
     const h16* xr[MT];
     bool xok[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int m = t * 16 + li;
         xok[t] = m < M;
-        xr[t] = x + (int64_t)(xok[t] ? m : 0) * ldx + 8 * g;
+        xr[t] = x + (int64_t)(xok[t] ? m : 0) * xa.sm + (int64_t)g * xa.sk;
     }
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    constexpr int U = SG_U;
 
     // first weight chunks of this wave: issued before the norm prologue so HBM is already streaming under it
-    half8 a_pre[U], a2_pre[U];
+    half8 a_pre[U][P][NA];
     const bool pre = NORM && (c0 + U <= c1);
     if (pre) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            a_pre[u] = SG_LOAD(wa + (int64_t)(c0 + u) * 64);
-            if (GATEUP) a2_pre[u] = SG_LOAD(wu + (int64_t)(c0 + u) * 64);
-        }
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                a_pre[u][j][0] = SG_LOAD(wa + j * pstride + (int64_t)(c0 + u) * 64);
+                if (GATEUP) a_pre[u][j][NA - 1] = SG_LOAD(wu + j * pstride + (int64_t)(c0 + u) * 64);
+            }
     }
 
     float inv[MT];
@@ -168,7 +199,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
-                    for (int t = 0; t < MT; ++t) v[j][t] = xok[t] ? load_half8(xr[t] + 32 * (cc + j)) : zero8;
+                    for (int t = 0; t < MT; ++t) v[j][t] = xok[t] ? load_half8(xr[t] + xcs * (cc + j)) : zero8;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -182,7 +213,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
             for (; cc < c1; ++cc) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
-                    const half8 v = xok[t] ? load_half8(xr[t] + 32 * cc) : zero8;
+                    const half8 v = xok[t] ? load_half8(xr[t] + xcs * cc) : zero8;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float f = (float)v[e];
@@ -208,10 +239,14 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
         for (int t = 0; t < MT; ++t) inv[t] = 1.0f / sqrtf(tot[t] / (float)K + eps);
     }
 
-    // RoPE epilogue operands (wave 0 only): cos / sin of this lane's 4 output columns, fetched now so that the
+    // Epilogue waves: wave j < P finishes panel panel0 + j.
+    const bool epi = wave < P;
+    const int panel = panel0 + (epi ? wave : 0);
+
+    // RoPE epilogue operands (epilogue waves only): cos / sin of this lane's 4 output columns, fetched now so that the
     // positions -> table dependent loads do not sit at the tail of the kernel
     half4 rope_cs[MT], rope_sn[MT];
-    if (MODE == SG_QKV && wave == 0) {
+    if (MODE == SG_QKV && epi) {
         const int H = rp.H, D = rp.D, pph = D >> 4;
         const int sec = panel / (H * pph), pp = panel % pph;
         const int d = 8 * pp + 4 * (g & 1) + ((g >= 2) ? (D >> 1) : 0);
@@ -228,70 +263,83 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
         }
     }
 
-    // residual epilogue operands (wave 0 only): this lane's 4 residual values per row tile, fetched now — at the tail
-    // they would be one more exposed memory round trip between the split-K merge and the store.  (resid may alias y:
-    // every element is read and written by the same lane only.)
+    // residual epilogue operands (epilogue waves only): this lane's 4 residual values per row tile, fetched now — at the
+    // tail they would be one more exposed memory round trip between the split-K merge and the store.  (resid may alias
+    // y: every element is read and written by the same lane only.)
     half4 res_pre[MT];
-    const bool res_early = TF_SG_RES_EARLY && MODE == SG_PLAIN && resid != nullptr && wave == 0 && (ldr % 4) == 0 &&
-                           (reinterpret_cast<uintptr_t>(resid) % 8) == 0;
+    const int64_t r_off = (int64_t)(2 * panel + (g >> 1)) * ra.sk + 4 * (g & 1);   // this lane's 4 columns, piece form
+    const int64_t y_off = (int64_t)(2 * panel + (g >> 1)) * ya.sk + 4 * (g & 1);
+    const bool res_early = TF_SG_RES_EARLY && MODE == SG_PLAIN && resid != nullptr && epi && (ra.sm % 4) == 0 &&
+                           (ra.sk % 4) == 0 && (reinterpret_cast<uintptr_t>(resid) % 8) == 0;
     if (res_early) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const int m = t * 16 + li;
             res_pre[t] = half4{0, 0, 0, 0};
-            if (m < M) res_pre[t] = *reinterpret_cast<const half4*>(resid + (int64_t)m * ldr + panel * 16 + 4 * g);
+            if (m < M) res_pre[t] = *reinterpret_cast<const half4*>(resid + (int64_t)m * ra.sm + r_off);
         }
     }
 
     int c = c0;
     for (; c + U <= c1; c += U) {
-        half8 a[U], a2[U], b[U][MT];
+        half8 a[U][P][NA], b[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (NORM && c == c0 && pre) {
-                a[u] = a_pre[u];
-                if (GATEUP) a2[u] = a2_pre[u];
-            } else {
-                a[u] = SG_LOAD(wa + (int64_t)(c + u) * 64);
-                if (GATEUP) a2[u] = SG_LOAD(wu + (int64_t)(c + u) * 64);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                if (NORM && c == c0 && pre) {
+                    a[u][j][0] = a_pre[u][j][0];
+                    if (GATEUP) a[u][j][NA - 1] = a_pre[u][j][NA - 1];
+                } else {
+                    a[u][j][0] = SG_LOAD(wa + j * pstride + (int64_t)(c + u) * 64);
+                    if (GATEUP) a[u][j][NA - 1] = SG_LOAD(wu + j * pstride + (int64_t)(c + u) * 64);
+                }
             }
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                b[u][t] = xok[t] ? load_half8(xr[t] + 32 * (c + u)) : zero8;
+                b[u][t] = xok[t] ? load_half8(xr[t] + xcs * (c + u)) : zero8;
                 if (NORM) b[u][t] = sg_normalise(b[u][t], load_half8(ln_w + 32 * (c + u) + 8 * g), inv[t]);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b[u][t], acc[t], 0, 0, 0);
-                if (GATEUP) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[u], b[u][t], acc2[t], 0, 0, 0);
-            }
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int j = 0; j < P; ++j)
+#pragma unroll
+                    for (int aa = 0; aa < NA; ++aa)
+                        acc[j][aa][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u][j][aa], b[u][t], acc[j][aa][t], 0, 0, 0);
     }
     for (; c < c1; ++c) {
-        const half8 a = SG_LOAD(wa + (int64_t)c * 64);
-        half8 a2 = zero8;
-        if (GATEUP) a2 = SG_LOAD(wu + (int64_t)c * 64);
+        half8 a[P][NA];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            a[j][0] = SG_LOAD(wa + j * pstride + (int64_t)c * 64);
+            if (GATEUP) a[j][NA - 1] = SG_LOAD(wu + j * pstride + (int64_t)c * 64);
+        }
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            half8 b = xok[t] ? load_half8(xr[t] + 32 * c) : zero8;
+            half8 b = xok[t] ? load_half8(xr[t] + xcs * c) : zero8;
             if (NORM) b = sg_normalise(b, load_half8(ln_w + 32 * c + 8 * g), inv[t]);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[t], 0, 0, 0);
-            if (GATEUP) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b, acc2[t], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < P; ++j)
+#pragma unroll
+                for (int aa = 0; aa < NA; ++aa)
+                    acc[j][aa][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j][aa], b, acc[j][aa][t], 0, 0, 0);
         }
     }
 
     // split-K merge across the waves; C layout: lane holds D[n = 4g + r][m = li]
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int j = 0; j < P; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            sm[wave][0][t][lane][r] = acc[t][r];
-            if (GATEUP) sm[wave][GATEUP ? 1 : 0][t][lane][r] = acc2[t][r];
-        }
+        for (int aa = 0; aa < NA; ++aa)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                *reinterpret_cast<f32x4*>(&sm[wave][j * NA + aa][t][lane][0]) = acc[j][aa][t];
     __syncthreads();
-    if (wave != 0) return;
+    if (!epi) return;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int m = t * 16 + li;
@@ -300,10 +348,16 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
         for (int r = 0; r < 4; ++r) {
             s[r] = 0.f;
             s2[r] = 0.f;
+        }
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) {
-                s[r] += sm[w][0][t][lane][r];
-                if (GATEUP) s2[r] += sm[w][GATEUP ? 1 : 0][t][lane][r];
+        for (int w = 0; w < WAVES; ++w) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&sm[w][wave * NA][t][lane][0]);
+            f32x4 v2 = {0.f, 0.f, 0.f, 0.f};
+            if (GATEUP) v2 = *reinterpret_cast<const f32x4*>(&sm[w][wave * NA + NA - 1][t][lane][0]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[r] += v[r];
+                if (GATEUP) s2[r] += v2[r];
             }
         }
         if (MODE == SG_QKV) {
@@ -350,22 +404,37 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
         if (!row_ok) {                               // keep the wave converged for the shuffles below
             s2[0] = s2[1] = s2[2] = s2[3] = 0.f;
         }
+        if (row_ok) {
+            if (MODE == SG_F32) {                    // logits.float(): fp16 GEMM, then cast; row-major fp32 rows
+                float* dst = (float*)yv + (int64_t)m * ya.sm + panel * 16 + 4 * g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (!row_ok) break;
-            const int n = panel * 16 + 4 * g + r;
-            if (GATEUP) {
-                const h16 gt = (h16)s[r], up = (h16)s2[r];
-                const float gf = (float)gt;
-                const h16 act = (h16)(gf / (1.0f + expf(-gf)));
-                ((h16*)yv)[(int64_t)m * ldy + n] = hmul_rn(act, up);
-            } else if (MODE == SG_F32) {
-                ((float*)yv)[(int64_t)m * ldy + n] = (float)(h16)s[r];          // logits.float(): fp16 GEMM, then cast
+                for (int r = 0; r < 4; ++r) dst[r] = (float)(h16)s[r];
             } else {
-                h16 o = (h16)s[r];
-                if (resid) o = hadd_rn(res_early ? res_pre[t][r] : resid[(int64_t)m * ldr + n], o);   // residual + hidden, fp16 add
-                ((h16*)yv)[(int64_t)m * ldy + n] = o;
-                s2[r] = (float)o;
+                half4 o;
+                if (GATEUP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const h16 gt = (h16)s[r], up = (h16)s2[r];
+                        const float gf = (float)gt;
+                        const h16 act = (h16)(gf / (1.0f + expf(-gf)));
+                        o[r] = hmul_rn(act, up);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        o[r] = (h16)s[r];
+                        if (resid)               // residual + hidden, fp16 add
+                            o[r] = hadd_rn(res_early ? res_pre[t][r] : resid[(int64_t)m * ra.sm + r_off + r], o[r]);
+                        s2[r] = (float)o[r];
+                    }
+                }
+                h16* dst = (h16*)yv + (int64_t)m * ya.sm + y_off;
+                if (((ya.sm | ya.sk) % 4) == 0 && (reinterpret_cast<uintptr_t>(yv) % 8) == 0) {
+                    *reinterpret_cast<half4*>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[r] = o[r];
+                }
             }
         }
         if (MODE == SG_PLAIN && ss_out) {            // this panel's share of sum(y^2) per row, for the next norm prologue
@@ -377,52 +446,94 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
     }
 }
 
-template <int MT, int MODE, bool NORM, int WAVES>
-static void launch_sg_w(const void* wp, const void* wp_up, const void* x, int64_t ldx, const void* ln_w, float eps,
-                        const void* resid, int64_t ldr, void* y, int64_t ldy, int M, int N, int K, const SgRope& rp,
-                        const float* ss_in, float* ss_out, hipStream_t st) {
-    hipLaunchKernelGGL((skinny_gemm_kernel<MT, MODE, NORM, WAVES>), dim3(N / 16), dim3(WAVES * 64), 0, st,
-                       (const half8*)wp, (const half8*)wp_up, (const h16*)x, ldx, (const h16*)ln_w, eps,
-                       (const h16*)resid, ldr, y, ldy, M, N, K, rp, ss_in, ss_out);
+struct SgArgs {                       // one GEMM call: operands with their layouts
+    const void *wp, *wp_up, *x, *ln_w, *resid;
+    void* y;
+    SgAct xa, ra, ya;
+    float eps;
+    int M, N, K;
+    const float* ss_in;
+    float* ss_out;
+};
+
+template <int MT, int MODE, bool NORM, int WAVES, int P>
+static void launch_sg_w(const SgArgs& a, const SgRope& rp, hipStream_t st) {
+    hipLaunchKernelGGL((skinny_gemm_kernel<MT, MODE, NORM, WAVES, P>), dim3(a.N / 16 / P), dim3(WAVES * 64), 0, st,
+                       (const half8*)a.wp, (const half8*)a.wp_up, (const h16*)a.x, a.xa, (const h16*)a.ln_w, a.eps,
+                       (const h16*)a.resid, a.ra, a.y, a.ya, a.M, a.N, a.K, rp, a.ss_in, a.ss_out);
 }
 
 template <int MODE, bool NORM>
-static int launch_sg(const void* wp, const void* wp_up, const void* x, int64_t ldx, const void* ln_w, float eps,
-                     const void* resid, int64_t ldr, void* y, int64_t ldy, int M, int N, int K, const SgRope& rp,
-                     hipStream_t st, const float* ss_in = nullptr, float* ss_out = nullptr) {
+static int launch_sg(const SgArgs& a, const SgRope& rp, hipStream_t st) {
+    const int panels = a.N / 16, nchunks = a.K >> 5;
+    // two panels per wave (x read once per 2 KiB of weights): from g_sg_p2_rows activation rows up, while the halved
+    // grid still covers every CU; the 8 waves of such a workgroup split K.
+    const bool p2 = a.M >= g_sg_p2_rows && (panels % 2) == 0 && panels / 2 >= g_sg_p2_groups && nchunks >= 16;
+    if (p2) {
+        if (g_sg_p2_waves == 4) {
+            if (a.M <= 16) launch_sg_w<1, MODE, NORM, 4, 2>(a, rp, st);
+            else launch_sg_w<2, MODE, NORM, 4, 2>(a, rp, st);
+        } else {
+            if (a.M <= 16) launch_sg_w<1, MODE, NORM, 8, 2>(a, rp, st);
+            else launch_sg_w<2, MODE, NORM, 8, 2>(a, rp, st);
+        }
+        TF_LAUNCH_CHECK();
+        return TF_OK;
+    }
     // wide variant: few panels and enough k-chunks that every wave still gets >= 2 of them
     constexpr bool CAN_WIDE = MODE != SG_GATEUP;
-    const bool wide = CAN_WIDE && (N / 16) <= SG_WIDE_MAX_PANELS && (K >> 5) >= 2 * SG_WAVES_WIDE;
+    const bool wide = CAN_WIDE && panels <= SG_WIDE_MAX_PANELS && nchunks >= 2 * SG_WAVES_WIDE;
     constexpr int WW = CAN_WIDE ? SG_WAVES_WIDE : SG_WAVES;
-    if (M <= 16) {
-        if (wide) launch_sg_w<1, MODE, NORM, WW>(wp, wp_up, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, ss_in, ss_out, st);
-        else launch_sg_w<1, MODE, NORM, SG_WAVES>(wp, wp_up, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, ss_in, ss_out, st);
+    if (a.M <= 16) {
+        if (wide) launch_sg_w<1, MODE, NORM, WW, 1>(a, rp, st);
+        else launch_sg_w<1, MODE, NORM, SG_WAVES, 1>(a, rp, st);
     } else {
-        if (wide) launch_sg_w<2, MODE, NORM, WW>(wp, wp_up, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, ss_in, ss_out, st);
-        else launch_sg_w<2, MODE, NORM, SG_WAVES>(wp, wp_up, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, ss_in, ss_out, st);
+        if (wide) launch_sg_w<2, MODE, NORM, WW, 1>(a, rp, st);
+        else launch_sg_w<2, MODE, NORM, SG_WAVES, 1>(a, rp, st);
     }
     TF_LAUNCH_CHECK();
     return TF_OK;
 }
 
-static bool sg_shape_ok(int M, int N, int K, int64_t ldx) {
-    return M >= 1 && M <= 32 && N >= 16 && (N % 16) == 0 && K >= 32 && (K % 32) == 0 && (ldx % 8) == 0;
+static bool sg_act_ok(const SgAct& s) { return s.sm > 0 && s.sk > 0 && (s.sm % 8) == 0 && (s.sk % 8) == 0; }
+
+static bool sg_shape_ok(int M, int N, int K, const SgAct& xa) {
+    return M >= 1 && M <= 32 && N >= 16 && (N % 16) == 0 && K >= 32 && (K % 32) == 0 && sg_act_ok(xa);
+}
+
+// A/B knobs of the launch rule (tools/gemm_layout_ab.py): key 0 = rows from which two panels per wave are used (33:
+// never), key 1 = waves per workgroup of that form (4 or 8), key 2 = smallest halved grid (panels / 2) that takes it.  Returns the previous value, -1 for an unknown key.
+extern "C" int tf_sg_tune(int key, int value) {
+    int* slot = key == 0 ? &g_sg_p2_rows : key == 1 ? &g_sg_p2_waves : key == 2 ? &g_sg_p2_groups : nullptr;
+    if (!slot) return -1;
+    const int old = *slot;
+    if (key == 1 && value != 4 && value != 8) return old;
+    *slot = value;
+    return old;
+}
+
+extern "C" int tf_skinny_gemm_act(const void* w_packed, const void* x, int64_t xs_m, int64_t xs_k, const void* ln_w,
+                                  float eps, const float* ss_in, const void* resid, int64_t rs_m, int64_t rs_k,
+                                  float* ss_out, void* y, int64_t ys_m, int64_t ys_k, int M, int N, int K, int out_f32,
+                                  void* stream) {
+    SgArgs a = {};
+    a.wp = w_packed, a.x = x, a.ln_w = ln_w, a.resid = resid, a.y = y;
+    a.xa = SgAct{xs_m, xs_k}, a.ra = SgAct{rs_m, rs_k}, a.ya = SgAct{ys_m, ys_k};
+    a.eps = eps, a.M = M, a.N = N, a.K = K, a.ss_in = ss_in, a.ss_out = ss_out;
+    if (!w_packed || !x || !y || !sg_shape_ok(M, N, K, a.xa)) return TF_EINVAL;
+    if ((out_f32 && (resid || ss_out)) || (ss_in && !ln_w)) return TF_EINVAL;
+    if (ys_m <= 0 || (!out_f32 && ys_k <= 0) || (resid && (rs_m <= 0 || rs_k <= 0))) return TF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const SgRope rp = {};
+    if (out_f32) return ln_w ? launch_sg<SG_F32, true>(a, rp, st) : launch_sg<SG_F32, false>(a, rp, st);
+    return ln_w ? launch_sg<SG_PLAIN, true>(a, rp, st) : launch_sg<SG_PLAIN, false>(a, rp, st);
 }
 
 extern "C" int tf_skinny_gemm_ex(const void* w_packed, const void* x, int64_t ldx, const void* ln_w, float eps,
                                  const float* ss_in, const void* resid, int64_t ldr, float* ss_out, void* y,
                                  int64_t ldy, int M, int N, int K, int out_f32, void* stream) {
-    if (!w_packed || !x || !y || !sg_shape_ok(M, N, K, ldx)) return TF_EINVAL;
-    if ((out_f32 && (resid || ss_out)) || (ss_in && !ln_w)) return TF_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    const SgRope rp = {};
-    if (out_f32)
-        return ln_w ? launch_sg<SG_F32, true>(w_packed, nullptr, x, ldx, ln_w, eps, nullptr, 0, y, ldy, M, N, K, rp, st, ss_in)
-                    : launch_sg<SG_F32, false>(w_packed, nullptr, x, ldx, nullptr, 0.f, nullptr, 0, y, ldy, M, N, K, rp, st);
-    return ln_w ? launch_sg<SG_PLAIN, true>(w_packed, nullptr, x, ldx, ln_w, eps, resid, ldr, y, ldy, M, N, K, rp, st, ss_in,
-                                            ss_out)
-                : launch_sg<SG_PLAIN, false>(w_packed, nullptr, x, ldx, nullptr, 0.f, resid, ldr, y, ldy, M, N, K, rp, st,
-                                             nullptr, ss_out);
+    return tf_skinny_gemm_act(w_packed, x, ldx, 8, ln_w, eps, ss_in, resid, ldr, 8, ss_out, y, ldy, 8, M, N, K, out_f32,
+                              stream);
 }
 
 extern "C" int tf_skinny_gemm(const void* w_packed, const void* x, int64_t ldx, void* y, int64_t ldy, int M, int N,
@@ -430,16 +541,24 @@ extern "C" int tf_skinny_gemm(const void* w_packed, const void* x, int64_t ldx, 
     return tf_skinny_gemm_ex(w_packed, x, ldx, nullptr, 0.f, nullptr, nullptr, 0, nullptr, y, ldy, M, N, K, out_f32, stream);
 }
 
+extern "C" int tf_skinny_gemm_swiglu_act(const void* gate_packed, const void* up_packed, const void* x, int64_t xs_m,
+                                         int64_t xs_k, const void* ln_w, float eps, const float* ss_in, void* act,
+                                         int64_t ys_m, int64_t ys_k, int M, int I, int K, void* stream) {
+    SgArgs a = {};
+    a.wp = gate_packed, a.wp_up = up_packed, a.x = x, a.ln_w = ln_w, a.y = act;
+    a.xa = SgAct{xs_m, xs_k}, a.ya = SgAct{ys_m, ys_k}, a.ra = SgAct{8, 8};
+    a.eps = eps, a.M = M, a.N = I, a.K = K, a.ss_in = ss_in;
+    if (!gate_packed || !up_packed || !x || !act || !sg_shape_ok(M, I, K, a.xa) || (ss_in && !ln_w)) return TF_EINVAL;
+    if (ys_m <= 0 || ys_k <= 0) return TF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const SgRope rp = {};
+    return ln_w ? launch_sg<SG_GATEUP, true>(a, rp, st) : launch_sg<SG_GATEUP, false>(a, rp, st);
+}
+
 extern "C" int tf_skinny_gemm_swiglu_ex(const void* gate_packed, const void* up_packed, const void* x, int64_t ldx,
                                         const void* ln_w, float eps, const float* ss_in, void* act, int64_t ldy, int M,
                                         int I, int K, void* stream) {
-    if (!gate_packed || !up_packed || !x || !act || !sg_shape_ok(M, I, K, ldx) || (ss_in && !ln_w)) return TF_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    const SgRope rp = {};
-    return ln_w ? launch_sg<SG_GATEUP, true>(gate_packed, up_packed, x, ldx, ln_w, eps, nullptr, 0, act, ldy, M, I, K, rp, st,
-                                             ss_in)
-                : launch_sg<SG_GATEUP, false>(gate_packed, up_packed, x, ldx, nullptr, 0.f, nullptr, 0, act, ldy, M, I, K,
-                                              rp, st);
+    return tf_skinny_gemm_swiglu_act(gate_packed, up_packed, x, ldx, 8, ln_w, eps, ss_in, act, ldy, 8, M, I, K, stream);
 }
 
 extern "C" int tf_skinny_gemm_swiglu(const void* gate_packed, const void* up_packed, const void* x, int64_t ldx,
@@ -447,13 +566,17 @@ extern "C" int tf_skinny_gemm_swiglu(const void* gate_packed, const void* up_pac
     return tf_skinny_gemm_swiglu_ex(gate_packed, up_packed, x, ldx, nullptr, 0.f, nullptr, act, ldy, M, I, K, stream);
 }
 
-extern "C" int tf_skinny_qkv_rope(const void* wqkv_packed, const void* x, int64_t ldx, const void* ln_w, float eps,
-                                  const float* ss_in, const void* cosb, const void* sinb, const int64_t* positions,
-                                  void* q_out, void* k_cache, void* v_cache, int64_t stride_t, int64_t stride_h,
-                                  int slot0, const int32_t* slot0_dev, int M, int H, int D, int K, int rotate_k,
-                                  void* stream) {
+extern "C" int tf_skinny_qkv_rope_act(const void* wqkv_packed, const void* x, int64_t xs_m, int64_t xs_k,
+                                      const void* ln_w, float eps, const float* ss_in, const void* cosb,
+                                      const void* sinb, const int64_t* positions, void* q_out, void* k_cache,
+                                      void* v_cache, int64_t stride_t, int64_t stride_h, int slot0,
+                                      const int32_t* slot0_dev, int M, int H, int D, int K, int rotate_k, void* stream) {
     if (!wqkv_packed || !x || !cosb || !sinb || !positions || !q_out || !k_cache || !v_cache) return TF_EINVAL;
-    if (H < 1 || D < 32 || (D % 32) || !sg_shape_ok(M, 3 * H * D, K, ldx) || (ss_in && !ln_w)) return TF_EINVAL;
+    SgArgs a = {};
+    a.wp = wqkv_packed, a.x = x, a.ln_w = ln_w;
+    a.xa = SgAct{xs_m, xs_k}, a.ra = SgAct{8, 8}, a.ya = SgAct{8, 8};
+    a.eps = eps, a.M = M, a.N = 3 * H * D, a.K = K, a.ss_in = ss_in;
+    if (H < 1 || D < 32 || (D % 32) || !sg_shape_ok(M, a.N, K, a.xa) || (ss_in && !ln_w)) return TF_EINVAL;
     if ((stride_t % 4) || (stride_h % 4)) return TF_EINVAL;                          // 8-byte epilogue stores
     hipStream_t st = (hipStream_t)stream;
     SgRope rp;
@@ -470,9 +593,14 @@ extern "C" int tf_skinny_qkv_rope(const void* wqkv_packed, const void* x, int64_
     rp.H = H;
     rp.D = D;
     rp.rotate_k = rotate_k;
-    const int N = 3 * H * D;
-    return ln_w ? launch_sg<SG_QKV, true>(wqkv_packed, nullptr, x, ldx, ln_w, eps, nullptr, 0, nullptr, 0, M, N, K, rp, st,
-                                          ss_in)
-                : launch_sg<SG_QKV, false>(wqkv_packed, nullptr, x, ldx, nullptr, 0.f, nullptr, 0, nullptr, 0, M, N, K, rp,
-                                           st);
+    return ln_w ? launch_sg<SG_QKV, true>(a, rp, st) : launch_sg<SG_QKV, false>(a, rp, st);
+}
+
+extern "C" int tf_skinny_qkv_rope(const void* wqkv_packed, const void* x, int64_t ldx, const void* ln_w, float eps,
+                                  const float* ss_in, const void* cosb, const void* sinb, const int64_t* positions,
+                                  void* q_out, void* k_cache, void* v_cache, int64_t stride_t, int64_t stride_h,
+                                  int slot0, const int32_t* slot0_dev, int M, int H, int D, int K, int rotate_k,
+                                  void* stream) {
+    return tf_skinny_qkv_rope_act(wqkv_packed, x, ldx, 8, ln_w, eps, ss_in, cosb, sinb, positions, q_out, k_cache,
+                                  v_cache, stride_t, stride_h, slot0, slot0_dev, M, H, D, K, rotate_k, stream);
 }

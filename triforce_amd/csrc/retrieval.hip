@@ -12,6 +12,10 @@
 // per 16-lane group), nothing is staged in a temporary, the top-k runs in LDS.
 #include "common.h"
 
+#ifndef TF_RSCORE_CAP_CEIL
+#define TF_RSCORE_CAP_CEIL 0
+#endif
+
 // ---- scoring ------------------------------------------------------------------------------
 // One 16-lane group per chunk (a wave scores 4 chunks per step); lane (c4, li) owns 8 d's.
 // Rounding points follow the reference: mean -> fp16, dot -> fp16.
@@ -234,7 +238,14 @@ extern "C" int tf_retrieval_score(const void* k, int64_t stride_t, int64_t strid
     hipStream_t st = (hipStream_t)stream;
     const int gpb = 256 / (D / 8);
     int gx = (C + gpb - 1) / gpb;
-    const int cap = (2048 + H - 1) / H;              // ~8 workgroups per CU, grid-stride beyond
+#if TF_RSCORE_CAP_CEIL
+    const int cap = (2048 + H - 1) / H;              // round 1-3 rule: 2 080 workgroups at H = 40, 2 050 at H = 5
+#else
+    // 8 resident workgroups per CU and NOT ONE MORE: with ceil(2048 / H) the 32 (H = 40) or 2 (H = 5) workgroups past
+    // 2 048 start when the others retire and stream their share alone, latency-bound (0.59 of peak at H = 40 against
+    // 0.81 at H = 32, profiles/r03_bench_13b_cfg4_world1.json); grid-stride beyond
+    const int cap = H <= 2048 ? 2048 / H : 1;
+#endif
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     if (D == 128)

@@ -19,6 +19,8 @@ SIGNATURES = {
     "tf_attn_decode": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _i32, _f32, _i32, _vp, _i64, _vp]),
     "tf_attn_decode_fused": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _i32, _f32, _i32, _vp, _i64, _vp,
                                     _vp]),
+    "tf_attn_decode_act": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _i32, _i32, _f32, _i32, _vp,
+                                  _i64, _vp, _vp]),
     "tf_attn_block_ws_floats": (_i64, [_i32, _i32, _i32]),
     "tf_attn_block_pick_nsplit": (_i32, [_i32, _i32, _i32]),
     "tf_attn_prefill_pick_nsplit": (_i32, [_i32, _i32, _i32]),
@@ -38,12 +40,19 @@ SIGNATURES = {
     "tf_rmsnorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "tf_rope_append": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "tf_silu_mul": (_i32, [_vp, _vp, _i32, _i32, _vp]),
+    "tf_embed_rows": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "tf_skinny_gemm": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "tf_skinny_gemm_ex": (_i32, [_vp, _vp, _i64, _vp, _f32, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "tf_skinny_gemm_swiglu_ex": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "tf_skinny_qkv_rope": (_i32, [_vp, _vp, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp,
                                   _i32, _i32, _i32, _i32, _i32, _vp]),
     "tf_skinny_gemm_swiglu": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "tf_skinny_gemm_act": (_i32, [_vp, _vp, _i64, _i64, _vp, _f32, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32,
+                                  _i32, _i32, _vp]),
+    "tf_skinny_gemm_swiglu_act": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _f32, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "tf_skinny_qkv_rope_act": (_i32, [_vp, _vp, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32,
+                                      _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "tf_sg_tune": (_i32, [_i32, _i32]),
     "tf_topp_probs": (_i32, [_vp, _vp, _i32, _i32, _f32, _f32, _vp]),
     "tf_sample_inverse_cdf": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "tf_accept_chain": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
@@ -61,7 +70,10 @@ SIGNATURES = {
     "tf_allreduce_oneshot_add": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i64, _vp]),
     "tf_allreduce_oneshot_add_ss": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
     "tf_allreduce_oneshot_alt": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp]),
+    "tf_allreduce_oneshot_act": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp]),
     "tf_ar_error": (_i32, [_vp]),
+    "tf_ar_epoch": (_i64, [_vp]),
+    "tf_ar_set_error_mirror": (_i32, [_vp, _vp]),
     "tf_ar_inject_error": (_i32, [_vp, _i32]),
 }
 

@@ -304,7 +304,10 @@ class DistributedLlama:
         # --local-exchange, profiles/r02_tp_shard_fused_vs_unfused.jsonl) the fused layer wins at 1 and 7 rows (7B, 8 ranks:
         # retrieval verify 2 001 -> 1 893 us, autoregressive step 4 021 -> 3 333) and loses 1-2 % at the 17 rows of a
         # gamma = 16 verify, where every norm prologue works on two row tiles
-        if tree is not None or q_len > 16 or self.device.type != "cuda":
+        # (with k-octet-major activations — ops.act_packed — the second row tile costs the norm prologue far less; the
+        #  row limit of the fused layer is then TRIFORCE_TP_FUSE_MAX_ROWS, default 32)
+        limit = int(os.environ.get("TRIFORCE_TP_FUSE_MAX_ROWS", "32" if ops.act_packed(q_len) else "16"))
+        if tree is not None or q_len > limit or self.device.type != "cuda":
             return False
         if ops.FUSE_MODE != "all" or os.environ.get("TRIFORCE_TP_FUSE", "1") == "0":
             return False
@@ -319,15 +322,16 @@ class DistributedLlama:
         buffer, or None at world size 1 (x and ss already updated by the GEMM's own epilogue)."""
         W = self.weights
         Hl, D = W.H_local, W.D
+        packed = isinstance(x, ops.Act)                   # k-octet-major residual stream (ops.act_packed)
         q = ops.qkv_rope(x, W.wqkv[i], W.ln1[i], W.eps, self.cos_cache, self.sin_cache, pos, kl, vl, slot, Hl, D,
                          slot0_dev=slot_dev, ss_in=ss if i > 0 else None)
         if retrieval_build:                               # tensor_op.py:161-162
             self.retrieval_cache.init_graph_cache((kl, vl), q, i)
-        a = ops.attn_decode(q, kl, vl, sk, self.scale, sk_dev=sk_dev)
+        a = ops.attn_decode(q, kl, vl, sk, self.scale, sk_dev=sk_dev, packed=packed)
         if self.world_size == 1:
             ops.linear(a, W.wo[i], resid=x, out=x, ss_out=ss)
             return None
-        return ops.linear(a, W.wo[i], out=self._ar.staging(x.shape[0], self.hidden_size))
+        return ops.linear(a, W.wo[i], out=self._ar.staging(x.shape[0], self.hidden_size, packed=packed))
 
     def _mlp_half_fused(self, i, x, ss):
         W = self.weights
@@ -335,7 +339,7 @@ class DistributedLlama:
         if self.world_size == 1:
             ops.linear(act, W.wd[i], resid=x, out=x, ss_out=ss)
             return None
-        return ops.linear(act, W.wd[i], out=self._ar.staging(x.shape[0], self.hidden_size))
+        return ops.linear(act, W.wd[i], out=self._ar.staging(x.shape[0], self.hidden_size, packed=isinstance(x, ops.Act)))
 
     def _exchange_fused(self, part, x, ss):
         """x += sum over ranks of ``part`` (tensor_op.py:179-181,359-360) and ss <- panel sums of squares of the new x."""
@@ -349,7 +353,7 @@ class DistributedLlama:
     def _finish_fused(self, x, ss):
         W = self.weights
         if W.capture is not None:
-            W.capture.append(x.clone())
+            W.capture.append(x.rows() if isinstance(x, ops.Act) else x.clone())
         return ops.linear(x, W.lm_head, out_f32=True, ln=W.norm, eps=W.eps, ss_in=ss).unsqueeze(0)
 
     def _finish(self, x, d):
@@ -376,7 +380,8 @@ class DistributedLlama:
         if position_ids is None:
             position_ids = (S + torch.arange(q_len, dtype=torch.long, device=self.device)).unsqueeze(0)
         pos = position_ids.reshape(-1).contiguous()
-        x = self.embed_tokens[input_ids.reshape(-1)]
+        fused = self._fused_decode(q_len, tree)
+        x = ops.embed_rows(self.embed_tokens, input_ids, fused and ops.act_packed(q_len))
         build = retrieval_cache is not None
         n_on, L = self.on_chip_layers, self.num_layers
         tail = self.retrieval_cache if (self.retrieval_cache is not None and S >= self.prefill_len) else None
@@ -391,7 +396,6 @@ class DistributedLlama:
                     ready[idx] = torch.cuda.Event()
                     ready[idx].record(cs)
         d = None
-        fused = self._fused_decode(q_len, tree)
         ss = ops.ss_buffer(self.hidden_size, self.device) if fused else None
         for idx in range(L):
             if idx < n_on:
@@ -461,7 +465,9 @@ class DistributedLlama:
                     base=torch.arange(q_len, device=dev, dtype=torch.long),
                     slot=torch.zeros(1, dtype=torch.int32, device=dev),
                     sk=torch.full((1,), q_len, dtype=torch.int32, device=dev),
-                    x=torch.zeros(q_len, hid, dtype=torch.float16, device=dev),
+                    x=(ops.Act(torch.zeros(hid // 8, q_len, 8, dtype=torch.float16, device=dev), q_len)
+                       if (self._fused_decode(q_len) and ops.act_packed(q_len))
+                       else torch.zeros(q_len, hid, dtype=torch.float16, device=dev)),
                     o=torch.zeros(q_len, hid, dtype=torch.float16, device=dev),
                     d=torch.zeros(q_len, hid, dtype=torch.float16, device=dev),
                     ss=torch.zeros(hid // 16, 32, dtype=torch.float32, device=dev))
@@ -476,26 +482,30 @@ class DistributedLlama:
         q_len = st["x"].shape[0]
         if self._fused_decode(q_len):
             return self._stages_fused(st, kind)
-        part_o, part_d = self._partial_out(q_len, st["o"]), self._partial_out(q_len, st["d"])   # staging, or in place
+        # Where a stage writes its partial is resolved WHEN THE STAGE RUNS (or is captured), and each stage hands it to
+        # its own exchange step through its own cell: with alternating staging halves (TRIFORCE_AR_ALTERNATE=1)
+        # consecutive exchanges read different halves, so two partials taken from staging() up front would share one.
 
-        def attn(i):
+        def attn(i, cell):
             def run():
                 if i == 0:
                     st["x"].copy_(self.embed_tokens[st["ids"].reshape(-1)])
                 d = None if i == 0 else st["d"]
+                part = cell["p"] = self._partial_out(q_len, st["o"])          # staging, or in place
                 if kind == "retrieval":
                     kl, vl = rc.layer_kv(i)
-                    self._attn_half(i, st["x"], d, st["pos"], kl, vl, rc.spec_slot, rc.real_budget, out=part_o)
+                    self._attn_half(i, st["x"], d, st["pos"], kl, vl, rc.spec_slot, rc.real_budget, out=part)
                 else:
                     kl, vl = kvc.layer_kv(i)
-                    self._attn_half(i, st["x"], d, st["pos"], kl, vl, 0, kvc.max_budget, out=part_o,
+                    self._attn_half(i, st["x"], d, st["pos"], kl, vl, 0, kvc.max_budget, out=part,
                                     slot_dev=st["slot"], sk_dev=st["sk"])
-                return part_o
+                return part
             return run
 
-        def mlp(i):
+        def mlp(i, cell):
             def run():
-                return self._mlp_half(i, st["x"], st["o"], out=part_d)
+                part = cell["p"] = self._partial_out(q_len, st["d"])
+                return self._mlp_half(i, st["x"], st["o"], out=part)
             return run
 
         def finish():
@@ -506,8 +516,9 @@ class DistributedLlama:
 
         stages = []                                   # (collective-free stage, its exchange step | None)
         for i in range(L):
-            stages.append((attn(i), lambda: self._reduce(part_o, st["o"])))
-            stages.append((mlp(i), lambda: self._reduce(part_d, st["d"])))
+            ca, cm = {}, {}
+            stages.append((attn(i, ca), lambda c=ca: self._reduce(c["p"], st["o"])))
+            stages.append((mlp(i, cm), lambda c=cm: self._reduce(c["p"], st["d"])))
         stages.append((finish, None))
         return stages
 
@@ -516,25 +527,24 @@ class DistributedLlama:
         L = self.num_layers
         rc, kvc = self.retrieval_cache, self.kv_cache
         x, ss = st["x"], st["ss"]
-        box = {}                                          # partial handed from a stage to its exchange step
 
-        def attn(i):
+        def attn(i, cell):                                # cell: partial handed from this stage to ITS exchange step
             def run():
                 if i == 0:
-                    x.copy_(self.embed_tokens[st["ids"].reshape(-1)])
+                    ops.embed_rows(self.embed_tokens, st["ids"], isinstance(x, ops.Act), out=x)
                 if kind == "retrieval":
                     kl, vl = rc.layer_kv(i)
-                    box["p"] = self._attn_half_fused(i, x, ss, st["pos"], kl, vl, rc.spec_slot, rc.real_budget)
+                    cell["p"] = self._attn_half_fused(i, x, ss, st["pos"], kl, vl, rc.spec_slot, rc.real_budget)
                 else:
                     kl, vl = kvc.layer_kv(i)
-                    box["p"] = self._attn_half_fused(i, x, ss, st["pos"], kl, vl, 0, kvc.max_budget,
-                                                     slot_dev=st["slot"], sk_dev=st["sk"])
+                    cell["p"] = self._attn_half_fused(i, x, ss, st["pos"], kl, vl, 0, kvc.max_budget,
+                                                      slot_dev=st["slot"], sk_dev=st["sk"])
                 return x
             return run
 
-        def mlp(i):
+        def mlp(i, cell):
             def run():
-                box["p"] = self._mlp_half_fused(i, x, ss)
+                cell["p"] = self._mlp_half_fused(i, x, ss)
                 return x
             return run
 
@@ -544,11 +554,12 @@ class DistributedLlama:
                 return norm_logits(logits[0], temperature=self.temperature, top_k=-1, top_p=self.top_p)
             return logits
 
-        exchange = (lambda: self._exchange_fused(box["p"], x, ss)) if self.world_size > 1 else None
+        multi = self.world_size > 1
         stages = []
         for i in range(L):
-            stages.append((attn(i), exchange))
-            stages.append((mlp(i), exchange))
+            ca, cm = {}, {}
+            stages.append((attn(i, ca), (lambda c=ca: self._exchange_fused(c["p"], x, ss)) if multi else None))
+            stages.append((mlp(i, cm), (lambda c=cm: self._exchange_fused(c["p"], x, ss)) if multi else None))
         stages.append((finish, None))
         return stages
 
@@ -566,17 +577,33 @@ class DistributedLlama:
                 return out
             graph, out = _capture(run_all, (), self._mempool, 3)
             return dict(form="whole", graph=graph, out=out, st=st, T=self.temperature, P=self.top_p)
+        # segments: the exchanges run eagerly BETWEEN the stage graphs at replay time, so none is issued while the stages
+        # are captured one after the other.  With alternating staging halves every stage must still be captured against
+        # the half its exchange will read at replay: count the (not yet issued) exchanges by hand while capturing and put
+        # the count back afterwards; a replay must then start at the same parity (checked in _replay).
+        ar = self._ar
+        base = ar._issued if ar is not None else 0
         graphs = []
         out = None
-        for fn, exchange in stages:
-            g, out = _capture(fn, (), self._mempool, 2)
-            graphs.append((g, exchange))
-        return dict(form="segments", graphs=graphs, out=out, st=st, T=self.temperature, P=self.top_p)
+        try:
+            for fn, exchange in stages:
+                g, out = _capture(fn, (), self._mempool, 2)
+                graphs.append((g, exchange))
+                if ar is not None and exchange is not None:
+                    ar._issued += 1
+        finally:
+            if ar is not None:
+                ar._issued = base
+        return dict(form="segments", graphs=graphs, out=out, st=st, T=self.temperature, P=self.top_p,
+                    parity=(base & 1) if (ar is not None and ar.alternate) else None)
 
     def _replay(self, cap):
         if cap["form"] == "whole":
             cap["graph"].replay()
         else:
+            if cap.get("parity") is not None and (self._ar._issued & 1) != cap["parity"]:
+                raise RuntimeError("alternating one-shot all-reduce: this forward's stage graphs were captured at the other "
+                                   "exchange parity (an odd number of exchanges ran since) — re-run initialize_graphs()")
             for g, exchange in cap["graphs"]:
                 g.replay()
                 if exchange is not None:
@@ -613,6 +640,11 @@ class DistributedLlama:
             torch.cuda.synchronize(self.device)
         except Exception as ex:                            # capture of a collective refused / failed: use segments
             ok = False
+            if self._ar is not None:
+                try:
+                    self._ar.resync()                       # the failed capture may have counted an odd number of exchanges
+                except Exception:
+                    pass
             if verbose or self.local_rank == 0:
                 print(f"[TP graphs] whole-forward capture ({kind}, q={q_len}) unavailable: {type(ex).__name__}: {ex}",
                       flush=True)
@@ -626,6 +658,8 @@ class DistributedLlama:
         mode = {"1": "whole", "": "auto"}.get(mode, mode)
         if capture_verify is not None:
             mode = "whole" if capture_verify else "0"
+        if self._ar is not None:          # host exchange count <- device epoch (a discarded capture or a forward that
+            self._ar.resync()             # raised midway may have counted exchanges the device never ran)
         self._mempool = torch.cuda.graphs.graph_pool_handle()
         self._draft_graphs = {}
         for off in range(gamma + 3):                       # replicated 68M draft steps: no collective inside
@@ -729,8 +763,9 @@ class DistributedLlama:
         q_len = input_ids.shape[1]
         assert q_len == rc.gamma + 1
         pos = position_ids.reshape(-1).contiguous()
-        x = self.embed_tokens[input_ids.reshape(-1)]
-        if self._fused_decode(q_len):
+        fused = self._fused_decode(q_len)
+        x = ops.embed_rows(self.embed_tokens, input_ids, fused and ops.act_packed(q_len))
+        if fused:
             ss = ops.ss_buffer(self.hidden_size, self.device)
             for idx in range(self.num_layers):
                 kl, vl = rc.layer_kv(idx)

@@ -87,7 +87,6 @@ class LlamaForCausalLM:
             position_ids = torch.arange(kv_cache.seq_len, kv_cache.seq_len + q_len, dtype=torch.long,
                                         device=self.device).unsqueeze(0)
         pos = position_ids.reshape(-1).contiguous()
-        x = W.embed[input_ids.reshape(-1)]              # (q, hidden) fp16 gather
         build = (not spec) and q_len == 1 and isinstance(graph_cache, RetrievalCache)
         # periodic rebuild (described in the reference's blog, absent from its code): during a
         # target verify, re-select the prefill chunks with the query of the first — already confirmed — token
@@ -97,9 +96,13 @@ class LlamaForCausalLM:
             kv_cache.begin_forward()
         # decode-sized blocks run the fused kernels: [norm ->] qkv GEMM -> RoPE -> KV append in one launch, the
         # residual adds in the o / down GEMM epilogues, the post-attention norm in the gate|up GEMM prologue
-        mode = ops.FUSE_MODE if (ops.can_fuse(x, W.wqkv[0], W.wo[0], W.wgu[0], W.wd[0], W.lm_head)
+        mode = ops.FUSE_MODE if (ops.can_fuse_rows(q_len, W.embed, W.wqkv[0], W.wo[0], W.wgu[0], W.wd[0], W.lm_head)
                                  and W.wqkv[0].wp_rope is not None) else "none"
         fused = mode in ("all", "all2")
+        # the fused layer keeps residual stream / attention output / SwiGLU output k-octet-major (ops.Act): the GEMMs' B
+        # operand is then read in 256-byte runs (ops.py, "activation layouts")
+        packed = fused and ops.act_packed(q_len)
+        x = ops.embed_rows(W.embed, input_ids, packed)   # (q, hidden) fp16 gather
         ss = ops.ss_buffer(x.shape[1], x.device) if mode == "all" else None     # sum(x^2) hand-off between GEMMs
         d = None
         for i in range(W.L):
@@ -127,10 +130,10 @@ class LlamaForCausalLM:
                 else:
                     q = ops.rope_append(ops.linear(h, W.wqkv[i]), self.cos, self.sin, pos, kl, vl, slot, H, D)
             if spec:
-                a = ops.attn_decode(q, kl, vl, sk, self.scale)
+                a = ops.attn_decode(q, kl, vl, sk, self.scale, packed=packed)
             elif dev_len is not None:
                 assert fused, "the captured full-cache forward needs the fused decode kernels"
-                a = ops.attn_decode(q, kl, vl, sk, self.scale, sk_dev=dev_len[1])
+                a = ops.attn_decode(q, kl, vl, sk, self.scale, sk_dev=dev_len[1], packed=packed)
             else:
                 if build:
                     if not graph_cache.init_graph:
@@ -139,7 +142,8 @@ class LlamaForCausalLM:
                         graph_cache.update_graph_cache_retrieval(kv_cache, q, i)
                 elif rebuild:                           # generated tail is re-copied by update_graph_cache() after accept
                     graph_cache.init_graph_cache(kv_cache, q[:1], i)
-                a = ops.attn_prefill(q, kl, vl, sk, self.scale)
+                a = ops.attn_decode(q, kl, vl, sk, self.scale, packed=True) if packed else \
+                    ops.attn_prefill(q, kl, vl, sk, self.scale)
                 if streaming:
                     kv_cache.layer_done(i, slot, q_len)
             if fused:
@@ -155,7 +159,7 @@ class LlamaForCausalLM:
             kv_cache.end_forward()
         if fused:
             if W.capture is not None:
-                W.capture.append(x.clone())
+                W.capture.append(x.rows() if packed else x.clone())
             logits = ops.linear(x, W.lm_head, out_f32=True, ln=W.norm, eps=W.eps, ss_in=ss).unsqueeze(0)
         else:
             h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)

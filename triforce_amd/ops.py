@@ -106,9 +106,132 @@ def _w(w):
     return w.w if isinstance(w, PackedLinear) else w
 
 
+# ---- activation layouts of the decode path (include/triforce_hip.h, tf_skinny_gemm_act) -------------------------------
+# Element (m, k) of an activation block lives at base[m * sm + (k // 8) * sk + k % 8].  The reference's tensors are
+# row-major (sm = row stride, sk = 8).  The decode layer of this package keeps its residual stream, attention output and
+# SwiGLU output K-OCTET-MAJOR (sm = 8, sk = 8 * rows): the B operand of a 16-row MFMA tile is then 4 runs of 256 bytes
+# instead of 16 row fragments of 64 bytes — the 17..32-row GEMMs of the gamma = 16 verifies were bound by exactly those
+# fragments (profiles/r03_gemm_rows_ab.jsonl: 13B q|k|v 29.7 us at 8 rows, 44.0 at 17; k-octet-major: 27.6 at 17,
+# profiles/r04_gemm_layout_ab.jsonl).  TRIFORCE_ACT_LAYOUT = auto (default: see act_packed) | packed | rows.
+ACT_LAYOUT = _os.environ.get("TRIFORCE_ACT_LAYOUT", "auto")
+ACT_PACKED_MIN_ROWS = int(_os.environ.get("TRIFORCE_ACT_PACKED_MIN_ROWS", "1"))
+
+
+def act_packed(rows):
+    """Should a decode forward of ``rows`` rows keep its activations k-octet-major?"""
+    if ACT_LAYOUT == "packed":
+        return True
+    if ACT_LAYOUT == "rows":
+        return False
+    return rows >= ACT_PACKED_MIN_ROWS
+
+
+class Act:
+    """A k-octet-major activation block: ``t`` is a contiguous (K/8, R, 8) fp16 tensor holding rows 0..M-1 of an (M, K)
+    block (R >= M).  Quacks like the (M, K) tensor where the model code looks at it (shape, device, dtype, clone)."""
+    __slots__ = ("t", "M", "K")
+
+    def __init__(self, t, M):
+        assert t.dim() == 3 and t.shape[2] == 8 and t.is_contiguous() and t.dtype == _HALF and t.shape[1] >= M
+        self.t, self.M, self.K = t, M, t.shape[0] * 8
+
+    @classmethod
+    def empty(cls, M, K, device, R=None):
+        return cls(torch.empty(K // 8, M if R is None else R, 8, dtype=_HALF, device=device), M)
+
+    @classmethod
+    def from_rows(cls, x, R=None):
+        return cls(pack_act(x, R), x.shape[0])
+
+    @classmethod
+    def over(cls, flat, M, K):
+        """View a flat fp16 buffer of M * K elements (e.g. the all-reduce staging area) as an M-row block."""
+        assert flat.numel() == M * K and flat.is_contiguous()
+        return cls(flat.view(K // 8, M, 8), M)
+
+    R = property(lambda self: self.t.shape[1])
+    sm = property(lambda self: 8)
+    sk = property(lambda self: 8 * self.t.shape[1])
+    shape = property(lambda self: (self.M, self.K))
+    device = property(lambda self: self.t.device)
+    dtype = property(lambda self: self.t.dtype)
+    is_cuda = property(lambda self: self.t.is_cuda)
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+    def numel(self):
+        return self.M * self.K
+
+    def rows(self):
+        """Row-major (M, K) copy."""
+        return unpack_act(self.t, self.M)
+
+    def clone(self):
+        return Act(self.t.clone(), self.M)
+
+    def copy_(self, other):
+        if isinstance(other, Act):
+            assert other.shape == self.shape and other.R == self.R
+            self.t.copy_(other.t)
+        else:
+            self.t[:, :self.M].copy_(other.view(self.M, self.K // 8, 8).permute(1, 0, 2))
+        return self
+
+
+def _lay(x):
+    """(pointer, sm, sk) of an activation operand: an Act, a row-major 2-D tensor, or None."""
+    if x is None:
+        return None, 8, 8
+    if isinstance(x, Act):
+        return _ptr(x.t), x.sm, x.sk
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == _HALF
+    return _ptr(x), x.stride(0), 8
+
+
+def pack_act(x, R=None):
+    """Row-major (M, K) fp16 -> k-octet-major block (K/8, R, 8): element (m, k) at [(k // 8), m, k % 8]; R >= M rows
+    (rows M..R-1 are zero).  Strides for the *_act entry points: s_m = 8, s_k = 8 * R."""
+    M, K = x.shape
+    R = M if R is None else R
+    assert K % 8 == 0 and R >= M and x.dtype == _HALF
+    out = torch.zeros(K // 8, R, 8, dtype=_HALF, device=x.device)
+    out[:, :M] = x.reshape(M, K // 8, 8).permute(1, 0, 2)
+    return out
+
+
+def unpack_act(xp, M):
+    """Inverse of pack_act: (K/8, R, 8) -> row-major (M, K)."""
+    K8, R, _ = xp.shape
+    return xp[:, :M].permute(1, 0, 2).reshape(M, K8 * 8).contiguous()
+
+
+def embed_rows(embed, ids, packed, out=None):
+    """x = embed[ids] for the <= 32 rows of a decode forward: a row-major tensor, or (packed) an Act written by
+    tf_embed_rows straight in the k-octet-major form.  ``out``: write into this tensor / Act (static graph buffers)."""
+    ids = ids.reshape(-1)
+    if not packed:
+        if out is None:
+            return embed[ids]
+        return out.copy_(embed[ids])
+    _dev(embed, ids)
+    assert embed.dtype == _HALF and embed.is_contiguous() and ids.dtype == torch.int64 and ids.is_contiguous()
+    n, (V, hid) = ids.numel(), embed.shape
+    x = Act.empty(n, hid, embed.device) if out is None else out
+    assert isinstance(x, Act) and x.shape == (n, hid)
+    hip.check(hip.lib().tf_embed_rows(_ptr(embed), _ptr(ids), _ptr(x.t), x.sm, x.sk, n, hid, V, _stream()), "tf_embed_rows")
+    return x
+
+
 def can_fuse(x, *ws):
     """True when the fused decode kernels apply: HIP tensors, <= 32 rows, every weight packed."""
     return (x.is_cuda and x.dim() == 2 and x.shape[0] <= SKINNY_MAX_ROWS and x.dtype == _HALF and x.stride(1) == 1
+            and all(isinstance(w, PackedLinear) and w.parts is not None for w in ws))
+
+
+def can_fuse_rows(rows, embed, *ws):
+    """can_fuse before the embedding rows exist: ``rows`` rows of ``embed`` (device fp16 table) against packed weights."""
+    return (embed.is_cuda and embed.dtype == _HALF and rows <= SKINNY_MAX_ROWS
             and all(isinstance(w, PackedLinear) and w.parts is not None for w in ws))
 
 
@@ -118,41 +241,57 @@ def linear(x, w, out_f32=False, ln=None, eps=0.0, resid=None, out=None, ss_in=No
     Fused forms of the skinny kernel (only valid when ``can_fuse``): ``ln`` = RMSNorm weight applied to x first
     (h = ln * fp16(x * rsqrt(mean(x^2)+eps))), ``resid`` = fp16 residual added to the fp16 result, ``out`` = where
     to write (may be ``resid`` itself); ``ss_out`` (N/16, 32) fp32 receives the per-panel sums of squares of the
-    output rows and ``ss_in`` feeds such partials of x to the norm prologue (see ``ss_buffer``)."""
-    if isinstance(w, PackedLinear) and w.wp is not None and x.shape[0] <= SKINNY_MAX_ROWS and x.is_cuda:
-        assert x.dtype == _HALF and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == w.K
+    output rows and ``ss_in`` feeds such partials of x to the norm prologue (see ``ss_buffer``).
+    x / resid / out may be ``Act`` blocks (k-octet-major); an Act input gives an Act output unless ``out`` says
+    otherwise (fp32 logits are always a row-major tensor)."""
+    M = x.shape[0]
+    if isinstance(w, PackedLinear) and w.wp is not None and M <= SKINNY_MAX_ROWS and x.is_cuda:
+        assert x.dtype == _HALF and x.shape[1] == w.K
         if out is None:
-            out = torch.empty(x.shape[0], w.N, dtype=torch.float32 if out_f32 else _HALF, device=x.device)
-        assert out.shape == (x.shape[0], w.N) and out.stride(1) == 1
+            if out_f32 or not isinstance(x, Act):
+                out = torch.empty(M, w.N, dtype=torch.float32 if out_f32 else _HALF, device=x.device)
+            else:
+                out = Act.empty(M, w.N, x.device)
+        assert tuple(out.shape) == (M, w.N)
         if resid is not None:
-            assert resid.shape == out.shape and resid.dtype == _HALF and resid.stride(1) == 1 and not out_f32
+            assert tuple(resid.shape) == tuple(out.shape) and resid.dtype == _HALF and not out_f32
         if ss_in is not None:
             assert ss_in.dtype == torch.float32 and ss_in.shape == (w.K // 16, 32) and ss_in.is_contiguous()
         if ss_out is not None:
             assert ss_out.dtype == torch.float32 and ss_out.shape == (w.N // 16, 32) and ss_out.is_contiguous()
-        hip.check(hip.lib().tf_skinny_gemm_ex(_ptr(w.wp), _ptr(x), x.stride(0), _ptr(ln), float(eps), _ptr(ss_in),
-                                              _ptr(resid), resid.stride(0) if resid is not None else 0, _ptr(ss_out),
-                                              _ptr(out), out.stride(0), x.shape[0], w.N, w.K, 1 if out_f32 else 0,
-                                              _stream()), "tf_skinny_gemm_ex")
+        xp, xsm, xsk = _lay(x)
+        rp, rsm, rsk = _lay(resid)
+        if out_f32:
+            assert out.dtype == torch.float32 and out.stride(1) == 1
+            yp, ysm, ysk = _ptr(out), out.stride(0), 8
+        else:
+            yp, ysm, ysk = _lay(out)
+        hip.check(hip.lib().tf_skinny_gemm_act(_ptr(w.wp), xp, xsm, xsk, _ptr(ln), float(eps), _ptr(ss_in), rp, rsm, rsk,
+                                               _ptr(ss_out), yp, ysm, ysk, M, w.N, w.K, 1 if out_f32 else 0, _stream()),
+                  "tf_skinny_gemm_act")
         return out
     assert ln is None and resid is None and out is None and ss_in is None and ss_out is None, \
         "fused linear needs the skinny kernel (ops.can_fuse)"
+    assert not isinstance(x, Act), "k-octet-major activations exist only on the skinny decode path"
     y = F.linear(x, _w(w))
     return y.float() if out_f32 else y
 
 
 def mlp_act(h, wgu, ln=None, eps=0.0, ss_in=None):
     """fp16(silu(gate(h))) * up(h) for a fused gate|up weight: one kernel for <=32 rows (optionally with the
-    RMSNorm of h folded in, ``ln``), GEMM + silu_mul otherwise."""
-    if isinstance(wgu, PackedLinear) and wgu.parts is not None and wgu.split == 2 and h.shape[0] <= SKINNY_MAX_ROWS \
+    RMSNorm of h folded in, ``ln``), GEMM + silu_mul otherwise.  An Act input gives an Act output."""
+    M = h.shape[0]
+    if isinstance(wgu, PackedLinear) and wgu.parts is not None and wgu.split == 2 and M <= SKINNY_MAX_ROWS \
             and h.is_cuda:
         I = wgu.N // 2
-        act = torch.empty(h.shape[0], I, dtype=_HALF, device=h.device)
-        hip.check(hip.lib().tf_skinny_gemm_swiglu_ex(_ptr(wgu.parts[0]), _ptr(wgu.parts[1]), _ptr(h), h.stride(0),
-                                                     _ptr(ln), float(eps), _ptr(ss_in), _ptr(act), I, h.shape[0], I,
-                                                     wgu.K, _stream()), "tf_skinny_gemm_swiglu_ex")
+        act = Act.empty(M, I, h.device) if isinstance(h, Act) else torch.empty(M, I, dtype=_HALF, device=h.device)
+        hp, hsm, hsk = _lay(h)
+        ap, asm, ask = _lay(act)
+        hip.check(hip.lib().tf_skinny_gemm_swiglu_act(_ptr(wgu.parts[0]), _ptr(wgu.parts[1]), hp, hsm, hsk, _ptr(ln),
+                                                      float(eps), _ptr(ss_in), ap, asm, ask, M, I, wgu.K, _stream()),
+                  "tf_skinny_gemm_swiglu_act")
         return act
-    assert ln is None, "fused mlp_act needs the skinny kernel (ops.can_fuse)"
+    assert ln is None and not isinstance(h, Act), "fused mlp_act needs the skinny kernel (ops.can_fuse)"
     return silu_mul(F.linear(h, _w(wgu)))
 
 
@@ -164,22 +303,22 @@ def ss_buffer(hidden, device):
 def qkv_rope(x, wqkv, ln, eps, cos, sin, positions, k_layer, v_layer, slot0, H, D, rotate_k=True, slot0_dev=None,
              ss_in=None):
     """One kernel for [RMSNorm ->] fused q|k|v GEMM -> RoPE -> KV append: x (rows, hidden) is the residual stream
-    (ln = input_layernorm weight, or None when x is already normalised); q (rows,H,D) is returned rotated, the k
-    (rotated unless rotate_k is False) and v rows land in the cache at slot0+i."""
-    _dev(x, ln, cos, sin, positions, k_layer, v_layer, slot0_dev)
+    (ln = input_layernorm weight, or None when x is already normalised; a row-major tensor or an Act); q (rows,H,D)
+    is returned rotated, the k (rotated unless rotate_k is False) and v rows land in the cache at slot0+i."""
+    _dev(ln, cos, sin, positions, k_layer, v_layer, slot0_dev)
     assert isinstance(wqkv, PackedLinear) and wqkv.wp_rope is not None and wqkv.rope == (H, D)
     rows = x.shape[0]
-    assert x.dtype == _HALF and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == wqkv.K and rows <= SKINNY_MAX_ROWS
+    assert x.is_cuda and x.dtype == _HALF and x.shape[1] == wqkv.K and rows <= SKINNY_MAX_ROWS
     assert positions.dtype == torch.int64 and positions.numel() == rows and positions.is_contiguous()
     assert cos.dtype == _HALF and cos.is_contiguous() and cos.shape[1] == D
     st, sh = _kv(k_layer)
     assert _kv(v_layer) == (st, sh)
     q = torch.empty(rows, H, D, dtype=_HALF, device=x.device)
-    hip.check(hip.lib().tf_skinny_qkv_rope(_ptr(wqkv.wp_rope), _ptr(x), x.stride(0), _ptr(ln), float(eps), _ptr(ss_in),
-                                           _ptr(cos), _ptr(sin), _ptr(positions), _ptr(q), _ptr(k_layer), _ptr(v_layer),
-                                           st, sh,
-                                           int(slot0), _ptr(slot0_dev), rows, H, D, wqkv.K, 1 if rotate_k else 0,
-                                           _stream()), "tf_skinny_qkv_rope")
+    xp, xsm, xsk = _lay(x)
+    hip.check(hip.lib().tf_skinny_qkv_rope_act(_ptr(wqkv.wp_rope), xp, xsm, xsk, _ptr(ln), float(eps), _ptr(ss_in),
+                                               _ptr(cos), _ptr(sin), _ptr(positions), _ptr(q), _ptr(k_layer),
+                                               _ptr(v_layer), st, sh, int(slot0), _ptr(slot0_dev), rows, H, D, wqkv.K,
+                                               1 if rotate_k else 0, _stream()), "tf_skinny_qkv_rope_act")
     return q
 
 
@@ -264,9 +403,9 @@ def _ticket_row(device, stream):
     return block[row]
 
 
-def attn_decode(q, k_layer, v_layer, sk, scale, sk_dev=None, nsplit=None):
+def attn_decode(q, k_layer, v_layer, sk, scale, sk_dev=None, nsplit=None, packed=False):
     """flash_attn_with_kvcache(q, k, v, softmax_scale, causal=True) for sq<=32 rows (bottom-right causal).
-    q (sq,H,D); returns (sq, H*D) fp16."""
+    q (sq,H,D); returns (sq, H*D) fp16 — a row-major tensor, or with ``packed`` an Act (what o_proj then reads)."""
     _dev(q, k_layer, v_layer, sk_dev)
     sq, H, D = q.shape
     assert q.dtype == _HALF and q.is_contiguous()
@@ -276,7 +415,8 @@ def attn_decode(q, k_layer, v_layer, sk, scale, sk_dev=None, nsplit=None):
     if nsplit is None:
         nsplit = _pick_nsplit(H, int(sk))
     ws = _workspace(q.device, _ws_floats(H, sq, D, nsplit))
-    out = torch.empty(sq, H * D, dtype=_HALF, device=q.device)
+    out = Act.empty(sq, H * D, q.device) if packed else torch.empty(sq, H * D, dtype=_HALF, device=q.device)
+    op, osm, osk = _lay(out)
     timed = False
     if ATTN_TIMER is not None and not torch.cuda.is_current_stream_capturing():
         global _attn_calls
@@ -287,13 +427,9 @@ def attn_decode(q, k_layer, v_layer, sk, scale, sk_dev=None, nsplit=None):
         ev0.record()
     stream = _stream()
     tickets = _ticket_row(q.device, stream.value or 0) if ATTN_FUSED_MERGE and H <= _TICKET_WORDS else None
-    if tickets is not None:
-        hip.check(L.tf_attn_decode_fused(_ptr(q), _ptr(k_layer), _ptr(v_layer), _ptr(out), st, sh, sq, int(sk),
-                                         _ptr(sk_dev), H, D, float(scale), nsplit, _ptr(ws), ws.numel(), _ptr(tickets),
-                                         stream), "tf_attn_decode_fused")
-    else:
-        hip.check(L.tf_attn_decode(_ptr(q), _ptr(k_layer), _ptr(v_layer), _ptr(out), st, sh, sq, int(sk), _ptr(sk_dev),
-                                   H, D, float(scale), nsplit, _ptr(ws), ws.numel(), stream), "tf_attn_decode")
+    hip.check(L.tf_attn_decode_act(_ptr(q), _ptr(k_layer), _ptr(v_layer), op, osm, osk, st, sh, sq, int(sk), _ptr(sk_dev),
+                                   H, D, float(scale), nsplit, _ptr(ws), ws.numel(), _ptr(tickets), stream),
+              "tf_attn_decode_act")
     if timed:
         ev1.record()
         ATTN_TIMER.append((ev0, ev1, int(sk), H, D))

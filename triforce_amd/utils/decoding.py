@@ -328,7 +328,9 @@ class TriForceRunner:
         next_token = self.next_token
         n0 = self.n
         ids, spec_rows, acc_mid = Middle_Spec(next_token, ge, gamma, False, tokenizer, rng=rng, buffers=bufs,
-                                              sync_record=self.sync_record, health=self.health)
+                                              sync_record=self.sync_record)
+        # (the exchange health poll — a blocking copy of the control block — runs once per OUTER step, below: nothing an
+        #  inner iteration computes is emitted before the outer accept record has been read)
         self.acc_rate_middle_list.append(acc_mid)
         generated = ids[1:]
         g2 = len(generated)

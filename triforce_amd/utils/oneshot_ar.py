@@ -59,6 +59,16 @@ class OneShotAllReduce:
         self.data_ptr, self.flags_ptr = own
         self._stage = torch.as_tensor(_RawBuffer(self.data_ptr, (self.max_elems * (2 if self.alternate else 1),), "<f2"),
                                       device=self.device)
+        # the sticky error word is mirrored into pinned host memory: error() is then a plain host read (valid after any
+        # stream synchronisation or host read of later work of the stream), not a blocking copy of the control block
+        self._err_host = None
+        try:
+            word = torch.zeros(1, dtype=torch.int32).pin_memory()
+            hip.check(L.tf_ar_set_error_mirror(ctypes.c_void_p(self.flags_ptr), ctypes.c_void_p(word.data_ptr())),
+                      "tf_ar_set_error_mirror")
+            self._err_host = word
+        except Exception:                              # no pinned memory / no mapping: fall back to the copying read
+            self._err_host = None
         if peer_data is not None:
             self._set_peers(peer_data, peer_flags)
         elif connect:
@@ -119,11 +129,17 @@ class OneShotAllReduce:
         alternation."""
         return (self._issued + 1) & 1 if self.alternate else 0
 
-    def staging(self, rows, cols):
-        """(rows, cols) fp16 view of this rank's staging buffer: the producer kernel's output tensor."""
+    def staging(self, rows, cols, packed=False):
+        """(rows, cols) fp16 view of this rank's staging buffer: the producer kernel's output tensor — or, ``packed``,
+        the same elements as a k-octet-major ops.Act block (the layout is the producer's and the consumer's business:
+        the sum is element-wise)."""
         assert rows * cols <= self.max_elems and (rows * cols) % 8 == 0
         lo = self._half() * self.max_elems
-        return self._stage[lo:lo + rows * cols].view(rows, cols)
+        flat = self._stage[lo:lo + rows * cols]
+        if packed:
+            from ..ops import Act
+            return Act.over(flat, rows, cols)
+        return flat.view(rows, cols)
 
     def is_staged(self, t):
         """True when ``t`` starts where the next exchange will read this rank's partial."""
@@ -137,39 +153,75 @@ class OneShotAllReduce:
         ``staging()``; ``resid`` (fp16, may be ``out`` itself) is added in fp16 to the rounded sum; ``ss_out``
         (hidden / 16, 32) fp32 receives the per-panel sums of squares of the result rows (ops.ss_buffer)."""
         assert self._data is not None, "OneShotAllReduce.connect() has not run"
-        assert self.is_staged(staged) and out.dtype == torch.float16 and out.is_contiguous()
+        from ..ops import Act
+        pack_rows = 0
+        if isinstance(out, Act):                       # k-octet-major residual stream: every operand in the same form
+            assert isinstance(staged, Act) and staged.R == out.R == out.M and ss_out is not None
+            assert resid is None or (isinstance(resid, Act) and resid.R == out.R)
+            pack_rows = out.R
+        else:
+            assert not isinstance(staged, Act) and not isinstance(resid, Act)
+            assert out.is_contiguous() and (resid is None or resid.is_contiguous())
+        assert self.is_staged(staged) and out.dtype == torch.float16
         assert out.numel() == staged.numel() and out.data_ptr() != staged.data_ptr()
         if resid is not None:
-            assert resid.dtype == torch.float16 and resid.is_contiguous() and resid.numel() == out.numel()
+            assert resid.dtype == torch.float16 and resid.numel() == out.numel()
         rp = ctypes.c_void_p(resid.data_ptr()) if resid is not None else None
         st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         hidden = out.shape[-1]
         if ss_out is not None:
             assert ss_out.dtype == torch.float32 and ss_out.is_contiguous() and ss_out.shape == (hidden // 16, 32)
-        if self.alternate:
-            half = self._half()
+        if pack_rows:
+            hip.check(hip.lib().tf_allreduce_oneshot_act(self._data, self._flags, self.rank, self.world, rp,
+                                                         ctypes.c_void_p(out.data_ptr()), staged.numel(), hidden, pack_rows,
+                                                         ctypes.c_void_p(ss_out.data_ptr()),
+                                                         self.max_elems if self.alternate else 0,
+                                                         self._half() if self.alternate else 0, st),
+                      "tf_allreduce_oneshot_act")
             self._issued += 1
+            return out
+        # _issued counts exchanges that were actually enqueued (or captured): it advances only after the launch call
+        # returned success, so a refused launch leaves host parity and device epoch in step
+        if self.alternate:
             hip.check(hip.lib().tf_allreduce_oneshot_alt(self._data, self._flags, self.rank, self.world, rp,
                                                          ctypes.c_void_p(out.data_ptr()), staged.numel(), hidden,
                                                          ctypes.c_void_p(ss_out.data_ptr()) if ss_out is not None else None,
-                                                         self.max_elems, half, st), "tf_allreduce_oneshot_alt")
-            return out
-        if ss_out is not None:
+                                                         self.max_elems, self._half(), st), "tf_allreduce_oneshot_alt")
+        elif ss_out is not None:
             hip.check(hip.lib().tf_allreduce_oneshot_add_ss(self._data, self._flags, self.rank, self.world, rp,
                                                             ctypes.c_void_p(out.data_ptr()), staged.numel(), hidden,
                                                             ctypes.c_void_p(ss_out.data_ptr()), st),
                       "tf_allreduce_oneshot_add_ss")
-            return out
-        hip.check(hip.lib().tf_allreduce_oneshot_add(self._data, self._flags, self.rank, self.world, rp,
-                                                     ctypes.c_void_p(out.data_ptr()), staged.numel(), st),
-                  "tf_allreduce_oneshot_add")
+        else:
+            hip.check(hip.lib().tf_allreduce_oneshot_add(self._data, self._flags, self.rank, self.world, rp,
+                                                         ctypes.c_void_p(out.data_ptr()), staged.numel(), st),
+                      "tf_allreduce_oneshot_add")
+        self._issued += 1
         return out
+
+    def resync(self):
+        """Set the host-side exchange count from the device epoch (blocking; the stream must be idle — the caller
+        synchronises first).  Needed after anything that may have counted an exchange the device never ran: a forward
+        that raised midway, a graph capture that failed or was discarded (captured exchanges advance ``_issued`` but
+        not the epoch).  Returns the count."""
+        torch.cuda.synchronize(self.device)
+        e = hip.lib().tf_ar_epoch(ctypes.c_void_p(self.flags_ptr))
+        if e < 0:
+            raise hip.TriforceHipError(f"tf_ar_epoch failed: {e}")
+        self._issued = int(e)
+        return self._issued
 
     def error(self):
         """0, or which wait timed out (1 READY, 2 DONE) at some point since creation (3: the alternating form found the
         partial staged in the other half than its epoch selects — an odd number of exchanges in a captured forward).  Sticky: after a timeout every
         later reduce returns at once and fills ``out`` with NaN (csrc/allreduce.hip) — callers poll this once per
         decode step (``check()``) and stop instead of emitting tokens computed from a reduction that never happened."""
+        if self._err_host is not None:
+            return int(self._err_host[0])
+        return hip.lib().tf_ar_error(ctypes.c_void_p(self.flags_ptr))
+
+    def error_device(self):
+        """The error word as the control block holds it (blocking copy) — what error() mirrors."""
         return hip.lib().tf_ar_error(ctypes.c_void_p(self.flags_ptr))
 
     def inject_error(self, code):
@@ -189,6 +241,8 @@ class OneShotAllReduce:
         L = hip.lib()
         for p in self._opened:
             L.tf_ar_close_ipc_handle(ctypes.c_void_p(p))
+        if self._err_host is not None and self._owned:
+            L.tf_ar_set_error_mirror(ctypes.c_void_p(self.flags_ptr), None)
         for p in self._owned:
             L.tf_ar_free(ctypes.c_void_p(p))
         self._opened, self._owned = [], ()
