@@ -392,6 +392,13 @@ int tf_allreduce_oneshot_alt(void* const* peer_data, void* const* peer_flags, in
 int tf_allreduce_oneshot_act(void* const* peer_data, void* const* peer_flags, int rank, int world, const void* resid,
                              void* out, int64_t n, int hidden, int pack_rows, float* ss_out, int64_t half_elems,
                              int expect_half, void* stream);
+/* Message-passing litmus around the exchange (tools/xgmi_litmus.py): tf_ar_litmus_stage advances the device counter
+ * *it_dev and then writes, with PLAIN stores from an ordinary kernel (the role of the o_proj / down_proj epilogue), the
+ * pattern v_rank[i] = (7 i + 13 it + 101 rank) mod 509 into `staging` (n fp16 values); after an all-reduce of those
+ * partials tf_ar_litmus_check adds to *bad (uint64, device) the number of elements of `out` that differ from
+ * fp16(sum over ranks of v_r[i]) for the same iteration.  Both are capturable. */
+int tf_ar_litmus_stage(void* staging, int64_t n, int rank, uint32_t* it_dev, void* stream);
+int tf_ar_litmus_check(const void* out, int64_t n, int world, const uint32_t* it_dev, uint64_t* bad, void* stream);
 int tf_ar_error(const void* flags_local);
 /* completed exchanges of this control block (device-side epoch), blocking host read: lets a caller that counts its
  * exchanges (expect_half) resynchronise after a failed launch / capture; TF_EINVAL for NULL, -(hip error) on failure */

@@ -410,7 +410,7 @@ def test_oneshot_allreduce_across_two_processes_through_hipipc(alternate):
         assert ok, f"rank {rank}: result differs from the collective by up to {worst}"
 
 
-def _tp2_worker(rank, world, port, q, alternate=False):
+def _tp2_worker(rank, world, port, q, alternate=False, extra_env=None, loop_gamma=None):
     """One rank of the tensor-parallel engine at world size 2 with BOTH ranks on this box's single GPU: real kernels on
     each rank's head / MLP-column shard, the decode-sized all-reduces through the one-shot kernel over hipIpc mappings
     (the production path), prefill-sized ones and the token broadcast through gloo."""
@@ -422,6 +422,7 @@ def _tp2_worker(rank, world, port, q, alternate=False):
         sys.path.insert(0, root)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                           LOCAL_RANK="0", TRIFORCE_AR_ALTERNATE="1" if alternate else "0")
+        os.environ.update(extra_env or {})
         import torch.distributed as dist
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -455,7 +456,7 @@ def _tp2_worker(rank, world, port, q, alternate=False):
         del llm
         # 2) the whole decode loop (draft + retrieval verify + target verify, hipGraphs) on the small_gamma6 fixture
         g = Hh.load_golden("small_gamma6")
-        gamma = g["gamma"]
+        gamma = loop_gamma or g["gamma"]
         draft = Draft.from_state_dict(LlamaConfig.from_dict(g["dcfg"]),
                                       specs.random_state_dict(g["dcfg"], g["dseed"], head_std=g["head_std"]), DEV)
         dcache = StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - gamma, gamma=gamma)
@@ -524,6 +525,88 @@ def test_tp_world2_on_one_device_real_kernels_and_oneshot_allreduce(alternate):
     gaps = Hh.teacher_forced_gaps(g6, a["tokens"])
     assert max(gaps) < 8e-3, f"TP stream leaves the oracle's greedy path: gap {max(gaps):.4f}"
     assert Hh.common_prefix(a["tokens"], g6["ar_tokens"]) >= 12
+
+
+@pytest.mark.parametrize("fuse", ["1", "0"], ids=["fused-layer", "unfused-layer"])
+def test_tp_world2_gamma16_segment_graphs_with_alternating_halves(fuse):
+    """The advisor's round-3 case: alternating staging halves + the collective-free SEGMENT graphs + a gamma = 16 verify
+    (17 / 18 rows), in the fused layer (k-octet-major activations) and in the un-fused one, whose two partials per layer
+    used to be taken from staging() once — both in the same half.  Every stage must be captured against the half its
+    exchange reads at replay; any disagreement is the sticky error 3 with NaN output.  Both ranks must stay on the
+    oracle's greedy path with error word 0."""
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {"TRIFORCE_TP_GRAPHS": "segments", "TRIFORCE_TP_FUSE": fuse}
+    procs = [ctx.Process(target=_tp2_worker, args=(r, 2, port, q, True, env, 16)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = {}
+    try:
+        for _ in range(2):
+            o = q.get(timeout=600)
+            outs[o[0]] = o
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    for o in outs.values():
+        assert o[1] == "ok", o[2]
+    a, b = outs[0][2], outs[1][2]
+    for r, o in ((0, a), (1, b)):
+        assert o["oneshot_decode"] and o["graph_form"] == "segments", (r, o["graph_form"])
+        assert o["ar_error_stage"] == 0 and o["ar_error_decode"] == 0, f"rank {r}: exchange error {o['ar_error_decode']}"
+    assert a["tokens"] == b["tokens"] and a["counts"] == b["counts"]
+    g6 = Hh.load_golden("small_gamma6")
+    gaps = Hh.teacher_forced_gaps(g6, a["tokens"])
+    assert max(gaps) < 8e-3, f"stream leaves the oracle's greedy path: gap {max(gaps):.4f}"
+
+
+def _run_litmus(nproc, extra):
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "tools", "xgmi_litmus.py"), *extra]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, lines, p.stderr[-2000:]
+
+
+@pytest.mark.parametrize("alternate", [False, True], ids=["done-handshake", "alternating-halves"])
+def test_exchange_litmus_dry_run_two_processes_one_device(alternate):
+    """tools/xgmi_litmus.py as two processes sharing this box's one GPU (gloo + hipIpc mappings): plain-store producer
+    kernel -> kernel boundary -> READY flag -> peer's fine-grained loads, eager and inside a hipGraph, one rank delayed
+    now and then.  On one device the mappings resolve to local HBM, so this is a dry run of the tool and of the
+    protocol across processes; `bash tools/gpu_validate.sh tp N` runs it across N devices before the bench legs."""
+    rc, lines, err = _run_litmus(2, ["--share-device", "--eager-iters", "3000", "--iters", "40000", "--budget-s", "40"]
+                                 + (["--alternate"] if alternate else []))
+    assert rc == 0 and len(lines) == 1, err
+    j = lines[0]
+    assert j["litmus_ok"] and j["failures"] == 0 and j["world"] == 2
+    assert j["eager"]["iterations"] == 3000 and j["graph"]["iterations"] >= 2000
+    assert all(e["error_word"] == 0 and e["mismatched_elements"] == 0 for e in j["per_rank"])
+
+
+def test_rccl_world2_and_exchange_litmus_across_two_devices():
+    """The first N > 1 execution on a multi-GPU box: RCCL initialised at world size 2 (one process per device), the
+    exchange litmus across the two devices (xGMI remote loads and flag stores).  Skipped on a one-GPU box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible devices")
+    rc, lines, err = _run_litmus(2, ["--eager-iters", "5000", "--iters", "200000", "--budget-s", "40"])
+    assert rc == 0 and len(lines) == 1, err
+    assert lines[0]["litmus_ok"] and lines[0]["failures"] == 0 and not lines[0]["share_device"]
 
 
 def test_oneshot_allreduce_error_path_poisons_output_and_raises():

@@ -9,6 +9,11 @@ O=gpurun_out/validate; mkdir -p $O
 R=${GRAFT_REPO_ROOT:-$PWD}
 if [ "$1" = "tp" ]; then
   N=${2:-8}; rc=0
+  # (0) message-passing litmus of the exchange across the N devices (< 60 s each): READY/DONE form, then alternating halves;
+  #     a failure COUNT, not a hang — run before anything that trusts the exchange (assumptions 1-3)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29541 tools/xgmi_litmus.py > $O/litmus_tp${N}.json 2> $O/litmus_tp${N}.err || rc=1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29542 tools/xgmi_litmus.py --alternate > $O/litmus_tp${N}_alt.json 2> $O/litmus_tp${N}_alt.err || rc=1
+  tail -c 600 $O/litmus_tp${N}.json $O/litmus_tp${N}_alt.json
   # (1) one-shot exchange REQUIRED (no silent RCCL fallback), whole-forward hipGraphs REQUIRED, world size checked
   python bench.py --gpus $N --steps 20 --warmup 5 --allreduce oneshot --require-graph-form whole > $O/bench_tp${N}_oneshot.json 2> $O/bench_tp${N}_oneshot.err || rc=1
   # (2) the same run over RCCL, for the A/B

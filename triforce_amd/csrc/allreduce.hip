@@ -382,3 +382,68 @@ extern "C" int64_t tf_ar_epoch(const void* flags_local) {
     if (e != hipSuccess) return -(int64_t)e;
     return (int64_t)f.epoch;
 }
+
+// ---- message-passing litmus for the exchange (tools/xgmi_litmus.py; DESIGN section 12.5 assumptions 1-3) ----------------
+// tf_ar_litmus_stage: the "producer GEMM" of the litmus — PLAIN stores of a pattern that changes every iteration into
+// this rank's staging buffer, by an ordinary kernel that precedes the exchange in stream order (exactly how the o_proj /
+// down_proj epilogues stage their partials).  it_dev is a device counter the kernel of rank-local thread 0 of block 0
+// one-thread launch advances FIRST (so a captured launch stages fresh data on every replay); small integer values:
+//     v_r[i] = (7 i + 13 it + 101 r) mod 509        (sum over <= 8 ranks < 4 072: exact in the fp32 accumulation,
+//                                                      and the fp16 result is exact up to 2 048 — the check below
+//                                                      compares against the correctly rounded fp16 of the exact sum)
+// tf_ar_litmus_check: after the exchange, compares out[i] with fp16(sum over ranks of v_r[i]) for the SAME iteration and
+// adds the number of mismatching elements to *bad (device counter, never reset by the kernel); a stale staging line, a
+// READY flag that overtook its partial, or a torn read all show up as a count, not as a hang.
+__global__ __launch_bounds__(256) void ar_litmus_stage_kernel(h16* __restrict__ staging, int64_t n, int rank,
+                                                              const unsigned* __restrict__ it_dev) {
+    const unsigned it = *it_dev;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        staging[i] = (h16)(float)((7u * (unsigned)i + 13u * it + 101u * (unsigned)rank) % 509u);
+}
+// the counter is advanced by its own one-thread launch in front of the stage kernel: every block of the stage / check
+// kernels of one iteration then reads the same value
+__global__ void ar_litmus_advance_kernel(unsigned* it_dev) { *it_dev += 1u; }
+
+__global__ __launch_bounds__(256) void ar_litmus_check_kernel(const h16* __restrict__ out, int64_t n, int world,
+                                                              const unsigned* __restrict__ it_dev,
+                                                              unsigned long long* __restrict__ bad) {
+    const unsigned it = *it_dev;                       // already advanced past the iteration being checked
+    unsigned mism = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float acc = 0.f;
+        for (int r = 0; r < world; ++r) acc += (float)((7u * (unsigned)i + 13u * it + 101u * (unsigned)r) % 509u);
+        if ((float)out[i] != (float)(h16)acc) ++mism;
+    }
+    mism += __shfl_xor(mism, 32, 64);
+    mism += __shfl_xor(mism, 16, 64);
+    mism += __shfl_xor(mism, 8, 64);
+    mism += __shfl_xor(mism, 4, 64);
+    mism += __shfl_xor(mism, 2, 64);
+    mism += __shfl_xor(mism, 1, 64);
+    if ((threadIdx.x & 63) == 0 && mism) atomicAdd(bad, (unsigned long long)mism);
+}
+
+// stage: it_dev is advanced (by its own one-thread launch) BEFORE the pattern is written, so stage / exchange / check of
+// one iteration all see the same value.
+extern "C" int tf_ar_litmus_stage(void* staging, int64_t n, int rank, uint32_t* it_dev, void* stream) {
+    if (!staging || !it_dev || n < 1 || rank < 0 || rank >= AR_MAX_WORLD) return TF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ar_litmus_advance_kernel, dim3(1), dim3(1), 0, st, it_dev);
+    TF_LAUNCH_CHECK();
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(ar_litmus_stage_kernel, dim3(blocks), dim3(256), 0, st, (h16*)staging, n, rank, it_dev);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}
+
+extern "C" int tf_ar_litmus_check(const void* out, int64_t n, int world, const uint32_t* it_dev, uint64_t* bad,
+                                  void* stream) {
+    if (!out || !it_dev || !bad || n < 1 || world < 1 || world > AR_MAX_WORLD) return TF_EINVAL;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(ar_litmus_check_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const h16*)out, n, world,
+                       it_dev, (unsigned long long*)bad);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}

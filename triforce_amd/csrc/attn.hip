@@ -117,6 +117,16 @@ __device__ __forceinline__ float group_max4(float v) {
 #ifndef TF_ATTN_P_SPLIT
 #define TF_ATTN_P_SPLIT 1
 #endif
+// The same hi + lo feed in the block / prefill / tree kernels (pair_softmax_pv, lds_softmax_*) and in the 68M draft's
+// rope-on-read kernel: TF_BLOCK_P_SPLIT / TF_DRAFT_P_SPLIT.  Measured in round 4 (tools/prefill_psplit_ab.py,
+// profiles/r04_psplit_block_ab.jsonl) — see the note there for what ships and why.
+#ifndef TF_BLOCK_P_SPLIT
+#define TF_BLOCK_P_SPLIT 0
+#endif
+#ifndef TF_DRAFT_P_SPLIT
+#define TF_DRAFT_P_SPLIT 1
+#endif
+
 
 template <int D, int QT>
 struct AttnState {
@@ -589,12 +599,13 @@ __device__ __forceinline__ void pair_softmax_pv(AttnState<D, QT>& st, const Pair
         tmax = group_max4(tmax);
         const float mnew = fmaxf(st.m[qt], tmax);
         float psum = 0.f;
-        half8 pb;
+        half8 pb, pl;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const float p = ok[r] ? exp2f(x[r] - mnew) : 0.f;
             psum += p;
             pb[r] = (h16)p;
+            pl[r] = (h16)(p - (float)pb[r]);
         }
         if (__builtin_amdgcn_ballot_w64(mnew != st.m[qt])) {
             const float alpha = exp2f(st.m[qt] - mnew);
@@ -608,8 +619,12 @@ __device__ __forceinline__ void pair_softmax_pv(AttnState<D, QT>& st, const Pair
         }
         st.l[qt] += psum;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
             st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ps.va8[t], pb, st.acc[qt][t], 0, 0, 0);
+#if TF_BLOCK_P_SPLIT > 0
+            st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ps.va8[t], pl, st.acc[qt][t], 0, 0, 0);
+#endif
+        }
     }
 }
 
@@ -776,7 +791,7 @@ __device__ __forceinline__ void lds_softmax_pv(AttnState<D, QT>& st, const f32x4
                                                const h16* __restrict__ svt, int g0, int key0, int sk, int sq,
                                                float scale_log2, int li, int g, int qbase, TreeMask tm) {
     constexpr int NT = D / 16, VS = BLK_SLAB + 8;
-    half8 pb[QT];
+    half8 pb[QT], pl[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const int qrow = qbase + qt * 16 + li;
@@ -828,6 +843,7 @@ __device__ __forceinline__ void lds_softmax_pv(AttnState<D, QT>& st, const f32x4
             const float p = ok[r] ? __builtin_amdgcn_exp2f(fmaf(x[r], scale_log2, -mnew)) : 0.f;
             psum += p;
             pb[qt][r] = (h16)p;
+            pl[qt][r] = (h16)(p - (float)pb[qt][r]);
         }
         if (__builtin_amdgcn_ballot_w64(mnew != st.m[qt])) {
             const float alpha = __builtin_amdgcn_exp2f(st.m[qt] - mnew);
@@ -851,8 +867,12 @@ __device__ __forceinline__ void lds_softmax_pv(AttnState<D, QT>& st, const f32x4
             const half4 lo = lds_read_tr4(vrow + pos), hi = lds_read_tr4(vrow + 4 * D + pos);
             const half8 vt = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
+            for (int qt = 0; qt < QT; ++qt) {
                 st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vt, pb[qt], st.acc[qt][t], 0, 0, 0);
+#if TF_BLOCK_P_SPLIT > 0
+                st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vt, pl[qt], st.acc[qt][t], 0, 0, 0);
+#endif
+            }
         }
     } else {
 #pragma unroll
@@ -860,8 +880,12 @@ __device__ __forceinline__ void lds_softmax_pv(AttnState<D, QT>& st, const f32x4
             const int d = 16 * t + li;                                              // V^T[d][keys 8(g0+g) .. +7]
             const half8 vt = load_half8(svt + d * VS + 8 * ((g0 + g) ^ BLK_VSWZ(d)));
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
+            for (int qt = 0; qt < QT; ++qt) {
                 st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vt, pb[qt], st.acc[qt][t], 0, 0, 0);
+#if TF_BLOCK_P_SPLIT > 0
+                st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vt, pl[qt], st.acc[qt][t], 0, 0, 0);
+#endif
+            }
         }
     }
 }
@@ -883,7 +907,7 @@ __device__ __forceinline__ void lds_softmax_pv(AttnState<D, QT>& st, const f32x4
 #endif
 template <int D, int QT>
 __device__ __forceinline__ void lds_softmax_clear(AttnState<D, QT>& st, const f32x4 (&sa)[QT], const f32x4 (&sb)[QT],
-                                                  float scale_log2, half8 (&pb)[QT]) {
+                                                  float scale_log2, half8 (&pb)[QT], half8 (&pl)[QT]) {
     constexpr int NT = D / 16;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -900,6 +924,7 @@ __device__ __forceinline__ void lds_softmax_clear(AttnState<D, QT>& st, const f3
             const float p = __builtin_amdgcn_exp2f(fmaf(x[r], scale_log2, -mnew));
             psum += p;
             pb[qt][r] = (h16)p;
+            pl[qt][r] = (h16)(p - (float)pb[qt][r]);
         }
         if (__builtin_amdgcn_ballot_w64(mnew != st.m[qt])) {
             const float alpha = __builtin_amdgcn_exp2f(st.m[qt] - mnew);
@@ -917,7 +942,7 @@ __device__ __forceinline__ void lds_softmax_clear(AttnState<D, QT>& st, const f3
 template <int D, int QT>
 __device__ __forceinline__ void lds_softmax_clear2(AttnState<D, QT>& st, const f32x4 (&s0a)[QT], const f32x4 (&s0b)[QT],
                                                    const f32x4 (&s1a)[QT], const f32x4 (&s1b)[QT], float scale_log2,
-                                                   half8 (&p0)[QT], half8 (&p1)[QT]) {
+                                                   half8 (&p0)[QT], half8 (&p1)[QT], half8 (&l0)[QT], half8 (&l1)[QT]) {
     constexpr int NT = D / 16;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -936,8 +961,9 @@ __device__ __forceinline__ void lds_softmax_clear2(AttnState<D, QT>& st, const f
         for (int r = 0; r < 16; ++r) {
             const float p = __builtin_amdgcn_exp2f(fmaf(x[r], scale_log2, -mnew));
             psum += p;
-            if (r < 8) p0[qt][r] = (h16)p;
-            else p1[qt][r - 8] = (h16)p;
+            const h16 ph = (h16)p, pw = (h16)(p - (float)ph);
+            if (r < 8) { p0[qt][r] = ph; l0[qt][r] = pw; }
+            else { p1[qt][r - 8] = ph; l1[qt][r - 8] = pw; }
         }
         if (__builtin_amdgcn_ballot_w64(mnew != st.m[qt])) {
             const float alpha = __builtin_amdgcn_exp2f(st.m[qt] - mnew);
@@ -953,8 +979,8 @@ __device__ __forceinline__ void lds_softmax_clear2(AttnState<D, QT>& st, const f
     }
 }
 template <int D, int QT>
-__device__ __forceinline__ void lds_pv_tr(AttnState<D, QT>& st, const half8 (&pb)[QT], const h16* __restrict__ svt, int g0,
-                                          int li, int g) {
+__device__ __forceinline__ void lds_pv_tr(AttnState<D, QT>& st, const half8 (&pb)[QT], const half8 (&pl)[QT],
+                                          const h16* __restrict__ svt, int g0, int li, int g) {
     constexpr int NT = D / 16;
     const int fv = (li >> 2) | ((g & 1) << 2);
     const h16* vrow = svt + (8 * (g0 + g) + (li >> 2)) * D + 4 * (li & 3);
@@ -964,8 +990,12 @@ __device__ __forceinline__ void lds_pv_tr(AttnState<D, QT>& st, const half8 (&pb
         const half4 lo = lds_read_tr4(vrow + pos), hi = lds_read_tr4(vrow + 4 * D + pos);
         const half8 vt = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
+        for (int qt = 0; qt < QT; ++qt) {
             st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vt, pb[qt], st.acc[qt][t], 0, 0, 0);
+#if TF_BLOCK_P_SPLIT > 0
+            st.acc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vt, pl[qt], st.acc[qt][t], 0, 0, 0);
+#endif
+        }
     }
 }
 
@@ -1123,16 +1153,16 @@ __device__ __forceinline__ void attn_block_lds_body(
                         s1b[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kb, st.qf[qt][c], s1b[qt], 0, 0, 0);
                     }
                 }
-                half8 p0[QT], p1[QT];
+                half8 p0[QT], p1[QT], l0[QT], l1[QT];
                 if constexpr (TF_BLOCK_PIPE >= 2) {
-                    lds_softmax_clear2<D, QT>(st, s0a, s0b, s1a, s1b, scale_log2, p0, p1);
-                    lds_pv_tr<D, QT>(st, p0, bv, 0, li, g);
-                    lds_pv_tr<D, QT>(st, p1, bv, 4, li, g);
+                    lds_softmax_clear2<D, QT>(st, s0a, s0b, s1a, s1b, scale_log2, p0, p1, l0, l1);
+                    lds_pv_tr<D, QT>(st, p0, l0, bv, 0, li, g);
+                    lds_pv_tr<D, QT>(st, p1, l1, bv, 4, li, g);
                 } else {
-                    lds_softmax_clear<D, QT>(st, s0a, s0b, scale_log2, p0);
-                    lds_pv_tr<D, QT>(st, p0, bv, 0, li, g);
-                    lds_softmax_clear<D, QT>(st, s1a, s1b, scale_log2, p1);
-                    lds_pv_tr<D, QT>(st, p1, bv, 4, li, g);
+                    lds_softmax_clear<D, QT>(st, s0a, s0b, scale_log2, p0, l0);
+                    lds_pv_tr<D, QT>(st, p0, l0, bv, 0, li, g);
+                    lds_softmax_clear<D, QT>(st, s1a, s1b, scale_log2, p1, l1);
+                    lds_pv_tr<D, QT>(st, p1, l1, bv, 4, li, g);
                 }
             }
         }
@@ -1322,11 +1352,11 @@ __device__ __forceinline__ void attn_prefill_ahead_body(
             f32x4 n0a[QT], n0b[QT], n1a[QT], n1b[QT];
             const int last = sl * SLAB + SLAB - 1;
             if (last < sk && last <= sk - sq + qbase) {      // wave-uniform: the whole slab is visible to every row of the wave
-                half8 p0[QT], p1[QT];
+                half8 p0[QT], p1[QT], l0[QT], l1[QT];
                 qk_slab(bk_next, n0a, n0b, n1a, n1b);        // next slab's QK^T (past the end: finite garbage, never used)
-                lds_softmax_clear2<D, QT>(st, c0a, c0b, c1a, c1b, scale_log2, p0, p1);
-                lds_pv_tr<D, QT>(st, p0, bv, 0, li, g);
-                lds_pv_tr<D, QT>(st, p1, bv, 4, li, g);
+                lds_softmax_clear2<D, QT>(st, c0a, c0b, c1a, c1b, scale_log2, p0, p1, l0, l1);
+                lds_pv_tr<D, QT>(st, p0, l0, bv, 0, li, g);
+                lds_pv_tr<D, QT>(st, p1, l1, bv, 4, li, g);
             } else {
                 qk_slab(bk_next, n0a, n0b, n1a, n1b);
                 const int key0 = sl * SLAB;
@@ -1607,7 +1637,12 @@ __global__ __launch_bounds__(256) void attn_rope_on_read_mfma_kernel(
     h16* sK = reinterpret_cast<h16*>(smem_raw);       // [kvp][KS]
     h16* sVt = sK + (size_t)kvp * KS;                 // [D][PS]
     h16* sP = sVt + (size_t)D * PS;                   // [16][PS]
+#if TF_DRAFT_P_SPLIT > 0
+    h16* sPl = sP + (size_t)16 * PS;                  // [16][PS]  low-order parts of P
+    float* sS = reinterpret_cast<float*>(sPl + (size_t)16 * PS);  // [16][kvp]
+#else
     float* sS = reinterpret_cast<float*>(sP + (size_t)16 * PS);   // [16][kvp]
+#endif
     float* sL = sS + (size_t)16 * kvp;                // [16]
 
     const int h = blockIdx.x, q0 = blockIdx.y * 16;
@@ -1679,7 +1714,11 @@ __global__ __launch_bounds__(256) void attn_rope_on_read_mfma_kernel(
                 p = __expf(sS[(size_t)row * kvp + j] - mx);
                 lsum += p;
             }
-            sP[(size_t)row * PS + j] = (h16)p;
+            const h16 ph = (h16)p;
+            sP[(size_t)row * PS + j] = ph;
+#if TF_DRAFT_P_SPLIT > 0
+            sPl[(size_t)row * PS + j] = (h16)(p - (float)ph);          // low-order part of P: its own A operand below
+#endif
         }
         lsum = wave_sum(lsum);
         if (lane == 0) sL[row] = lsum;
@@ -1692,6 +1731,9 @@ __global__ __launch_bounds__(256) void attn_rope_on_read_mfma_kernel(
         const half8 ap = load_half8(sP + (size_t)li * PS + 32 * c + 8 * g);
         const half8 bv = load_half8(sVt + (size_t)(16 * wave + li) * PS + 32 * c + 8 * g);
         o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ap, bv, o, 0, 0, 0);
+#if TF_DRAFT_P_SPLIT > 0
+        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(load_half8(sPl + (size_t)li * PS + 32 * c + 8 * g), bv, o, 0, 0, 0);
+#endif
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1702,7 +1744,7 @@ __global__ __launch_bounds__(256) void attn_rope_on_read_mfma_kernel(
 
 static size_t draft_mfma_lds_bytes(int kv_len) {
     const size_t kvp = (size_t)((kv_len + 31) & ~31), PS = kvp + DRAFT_KPAD;
-    return kvp * (64 + DRAFT_KPAD) * 2 + 64 * PS * 2 + 16 * PS * 2 + 16 * kvp * 4 + 16 * 4;
+    return kvp * (64 + DRAFT_KPAD) * 2 + 64 * PS * 2 + (TF_DRAFT_P_SPLIT > 0 ? 2 : 1) * 16 * PS * 2 + 16 * kvp * 4 + 16 * 4;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -71,6 +71,8 @@ SIGNATURES = {
     "tf_allreduce_oneshot_add_ss": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
     "tf_allreduce_oneshot_alt": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp]),
     "tf_allreduce_oneshot_act": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "tf_ar_litmus_stage": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "tf_ar_litmus_check": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "tf_ar_error": (_i32, [_vp]),
     "tf_ar_epoch": (_i64, [_vp]),
     "tf_ar_set_error_mirror": (_i32, [_vp, _vp]),
