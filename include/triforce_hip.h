@@ -283,6 +283,13 @@ int tf_skinny_qkv_rope_act(const void* wqkv_packed, const void* x, int64_t xs_m,
                            void* q_out, void* k_cache, void* v_cache, int64_t stride_t, int64_t stride_h, int slot0,
                            const int32_t* slot0_dev, int M, int H, int D, int K, int rotate_k, void* stream);
 int tf_sg_tune(int key, int value);
+/* Split-K workspace of the CURRENT device (csrc/gemv.hip, SgKsplit): GEMMs with few output panels — the q|k|v and
+ * gate|up shards of a tensor-parallel rank — split K across up to 4 workgroups per panel; their partial sums meet in
+ * `ws` (zero-filled device memory, first 16 KiB = per-panel tickets, left zero by every launch; 8 MiB covers every shape
+ * the rule splits), summed in split order by the last workgroup to arrive.  Without a registered workspace no GEMM is
+ * split.  GEMMs running CONCURRENTLY on one device must not share a workspace.  ws = NULL removes it.  (tf_sg_tune key
+ * 3: panel-group count below which the split applies, 0 = never.) */
+int tf_sg_workspace(void* ws, int64_t bytes);
 
 /* -------------------------------------------------------------------------------------------
  * Sampling / accept-rollback (utils/sampling.py:63-75, utils/decoding.py:97-134,190-220).

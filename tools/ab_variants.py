@@ -31,6 +31,10 @@ VARIANTS = {"q2occ1": ["TF_ATTN_QT2_OCC=0"],
             "q2w8": ["TF_ATTN_Q2_WAVES=8"],
             "reslate": ["TF_SG_RES_EARLY=0"],        # residual operands loaded at the GEMM's tail (tools/gemm_resid_ab.py)
             "dma0": ["TF_BLOCK_DMA=0"], "dma1": ["TF_BLOCK_DMA=1"],
+            # round 4: P fed to the PV MFMA as hi + lo fp16 in the block / prefill / tree kernels too (tools/prefill_variants_ab.py),
+            # the many-split in-launch attention merge off, the retrieval scorer's round-3 grid rule
+            "psplitblk": ["TF_BLOCK_P_SPLIT=1"], "draftps0": ["TF_DRAFT_P_SPLIT=0"],
+            "nobigmerge": ["FUSED_MERGE_BIG_SPLITS=8"], "rscoreceil": ["TF_RSCORE_CAP_CEIL=1"],
             "ring4ps1": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_RING_Q1=4", "TF_ATTN_RING_Q2=4", "TF_ATTN_QT2_OCC=1", "TF_ATTN_P_SPLIT=1"]}
 
 if __name__ == "__main__":

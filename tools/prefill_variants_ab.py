@@ -48,7 +48,24 @@ def worker(tag):
             got = out.view(chunk, H, D)[r0:, hs].double()
             row["max_abs_err_vs_fp64"] = float((got - want).abs().max())
             row["mean_abs_err_vs_fp64"] = float((got - want).abs().mean())
+            # how many fp16 outputs are NOT the correctly rounded value of the fp64 result (round 3's measure for the
+            # decode kernel: 36 % with P rounded once to fp16, 0.16 % with P fed as hi + lo)
+            row["frac_not_correctly_rounded"] = float((got.half() != want.half()).float().mean())
         print(json.dumps(row), flush=True)
+    # Sequoia verify: 512 tree rows behind a 124 928-token prefix (TREE form of the LDS block kernel), random ancestor masks
+    sk, T = 124928 - 512, 512
+    vis = torch.tril(torch.rand(T, T, generator=g, device=DEV) < 0.1) | torch.eye(T, dtype=torch.bool, device=DEV)
+    bits = ops.pack_tree_mask(vis)
+    qt = torch.randn(T, H, D, generator=g, device=DEV, dtype=torch.float16)
+    ops.attn_tree(qt, k, v, sk + T, scale, bits, sk)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(4):
+        ops.attn_tree(qt, k, v, sk + T, scale, bits, sk)
+    e1.record()
+    torch.cuda.synchronize()
+    print(json.dumps({"lib": tag, "tree_verify_512_nodes_us": round(e0.elapsed_time(e1) * 1e3 / 4, 1)}), flush=True)
 
 
 def main():

@@ -45,6 +45,18 @@
 #define COMBINE_GROUPS 8           // independent accumulation chains of the split merge (fixed: part of the arithmetic)
 #define COMBINE_MAX_SPLITS 128
 #define FUSED_MERGE_MAX_SPLITS 8   // = COMBINE_GROUPS: each split is then one chain, merged in registers by one workgroup
+// Round 4: the in-launch merge also for MANY splits when the grid is small — the 4 / 5 heads of a tensor-parallel rank run
+// 32-64 splits per head (one workgroup per CU), whose merge was a second launch: 6.0 us of attn_combine_kernel behind an
+// 8.9 us split kernel (profiles/r04_tp8_7b_kernel_timeline_before.json).  The last workgroup of a head folds all splits
+// with attn_combine_kernel's arithmetic (8 chains over s = g, g + 8, ..., summed in chain order: bit-identical).  Only
+// while H * nsplit <= FUSED_MERGE_BIG_MAX_WGS: with 512+ workgroups the parallel merge kernel wins (16 splits x 32
+// heads: 28.0 vs 21.1 us).
+#ifndef FUSED_MERGE_BIG_SPLITS
+#define FUSED_MERGE_BIG_SPLITS 64
+#endif
+#ifndef FUSED_MERGE_BIG_MAX_WGS
+#define FUSED_MERGE_BIG_MAX_WGS 320
+#endif
 #ifndef TF_ATTN_EAGER_TILES
 #define TF_ATTN_EAGER_TILES 16 // splits of up to this many 16-key tiles per wave use the unconditional-prefetch loop
 #endif
@@ -446,9 +458,70 @@ __device__ __forceinline__ void attn_split_body(
         s_last = __hip_atomic_fetch_add(&tickets[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nsplit - 1);
     __syncthreads();
     if (!s_last) return;
-    // nsplit <= FUSED_MERGE_MAX_SPLITS (host-checked): every load of an output element is issued up front — one memory
-    // latency — and each split is its own accumulation chain of attn_combine_kernel
     const int64_t hbase = (int64_t)h * nsplit * QR;
+    if (D == 128 && nsplit > FUSED_MERGE_MAX_SPLITS) {
+        // ---- many splits (host-checked: <= FUSED_MERGE_BIG_SPLITS): weights per (row, split) through LDS first, then
+        // every thread folds its (row, 4 d) elements over the splits in attn_combine_kernel's order ----
+        float* sw = &sm_o[0][0][0];                                   // [QR][BIG]: m_s, then exp(m_s - mm); reuses the wave-merge buffer
+        float* sl2 = sw + QR * FUSED_MERGE_BIG_SPLITS;                // [QR][BIG]: l_s
+        float* sl = sl2 + QR * FUSED_MERGE_BIG_SPLITS;                // [QR]: sum_s l_s * w_s
+        static_assert(D != 128 || (size_t)2 * QR * FUSED_MERGE_BIG_SPLITS + QR <= (size_t)NW * 16 * (DH + 1), "merge scratch");
+        for (int e = tid; e < sq * nsplit; e += 64 * NW) {            // all (row, split) statistics in flight at once
+            const int r = e / nsplit, sp = e - r * nsplit;
+            sw[r * FUSED_MERGE_BIG_SPLITS + sp] = ld_agent(&ws_m[hbase + (int64_t)sp * QR + r]);
+            sl2[r * FUSED_MERGE_BIG_SPLITS + sp] = ld_agent(&ws_l[hbase + (int64_t)sp * QR + r]);
+        }
+        __syncthreads();
+        for (int r = tid; r < sq; r += 64 * NW) {
+            float mm = NEG_BIG;
+            for (int sp = 0; sp < nsplit; ++sp) mm = fmaxf(mm, sw[r * FUSED_MERGE_BIG_SPLITS + sp]);
+            float l = 0.f;
+            for (int sp = 0; sp < nsplit; ++sp) {
+                const float w = __expf(sw[r * FUSED_MERGE_BIG_SPLITS + sp] - mm);
+                sw[r * FUSED_MERGE_BIG_SPLITS + sp] = w;
+                const float lw = sl2[r * FUSED_MERGE_BIG_SPLITS + sp] * w;      // attn_combine_kernel: sm_l[s] *= w, then the sum
+                l += lw;
+            }
+            sl[r] = l;
+        }
+        __syncthreads();
+        for (int e = tid; e < sq * (D / 4); e += 64 * NW) {
+            const int r = e / (D / 4), d4 = e - r * (D / 4);
+            f32x4 ch[COMBINE_GROUPS];
+#pragma unroll
+            for (int gg = 0; gg < COMBINE_GROUPS; ++gg) ch[gg] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int s0 = 0; s0 < nsplit; s0 += COMBINE_GROUPS) {     // 8 splits' loads in flight, one per chain
+                f32x4 px[COMBINE_GROUPS];
+#pragma unroll
+                for (int gg = 0; gg < COMBINE_GROUPS; ++gg) {
+                    const int sp = min(s0 + gg, nsplit - 1);
+                    const float* xp = ws_o + (hbase + (int64_t)sp * QR + r) * D + 4 * d4;
+                    px[gg] = f32x4{ld_agent(xp), ld_agent(xp + 1), ld_agent(xp + 2), ld_agent(xp + 3)};
+                }
+#pragma unroll
+                for (int gg = 0; gg < COMBINE_GROUPS; ++gg)
+                    if (s0 + gg < nsplit) {
+                        const float w = sw[r * FUSED_MERGE_BIG_SPLITS + s0 + gg];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) ch[gg][c] = fmaf(px[gg][c], w, ch[gg][c]);
+                    }
+            }
+            const float l = sl[r];
+            half4 o4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float acc = 0.f;
+#pragma unroll
+                for (int gg = 0; gg < COMBINE_GROUPS; ++gg) acc += ch[gg][c];
+                o4[c] = (h16)(acc / l);
+            }
+            *reinterpret_cast<half4*>(out + (int64_t)r * osm + (int64_t)((h * D + 4 * d4) >> 3) * osk + ((4 * d4) & 7)) = o4;
+        }
+        if (tid == 0) __hip_atomic_store(&tickets[h], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // nsplit <= FUSED_MERGE_MAX_SPLITS: every load of an output element is issued up front — one memory
+    // latency — and each split is its own accumulation chain of attn_combine_kernel
     for (int e = tid; e < sq * (D / 4); e += 64 * NW) {
         const int r = e / (D / 4), d4 = e - r * (D / 4);
         float pm[FUSED_MERGE_MAX_SPLITS], pl[FUSED_MERGE_MAX_SPLITS];
@@ -1781,7 +1854,11 @@ static int launch_attn(const void* q, const void* k, const void* v, void* out, i
                        int64_t stride_t, int64_t stride_h, int sq, int sk, const int32_t* sk_dev, int H, float scale,
                        int nsplit, float* ws, unsigned* tickets, hipStream_t st) {
     dim3 grid(nsplit, H), block(256);
-    if (tickets && nsplit > FUSED_MERGE_MAX_SPLITS) tickets = nullptr;    // many splits: the parallel merge kernel wins
+    // many splits on a big grid: the parallel merge kernel wins; on a small grid (few heads) the last workgroup of a head
+    // folds them inside the launch (see FUSED_MERGE_BIG_SPLITS)
+    if (tickets && nsplit > FUSED_MERGE_MAX_SPLITS &&
+        (D != 128 || nsplit > FUSED_MERGE_BIG_SPLITS || (int64_t)nsplit * H > FUSED_MERGE_BIG_MAX_WGS || TF_ATTN_Q2_WAVES > 4))
+        tickets = nullptr;
     bool launched = false;
 #if TF_ATTN_DEEP_TILES > 0
     if constexpr (QT == 1) {

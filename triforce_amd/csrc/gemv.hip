@@ -72,6 +72,27 @@ struct SgAct {
 #ifndef SG_P_WIDE_MIN_GROUPS
 #define SG_P_WIDE_MIN_GROUPS 420
 #endif
+// K split ACROSS workgroups (round 4).  A GEMM with few output panels — the q|k|v and gate|up shards of a tensor-parallel
+// rank: 96 / 86 panels at 7B TP 8 — ran one workgroup per panel, i.e. on 86-96 of the 256 CUs: 13.2 / 9.1 us for 22.5 /
+// 12.6 MB (1.7 / 1.4 TB/s, profiles/r04_tp8_7b_kernel_timeline_before.json).  With gridDim.y = KS workgroups per panel
+// group each streams 1 / KS of the panel's K range; the per-panel partial sums (1 KiB per row tile) meet through a
+// workspace: written with agent-scope write-through stores, drained, one ticket per panel — the LAST workgroup to arrive
+// reads all KS partials back (agent-scope loads), adds them IN SPLIT ORDER (deterministic whoever arrives last) and runs
+// the epilogue.  Same hand-off as the one-launch attention merge (csrc/attn.hip).  The workspace (tickets first) belongs
+// to the caller: tf_sg_workspace registers one per device; without it KS = 1.
+#define SG_KSPLIT_MAX 4
+#define SG_TICKETS 4096
+struct SgKsplit {
+    float* ws;            // [panel][KS][NA][MT][64][4] fp32
+    unsigned* tickets;    // [SG_TICKETS], zero between launches
+};
+static void* g_sg_ws[16] = {};
+static int64_t g_sg_ws_bytes[16] = {};
+static int g_sg_ksplit_max_groups = 200;   // split K across workgroups below this many panel groups (tf_sg_tune key 3; 0 = never)
+
+__device__ __forceinline__ void sg_st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float sg_ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 static int g_sg_p2_rows = 1;       // P = 2 from this many rows (tf_sg_tune key 0; 33 = never)
 static int g_sg_p2_waves = 4;      // waves per workgroup of the P = 2 form (key 1)
 static int g_sg_p2_groups = SG_P_WIDE_MIN_GROUPS;   // ... while panels / 2 >= this (key 2)
@@ -97,7 +118,7 @@ __device__ __forceinline__ half8 sg_normalise(half8 xv, half8 wv, float inv) {
     return o;
 }
 
-template <int MT, int MODE, bool NORM, int WAVES, int P>
+template <int MT, int MODE, bool NORM, int WAVES, int P, bool KSPLIT>
 __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __restrict__ wp,
                                                                  const half8* __restrict__ wp_up,
                                                                  const h16* __restrict__ x, SgAct xa,
@@ -105,7 +126,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
                                                                  const h16* resid, SgAct ra, void* yv, SgAct ya,
                                                                  int M, int N, int K, SgRope rp,
                                                                  const float* __restrict__ ss_in,
-                                                                 float* __restrict__ ss_out) {
+                                                                 float* __restrict__ ss_out, SgKsplit kx) {
     constexpr bool GATEUP = MODE == SG_GATEUP;
     constexpr int NA = GATEUP ? 2 : 1;                       // weight streams (accumulator sets) per panel
     constexpr int U = (P * NA >= 2) ? (8 / (P * NA)) : SG_U;  // k-chunks in flight per wave: 8 KiB of weights (4 for P = NA = 1)
@@ -114,8 +135,12 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     const int nchunks = K >> 5;
-    const int cpw = (nchunks + WAVES - 1) / WAVES;
-    const int c0 = wave * cpw, c1 = min(nchunks, c0 + cpw);
+    // this workgroup's share of K (gridDim.y = KS workgroups per panel group), then its waves' shares of that
+    const int KS = KSPLIT ? (int)gridDim.y : 1, ks = KSPLIT ? (int)blockIdx.y : 0;   // (own instantiation: the fold below
+                                                                                      //  costs the one-workgroup form registers)
+    const int g0c = (int)((int64_t)nchunks * ks / KS), g1c = (int)((int64_t)nchunks * (ks + 1) / KS);
+    const int cpw = (g1c - g0c + WAVES - 1) / WAVES;
+    const int c0 = g0c + wave * cpw, c1 = min(g1c, c0 + cpw);
 
     __shared__ float sm[WAVES][P * NA][MT][64][4];
     __shared__ float sm_ss[NORM ? WAVES : 1][MT][16];
@@ -193,8 +218,11 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
             float ss[MT];
 #pragma unroll
             for (int t = 0; t < MT; ++t) ss[t] = 0.f;
-            int cc = c0;
-            for (; cc + 8 <= c1; cc += 8) {                             // 8 independent loads per row tile in flight
+            // the sum of squares runs over ALL of K (this wave's share of the whole row, not of the workgroup's K slice)
+            const int cpa = (nchunks + WAVES - 1) / WAVES;
+            const int n0 = wave * cpa, n1 = min(nchunks, n0 + cpa);
+            int cc = n0;
+            for (; cc + 8 <= n1; cc += 8) {                             // 8 independent loads per row tile in flight
                 half8 v[8][MT];
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
@@ -210,7 +238,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
                             ss[t] = fmaf(f, f, ss[t]);
                         }
             }
-            for (; cc < c1; ++cc) {
+            for (; cc < n1; ++cc) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
                     const half8 v = xok[t] ? load_half8(xr[t] + xcs * cc) : zero8;
@@ -340,14 +368,13 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
                 *reinterpret_cast<f32x4*>(&sm[wave][j * NA + aa][t][lane][0]) = acc[j][aa][t];
     __syncthreads();
     if (!epi) return;
+    float S[MT][4], S2[MT][4];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-        const int m = t * 16 + li;
-        float s[4], s2[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            s[r] = 0.f;
-            s2[r] = 0.f;
+            S[t][r] = 0.f;
+            S2[t][r] = 0.f;
         }
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
@@ -356,9 +383,64 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
             if (GATEUP) v2 = *reinterpret_cast<const f32x4*>(&sm[w][wave * NA + NA - 1][t][lane][0]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s[r] += v[r];
-                if (GATEUP) s2[r] += v2[r];
+                S[t][r] += v[r];
+                if (GATEUP) S2[t][r] += v2[r];
             }
+        }
+    }
+    if constexpr (KSPLIT) {
+        // publish this workgroup's partial of the panel, take a ticket; only the last arriver goes on (wave-uniform)
+        float* base = kx.ws + ((int64_t)panel * KS * NA * MT) * 256 + lane * 4;
+        float* mine = base + (int64_t)ks * NA * MT * 256;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sg_st_agent(mine + t * 256 + r, S[t][r]);
+                if (GATEUP) sg_st_agent(mine + (MT + t) * 256 + r, S2[t][r]);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // own write-through stores landed before the ticket
+        unsigned tk = 0;
+        if (lane == 0) tk = __hip_atomic_fetch_add(&kx.tickets[panel], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        if (tk != (unsigned)(KS - 1)) return;
+        float P1[SG_KSPLIT_MAX][MT][4], P2[SG_KSPLIT_MAX][MT][4];
+#pragma unroll
+        for (int k = 0; k < SG_KSPLIT_MAX; ++k)                 // every load issued up front: one memory round trip
+            if (k < KS) {
+                const float* src = base + (int64_t)k * NA * MT * 256;
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        P1[k][t][r] = sg_ld_agent(src + t * 256 + r);
+                        if (GATEUP) P2[k][t][r] = sg_ld_agent(src + (MT + t) * 256 + r);
+                    }
+            }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int k = 0; k < SG_KSPLIT_MAX; ++k)        // split order, whoever arrived last
+                    if (k < KS) {
+                        a += P1[k][t][r];
+                        if (GATEUP) b += P2[k][t][r];
+                    }
+                S[t][r] = a;
+                S2[t][r] = b;
+            }
+        if (lane == 0) __hip_atomic_store(&kx.tickets[panel], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = t * 16 + li;
+        float s[4], s2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[r] = S[t][r];
+            s2[r] = S2[t][r];
         }
         if (MODE == SG_QKV) {
             // panel -> (section, head, 8-wide rotary block): q and k panels hold rows d0..d0+7 | d0+D/2..d0+D/2+7
@@ -456,11 +538,41 @@ struct SgArgs {                       // one GEMM call: operands with their layo
     float* ss_out;
 };
 
+// Workgroups per panel group along K: only few-panel grids (see SgKsplit), only with a registered workspace that holds the
+// partials, and only while every wave of every workgroup still gets >= 2 k-chunks.
+template <int MT, int NA, int WAVES, int P>
+static int sg_pick_ksplit(const SgArgs& a, SgKsplit& kx) {
+    kx = SgKsplit{nullptr, nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !g_sg_ws[dev]) return 1;
+    const int panels = a.N / 16, groups = panels / P, nchunks = a.K >> 5;
+    if (groups >= g_sg_ksplit_max_groups || panels > SG_TICKETS) return 1;
+    int ks = (256 + groups - 1) / groups;
+    if (ks > SG_KSPLIT_MAX) ks = SG_KSPLIT_MAX;
+    while (ks > 1 && nchunks / ks < 2 * WAVES) --ks;
+    if (ks <= 1) return 1;
+    const int64_t need = (int64_t)SG_TICKETS * 4 + (int64_t)panels * ks * NA * MT * 256 * 4;
+    if (need > g_sg_ws_bytes[dev]) return 1;
+    kx.tickets = reinterpret_cast<unsigned*>(g_sg_ws[dev]);
+    kx.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(g_sg_ws[dev]) + (int64_t)SG_TICKETS * 4);
+    return ks;
+}
+
 template <int MT, int MODE, bool NORM, int WAVES, int P>
 static void launch_sg_w(const SgArgs& a, const SgRope& rp, hipStream_t st) {
-    hipLaunchKernelGGL((skinny_gemm_kernel<MT, MODE, NORM, WAVES, P>), dim3(a.N / 16 / P), dim3(WAVES * 64), 0, st,
+    SgKsplit kx = {nullptr, nullptr};
+    if constexpr (P == 1 && MODE != SG_F32) {                     // few-panel grids only: never the P = 2 form, never lm_head
+        const int ks = sg_pick_ksplit<MT, (MODE == SG_GATEUP ? 2 : 1), WAVES, P>(a, kx);
+        if (ks > 1) {
+            hipLaunchKernelGGL((skinny_gemm_kernel<MT, MODE, NORM, WAVES, P, true>), dim3(a.N / 16 / P, ks), dim3(WAVES * 64),
+                               0, st, (const half8*)a.wp, (const half8*)a.wp_up, (const h16*)a.x, a.xa, (const h16*)a.ln_w,
+                               a.eps, (const h16*)a.resid, a.ra, a.y, a.ya, a.M, a.N, a.K, rp, a.ss_in, a.ss_out, kx);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((skinny_gemm_kernel<MT, MODE, NORM, WAVES, P, false>), dim3(a.N / 16 / P), dim3(WAVES * 64), 0, st,
                        (const half8*)a.wp, (const half8*)a.wp_up, (const h16*)a.x, a.xa, (const h16*)a.ln_w, a.eps,
-                       (const h16*)a.resid, a.ra, a.y, a.ya, a.M, a.N, a.K, rp, a.ss_in, a.ss_out);
+                       (const h16*)a.resid, a.ra, a.y, a.ya, a.M, a.N, a.K, rp, a.ss_in, a.ss_out, kx);
 }
 
 template <int MODE, bool NORM>
@@ -502,14 +614,30 @@ static bool sg_shape_ok(int M, int N, int K, const SgAct& xa) {
 }
 
 // A/B knobs of the launch rule (tools/gemm_layout_ab.py): key 0 = rows from which two panels per wave are used (33:
-// never), key 1 = waves per workgroup of that form (4 or 8), key 2 = smallest halved grid (panels / 2) that takes it.  Returns the previous value, -1 for an unknown key.
+// never), key 1 = waves per workgroup of that form (4 or 8), key 2 = smallest halved grid (panels / 2) that takes it,
+// key 3 = panel-group count below which K is also split ACROSS workgroups (0 = never).  Returns the previous value, -1 for an unknown key.
 extern "C" int tf_sg_tune(int key, int value) {
-    int* slot = key == 0 ? &g_sg_p2_rows : key == 1 ? &g_sg_p2_waves : key == 2 ? &g_sg_p2_groups : nullptr;
+    int* slot = key == 0 ? &g_sg_p2_rows : key == 1 ? &g_sg_p2_waves : key == 2 ? &g_sg_p2_groups
+                : key == 3 ? &g_sg_ksplit_max_groups : nullptr;
     if (!slot) return -1;
     const int old = *slot;
     if (key == 1 && value != 4 && value != 8) return old;
     *slot = value;
     return old;
+}
+
+// Registers (ws != NULL) or removes the CURRENT device's split-K workspace: `bytes` of device memory, ZERO-filled, that
+// stays allocated while GEMMs may run; the first 16 KiB are the per-panel tickets (left zero by every launch), the rest
+// holds the partial sums of one launch at a time — GEMMs that may run CONCURRENTLY on one device (two streams) must not
+// share it (the engines issue their GEMMs on one stream).  8 MiB covers every shape the rule splits.
+extern "C" int tf_sg_workspace(void* ws, int64_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 16 || (ws && bytes < (int64_t)SG_TICKETS * 4 + 4096) || (reinterpret_cast<uintptr_t>(ws) % 16)) return TF_EINVAL;
+    g_sg_ws[dev] = ws;
+    g_sg_ws_bytes[dev] = ws ? bytes : 0;
+    return TF_OK;
 }
 
 extern "C" int tf_skinny_gemm_act(const void* w_packed, const void* x, int64_t xs_m, int64_t xs_k, const void* ln_w,

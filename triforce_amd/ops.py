@@ -73,6 +73,27 @@ def rope_row_order(H, D, device=None):
     return torch.cat([qk, torch.arange(2 * H * D, 3 * H * D, device=device)])
 
 
+# Split-K workspace of the skinny GEMM (csrc/gemv.hip SgKsplit, tf_sg_workspace): one zero-filled 8 MiB block per device,
+# registered when the first weight is packed there (i.e. before any hipGraph capture) and never freed.  Few-panel GEMMs
+# (the q|k|v / gate|up shards of a tensor-parallel rank) then split K across up to 4 workgroups per panel.
+# TRIFORCE_GEMM_KSPLIT=0 keeps every GEMM at one workgroup per panel.
+_SG_WS = {}
+_SG_WS_BYTES = 8 << 20
+
+
+def _ensure_sg_workspace(device):
+    device = torch.device(device)
+    if device.type != "cuda" or device in _SG_WS:
+        return
+    with torch.cuda.device(device):
+        ws = torch.zeros(_SG_WS_BYTES, dtype=torch.uint8, device=device)
+        torch.cuda.synchronize(device)
+        hip.check(hip.lib().tf_sg_workspace(_ptr(ws), ws.numel()), "tf_sg_workspace")
+        if _os.environ.get("TRIFORCE_GEMM_KSPLIT", "1") == "0":
+            hip.lib().tf_sg_tune(3, 0)
+    _SG_WS[device] = ws
+
+
 class PackedLinear:
     """A weight matrix with (on a HIP device) its pre-packed copy for the skinny decode GEMM.  ``w`` stays
     available for the >32-row prefill GEMMs (hipBLASLt).  ``split`` = number of equal row blocks that were
@@ -85,6 +106,8 @@ class PackedLinear:
         self.split = split
         pack = w.is_cuda if pack is None else pack
         ok = pack and (self.N // split) % 16 == 0 and self.K % 32 == 0
+        if ok and w.is_cuda:
+            _ensure_sg_workspace(w.device)
         self.parts = [pack_weight(b) for b in w.chunk(split, dim=0)] if ok else None
         self.wp = self.parts[0] if (ok and split == 1) else None
         self.rope = rope
@@ -114,7 +137,10 @@ def _w(w):
 # fragments (profiles/r03_gemm_rows_ab.jsonl: 13B q|k|v 29.7 us at 8 rows, 44.0 at 17; k-octet-major: 27.6 at 17,
 # profiles/r04_gemm_layout_ab.jsonl).  TRIFORCE_ACT_LAYOUT = auto (default: see act_packed) | packed | rows.
 ACT_LAYOUT = _os.environ.get("TRIFORCE_ACT_LAYOUT", "auto")
-ACT_PACKED_MIN_ROWS = int(_os.environ.get("TRIFORCE_ACT_PACKED_MIN_ROWS", "1"))
+# auto: from 17 rows (two MFMA row tiles) — measured in situ (profiles/r04_act_layout_in_situ.jsonl): 13B gamma = 16
+# retrieval verify 9 198 -> 8 319 us, target verify 25 640 -> 24 578; 7B gamma = 16 retrieval verify 5 287 -> 5 024; at
+# 7 rows 3 345 -> 3 303 (1 %) and the tensor-parallel shard's eager 1-row step LOSES (host cost of the Act wrappers)
+ACT_PACKED_MIN_ROWS = int(_os.environ.get("TRIFORCE_ACT_PACKED_MIN_ROWS", "17"))
 
 
 def act_packed(rows):
