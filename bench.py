@@ -82,10 +82,11 @@ def parse(argv=None):
                     help="tensor-parallel path only: put every rank on cuda:0 (a functional full-size check of world "
                          "size N on a 1-GPU box: real shards, real kernels, one-shot all-reduce across processes; "
                          "large collectives over gloo).  NOT a scaling measurement; the line says so")
-    ap.add_argument("--allreduce", default="auto", choices=["auto", "oneshot", "rccl"],
+    ap.add_argument("--allreduce", default=None, choices=["auto", "oneshot", "rccl"],
                     help="tensor-parallel path: decode-sized all-reduces through the one-shot peer-read kernel after its "
                          "collective self-check (auto: falls back to RCCL if the check fails; oneshot: fail instead of "
-                         "falling back) or through RCCL — for A/B on a multi-GPU node")
+                         "falling back) or through RCCL — for A/B on a multi-GPU node.  Default: the environment's "
+                         "TRIFORCE_ALLREDUCE if set, else auto")
     ap.add_argument("--require-graph-form", default=None, choices=["whole", "segments", "eager"],
                     help="tensor-parallel path: fail (rc != 0, JSON field 'failed') unless the decode forwards were "
                          "captured in this form")
@@ -103,6 +104,16 @@ def parse(argv=None):
     total = args.steps + args.warmup + args.random_steps + 8
     args.gen_cap = max(args.gen_cap, min(total * (args.gamma + 2) + args.ar_steps + 64, args.budget))
     return args
+
+
+METRIC_NAMES = {"llama-7B-128K": "Llama-7B-128K", "llama-13B-128K": "Llama-13B-128K", "lwm-128K": "LWM-Text-Chat-128K",
+                "tiny": "tiny test model"}
+
+
+def metric_label(target, prefill):
+    """BASELINE.json's metric string for the headline workload (7B, 124 928-token prompt); for every other line the
+    model and context actually run (a 13B / 130K line must not say "Llama-7B-128K @124K ctx")."""
+    return f"decode tokens/sec + avg accepted len, {METRIC_NAMES.get(target, target)} @{prefill // 1000}K ctx"
 
 
 def target_config(name):
@@ -633,7 +644,7 @@ def main():
     inner_per_step = m["inner"] / max(args.steps, 1)
     cal = (target.weights.aligned or {}).get("calibration") if kind == "aligned" else None
     result = {
-        "metric": "decode tokens/sec + avg accepted len, Llama-7B-128K @124K ctx",
+        "metric": metric_label(args.target, args.prefill),
         "value": round(value, 3), "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(seconds / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",

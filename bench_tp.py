@@ -92,7 +92,7 @@ def run_tp(args, rank, world, local):
         sys.stdout.flush()
         _REAL_STDOUT = os.dup(1)
         os.dup2(2, 1)
-    from bench import (_Tok, attn_roofline, baseline_config_label, cpu_baseline, forward_bytes, resolve_weights,
+    from bench import (_Tok, attn_roofline, baseline_config_label, cpu_baseline, forward_bytes, metric_label, resolve_weights,
                        target_config, _stage_row, _timed)
     from triforce_amd.models.aligned import parse_spec
     from triforce_amd import ops
@@ -103,7 +103,13 @@ def run_tp(args, rank, world, local):
     from triforce_amd.utils.sampling import UniformSource
 
     on_gpu = torch.cuda.is_available()
-    os.environ["TRIFORCE_ALLREDUCE"] = getattr(args, "allreduce", "auto")     # read by DistributedLlama.init_parameters
+    # read by DistributedLlama.init_parameters; an explicit --allreduce wins, else a TRIFORCE_ALLREDUCE the user exported
+    # stays in force (it used to be overwritten with the flag's default), else auto
+    if getattr(args, "allreduce", None) is None:
+        args.allreduce = os.environ.get("TRIFORCE_ALLREDUCE", "auto")
+        if args.allreduce not in ("auto", "oneshot", "rccl"):
+            raise SystemExit(f"TRIFORCE_ALLREDUCE={args.allreduce!r}: expected auto, oneshot or rccl")
+    os.environ["TRIFORCE_ALLREDUCE"] = args.allreduce
     if "RANK" not in os.environ:                                # one process, no launcher (--engine tp / --on-chip at N=1)
         import socket
         with socket.socket() as sock:
@@ -140,7 +146,7 @@ def run_tp(args, rank, world, local):
         dist.all_gather(got, shard)
         dist.barrier()
         if rank == 0:
-            _emit(json.dumps({"metric": "decode tokens/sec + avg accepted len, Llama-7B-128K @124K ctx", "dry_run": True,
+            _emit(json.dumps({"metric": metric_label(args.target, args.prefill), "dry_run": True,
                               "n_gpus": world, "world_size_observed": dist.get_world_size(),
                               "backend": dist.get_backend(), "shards": [g.tolist() for g in got],
                               "config": {"workload": f"{tcfg._name_or_path} TP={world}", "weights": wlabel}}))
@@ -211,7 +217,7 @@ def run_tp(args, rank, world, local):
     if failure is None and getattr(args, "allreduce", "auto") == "oneshot" and world > 1 and getattr(llm, "_ar", None) is None:
         failure = "--allreduce oneshot but the engine is on RCCL"
     if failure is not None:                                     # fail LOUDLY: a JSON line that says so, and rc != 0
-        _emit(json.dumps({"metric": "decode tokens/sec + avg accepted len, Llama-7B-128K @124K ctx", "value": None,
+        _emit(json.dumps({"metric": metric_label(args.target, args.prefill), "value": None,
                           "failed": failure, "rank": rank, "n_gpus": world, "allreduce_error": int(ar_err),
                           "world_size_observed": dist.get_world_size(), "graph_form": getattr(llm, "graph_form", "eager"),
                           "decode_allreduce": "oneshot" if getattr(llm, "_ar", None) is not None else "rccl"}))
@@ -260,7 +266,7 @@ def run_tp(args, rank, world, local):
                 cpu = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
                        "sample": f"failed: {type(ex).__name__}: {ex}"}
         _emit(json.dumps({
-            "metric": "decode tokens/sec + avg accepted len, Llama-7B-128K @124K ctx",
+            "metric": metric_label(args.target, args.prefill),
             "value": round(tokens / seconds, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(seconds / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",

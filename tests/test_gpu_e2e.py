@@ -198,8 +198,12 @@ def test_periodic_retrieval_rebuild_stays_lossless_on_device():
 
 
 def test_stochastic_triforce_with_injected_uniforms():
-    """cfg3-style sampling (T=0.6, top_p=0.9) over 32 uniform streams, product and oracle consuming the same explicit
-    uniforms.  Every accept / resample decision is a bit-exact function of (p, q, r) (tests/test_gpu_ops.py), but an
+    """cfg3-style sampling (T=0.6, top_p=0.9) over 128 uniform streams (round 3: 32 — the paired bias then sat at +1.6
+    standard errors on both metrics, the sign a subtle accept-test difference would have; the verdict asked for >= 128),
+    product and oracle consuming the same explicit uniforms.  The oracle's runs are cached (tests/golden/
+    stochastic_oracle_runs.json, written by oracle/gen_stochastic_runs.py from the pinned CPU oracle: the GPU box then
+    spends no time on the CPU side); four of them are re-run live here and any difference from the cache — the GPU box's
+    host CPU may order its fp32 GEMM sums differently — is written to the parity notes.  Every accept / resample decision is a bit-exact function of (p, q, r) (tests/test_gpu_ops.py), but an
     inverse-CDF draw from ~1000 comparably likely tokens flips as soon as the device's probabilities (fp16 logits:
     ~1e-3 relative) move a CDF boundary across the uniform — measured: a stream survives 5 draws at the median — after
     which the two runs are different draws from the same distributions.  So the end-to-end claim is distributional:
@@ -215,12 +219,24 @@ def test_stochastic_triforce_with_injected_uniforms():
     oeng, tsd, dsd = Hh.build_oracle(g, temperature=0.6, top_p=0.9)
     ge = Hh.build_product(g, DEV, tsd, dsd, temperature=0.6, top_p=0.9, graphs=True)
     prompt = Hh.prompt_of(g)
-    runs, max_len = 32, 24
+    runs, max_len = 128, 24
+    import json
+    import os
+    cached = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "stochastic_oracle_runs.json")))
+    assert cached["max_len"] == max_len and cached["gamma"] == g["gamma"] and len(cached["runs"]) >= runs
     prefixes, d_acc, d_tok = [], [], []
     acc_w = dr_w = acc_g = dr_g = tok_w = tok_g = steps_w = steps_g = 0
     for seed in range(runs):
         us = Hh.fixed_uniforms(n=2048, seed=500 + seed)
-        want = M.triforce(oeng, prompt, g["gamma"], max_len, 0.6, 0.9, rng=M.InjectedRng(us))
+        c = cached["runs"][seed]
+        assert c["seed"] == 500 + seed
+        want = {"tokens": c["tokens"], "accepted": c["accepted"], "drafted": c["drafted"], "n": c["n"],
+                "counts": [0] * c["steps"]}
+        if seed % 37 == 0:                                # the cache is the oracle: spot-check it live
+            live = M.triforce(oeng, prompt, g["gamma"], max_len, 0.6, 0.9, rng=M.InjectedRng(us))
+            if (live["accepted"], live["drafted"], live["n"]) != (c["accepted"], c["drafted"], c["n"]):
+                Hh.note(f"stochastic: live oracle run {seed} differs from the cached one (host-CPU GEMM order): "
+                        f"{(live['accepted'], live['drafted'], live['n'])} vs {(c['accepted'], c['drafted'], c['n'])}")
         got = TriForce(Hh.FakeTokenizer(), ge, prompt.to(DEV), gamma=g["gamma"], max_len=max_len, top_k=-1, top_p=0.9,
                        temperature=0.6, rng=UniformSource(DEV, values=us), return_details=True)
         n = min(len(got["tokens"]), len(want["tokens"]))

@@ -717,8 +717,10 @@ def test_swiglu_norm_prologue(M, I, K):
                                           ("swiglu", 1376, 4096, None), ("swiglu", 1728, 5120, None),
                                           ("plain", 3072, 4096, None), ("plain", 1024, 11008, None)])
 def test_gemm_split_across_workgroups(M, kind, N, K, HD):
-    """Few-panel GEMMs (the q|k|v / gate|up shards of a tensor-parallel rank: models/TP_layers.py:126-147) split K across
-    up to 4 workgroups per panel, the partial sums meeting through the registered workspace (csrc/gemv.hip SgKsplit).
+    """Few-panel GEMMs (the q|k|v / gate|up shards of a tensor-parallel rank: models/TP_layers.py:126-147) CAN split K
+    across up to 4 workgroups per panel, the partial sums meeting through the registered workspace (csrc/gemv.hip
+    SgKsplit) — built and measured in round 4, no gain in situ, so the launch rule leaves it off (tf_sg_tune key 3 = 0);
+    this test keeps the form correct for the next chip / shape where it may pay.
     Against the one-workgroup form: same fp16 results up to the fp32 re-association of the K sum (<= 1 ulp on a few %);
     run to run: bit-identical (the last arriver adds the partials in split order, whoever it is); tickets back to
     zero; norm prologue both ways (folding the hand-off / re-reading x over ALL of K); inside a hipGraph."""
@@ -734,13 +736,13 @@ def test_gemm_split_across_workgroups(M, kind, N, K, HD):
         H, D = HD
         w = rnd(N, K, seed=402, scale=0.05).to(DEV)
         pl = ops.PackedLinear(w, rope=(H, D))
-        cos, sin = R.rope_tables_yarn(D, 4096, 16.0, 256)
+        cos, sin = (t.to(DEV) for t in R.rope_tables_yarn(D, 4096, 16.0, 256))
         pos = torch.randint(0, 4096, (M,), generator=torch.Generator().manual_seed(M)).to(DEV)
 
         def run(ss_in=None):
             k = torch.zeros(H, 64, D, dtype=torch.float16, device=DEV)
             v = torch.zeros(H, 64, D, dtype=torch.float16, device=DEV)
-            q = ops.qkv_rope(x, pl, ln, eps, cos.to(DEV), sin.to(DEV), pos, k, v, 3, H, D, ss_in=ss_in)
+            q = ops.qkv_rope(x, pl, ln, eps, cos, sin, pos, k, v, 3, H, D, ss_in=ss_in)
             return torch.cat([q.reshape(-1), k.reshape(-1), v.reshape(-1)])
     elif kind == "swiglu":
         pl = ops.PackedLinear(rnd(2 * N, K, seed=403, scale=0.05).to(DEV), split=2)
@@ -756,33 +758,32 @@ def test_gemm_split_across_workgroups(M, kind, N, K, HD):
             ops.linear(x, pl, ln=ln, eps=eps, ss_in=ss_in, resid=buf, out=buf, ss_out=ss)
             return torch.cat([buf.reshape(-1), ss[:, :M].reshape(-1).half()])
     assert torch.device(DEV) in ops._SG_WS, "split-K workspace was not registered"
-    split = [run(), run(ssx)]
-    again = [run(), run(ssx)]
-    torch.cuda.synchronize()
-    assert torch.equal(split[0], again[0]) and torch.equal(split[1], again[1])
-    assert int(ops._SG_WS[torch.device(DEV)][:16384].sum()) == 0, "tickets were not left zero"
-    old = L.tf_sg_tune(3, 0)
+    one = [run(), run(ssx)]                                   # the shipped rule: one workgroup per panel (key 3 = 0)
+    old = L.tf_sg_tune(3, 200)                                # split below 200 panel groups
     try:
-        one = [run(), run(ssx)]
+        split = [run(), run(ssx)]
+        again = [run(), run(ssx)]
+        torch.cuda.synchronize()
+        assert torch.equal(split[0], again[0]) and torch.equal(split[1], again[1])
+        assert int(ops._SG_WS[torch.device(DEV)][:16384].sum()) == 0, "tickets were not left zero"
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            cap = run()
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(cap, split[0])
     finally:
         L.tf_sg_tune(3, old)
     for a, b in zip(split, one):
         d = (a.float() - b.float()).abs()
         tol = 2 * b.float().abs() * 2 ** -10 + 2e-3
         assert bool((d <= tol).all()) and float((d > 0).float().mean()) < 0.12, (float(d.max()), float((d > 0).float().mean()))
-    assert not torch.equal(split[0], one[0]) or M == 1 or True     # (usually differs in a few last bits; not required)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        run()
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        cap = run()
-    for _ in range(3):
-        graph.replay()
-    torch.cuda.synchronize()
-    assert torch.equal(cap, split[0])
 
 
 def test_row_copy_wrappers_refuse_out_of_range_rows():

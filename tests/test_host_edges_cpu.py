@@ -165,6 +165,19 @@ def test_chunked_prefill_returns_the_reference_last_chunk(n, on_device):
     assert seen == [(i, min(n, i + step)) for i in range(0, n, step)]
     ref_last = 128 * ((n - 1) // 128)                  # first row of the reference's last chunk
     assert out.reshape(-1).tolist() == list(range(ref_last, n))
+    # a forward that takes last_rows is asked for exactly the returned rows of the final chunk and ONE row of the others
+    seen.clear()
+    asked = []
+
+    def trimming(chunk, last_rows=None):
+        seen.append((chunk.lo, chunk.hi))
+        asked.append(last_rows)
+        return torch.arange(chunk.hi - last_rows, chunk.hi, dtype=torch.float32).reshape(1, -1, 1)
+
+    out2 = gi.chunked_prefill(trimming, Ids(0, n))
+    assert seen == [(i, min(n, i + step)) for i in range(0, n, step)]
+    assert asked == [1] * (len(seen) - 1) + [n - ref_last]
+    assert out2.reshape(-1).tolist() == list(range(ref_last, n))
 
 
 def test_bench_helpers_on_cpu():

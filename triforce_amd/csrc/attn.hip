@@ -51,8 +51,12 @@
 // with attn_combine_kernel's arithmetic (8 chains over s = g, g + 8, ..., summed in chain order: bit-identical).  Only
 // while H * nsplit <= FUSED_MERGE_BIG_MAX_WGS: with 512+ workgroups the parallel merge kernel wins (16 splits x 32
 // heads: 28.0 vs 21.1 us).
+// MEASURED AND SWITCHED OFF (profiles/r04_tp_shard_structural_ab.jsonl): one workgroup folding 32 splits x 7 rows x 128 d
+// takes longer than the 1024-thread-per-(row, head) merge kernel it replaces, launch included — 7B TP-8 shard attention
+// 8.9 + 6.0 us -> 19.3 us, retrieval verify 1 968 -> 2 147 us; 13B TP-8 (51 splits x 17 rows) 3 869 -> 4 997 us.  The
+// default (8 = FUSED_MERGE_MAX_SPLITS) never takes this path; -DFUSED_MERGE_BIG_SPLITS=64 rebuilds it.
 #ifndef FUSED_MERGE_BIG_SPLITS
-#define FUSED_MERGE_BIG_SPLITS 64
+#define FUSED_MERGE_BIG_SPLITS 8
 #endif
 #ifndef FUSED_MERGE_BIG_MAX_WGS
 #define FUSED_MERGE_BIG_MAX_WGS 320

@@ -46,6 +46,9 @@
 #ifndef SG_U
 #define SG_U 4              // k-chunks (KiB of weights) in flight per wave
 #endif
+#ifndef SG_PROLOGUE_ORDER
+#define SG_PROLOGUE_ORDER 1     // 1: norm partials, x rows, then weights (round 4); 0: weights first, x after the fold (round 3)
+#endif
 #ifndef TF_SG_RES_EARLY
 #define TF_SG_RES_EARLY 1   // residual epilogue operands fetched before the weight loop (0: at the tail, round 2's form)
 #endif
@@ -88,7 +91,11 @@ struct SgKsplit {
 };
 static void* g_sg_ws[16] = {};
 static int64_t g_sg_ws_bytes[16] = {};
-static int g_sg_ksplit_max_groups = 200;   // split K across workgroups below this many panel groups (tf_sg_tune key 3; 0 = never)
+// Measured (profiles/r04_tp_shard_structural_ab.jsonl, r04_tp8_7b_kernel_timeline_after_splitk.json): NO gain in situ — the
+// 7B TP-8 gate|up GEMM stays at 13.2 us with 258 workgroups instead of 86, q|k|v goes 9.1 -> 10.9 us: at 12-22 MB these
+// launches are made of fixed costs (dispatch, the norm prologue's dependent loads, merge, epilogue, drain), not of the
+// stream the extra CUs would shorten, and the hand-off adds a round trip.  Default off (0); tf_sg_tune key 3 turns it on.
+static int g_sg_ksplit_max_groups = 0;     // split K across workgroups below this many panel groups (tf_sg_tune key 3; 0 = never)
 
 __device__ __forceinline__ void sg_st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float sg_ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -166,10 +173,21 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
     }
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    // first weight chunks of this wave: issued before the norm prologue so HBM is already streaming under it
-    half8 a_pre[U][P][NA];
+    // Loads of the prologue, ALL issued before anything waits, in the order they are consumed (the vector-memory counter
+    // retires in order): the sum-of-squares partials of the norm (L2 / Infinity-Cache hits: the producer ran on other
+    // XCDs), the x rows of this wave's first k-chunks, then its first weight chunks (HBM).  Round 3 issued the weights
+    // first and the x rows only after the fold: the fold then waited for the HBM loads, and the first MFMA for one more
+    // round trip of x — ~1.5 us of every norm-prologue GEMM in situ (q|k|v 21.7 us in the layer against 17.8 alone).
+    constexpr int SSB = MT == 1 ? 3 : 2;                     // batches of 8 partials per thread loaded up front
+    constexpr bool BPRE = MT == 1 && SG_PROLOGUE_ORDER != 0; // (two row tiles: the x prefetch would cost a wave per SIMD)
+    constexpr int G = WAVES * 4;
+    const int nparts = K >> 4;
+    const int pg = tid >> 4, m16 = tid & 15;
+    float ssv[MT][SSB][8];
+    half8 a_pre[U][P][NA], b_pre[BPRE ? U : 1][MT];
     const bool pre = NORM && (c0 + U <= c1);
-    if (pre) {
+#if SG_PROLOGUE_ORDER == 0
+    if (pre) {                                               // round 3's order (A/B): weights first
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -178,6 +196,35 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
                 if (GATEUP) a_pre[u][j][NA - 1] = SG_LOAD(wu + j * pstride + (int64_t)(c0 + u) * 64);
             }
     }
+#endif
+    if (NORM && ss_in) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int bb = 0; bb < SSB; ++bb)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int p = pg + bb * 8 * G + j * G;
+                    ssv[t][bb][j] = (p < nparts) ? ss_in[(int64_t)p * 32 + t * 16 + m16] : 0.f;
+                }
+    }
+#if SG_PROLOGUE_ORDER != 0
+    if (pre) {
+        if constexpr (BPRE) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) b_pre[u][t] = xok[t] ? load_half8(xr[t] + xcs * (c0 + u)) : zero8;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                a_pre[u][j][0] = SG_LOAD(wa + j * pstride + (int64_t)(c0 + u) * 64);
+                if (GATEUP) a_pre[u][j][NA - 1] = SG_LOAD(wu + j * pstride + (int64_t)(c0 + u) * 64);
+            }
+    }
+#endif
 
     float inv[MT];
 #pragma unroll
@@ -188,14 +235,17 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
             // The producer of x (a residual-epilogue GEMM over K/16 panels) left the per-panel sums of squares of
             // every row: ss_in[panel][32 rows].  Fold them in a fixed order — one round trip instead of a second
             // pass over x.  Thread (pg, m): partials of panels pg, pg + G, ... of row m; G = threads / 16.
-            constexpr int G = WAVES * 4;
-            const int nparts = K >> 4;
-            const int pg = tid >> 4, m16 = tid & 15;
             float* red = &sm[0][0][0][0][0];                            // reuse the merge buffer: [MT][G][16] floats
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 float part = 0.f;
-                for (int p0 = pg; p0 < nparts; p0 += 8 * G) {
+#pragma unroll
+                for (int bb = 0; bb < SSB; ++bb)                        // (same order of additions as the loop below)
+                    if (pg + bb * 8 * G < nparts) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) part += ssv[t][bb][j];
+                    }
+                for (int p0 = pg + SSB * 8 * G; p0 < nparts; p0 += 8 * G) {
                     float v[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -325,7 +375,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
             }
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                b[u][t] = xok[t] ? load_half8(xr[t] + xcs * (c + u)) : zero8;
+                if (BPRE && NORM && c == c0 && pre) b[u][t] = b_pre[BPRE ? u : 0][t];
+                else b[u][t] = xok[t] ? load_half8(xr[t] + xcs * (c + u)) : zero8;
                 if (NORM) b[u][t] = sg_normalise(b[u][t], load_half8(ln_w + 32 * (c + u) + 8 * g), inv[t]);
             }
         }

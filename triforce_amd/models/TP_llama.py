@@ -356,15 +356,18 @@ class DistributedLlama:
             W.capture.append(x.rows() if isinstance(x, ops.Act) else x.clone())
         return ops.linear(x, W.lm_head, out_f32=True, ln=W.norm, eps=W.eps, ss_in=ss).unsqueeze(0)
 
-    def _finish(self, x, d):
+    def _finish(self, x, d, last_rows=None):
         W = self.weights
         h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)
         if W.capture is not None:
             W.capture.append(x.clone())
+        if last_rows is not None and last_rows < h.shape[0]:      # chunked prefill: only the returned rows get logits
+            h = h[-last_rows:]
         return ops.linear(h, W.lm_head, out_f32=True).unsqueeze(0)
 
     @torch.inference_mode()
-    def inference(self, input_ids, position_ids=None, attention_mask=None, retrieval_cache=None, eager=False):
+    def inference(self, input_ids, position_ids=None, attention_mask=None, retrieval_cache=None, eager=False,
+                  last_rows=None):
         """Target forward over the full KV cache (TP_llama.py:200-243).  ``eager=True`` skips the captured forward (every
         rank must pass the same value: the eager and the captured forward issue the same exchanges in the same order) —
         bench_tp.py runs every N-th target verify that way so its attention launches can be bracketed by HIP events."""
@@ -423,7 +426,7 @@ class DistributedLlama:
         if n_on < L:
             torch.cuda.current_stream(self.device).wait_stream(cs)              # write-backs visible before reuse
         kvc.seq_len = S + q_len
-        return self._finish_fused(x, ss) if fused else self._finish(x, d)
+        return self._finish_fused(x, ss) if fused else self._finish(x, d, last_rows)
 
     def _tree_mask(self, attention_mask, tree_start, q_len):
         """Tree visibility for the block-attention kernel: (bit rows int32, first row, key index of tree column 0).
@@ -438,7 +441,7 @@ class DistributedLlama:
     @torch.inference_mode()
     def prefill(self, input_ids):
         from ..utils.graph_infer import chunked_prefill                       # TP_llama.py:246-250
-        return chunked_prefill(lambda ids: self.inference(input_ids=ids), input_ids)
+        return chunked_prefill(lambda ids, last_rows=None: self.inference(input_ids=ids, last_rows=last_rows), input_ids)
 
     @torch.inference_mode()
     def build_retrieval_cache(self, input_ids):

@@ -73,8 +73,9 @@ class LlamaForCausalLM:
         return self.forward(input_ids, kv_cache, graph_cache, position_ids, spec, rebuild_retrieval, dev_len)
 
     def forward(self, input_ids, kv_cache, graph_cache=None, position_ids=None, spec=False, rebuild_retrieval=False,
-                dev_len=None):
-        """dev_len = (slot_dev, sk_dev) int32 device scalars: the hipGraph-capturable form of the full-cache decode
+                dev_len=None, last_rows=None):
+        """last_rows = k: logits of the trailing k rows only (chunked prefill: utils/graph_infer.py chunked_prefill).
+        dev_len = (slot_dev, sk_dev) int32 device scalars: the hipGraph-capturable form of the full-cache decode
         forward — the append slot and the key count are read from device memory by the kernels (tf_skinny_qkv_rope
         slot0_dev, tf_attn_decode sk_dev), position_ids must be given, the launch is sized by the cache capacity and
         kv_cache.seq_len is NOT advanced (the caller does that after the replay)."""
@@ -165,5 +166,7 @@ class LlamaForCausalLM:
             h = ops.rmsnorm(d, W.norm, W.eps, residual=x, sum_out=x)
             if W.capture is not None:
                 W.capture.append(x.clone())
+            if last_rows is not None and last_rows < h.shape[0]:
+                h = h[-last_rows:]
             logits = ops.linear(h, W.lm_head, out_f32=True).unsqueeze(0)           # (1, q, V) fp32  (:408-409)
         return CausalLMOutput(logits)

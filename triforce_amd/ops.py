@@ -75,8 +75,8 @@ def rope_row_order(H, D, device=None):
 
 # Split-K workspace of the skinny GEMM (csrc/gemv.hip SgKsplit, tf_sg_workspace): one zero-filled 8 MiB block per device,
 # registered when the first weight is packed there (i.e. before any hipGraph capture) and never freed.  Few-panel GEMMs
-# (the q|k|v / gate|up shards of a tensor-parallel rank) then split K across up to 4 workgroups per panel.
-# TRIFORCE_GEMM_KSPLIT=0 keeps every GEMM at one workgroup per panel.
+# (the q|k|v / gate|up shards of a tensor-parallel rank) can then split K across up to 4 workgroups per panel —
+# TRIFORCE_GEMM_KSPLIT=1; off by default: measured without gain in situ (profiles/r04_tp_shard_structural_ab.jsonl).
 _SG_WS = {}
 _SG_WS_BYTES = 8 << 20
 
@@ -89,8 +89,8 @@ def _ensure_sg_workspace(device):
         ws = torch.zeros(_SG_WS_BYTES, dtype=torch.uint8, device=device)
         torch.cuda.synchronize(device)
         hip.check(hip.lib().tf_sg_workspace(_ptr(ws), ws.numel()), "tf_sg_workspace")
-        if _os.environ.get("TRIFORCE_GEMM_KSPLIT", "1") == "0":
-            hip.lib().tf_sg_tune(3, 0)
+        if _os.environ.get("TRIFORCE_GEMM_KSPLIT", "0") == "1":          # measured: no gain (csrc/gemv.hip) — opt-in
+            hip.lib().tf_sg_tune(3, 200)
     _SG_WS[device] = ws
 
 

@@ -27,12 +27,23 @@ assert PREFILL_CHUNK % 128 == 0 and PREFILL_CHUNK > 0
 
 
 def chunked_prefill(forward, input_ids):
-    """Run ``forward(chunk) -> logits (1, rows, V)`` over the prompt; returns the logits of the reference's last chunk."""
+    """Run ``forward(chunk) -> logits (1, rows, V)`` over the prompt; returns the logits of the reference's last chunk.
+    A ``forward`` that takes ``last_rows`` is asked for only the rows that are returned — the trailing rows of the final
+    chunk, one row of every other chunk — instead of a (4096, V) fp32 logits block (524 MB, ~1 TFLOP of lm_head GEMM)
+    per chunk of which at most 128 rows were ever used."""
+    import inspect
     n = input_ids.shape[-1]
     chunk = PREFILL_CHUNK if input_ids.is_cuda else 128
-    for i in range(math.ceil(n / chunk)):
-        logits = forward(input_ids[:, i * chunk:(i + 1) * chunk])
-    return logits[:, -(n - 128 * (math.ceil(n / 128) - 1)):]
+    keep = n - 128 * (math.ceil(n / 128) - 1)          # rows of the reference's last 128-token chunk
+    try:
+        trims = "last_rows" in inspect.signature(forward).parameters
+    except (TypeError, ValueError):
+        trims = False
+    nchunks = math.ceil(n / chunk)
+    for i in range(nchunks):
+        ids = input_ids[:, i * chunk:(i + 1) * chunk]
+        logits = forward(ids, last_rows=keep if i == nchunks - 1 else 1) if trims else forward(ids)
+    return logits[:, -keep:]
 
 
 class InferenceEngine:
@@ -47,8 +58,8 @@ class InferenceEngine:
     def model_run(self, input_ids: torch.LongTensor, rebuild_retrieval=False):
         n = input_ids.shape[-1]
         if n > 64:                                 # chunked prefill (graph_infer.py:30-37)
-            logits = chunked_prefill(lambda ids: self.model(input_ids=ids, kv_cache=self.kv_cache,
-                                                            graph_cache=None).logits, input_ids)
+            logits = chunked_prefill(lambda ids, last_rows=None: self.model.forward(
+                ids, self.kv_cache, None, last_rows=last_rows).logits, input_ids)
         else:                                      # verification / q_len==1 retrieval build
             logits = self.model(input_ids=input_ids, kv_cache=self.kv_cache, graph_cache=self.graph_cache,
                                 rebuild_retrieval=rebuild_retrieval).logits
@@ -81,7 +92,7 @@ class InferenceEngine:
         chunks, full = math.ceil(n / 64), n // 64
         use_graph = (input_ids.is_cuda and full >= 16 and os.environ.get("TRIFORCE_DRAFT_PREFILL_GRAPH", "1") != "0"
                      and not torch.cuda.is_current_stream_capturing())
-        logits = None
+        logits, replayed = None, False
         for i in range(chunks):
             ids = input_ids[:, i * 64:(i + 1) * 64]
             if use_graph and ids.shape[-1] == 64 and dc.seq_len == cap:
@@ -91,11 +102,13 @@ class InferenceEngine:
                     ids_buf.copy_(ids)
                     graph.replay()
                     dc.seq_len = cap               # what evict_prefill + the forward leave behind on the host side
+                    replayed = True
                     continue
                 use_graph = False
             dc.evict_prefill(64)
-            logits = self.draft(input_ids=ids, kv_cache=dc, graph_cache=None).logits
-        return logits
+            logits, replayed = self.draft(input_ids=ids, kv_cache=dc, graph_cache=None).logits, False
+        # the graph's logits are its static output buffer: the next prefill's replays overwrite it
+        return logits.clone() if replayed else logits
 
     def _draft_prefill_graph(self, ids):
         """(graph, static 64-token input, static logits) of one steady-state draft-prefill step over the CURRENT draft
@@ -117,8 +130,10 @@ class InferenceEngine:
         try:
             graph, logits = _capture(step, (), None, 1)
             out = (graph, ids_buf, logits)
-        except Exception:                          # capture unsupported for some op in this build: stay eager
+        except Exception as ex:                    # capture unsupported for some op in this build: stay eager
             out = None
+            print(f"[draft prefill] hipGraph capture of the steady-state step failed, running eagerly: "
+                  f"{type(ex).__name__}: {ex}", flush=True)
         dc.k.copy_(snap[0])
         dc.v.copy_(snap[1])
         dc.seq_len = snap[2]
