@@ -184,6 +184,8 @@ def run_tp(args, rank, world, local):
     if inject and getattr(llm, "_ar", None) is not None:        # fault injection (tests): as if a peer had timed out
         torch.cuda.synchronize()
         llm._ar.inject_error(inject)
+        if getattr(llm, "_xchg", None) is not None:             # the decode layer's exchanges live in the GEMMs then
+            llm._xchg.inject_error(inject)
     if rank == 0:
         ops.ATTN_TIMER = []                                     # rank 0 samples its attention launches (HIP events)
     # every --roofline-every-th target verify runs eagerly on EVERY rank (same exchanges, same order as the captured
@@ -209,6 +211,8 @@ def run_tp(args, rank, world, local):
     run.eager_every = 0
     timer, ops.ATTN_TIMER = ops.ATTN_TIMER, None
     ar_err = llm._ar.error() if getattr(llm, "_ar", None) is not None else 0
+    if getattr(llm, "_xchg", None) is not None:
+        ar_err = ar_err or llm._xchg.error()
     if failure is None and ar_err:
         failure = f"one-shot all-reduce error word {ar_err} after the timed region"
     want_form = getattr(args, "require_graph_form", None)
@@ -287,9 +291,11 @@ def run_tp(args, rank, world, local):
             "acceptance_rate": round(accepted / max(drafted, 1), 4), "tokens": tokens,
             "tokens_per_step": round(tokens / args.steps, 3), "prefill_seconds": round(t_prefill, 2),
             "kv_seq_len": llm.kv_cache.seq_len, "graph_form": getattr(llm, "graph_form", "eager"),
-            "decode_allreduce": ("one-shot peer reads (tf_allreduce_oneshot_alt, alternating staging halves)"
-                                 if getattr(getattr(llm, "_ar", None), "alternate", False) else
-                                 "one-shot peer reads (tf_allreduce_oneshot)") if getattr(llm, "_ar", None) is not None
+            "decode_allreduce": (("one-shot peer reads inside the o_proj / down_proj GEMMs (tf_skinny_gemm_xchg)"
+                                  if getattr(llm, "_xchg", None) is not None else
+                                  "one-shot peer reads (tf_allreduce_oneshot_alt, alternating staging halves)"
+                                  if getattr(getattr(llm, "_ar", None), "alternate", False) else
+                                  "one-shot peer reads (tf_allreduce_oneshot)")) if getattr(llm, "_ar", None) is not None
             else ("rccl" if world > 1 else "none (one rank)"),
             "ranks_share_one_device": bool(share), "allreduce_error": int(ar_err),
             "allreduce_requested": getattr(args, "allreduce", "auto"),

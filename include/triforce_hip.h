@@ -399,6 +399,25 @@ int tf_allreduce_oneshot_alt(void* const* peer_data, void* const* peer_flags, in
 int tf_allreduce_oneshot_act(void* const* peer_data, void* const* peer_flags, int rank, int world, const void* resid,
                              void* out, int64_t n, int hidden, int pack_rows, float* ss_out, int64_t half_elems,
                              int expect_half, void* stream);
+/* GEMM + all-reduce in ONE launch (csrc/gemv.hip, SgXchg) — o_proj / down_proj of the tensor-parallel decode layer with
+ * their exchange in the GEMM epilogue: out = resid + sum over ranks of fp16(x . W^T)  (models/tensor_op.py:175-181,
+ * 353-360; the arithmetic of tf_skinny_gemm_act(out = staging) + tf_allreduce_oneshot_add_ss).  Every workgroup publishes
+ * its 16-column panel in this rank's staging half (half = device epoch & 1), flags the same panel on every peer, waits for
+ * the peers' flags of that panel, reads their panels and finishes — no grid-wide wait, no DONE phase, no host-side half.
+ * peer_stage[r] / peer_ctl[r], r < world: every rank's staging buffer (2 * half_elems fp16) and control buffer
+ * (tf_xchg_ctl_bytes() bytes, zero-filled once), fine-grained memory (tf_ar_alloc), own entries included, peers' mapped
+ * through hipIpc (tf_ar_get_ipc_handle / tf_ar_open_ipc_handle).  The result block `out` (may alias resid) and the
+ * staging halves share the activation layout (os_m, os_k); N / 16 <= 512; the block must fit a half.  ss_out: per-panel
+ * sums of squares of the result rows (may be NULL).  Bounded spins: a time-out NaN-fills the panel and sets the sticky
+ * error word (tf_xchg_error; tf_xchg_set_error(ctl, code, host_mirror, set_mirror) injects / clears it and registers a
+ * pinned host word that mirrors it). */
+int64_t tf_xchg_ctl_bytes(void);
+int tf_skinny_gemm_xchg(const void* w_packed, const void* x, int64_t xs_m, int64_t xs_k, void* const* peer_stage,
+                        void* const* peer_ctl, int rank, int world, int64_t half_elems, const void* resid, int64_t rs_m,
+                        int64_t rs_k, void* out, int64_t os_m, int64_t os_k, float* ss_out, int M, int N, int K,
+                        void* stream);
+int tf_xchg_error(const void* ctl);
+int tf_xchg_set_error(void* ctl, int code, void* host_mirror, int set_mirror);
 /* Message-passing litmus around the exchange (tools/xgmi_litmus.py): tf_ar_litmus_stage advances the device counter
  * *it_dev and then writes, with PLAIN stores from an ordinary kernel (the role of the o_proj / down_proj epilogue), the
  * pattern v_rank[i] = (7 i + 13 it + 101 rank) mod 509 into `staging` (n fp16 values); after an all-reduce of those

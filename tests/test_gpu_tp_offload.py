@@ -541,7 +541,7 @@ def test_tp_world2_gamma16_segment_graphs_with_alternating_halves(fuse):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = {"TRIFORCE_TP_GRAPHS": "segments", "TRIFORCE_TP_FUSE": fuse}
+    env = {"TRIFORCE_TP_GRAPHS": "segments", "TRIFORCE_TP_FUSE": fuse, "TRIFORCE_TP_GEMM_XCHG": "0"}
     procs = [ctx.Process(target=_tp2_worker, args=(r, 2, port, q, True, env, 16)) for r in range(2)]
     for p in procs:
         p.start()
@@ -565,6 +565,126 @@ def test_tp_world2_gamma16_segment_graphs_with_alternating_halves(fuse):
     g6 = Hh.load_golden("small_gamma6")
     gaps = Hh.teacher_forced_gaps(g6, a["tokens"])
     assert max(gaps) < 8e-3, f"stream leaves the oracle's greedy path: gap {max(gaps):.4f}"
+
+
+@pytest.mark.parametrize("world,hidden", [(2, 4096), (4, 1024)])
+def test_gemm_exchange_protocol_on_one_device(world, hidden):
+    """tf_skinny_gemm_xchg — o_proj / down_proj with the all-reduce inside the GEMM's epilogue — with `world` virtual ranks
+    in this process, one stream each: every workgroup publishes its panel, flags the same panel of the peers' concurrently
+    running kernels, reads theirs.  Must equal, bit for bit, GEMM -> fp16 partial -> fp32 sum in rank order -> one
+    rounding -> fp16 residual add (utils.oneshot_ar.reference_sum of the ranks' ops.linear outputs), in both activation
+    layouts, back to back over odd and even epochs with no host synchronisation in between, one rank delayed each trip.
+    (4 ranks run at hidden 1024 = 64 workgroups each: the grids of all virtual ranks must be resident together.)"""
+    from triforce_amd import ops
+    from triforce_amd.utils.oneshot_ar import GemmExchange, reference_sum
+    group = GemmExchange.local_group(world, DEV, 32 * hidden)
+    streams = _rank_streams(world)
+    gen = torch.Generator(device=DEV).manual_seed(7 + world)
+    K = 512
+    ws = [ops.PackedLinear((torch.randn(hidden, K, generator=gen, device=DEV) * 0.05).to(torch.float16)) for _ in range(world)]
+    try:
+        for it, rows in enumerate([1, 7, 17, 18, 32, 8, 7] * 2):
+            packed = it % 2 == 1
+            acts = [torch.randn(rows, K, generator=gen, device=DEV).to(torch.float16) for _ in range(world)]
+            resid = torch.randn(rows, hidden, generator=gen, device=DEV).to(torch.float16)
+            want = reference_sum([ops.linear(a, w) for a, w in zip(acts, ws)], resid=resid)
+            xs = [ops.Act.from_rows(resid) if packed else resid.clone() for _ in range(world)]
+            sss = [ops.ss_buffer(hidden, DEV) for _ in range(world)]
+            ins = [ops.Act.from_rows(a) if packed else a for a in acts]
+            torch.cuda.synchronize()
+            for r in range(world):
+                with torch.cuda.stream(streams[r]):
+                    if it % world == r:
+                        torch.cuda._sleep(100_000)                        # this rank arrives late
+                    group[r].linear_reduce(ins[r], ws[r], xs[r], sss[r])
+                    group[r].linear_reduce(ins[r], ws[r], xs[r], sss[r])  # back to back: the other staging half
+            torch.cuda.synchronize()
+            want2 = reference_sum([ops.linear(a, w) for a, w in zip(acts, ws)], resid=want)
+            for r in range(world):
+                got = xs[r].rows() if packed else xs[r]
+                assert torch.equal(got, want2), (f"trip {it}, rank {r}, {rows} rows, packed={packed}: max err "
+                                                 f"{(got.float() - want2.float()).abs().max()}, errors {[g.error() for g in group]}")
+                torch.testing.assert_close(sss[r][:, :rows], want2.float().square().view(rows, hidden // 16, 16).sum(-1).t(),
+                                           rtol=1e-5, atol=1e-6)
+        assert [g.error() for g in group] == [0] * world and [g.error_device() for g in group] == [0] * world
+        # error path: a poisoned control block NaN-fills the output and check() raises
+        group[0].inject_error(1)
+        x = torch.zeros(7, hidden, dtype=torch.float16, device=DEV)
+        with torch.cuda.stream(streams[0]):
+            group[0].linear_reduce(torch.randn(7, K, generator=gen, device=DEV).to(torch.float16), ws[0], x,
+                                   ops.ss_buffer(hidden, DEV))
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(x).all())
+        with pytest.raises(RuntimeError, match="GEMM \\+ exchange"):
+            group[0].check("test")
+    finally:
+        for g in group:
+            g.close()
+
+
+def _xchg_ipc_worker(rank, world, port, q):
+    """One rank of a 2-process group on ONE device: GemmExchange buffers exported / mapped through hipIpc, the GEMM kernels of
+    the two processes exchanging their panels through those mappings; against gloo's all-reduce of the fp16 partials."""
+    import os
+    import sys
+    import traceback
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from triforce_amd import ops
+        from triforce_amd.utils.oneshot_ar import GemmExchange
+        hidden, K = 4096, 512
+        xc = GemmExchange(rank, world, "cuda:0", 32 * hidden)
+        gen = torch.Generator(device="cuda:0").manual_seed(200 + rank)
+        w = ops.PackedLinear((torch.randn(hidden, K, generator=gen, device="cuda:0") * 0.05).to(torch.float16))
+        ok, worst = True, 0.0
+        for it, rows in enumerate([1, 7, 18, 32, 8, 7] * 3):
+            a = torch.randn(rows, K, generator=gen, device="cuda:0").to(torch.float16)
+            ring = ops.linear(a, w)
+            dist.all_reduce(ring, dist.ReduceOp.SUM)                       # gloo: fp16 sum of the two partials
+            x = torch.zeros(rows, hidden, dtype=torch.float16, device="cuda:0")
+            xc.linear_reduce(a, w, x, ops.ss_buffer(hidden, "cuda:0"))
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(x, ring)
+            worst = max(worst, float((x.float() - ring.float()).abs().max()))
+        err = xc.error()
+        dist.barrier()
+        xc.close()
+        q.put((rank, "ok", ok, worst, err))
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_gemm_exchange_across_two_processes_through_hipipc():
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_xchg_ipc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = []
+    try:
+        for _ in range(2):
+            outs.append(q.get(timeout=300))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    for o in outs:
+        assert o[1] == "ok", o[2]
+    for rank, _, ok, worst, err in outs:
+        assert err == 0, f"rank {rank}: a panel wait timed out (code {err})"
+        assert ok, f"rank {rank}: result differs from the collective by up to {worst}"
 
 
 def _run_litmus(nproc, extra):

@@ -44,6 +44,9 @@ def main():
                          "exchange step is launched like on a W-rank job and the fused decode layer (which needs it for "
                          "the sum-of-squares hand-off) is the one measured; without it exchanges are no-ops and the "
                          "layer is the un-fused one")
+    ap.add_argument("--gemm-exchange", action="store_true",
+                    help="with --local-exchange: o_proj / down_proj with the exchange in their epilogue (tf_skinny_gemm_xchg, "
+                         "one-rank group) instead of GEMM -> staging -> exchange kernel")
     ap.add_argument("--alternate", action="store_true",
                     help="with --local-exchange: the alternating-halves form of the exchange (tf_allreduce_oneshot_alt)")
     args = ap.parse_args()
@@ -70,6 +73,9 @@ def main():
         from triforce_amd.utils.oneshot_ar import OneShotAllReduce
         llm._ar = OneShotAllReduce.local_group(1, dev, llm.ONESHOT_MAX_ROWS * llm.hidden_size,
                                                alternate=args.alternate)[0]
+        if args.gemm_exchange:
+            from triforce_amd.utils.oneshot_ar import GemmExchange
+            llm._xchg = GemmExchange.local_group(1, dev, llm.ONESHOT_MAX_ROWS * llm.hidden_size)[0]
     llm.initialize_graphs(g)
     gen = torch.Generator(device=dev).manual_seed(3)
     for t in (llm.kv_cache.k, llm.kv_cache.v, llm.retrieval_cache.k, llm.retrieval_cache.v, dcache.k, dcache.v):
@@ -89,9 +95,12 @@ def main():
         llm.kv_cache.seq_len = S
     Hl, D, L = tcfg.num_attention_heads // W, tcfg.head_dim, tcfg.num_hidden_layers
     out = {"target": args.target, "emulated_world": W, "heads_per_rank": Hl, "layers": L, "prefill": S, "budget": args.budget,
-           "gamma": g, "graph_form": llm.graph_form, "exchange": ("one-rank one-shot kernel" + (", alternating halves" if args.alternate else ""))
+           "gamma": g, "graph_form": llm.graph_form,
+           "exchange": ("inside the o_proj / down_proj GEMMs (one-rank group)" if llm._xchg is not None else
+                        "one-rank one-shot kernel" + (", alternating halves" if args.alternate else ""))
            if llm._ar is not None else "no-op",
-           "decode_layer": "fused (8 launches)" if llm._fused_decode(g + 1) else "un-fused (11 launches)",
+           "decode_layer": ("fused (6 launches)" if llm._xchg is not None else "fused (8 launches)")
+           if llm._fused_decode(g + 1) else "un-fused (11 launches)",
            "draft_step_us": round(timed(lambda: llm.draft_run(ids[:, :3], gamma_offset=2)), 1),
            "retrieval_verify_us": round(timed(lambda: llm.retrieval_verify(ids[:, :g + 1], pos)), 1),
            "target_verify_us": round(timed(tv, 3), 1), "ar_step_eager_us": round(timed(ar, 3), 1)}

@@ -100,6 +100,45 @@ static int g_sg_ksplit_max_groups = 0;     // split K across workgroups below th
 __device__ __forceinline__ void sg_st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float sg_ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// GEMM + exchange in ONE launch (round 4; tf_skinny_gemm_xchg).  The tensor-parallel layer's o_proj / down_proj are
+// followed by an all-reduce of their (rows x hidden) partial outputs (models/tensor_op.py:179-181,359-360); as its own
+// launch that exchange is 6-7 us on the device before any xGMI hop — a chain of uncached round trips (epoch, READY, the
+// staged partials, ticket, DONE) behind a launch boundary (profiles/r04_tp8_7b_kernel_timeline_before.json) — twice per
+// layer of a 60 us layer.  Here every workgroup exchanges ITS OWN 16-column panel with the same workgroup of the other
+// ranks and nobody waits for a whole grid:
+//   partial panel (fp16) -> own staging half (system-scope 8-byte stores), drained        [what the GEMM epilogue wrote anyway]
+//   flag[rank][panel] = epoch on every peer; wait for the peers' flags of this panel      [one hop, per panel]
+//   read the peers' panels, add in rank order (fp32), round, + residual, store, sums of squares   [one remote round trip]
+// Exchange e uses staging half e & 1 (the device-side epoch): rank B rewrites a panel's half at exchange e + 2, after its
+// exchange e + 1 of that panel, which waited for every peer's flag e + 1 — set after that peer's exchange e of the panel
+// had finished reading.  No DONE phase, no host-side half bookkeeping (producer and exchange are one kernel).  Same
+// arithmetic as GEMM -> tf_allreduce_oneshot_add: fp16 partials, fp32 sum in rank order, one rounding, fp16 residual add.
+// Every spin is bounded; a time-out poisons the panel with NaN and sets the sticky error word (+ host mirror).
+#define XC_MAXP 512                          // panels (N / 16) an exchange GEMM may have
+#define XC_MAX_WORLD 8
+#define XC_SPIN_LIMIT (1u << 27)
+struct XcCtl {                               // head of a rank's control buffer (fine-grained memory); flags follow at +1024 B
+    unsigned epoch, ticket, error, pad;
+    unsigned long long mirror;               // 0 or a pinned host word that also receives error codes
+};
+struct SgXchg {
+    h16* stage[XC_MAX_WORLD];                // every rank's staging buffer (2 halves), own entry = local pointer
+    unsigned* pf[XC_MAX_WORLD];              // every rank's flag array [world][XC_MAXP]: pf[r][q * XC_MAXP + p] written by rank q
+    XcCtl* ctl;                              // own control block
+    int64_t half_elems;
+    int rank, world;
+};
+__device__ __forceinline__ unsigned xc_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void xc_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void xc_st8(h16* p, half4 v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ half4 xc_ld8(const h16* p) {
+    return __builtin_bit_cast(half4, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_SYSTEM));
+}
+
 static int g_sg_p2_rows = 1;       // P = 2 from this many rows (tf_sg_tune key 0; 33 = never)
 static int g_sg_p2_waves = 4;      // waves per workgroup of the P = 2 form (key 1)
 static int g_sg_p2_groups = SG_P_WIDE_MIN_GROUPS;   // ... while panels / 2 >= this (key 2)
@@ -125,7 +164,7 @@ __device__ __forceinline__ half8 sg_normalise(half8 xv, half8 wv, float inv) {
     return o;
 }
 
-template <int MT, int MODE, bool NORM, int WAVES, int P, bool KSPLIT>
+template <int MT, int MODE, bool NORM, int WAVES, int P, bool KSPLIT, bool XCHG = false>
 __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __restrict__ wp,
                                                                  const half8* __restrict__ wp_up,
                                                                  const h16* __restrict__ x, SgAct xa,
@@ -133,7 +172,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
                                                                  const h16* resid, SgAct ra, void* yv, SgAct ya,
                                                                  int M, int N, int K, SgRope rp,
                                                                  const float* __restrict__ ss_in,
-                                                                 float* __restrict__ ss_out, SgKsplit kx) {
+                                                                 float* __restrict__ ss_out, SgKsplit kx, SgXchg xc) {
+    static_assert(!XCHG || (MODE == SG_PLAIN && P == 1 && !KSPLIT), "the exchange form is the plain one-panel GEMM");
     constexpr bool GATEUP = MODE == SG_GATEUP;
     constexpr int NA = GATEUP ? 2 : 1;                       // weight streams (accumulator sets) per panel
     constexpr int U = (P * NA >= 2) ? (8 / (P * NA)) : SG_U;  // k-chunks in flight per wave: 8 KiB of weights (4 for P = NA = 1)
@@ -321,6 +361,15 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
     const bool epi = wave < P;
     const int panel = panel0 + (epi ? wave : 0);
 
+    // exchange form: this launch's epoch and the sticky error word, read now (uncached round trips) under the weight stream
+    unsigned xepoch = 0, xerr = 0;
+    if constexpr (XCHG) {
+        if (epi) {
+            xepoch = xc_ld(&xc.ctl->epoch) + 1u;     // bumped by the last workgroup to finish, i.e. after every read of it
+            xerr = xc_ld(&xc.ctl->error);
+        }
+    }
+
     // RoPE epilogue operands (epilogue waves only): cos / sin of this lane's 4 output columns, fetched now so that the
     // positions -> table dependent loads do not sit at the tail of the kernel
     half4 rope_cs[MT], rope_sn[MT];
@@ -484,6 +533,59 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
             }
         if (lane == 0) __hip_atomic_store(&kx.tickets[panel], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if constexpr (XCHG) {
+        // ---- this panel's all-reduce, inside the launch (see SgXchg) ----
+        xepoch = __builtin_amdgcn_readfirstlane(xepoch);
+        bool ok = __builtin_amdgcn_readfirstlane(xerr) == 0u;       // sticky: after one time-out nothing waits again
+        const int64_t hb = xc.half_elems * (int64_t)(xepoch & 1u);
+        half4 part[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[t][r] = (h16)S[t][r];
+            if (ok && t * 16 + li < M) xc_st8(xc.stage[xc.rank] + hb + (int64_t)(t * 16 + li) * ya.sm + y_off, part[t]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the partial has left this CU before any flag says so
+        if (ok) {
+            const bool peer = lane < xc.world && lane != xc.rank;
+            if (peer) xc_st(xc.pf[lane] + xc.rank * XC_MAXP + panel, xepoch);
+            bool seen = true;
+            if (peer) {
+                seen = false;
+                const unsigned* slot = xc.pf[xc.rank] + lane * XC_MAXP + panel;
+                for (unsigned spins = 0; spins < XC_SPIN_LIMIT; ++spins) {
+                    if ((int)(xc_ld(slot) - xepoch) >= 0) { seen = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            ok = __builtin_amdgcn_ballot_w64(!seen) == 0ull;
+            if (!ok && lane == 0) {
+                xc_st(&xc.ctl->error, 1u);
+                unsigned* mir = reinterpret_cast<unsigned*>(xc.ctl->mirror);
+                if (mir) xc_st(mir, 1u);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                // system scope: nothing read below predates the flags
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const bool rowv = t * 16 + li < M;
+            half4 pv[XC_MAX_WORLD];
+#pragma unroll
+            for (int q = 0; q < XC_MAX_WORLD; ++q) {
+                pv[q] = part[t];
+                if (ok && rowv && q < xc.world && q != xc.rank)
+                    pv[q] = xc_ld8(xc.stage[q] + hb + (int64_t)(t * 16 + li) * ya.sm + y_off);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < XC_MAX_WORLD; ++q)
+                    if (q < xc.world) acc += (float)pv[q][r];        // rank order, fp32, one rounding below
+                S[t][r] = ok ? (float)(h16)acc : __builtin_nanf("");
+            }
+        }
+    }
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int m = t * 16 + li;
@@ -577,6 +679,16 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
             if (g == 0) ss_out[(int64_t)panel * 32 + m] = q;
         }
     }
+    if constexpr (XCHG) {
+        // the last panel to finish advances the epoch: the next exchange launch (stream-ordered) reads epoch + 1
+        if (lane == 0) {
+            const unsigned tk = __hip_atomic_fetch_add(&xc.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tk == gridDim.x * P - 1) {
+                __hip_atomic_store(&xc.ctl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                xc_st(&xc.ctl->epoch, xepoch);
+            }
+        }
+    }
 }
 
 struct SgArgs {                       // one GEMM call: operands with their layouts
@@ -617,13 +729,13 @@ static void launch_sg_w(const SgArgs& a, const SgRope& rp, hipStream_t st) {
         if (ks > 1) {
             hipLaunchKernelGGL((skinny_gemm_kernel<MT, MODE, NORM, WAVES, P, true>), dim3(a.N / 16 / P, ks), dim3(WAVES * 64),
                                0, st, (const half8*)a.wp, (const half8*)a.wp_up, (const h16*)a.x, a.xa, (const h16*)a.ln_w,
-                               a.eps, (const h16*)a.resid, a.ra, a.y, a.ya, a.M, a.N, a.K, rp, a.ss_in, a.ss_out, kx);
+                               a.eps, (const h16*)a.resid, a.ra, a.y, a.ya, a.M, a.N, a.K, rp, a.ss_in, a.ss_out, kx, SgXchg{});
             return;
         }
     }
     hipLaunchKernelGGL((skinny_gemm_kernel<MT, MODE, NORM, WAVES, P, false>), dim3(a.N / 16 / P), dim3(WAVES * 64), 0, st,
                        (const half8*)a.wp, (const half8*)a.wp_up, (const h16*)a.x, a.xa, (const h16*)a.ln_w, a.eps,
-                       (const h16*)a.resid, a.ra, a.y, a.ya, a.M, a.N, a.K, rp, a.ss_in, a.ss_out, kx);
+                       (const h16*)a.resid, a.ra, a.y, a.ya, a.M, a.N, a.K, rp, a.ss_in, a.ss_out, kx, SgXchg{});
 }
 
 template <int MODE, bool NORM>
@@ -782,4 +894,82 @@ extern "C" int tf_skinny_qkv_rope(const void* wqkv_packed, const void* x, int64_
                                   void* stream) {
     return tf_skinny_qkv_rope_act(wqkv_packed, x, ldx, 8, ln_w, eps, ss_in, cosb, sinb, positions, q_out, k_cache,
                                   v_cache, stride_t, stride_h, slot0, slot0_dev, M, H, D, K, rotate_k, stream);
+}
+
+// y = resid + all_reduce(x . W^T) over `world` ranks, GEMM and exchange in ONE launch (see SgXchg above): replaces
+// ops.linear(a, w_o | w_down, out = staging) + tf_allreduce_oneshot_add_ss of the tensor-parallel decode layer
+// (models/tensor_op.py:175-181,353-360).  peer_stage[r] / peer_ctl[r]: every rank's staging buffer (2 x half_elems fp16,
+// fine-grained) and control buffer (tf_xchg_ctl_bytes(), fine-grained, zero-filled once), own entries included, peers'
+// mapped through hipIpc.  The output block (out, its strides) and the staging halves share one activation layout; N / 16
+// <= 512 panels, M * N <= half_elems.  out may alias resid.  ss_out: per-panel sums of squares of the result rows.
+extern "C" int64_t tf_xchg_ctl_bytes(void) { return 1024 + (int64_t)XC_MAX_WORLD * XC_MAXP * 4; }
+
+extern "C" int tf_skinny_gemm_xchg(const void* w_packed, const void* x, int64_t xs_m, int64_t xs_k,
+                                   void* const* peer_stage, void* const* peer_ctl, int rank, int world, int64_t half_elems,
+                                   const void* resid, int64_t rs_m, int64_t rs_k, void* out, int64_t os_m, int64_t os_k,
+                                   float* ss_out, int M, int N, int K, void* stream) {
+    SgArgs a = {};
+    a.wp = w_packed, a.x = x, a.resid = resid, a.y = out;
+    a.xa = SgAct{xs_m, xs_k}, a.ra = SgAct{rs_m, rs_k}, a.ya = SgAct{os_m, os_k};
+    a.M = M, a.N = N, a.K = K, a.ss_out = ss_out;
+    if (!w_packed || !x || !out || !peer_stage || !peer_ctl || !sg_shape_ok(M, N, K, a.xa) || !sg_act_ok(a.ya)) return TF_EINVAL;
+    if (world < 1 || world > XC_MAX_WORLD || rank < 0 || rank >= world || N / 16 > XC_MAXP) return TF_EINVAL;
+    if (half_elems < 8 || (half_elems % 8) || (resid && !sg_act_ok(a.ra))) return TF_EINVAL;
+    // the largest element offset of the block in its layout must stay inside a staging half
+    const int64_t last = (int64_t)(M - 1) * os_m + (int64_t)(N / 8 - 1) * os_k + 7;
+    if (last >= half_elems) return TF_EINVAL;
+    SgXchg xc = {};
+    for (int r = 0; r < world; ++r) {
+        if (!peer_stage[r] || !peer_ctl[r]) return TF_EINVAL;
+        xc.stage[r] = (h16*)peer_stage[r];
+        xc.pf[r] = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(peer_ctl[r]) + 1024);
+    }
+    xc.ctl = reinterpret_cast<XcCtl*>(peer_ctl[rank]);
+    xc.half_elems = half_elems, xc.rank = rank, xc.world = world;
+    if ((const void*)out == (const void*)xc.stage[rank] || (const void*)resid == (const void*)xc.stage[rank]) return TF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const SgRope rp = {};
+    const SgKsplit kx = {nullptr, nullptr};
+    const int nchunks = K >> 5;
+    const bool wide = nchunks >= 2 * SG_WAVES_WIDE;
+#define XCHG_LAUNCH(MT_, W_)                                                                                                  \
+    hipLaunchKernelGGL((skinny_gemm_kernel<MT_, SG_PLAIN, false, W_, 1, false, true>), dim3(N / 16), dim3(W_ * 64), 0, st,  \
+                       (const half8*)a.wp, (const half8*)nullptr, (const h16*)a.x, a.xa, (const h16*)nullptr, 0.f,          \
+                       (const h16*)a.resid, a.ra, a.y, a.ya, a.M, a.N, a.K, rp, (const float*)nullptr, a.ss_out, kx, xc)
+    if (M <= 16) {
+        if (wide) XCHG_LAUNCH(1, SG_WAVES_WIDE);
+        else XCHG_LAUNCH(1, SG_WAVES);
+    } else {
+        if (wide) XCHG_LAUNCH(2, SG_WAVES_WIDE);
+        else XCHG_LAUNCH(2, SG_WAVES);
+    }
+#undef XCHG_LAUNCH
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}
+
+// error word / epoch of an exchange control buffer (blocking host reads), fault injection, host mirror — the counterparts
+// of tf_ar_error / tf_ar_epoch / tf_ar_inject_error / tf_ar_set_error_mirror for the fused form
+extern "C" int tf_xchg_error(const void* ctl) {
+    if (!ctl) return TF_EINVAL;
+    XcCtl c;
+    hipError_t e = hipMemcpy(&c, ctl, sizeof(c), hipMemcpyDeviceToHost);
+    return e == hipSuccess ? (int)c.error : (int)e;
+}
+extern "C" int tf_xchg_set_error(void* ctl, int code, void* host_mirror, int set_mirror) {
+    if (!ctl || code < 0) return TF_EINVAL;
+    XcCtl* c = reinterpret_cast<XcCtl*>(ctl);
+    const unsigned v = (unsigned)code;
+    hipError_t e = hipMemcpy(&c->error, &v, sizeof(v), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return (int)e;
+    if (set_mirror) {
+        const unsigned long long m = (unsigned long long)(uintptr_t)host_mirror;
+        e = hipMemcpy(&c->mirror, &m, sizeof(m), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return (int)e;
+    }
+    unsigned long long m = 0;
+    e = hipMemcpy(&m, &c->mirror, sizeof(m), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
+    if (m) *reinterpret_cast<volatile unsigned*>(m) = v;
+    return TF_OK;
 }

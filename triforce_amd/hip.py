@@ -74,6 +74,11 @@ SIGNATURES = {
     "tf_allreduce_oneshot_act": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp]),
     "tf_ar_litmus_stage": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "tf_ar_litmus_check": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
+    "tf_xchg_ctl_bytes": (_i64, []),
+    "tf_skinny_gemm_xchg": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _i32, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp,
+                                   _i32, _i32, _i32, _vp]),
+    "tf_xchg_error": (_i32, [_vp]),
+    "tf_xchg_set_error": (_i32, [_vp, _i32, _vp, _i32]),
     "tf_ar_error": (_i32, [_vp]),
     "tf_ar_epoch": (_i64, [_vp]),
     "tf_ar_set_error_mirror": (_i32, [_vp, _vp]),

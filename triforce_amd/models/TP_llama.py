@@ -107,6 +107,7 @@ class DistributedLlama:
         self.num_layers = model_config.num_hidden_layers
         self._ev_ready = self._ev_done = None
         self._ar = None                               # utils.oneshot_ar.OneShotAllReduce once enabled (world_size > 1)
+        self._xchg = None                             # utils.oneshot_ar.GemmExchange: o_proj / down_proj + exchange, one launch
 
     # ---------------------------------------------------------------------------------------
     def init_parameters(self, hf_model=None):
@@ -199,6 +200,10 @@ class DistributedLlama:
             ok = stage(selftest, "self-test")
         if ok:
             self._ar = ar
+            # ... and the fused form of the decode layer's two exchanges: o_proj / down_proj with the all-reduce in their
+            # epilogue (TRIFORCE_TP_GEMM_XCHG=0 keeps GEMM -> staging -> exchange kernel)
+            if os.environ.get("TRIFORCE_TP_GEMM_XCHG", "1") != "0":
+                self._enable_gemm_exchange(stage, why)
         elif ar is not None:
             ar.close()
         self.allreduce_note = "; ".join(why)
@@ -211,11 +216,56 @@ class DistributedLlama:
                                + (self.allreduce_note or "a peer rank failed its stage"))
         return ok
 
+    def _enable_gemm_exchange(self, stage, why):
+        """Collective: allocate / connect / self-test utils.oneshot_ar.GemmExchange (the ranks agree after every stage, as
+        for the exchange kernel); on any failure the engine simply keeps the two-launch form."""
+        from ..utils.oneshot_ar import GemmExchange
+        xc = None
+
+        def alloc():
+            nonlocal xc
+            xc = GemmExchange(self.local_rank, self.world_size, self.device, self.ONESHOT_MAX_ROWS * self.hidden_size,
+                              connect=False)
+
+        ok = stage(alloc, "GEMM+exchange allocation")
+        ok = ok and stage(lambda: xc.connect(), "GEMM+exchange handle exchange")
+        if ok:
+            g = torch.Generator(device=self.device).manual_seed(4321 + self.local_rank)
+            K = 256
+            w = ops.PackedLinear((torch.randn(self.hidden_size, K, generator=g, device=self.device) * 0.05).to(torch.float16))
+            acts = [torch.randn(rows, K, generator=g, device=self.device).to(torch.float16) for rows in (1, 7, 18)]
+            wants = [ops.linear(a, w) for a in acts]                 # this rank's fp16 partial, summed by RCCL first
+            for t in wants:
+                dist.all_reduce(t, dist.ReduceOp.SUM)
+
+            def selftest():
+                for a, want in zip(acts, wants):
+                    for packed in (False, True):
+                        x = torch.zeros(a.shape[0], self.hidden_size, dtype=torch.float16, device=self.device)
+                        xa = ops.Act.from_rows(x) if packed else x
+                        xc.linear_reduce(ops.Act.from_rows(a) if packed else a, w, xa, ops.ss_buffer(self.hidden_size, self.device))
+                        torch.cuda.synchronize(self.device)
+                        got = xa.rows() if packed else xa
+                        err = (got.float() - want.float()).abs()
+                        tol = 0.0 if self.world_size == 2 else 2.0 ** -8 * float(want.float().abs().max())
+                        if not bool(torch.isfinite(got).all()) or float(err.max()) > tol:
+                            raise RuntimeError(f"GEMM+exchange self-test mismatch at {a.shape[0]} rows: {float(err.max())}")
+                xc.check("self-test")
+
+            ok = stage(selftest, "GEMM+exchange self-test")
+        if ok:
+            self._xchg = xc
+        elif xc is not None:
+            xc.close()
+        return ok
+
     def check_exchange(self, where=""):
         """Raise if the one-shot all-reduce ever timed out (its outputs are NaN-filled from then on).  Called once per
         decode step by the loops in utils/decoding.py, after the step's host read."""
         if self._ar is not None:
             self._ar.check(where)
+        if self._xchg is not None:
+            self._xchg.check(where)
 
     def reset(self):
         self.kv_cache.reset()
@@ -311,7 +361,7 @@ class DistributedLlama:
             return False
         if ops.FUSE_MODE != "all" or os.environ.get("TRIFORCE_TP_FUSE", "1") == "0":
             return False
-        if self.world_size > 1 and (self._ar is None or q_len > self.ONESHOT_MAX_ROWS):
+        if self.world_size > 1 and ((self._ar is None and self._xchg is None) or q_len > self.ONESHOT_MAX_ROWS):
             return False
         W = self.weights
         return (all(isinstance(w, ops.PackedLinear) and w.parts is not None for w in (W.wqkv[0], W.wo[0], W.wgu[0], W.wd[0], W.lm_head))
@@ -331,6 +381,9 @@ class DistributedLlama:
         if self.world_size == 1:
             ops.linear(a, W.wo[i], resid=x, out=x, ss_out=ss)
             return None
+        if self._xchg is not None:                        # o_proj + exchange + residual + sums of squares: one launch
+            self._xchg.linear_reduce(a, W.wo[i], x, ss)
+            return None
         return ops.linear(a, W.wo[i], out=self._ar.staging(x.shape[0], self.hidden_size, packed=packed))
 
     def _mlp_half_fused(self, i, x, ss):
@@ -338,6 +391,9 @@ class DistributedLlama:
         act = ops.mlp_act(x, W.wgu[i], ln=W.ln2[i], eps=W.eps, ss_in=ss)
         if self.world_size == 1:
             ops.linear(act, W.wd[i], resid=x, out=x, ss_out=ss)
+            return None
+        if self._xchg is not None:
+            self._xchg.linear_reduce(act, W.wd[i], x, ss)
             return None
         return ops.linear(act, W.wd[i], out=self._ar.staging(x.shape[0], self.hidden_size, packed=isinstance(x, ops.Act)))
 
@@ -708,11 +764,14 @@ class DistributedLlama:
         self.reset()
         # the probe replays above ran the one-shot all-reduce inside the captured forwards: if any rank saw a peer
         # wait time out there, every rank drops to RCCL and captures again — before any real state exists
-        if self._ar is not None and not self._agree(self._ar.error() == 0):
+        healthy = (self._ar is None or self._ar.error() == 0) and (self._xchg is None or self._xchg.error() == 0)
+        if (self._ar is not None or self._xchg is not None) and not self._agree(healthy):
             if verbose or self.local_rank == 0:
                 print("[TP] one-shot all-reduce timed out inside a captured forward: falling back to RCCL", flush=True)
-            self._ar.close()
-            self._ar = None
+            for obj in (self._ar, self._xchg):
+                if obj is not None:
+                    obj.close()
+            self._ar = self._xchg = None
             return self.initialize_graphs(gamma, capture_verify, verbose)
 
     def _inference_captured(self, cap, input_ids, advance=True):

@@ -261,3 +261,108 @@ class OneShotAllReduce:
         for g, o in zip(group, owned):
             g._owned = o
         return group
+
+
+class GemmExchange:
+    """GEMM + all-reduce in ONE launch (csrc/gemv.hip SgXchg, C ABI tf_skinny_gemm_xchg): the o_proj / down_proj of the
+    tensor-parallel decode layer with their exchange folded into the GEMM's epilogue — every workgroup exchanges its own
+    16-column panel with the same workgroup of the other ranks (reference: models/tensor_op.py:175-181,353-360).
+
+    Per rank: a staging buffer of two halves (exchange e uses half e & 1 of the DEVICE-side epoch, so there is no host
+    bookkeeping and a captured launch replays correctly) and a control buffer (epoch / ticket / error + per-panel flags),
+    both fine-grained and mapped by every peer through hipIpc.  Construction is collective like OneShotAllReduce's."""
+
+    def __init__(self, rank, world, device, max_elems, peer_stage=None, peer_ctl=None, own=None, connect=True):
+        self.rank, self.world, self.device, self.max_elems = rank, world, torch.device(device), int(max_elems)
+        assert self.max_elems % 8 == 0
+        L = hip.lib()
+        self._opened, self._stage, self._ctl = [], None, None
+        if own is None:
+            own = (OneShotAllReduce._alloc(self.max_elems * 2 * 2), OneShotAllReduce._alloc(L.tf_xchg_ctl_bytes()))
+            self._owned = own
+        else:
+            self._owned = ()
+        self.stage_ptr, self.ctl_ptr = own
+        self._err_host = None
+        try:
+            word = torch.zeros(1, dtype=torch.int32).pin_memory()
+            hip.check(L.tf_xchg_set_error(ctypes.c_void_p(self.ctl_ptr), 0, ctypes.c_void_p(word.data_ptr()), 1),
+                      "tf_xchg_set_error")
+            self._err_host = word
+        except Exception:
+            self._err_host = None
+        if peer_stage is not None:
+            self._set_peers(peer_stage, peer_ctl)
+        elif connect:
+            self.connect()
+
+    def _set_peers(self, stage, ctl):
+        self._stage = (ctypes.c_void_p * self.world)(*stage)
+        self._ctl = (ctypes.c_void_p * self.world)(*ctl)
+
+    def connect(self):
+        helper = OneShotAllReduce.__new__(OneShotAllReduce)         # reuse the handle exchange (all-gather + hipIpc maps)
+        helper.rank, helper.world, helper.data_ptr, helper.flags_ptr, helper._opened = \
+            self.rank, self.world, self.stage_ptr, self.ctl_ptr, self._opened
+        self._set_peers(*helper._exchange())
+
+    def fits(self, rows, cols):
+        return rows * cols <= self.max_elems and cols % 16 == 0 and cols // 16 <= 512
+
+    def linear_reduce(self, a, w, x, ss_out):
+        """x <- x + sum over ranks of (a . W^T) (fp16 partials, fp32 sum in rank order, one rounding, fp16 residual add:
+        the arithmetic of ops.linear(out=staging) + OneShotAllReduce.reduce(resid=x)); ss_out <- per-panel sums of
+        squares of the new x.  a / x: row-major tensors or ops.Act blocks (x's layout is also the staging layout)."""
+        from .. import ops
+        assert self._stage is not None, "GemmExchange.connect() has not run"
+        assert isinstance(w, ops.PackedLinear) and w.wp is not None
+        M = a.shape[0]
+        assert tuple(x.shape) == (M, w.N) and a.shape[1] == w.K and self.fits(M, w.N)
+        assert ss_out.dtype == torch.float32 and ss_out.is_contiguous() and ss_out.shape == (w.N // 16, 32)
+        ap, asm, ask = ops._lay(a)
+        xp, xsm, xsk = ops._lay(x)
+        st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        hip.check(hip.lib().tf_skinny_gemm_xchg(ops._ptr(w.wp), ap, asm, ask, self._stage, self._ctl, self.rank, self.world,
+                                                self.max_elems, xp, xsm, xsk, xp, xsm, xsk,
+                                                ctypes.c_void_p(ss_out.data_ptr()), M, w.N, w.K, st), "tf_skinny_gemm_xchg")
+        return x
+
+    def error(self):
+        if self._err_host is not None:
+            return int(self._err_host[0])
+        return self.error_device()
+
+    def error_device(self):
+        return hip.lib().tf_xchg_error(ctypes.c_void_p(self.ctl_ptr))
+
+    def inject_error(self, code):
+        hip.check(hip.lib().tf_xchg_set_error(ctypes.c_void_p(self.ctl_ptr), int(code), None, 0), "tf_xchg_set_error")
+
+    def check(self, where=""):
+        e = self.error()
+        if e:
+            raise RuntimeError(f"rank {self.rank}: GEMM + exchange timed out waiting for a peer's panel flag"
+                               f"{(' (' + where + ')') if where else ''}; its outputs since then are NaN-filled. "
+                               "Restart with TRIFORCE_TP_GEMM_XCHG=0 or TRIFORCE_ALLREDUCE=rccl.")
+
+    def close(self):
+        L = hip.lib()
+        for p in self._opened:
+            L.tf_ar_close_ipc_handle(ctypes.c_void_p(p))
+        if self._owned:
+            L.tf_xchg_set_error(ctypes.c_void_p(self.ctl_ptr), 0, None, 1)
+        for p in self._owned:
+            L.tf_ar_free(ctypes.c_void_p(p))
+        self._opened, self._owned = [], ()
+
+    @classmethod
+    def local_group(cls, world, device, max_elems):
+        """``world`` virtual ranks in one process on one device (kernels on different streams): tests / shard benches."""
+        L = hip.lib()
+        owned = [(OneShotAllReduce._alloc(max_elems * 2 * 2), OneShotAllReduce._alloc(L.tf_xchg_ctl_bytes()))
+                 for _ in range(world)]
+        stage, ctl = [o[0] for o in owned], [o[1] for o in owned]
+        group = [cls(r, world, device, max_elems, peer_stage=stage, peer_ctl=ctl, own=owned[r]) for r in range(world)]
+        for g, o in zip(group, owned):
+            g._owned = o
+        return group
