@@ -782,7 +782,10 @@ def test_gemm_split_across_workgroups(M, kind, N, K, HD):
         L.tf_sg_tune(3, old)
     for a, b in zip(split, one):
         d = (a.float() - b.float()).abs()
-        tol = 2 * b.float().abs() * 2 ** -10 + 2e-3
+        # a re-associated K sum moves a pre-RoPE value by at most one fp16 ulp; x * cos + rotate_half(x) * sin then adds two
+        # such values of magnitude up to ~8 with opposite signs, so the rotated q / k rows get an ABSOLUTE slack of two
+        # spacings at that magnitude (1.6e-2) where the other forms get 2 ulp of the result
+        tol = 2 * b.float().abs() * 2 ** -10 + (1.6e-2 if kind == "qkv" else 2e-3)
         assert bool((d <= tol).all()) and float((d > 0).float().mean()) < 0.12, (float(d.max()), float((d > 0).float().mean()))
 
 

@@ -137,3 +137,51 @@ def test_oneshot_allreduce_alternating_halves_host_bookkeeping():
         assert halves == [1, 0, 1, 0, 1]
     finally:
         M.hip.lib, torch.cuda.current_stream = old_lib, old_stream
+
+
+def test_predict_scaling_composes_stage_latencies_and_exchange_prices(tmp_path):
+    """tools/predict_scaling.py: step(W) = target verify + k * retrieval verify + (k + 1) * draft + host + X * extra with
+    X = 2 L (1 + k) exchanges at W > 1 — checked by hand on two synthetic shard lines; W = 1 pays no exchange, the RCCL
+    scenario is slower than the one-shot ones, efficiency = speed-up / W."""
+    lines = [{"target": "llama-7B-128K", "emulated_world": 1, "heads_per_rank": 32, "layers": 32, "prefill": 124928,
+              "budget": 4096, "gamma": 6, "draft_step_us": 120.0, "retrieval_verify_us": 3300.0, "target_verify_us": 13700.0},
+             {"target": "llama-7B-128K", "emulated_world": 8, "heads_per_rank": 4, "layers": 32, "prefill": 124928,
+              "budget": 4096, "gamma": 6, "draft_step_us": 130.0, "retrieval_verify_us": 1900.0, "target_verify_us": 3300.0}]
+    shards, out = tmp_path / "shards.jsonl", tmp_path / "pred.json"
+    shards.write_text("\n".join(json.dumps(l) for l in lines))
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "predict_scaling.py"), "--shards", str(shards), "--out",
+                    str(out)], check=True, capture_output=True)
+    res = json.load(open(out))
+    cfg = res["configs"]["configs[1]"]
+    k, tps, host = cfg["loop"]["inner_iterations"], cfg["loop"]["tokens_per_step"], cfg["loop"]["host_overhead_us"]
+    w1 = cfg["predictions"]["oneshot_done"][0]["low"]
+    step1 = 13700.0 + k * 3300.0 + (k + 1) * 120.0 + host
+    assert abs(w1["ms_per_step"] - step1 / 1e3) < 1e-3 and w1["exchanges_per_step"] == 0
+    assert abs(w1["tokens_per_s"] - tps / step1 * 1e6) < 0.1
+    w8 = cfg["predictions"]["oneshot_done"][1]
+    x = 2 * 32 * (1 + k)
+    lo, hi = res["scenarios_us_per_exchange"]["oneshot_done"]
+    step8 = 3300.0 + k * 1900.0 + (k + 1) * 130.0 + host + 2 * (k + 1) * res["broadcast_us"][0] + x * lo
+    assert abs(w8["low"]["ms_per_step"] - step8 / 1e3) < 1e-3 and w8["low"]["exchanges_per_step"] == round(x)
+    assert w8["high"]["tokens_per_s"] < w8["low"]["tokens_per_s"]
+    assert abs(w8["low"]["efficiency"] - w8["low"]["speedup_vs_w1"] / 8) < 2e-3
+    rccl8 = cfg["predictions"]["rccl"][1]
+    assert rccl8["low"]["tokens_per_s"] < w8["low"]["tokens_per_s"]
+    assert "| 8 |" in res["markdown"] and "configs[1]" in res["markdown"]
+
+
+def test_kernel_timeline_groups_by_kernel_and_grid_and_measures_gaps(tmp_path):
+    rows, t = [], 0
+    for i in range(20):
+        rows.append(("gemm_a", 256, 1, t, t + 5_000))
+        t += 5_000 + 1_500                                   # 1.5 us boundary
+        rows.append(("gemm_a", 96, 1, t, t + 9_000))         # same name, other grid: its own row
+        t += 9_000 + 100_000                                  # a 100 us host gap: counted as a long gap, not averaged
+    trace, out = tmp_path / "trace.csv", tmp_path / "tl.json"
+    _write(trace, rows)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_timeline.py"), str(trace), str(out), "synthetic"],
+                   check=True, capture_output=True)
+    ks = {r["kernel"]: r for r in json.load(open(out))["kernels"]}
+    a, b = ks["gemm_a | grid 256 wg 0"], ks["gemm_a | grid 96 wg 0"]
+    assert a["launches"] == 20 and abs(a["avg_us"] - 5.0) < 1e-6 and a["long_gaps"] == 19
+    assert b["launches"] == 20 and abs(b["avg_us"] - 9.0) < 1e-6 and abs(b["avg_gap_before_us"] - 1.5) < 1e-6

@@ -60,21 +60,27 @@ def call(pl, split, xbuf, xs, ybuf, ys, M, resid=None, rs=(8, 8)):
                                        _p(ybuf), ys[0], ys[1], M, pl.N, pl.K, 0, stream()), "gemm_act")
 
 
-RULES = {"p1": (33, 8), "p2w8": (1, 8), "p2w4": (1, 4)}       # p2*: wherever the halved grid still covers every CU
+# launch rules as tf_sg_tune settings: key 0 rows from which two panels per wave run (33 never), 1 its waves, 2 smallest halved
+# grid that takes it, 4 forced K-splits ACROSS workgroups (0 = one workgroup per panel)
+RULES = {"p1": {0: 33, 1: 8, 2: 256, 4: 0}, "p2w8": {0: 1, 1: 8, 2: 256, 4: 0}, "p2w4": {0: 1, 1: 4, 2: 256, 4: 0},
+         "p1ks2": {0: 33, 1: 8, 2: 256, 4: 2}, "p1ks3": {0: 33, 1: 8, 2: 256, 4: 3}}
+if os.environ.get("GEMM_RULES"):
+    RULES = {k: RULES[k] for k in os.environ["GEMM_RULES"].split(",")}
 
 
 def set_rule(name):
-    rows, waves = RULES[name]
-    L.tf_sg_tune(0, rows)
-    L.tf_sg_tune(1, waves)
-    L.tf_sg_tune(2, 256)
+    for key, val in RULES[name].items():
+        L.tf_sg_tune(key, val)
 
 
 def main():
     rows_list = [int(v) for v in os.environ.get("GEMM_ROWS", "8,16,17,24,32").split(",")]
+    only = set(os.environ.get("GEMM_ONLY", "").split(",")) - {""}            # e.g. "13B:o,13B:down"
     for model, hid, inter in (("7B", 4096, 11008), ("13B", 5120, 13824)):
         for name, N, K, split in (("qkv", 3 * hid, hid, 1), ("o", hid, hid, 1), ("gate_up", 2 * inter, hid, 2),
                                   ("down", hid, inter, 1)):
+            if only and f"{model}:{name}" not in only:
+                continue
             copies = max(2, int(700e6 // (N * K * 2)) + 1)
             pls = [ops.PackedLinear(torch.randn(N, K, device=DEV, dtype=torch.float16) * 0.02, split=split)
                    for _ in range(copies)]
@@ -106,12 +112,14 @@ def main():
                         ok = err <= tol and bool(torch.isfinite(got).all())
                         if lname == "rm":
                             base = got.clone()
+                        if RULES[rule].get(4, 0) > 1 and lname == "rm":
+                            base = got.clone()                       # split-K re-associates the K sum: compare layouts within the rule
                         same = bool(torch.equal(got, base))
                         us = timeit([(lambda p=p: call(p, split, xb, xs, yb, ys, M)) for p in pls])
                         row[f"M{M}_{lname}_{rule}_us"] = round(us, 2)
                         if not (ok and same):
                             row[f"M{M}_{lname}_{rule}_BAD"] = {"err": err, "tol": tol, "same_as_rm": same}
-            L.tf_sg_tune(0, 1), L.tf_sg_tune(1, 4), L.tf_sg_tune(2, 420)      # the shipped rule
+            L.tf_sg_tune(0, 1), L.tf_sg_tune(1, 4), L.tf_sg_tune(2, 420), L.tf_sg_tune(4, 0)      # the shipped rule
             print(json.dumps(row), flush=True)
             del pls
 

@@ -95,6 +95,7 @@ static int64_t g_sg_ws_bytes[16] = {};
 // 7B TP-8 gate|up GEMM stays at 13.2 us with 258 workgroups instead of 86, q|k|v goes 9.1 -> 10.9 us: at 12-22 MB these
 // launches are made of fixed costs (dispatch, the norm prologue's dependent loads, merge, epilogue, drain), not of the
 // stream the extra CUs would shorten, and the hand-off adds a round trip.  Default off (0); tf_sg_tune key 3 turns it on.
+static int g_sg_ksplit_force = 0;          // > 1: that many K-splits across workgroups for EVERY P = 1 GEMM (tf_sg_tune key 4; A/B)
 static int g_sg_ksplit_max_groups = 0;     // split K across workgroups below this many panel groups (tf_sg_tune key 3; 0 = never)
 
 __device__ __forceinline__ void sg_st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -709,8 +710,14 @@ static int sg_pick_ksplit(const SgArgs& a, SgKsplit& kx) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !g_sg_ws[dev]) return 1;
     const int panels = a.N / 16, groups = panels / P, nchunks = a.K >> 5;
-    if (groups >= g_sg_ksplit_max_groups || panels > SG_TICKETS) return 1;
-    int ks = (256 + groups - 1) / groups;
+    if (panels > SG_TICKETS) return 1;
+    int ks;
+    if (g_sg_ksplit_force > 1) {                       // A/B (tf_sg_tune key 4): this many workgroups per panel, any grid
+        ks = g_sg_ksplit_force;
+    } else {
+        if (groups >= g_sg_ksplit_max_groups) return 1;
+        ks = (256 + groups - 1) / groups;
+    }
     if (ks > SG_KSPLIT_MAX) ks = SG_KSPLIT_MAX;
     while (ks > 1 && nchunks / ks < 2 * WAVES) --ks;
     if (ks <= 1) return 1;
@@ -781,7 +788,7 @@ static bool sg_shape_ok(int M, int N, int K, const SgAct& xa) {
 // key 3 = panel-group count below which K is also split ACROSS workgroups (0 = never).  Returns the previous value, -1 for an unknown key.
 extern "C" int tf_sg_tune(int key, int value) {
     int* slot = key == 0 ? &g_sg_p2_rows : key == 1 ? &g_sg_p2_waves : key == 2 ? &g_sg_p2_groups
-                : key == 3 ? &g_sg_ksplit_max_groups : nullptr;
+                : key == 3 ? &g_sg_ksplit_max_groups : key == 4 ? &g_sg_ksplit_force : nullptr;
     if (!slot) return -1;
     const int old = *slot;
     if (key == 1 && value != 4 && value != 8) return old;
