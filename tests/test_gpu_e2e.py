@@ -13,6 +13,7 @@ import torch
 
 from oracle import ref_model as M
 from oracle import ref_ops as R
+from oracle import specs
 from tests import helpers as Hh
 
 pytestmark = pytest.mark.gpu
@@ -260,6 +261,64 @@ def test_stochastic_triforce_with_injected_uniforms():
     Hh.note(f"stochastic pooled acceptance device {p_g:.3f} vs oracle {p_w:.3f}; tokens/step {per_g:.2f} vs {per_w:.2f}")
     assert abs(p_g - p_w) <= 0.2 * max(p_w, 0.05) + 0.02 and abs(per_g - per_w) <= 0.2 * per_w
     assert acc_g > 0
+
+
+def test_expected_acceptance_at_identical_states_matches_the_oracle():
+    """The sampling-free companion of the stochastic test above (round-3 verdict: its paired bias sat at +1.6 standard
+    errors on both metrics — is the device's accept test subtly more generous?).  Device and oracle are walked through
+    the SAME states — same prompt, same teacher-forced tokens (the oracle's most likely draft / follow-up token at every
+    step) — and the quantity the accept tests are draws from is compared directly:
+        inner loop   alpha_1(n) = sum_v min(p_retrieval[n][v], q_draft[v])     (decoding.py:190-193)
+        outer loop   alpha_2(i) = sum_v min(p_target[i][v], p_retrieval[i][v]) (decoding.py:97-99)
+    i.e. the probability that a draft from that distribution is accepted.  No uniforms, no trajectories that diverge: a
+    device whose probabilities made acceptance likelier would show here as a mean difference far above fp16 noise."""
+    from triforce_amd.utils.decoding import TriForceRunner
+    g = Hh.load_golden("small_gamma6")
+    oeng, tsd, dsd = Hh.build_oracle(g, temperature=0.6, top_p=0.9)
+    ge = Hh.build_product(g, DEV, tsd, dsd, temperature=0.6, top_p=0.9, graphs=False)
+    gamma, V = g["gamma"], g["tcfg"]["vocab_size"]
+    d1, d2 = [], []
+    for ps in range(6):
+        prompt = specs.random_prompt(V, g["prefill"], g["pseed"] + 17 * ps)
+        # the reference's prefill protocol on both sides (decoding.py:44-62)
+        oeng.kv_cache.reset(); oeng.graph_cache.reset(); oeng.draft_cache.reset()
+        oeng.inference(prompt[:, :-1])
+        ologits = oeng.inference(prompt[:, -1:])
+        oeng.graph_draft_prefill(prompt)
+        run = TriForceRunner(Hh.FakeTokenizer(), ge, gamma, -1, 0.9, 0.6)
+        pd = prompt.to(DEV)
+        eng = ge.engine
+        eng.kv_cache.reset(); eng.graph_cache.reset(); eng.draft_cache.reset()
+        ge.inference(input_ids=pd[:, :-1])
+        ge.inference(input_ids=pd[:, -1:])
+        ge.graph_draft_prefill(input_ids=pd)
+        nxt = int(ologits[0, -1].argmax())
+        S = oeng.kv_cache.seq_len
+        assert eng.kv_cache.seq_len == S
+        vt = torch.full((1, gamma + 1), 100, dtype=torch.long)
+        vt[0, 0] = nxt
+        pos = torch.arange(S, S + gamma + 1).unsqueeze(0)
+        rows_o, rows_d = [], []
+        for n in range(gamma):                               # every iteration "rejects": one position per iteration
+            qo = oeng.graph_draft_inference(vt[:, :n + 1], gamma_offset=n)
+            qd = ge.graph_draft_inference(input_ids=vt[:, :n + 1].to(DEV), gamma_offset=n).float().cpu()
+            vt[0, n + 1] = int(qo.argmax())                  # the drafted token both sides verify
+            po = oeng.graph_verify(vt, pos)
+            pdv = ge.graph_verify(input_ids=vt.to(DEV), position_ids=pos.to(DEV)).float().cpu()
+            d1.append(float(torch.minimum(pdv[n], qd).sum() - torch.minimum(po[n], qo).sum()))
+            rows_o.append(po[n]); rows_d.append(pdv[n])
+            vt[0, n + 1] = int(po[n].argmax())               # follow-up token of a rejection: the position is decided
+        ids = vt[:, :gamma + 1]
+        lo = oeng.inference(ids)
+        po_full = R.norm_logits(lo[0], 0.6, -1, 0.9)
+        pd_full = ge.verify_probs(ids.to(DEV), 0.6, 0.9).float().cpu()
+        for i in range(gamma):
+            d2.append(float(torch.minimum(pd_full[i], rows_d[i]).sum() - torch.minimum(po_full[i], rows_o[i]).sum()))
+    for what, d in (("inner (draft vs retrieval model)", d1), ("outer (retrieval vs full-cache model)", d2)):
+        t = torch.tensor(d)
+        Hh.note(f"expected acceptance at identical states, {what}: device - oracle over {len(d)} positions: mean "
+                f"{float(t.mean()):+.5f}, max |d| {float(t.abs().max()):.5f}")
+        assert abs(float(t.mean())) < 5e-3 and float(t.abs().max()) < 5e-2, (what, d)
 
 
 def test_greedy_divergence_from_golden_happens_only_at_near_ties():

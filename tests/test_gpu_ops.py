@@ -758,7 +758,7 @@ def test_gemm_split_across_workgroups(M, kind, N, K, HD):
             ops.linear(x, pl, ln=ln, eps=eps, ss_in=ss_in, resid=buf, out=buf, ss_out=ss)
             return torch.cat([buf.reshape(-1), ss[:, :M].reshape(-1).half()])
     assert torch.device(DEV) in ops._SG_WS, "split-K workspace was not registered"
-    one = [run(), run(ssx)]                                   # the shipped rule: one workgroup per panel (key 3 = 0)
+    one = [run(), run(ssx)]                                   # the shipped rule at these shapes: one workgroup per panel
     old = L.tf_sg_tune(3, 200)                                # split below 200 panel groups
     try:
         split = [run(), run(ssx)]
@@ -845,3 +845,38 @@ def test_attn_fused_merge_never_folds_stale_partials_under_uneven_load(monkeypat
                 assert torch.equal(o, want[i]), f"launch {it - 59 + j}: one-launch merge differs from the two-launch form"
             outs = []
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M", [7, 17])
+def test_13b_down_proj_takes_the_three_way_split_by_rule(M):
+    """The one shape the shipped rule splits across workgroups: 256 < panels <= 384 with K >= 8192 — Llama-2-13B's
+    down_proj (N 5120, K 13824: 41.8 -> 34.8 us at 17 rows, profiles/r04_gemm_ksplit_force_ab.jsonl).  Residual + sums of
+    squares, both layouts: deterministic, equal to the one-workgroup form up to the re-association of the K sum, and
+    against the oracle's fp32-accumulated linear."""
+    ops = _ops()
+    from triforce_amd import hip
+    L = hip.lib()
+    N, K = 5120, 13824
+    w = rnd(N, K, seed=500, scale=0.02)
+    x, res = rnd(M, K, seed=501 + M), rnd(M, N, seed=502)
+    pl = ops.PackedLinear(w.to(DEV))
+    xd, resd = x.to(DEV), res.to(DEV)
+
+    def run(packed):
+        buf = ops.Act.from_rows(resd) if packed else resd.clone()
+        ss = ops.ss_buffer(N, DEV)
+        ops.linear(ops.Act.from_rows(xd) if packed else xd, pl, resid=buf, out=buf, ss_out=ss)
+        return (buf.rows() if packed else buf), ss[:, :M].clone()
+    a, sa = run(False)
+    b, sb = run(True)
+    a2, _ = run(False)
+    assert torch.equal(a, b) and torch.equal(sa, sb) and torch.equal(a, a2)
+    old = L.tf_sg_tune(4, 1)                                   # never split
+    try:
+        one, _ = run(False)
+    finally:
+        L.tf_sg_tune(4, old)
+    d = (a.float() - one.float()).abs()
+    assert bool((d <= 2 * one.float().abs() * 2 ** -10 + 2e-3).all()) and float((d > 0).float().mean()) < 0.12
+    want = res + R.linear(x, w)                                # fp16 residual add of the fp16 GEMM result
+    ulp_report("13B down_proj, 3 K-splits across workgroups", a, want, max_ulp_frac=8e-2, ulps=2, atol=2e-3)

@@ -154,13 +154,13 @@ def test_predict_scaling_composes_stage_latencies_and_exchange_prices(tmp_path):
     res = json.load(open(out))
     cfg = res["configs"]["configs[1]"]
     k, tps, host = cfg["loop"]["inner_iterations"], cfg["loop"]["tokens_per_step"], cfg["loop"]["host_overhead_us"]
-    w1 = cfg["predictions"]["oneshot_done"][0]["low"]
+    w1 = cfg["predictions"]["gemm_exchange"][0]["low"]
     step1 = 13700.0 + k * 3300.0 + (k + 1) * 120.0 + host
     assert abs(w1["ms_per_step"] - step1 / 1e3) < 1e-3 and w1["exchanges_per_step"] == 0
     assert abs(w1["tokens_per_s"] - tps / step1 * 1e6) < 0.1
-    w8 = cfg["predictions"]["oneshot_done"][1]
+    w8 = cfg["predictions"]["gemm_exchange"][1]
     x = 2 * 32 * (1 + k)
-    lo, hi = res["scenarios_us_per_exchange"]["oneshot_done"]
+    lo, hi = res["scenarios_us_per_exchange"]["gemm_exchange"]
     step8 = 3300.0 + k * 1900.0 + (k + 1) * 130.0 + host + 2 * (k + 1) * res["broadcast_us"][0] + x * lo
     assert abs(w8["low"]["ms_per_step"] - step8 / 1e3) < 1e-3 and w8["low"]["exchanges_per_step"] == round(x)
     assert w8["high"]["tokens_per_s"] < w8["low"]["tokens_per_s"]

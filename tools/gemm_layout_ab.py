@@ -61,8 +61,8 @@ def call(pl, split, xbuf, xs, ybuf, ys, M, resid=None, rs=(8, 8)):
 
 
 # launch rules as tf_sg_tune settings: key 0 rows from which two panels per wave run (33 never), 1 its waves, 2 smallest halved
-# grid that takes it, 4 forced K-splits ACROSS workgroups (0 = one workgroup per panel)
-RULES = {"p1": {0: 33, 1: 8, 2: 256, 4: 0}, "p2w8": {0: 1, 1: 8, 2: 256, 4: 0}, "p2w4": {0: 1, 1: 4, 2: 256, 4: 0},
+# grid that takes it, 4 K-splits ACROSS workgroups (1 = one workgroup per panel, > 1 forced, 0 = the shipped rule)
+RULES = {"p1": {0: 33, 1: 8, 2: 256, 4: 1}, "p2w8": {0: 1, 1: 8, 2: 256, 4: 1}, "p2w4": {0: 1, 1: 4, 2: 256, 4: 1},
          "p1ks2": {0: 33, 1: 8, 2: 256, 4: 2}, "p1ks3": {0: 33, 1: 8, 2: 256, 4: 3}}
 if os.environ.get("GEMM_RULES"):
     RULES = {k: RULES[k] for k in os.environ["GEMM_RULES"].split(",")}

@@ -5,9 +5,10 @@ line by line.  (The reference's own 2-GPU table: /root/reference/index.html:183-
 
 Inputs
   --shards  JSONL of tools/tp_shard_bench.py lines (rank 0's shard of a W-way engine on one GPU, whole-forward hipGraphs,
-            --local-exchange: every exchange launches the real one-shot kernel with a one-rank group, so its ON-DEVICE
-            cost — launch boundary, flag / ticket / epoch round trips through fine-grained memory — is inside the stage
-            latencies; W = 1 lines are the engine at world size 1).
+            --local-exchange --gemm-exchange: every exchange runs in its shipped form — inside the o_proj / down_proj
+            GEMM, tf_skinny_gemm_xchg — against a one-rank group, so its ON-DEVICE cost (staging store, epoch / flag
+            round trips through fine-grained memory) is inside the stage latencies; W = 1 lines are the engine at
+            world size 1).
   loop statistics per configuration (tokens per step, inner iterations, host overhead per step) from tracked bench lines
             of the single-GPU run at the same acceptance dial (LOOP below cites the files).
 
@@ -15,12 +16,16 @@ Model (one outer step):
   step(W) = target_verify(W) + k * retrieval_verify(W) + (k + 1) * draft_step + host(W) + X(W) * extra_per_exchange
   X(W)    = exchanges per outer step = 2 L (1 + k)           (two per layer and forward; none at W = 1)
   host(W) = step overhead measured at W = 1 + (k + 1) * 2 small broadcasts (drafted token, decision record) at W > 1
-  extra_per_exchange: what xGMI adds to the on-device exchange — one scenario per exchange form, low / high:
-      one-shot DONE form   READY hop + one remote-read round trip + DONE hop            +4 .. +10 us
-      alternating halves   READY hop + one remote-read round trip                        +2.5 .. +6 us
-      RCCL all-reduce      replaces the 5.8 us on-device kernel by a ring collective      +10 .. +20 us (15-25 us each)
-  (hop prices: MI355X_MICROARCH.md handoff-flag rows, 2-5 us per cross-device flag hop; the payload — rows x hidden fp16
-   from W - 1 peers, <= 1.2 MB — is one loop trip of 16-byte loads issued together: one round trip, not bandwidth.)
+  extra_per_exchange: what a multi-GPU node adds per exchange to the measured one-GPU figure — one scenario per
+  exchange form, low / high:
+      gemm_exchange         (shipped) per-panel flag hop + one remote-read round trip over xGMI      +2.5 .. +6 us
+      exchange_kernel_done  GEMM, then tf_allreduce_oneshot_add_ss as its own launch: +1 .. +3.6 us on the device
+                            (profiles/r04_tp_shard_gemm_exchange_ab.jsonl: 0.7 us at 7 rows, 3.6 at 17) + READY hop +
+                            remote read + DONE hop                                                     +5.5 .. +14.6 us
+      rccl                  GEMM, then a ring all-reduce of 15-25 us instead of the ~4.4 us the fused exchange costs
+                            on the device                                                              +10 .. +20 us
+  (hop prices: MI355X_MICROARCH.md handoff-flag rows, 2-5 us per cross-device flag hop; the payload — a 16-column panel
+   of <= 32 rows from each of W - 1 peers per workgroup — is one round trip of 8-byte loads issued together, not bandwidth.)
 
     python tools/predict_scaling.py --shards profiles/r04_tp_shard_by_world.jsonl --out profiles/r04_predicted_scaling.json
 """
@@ -41,7 +46,7 @@ LOOP = {
                    "tokens_per_step": 7.1, "inner_iterations": 9.5, "host_overhead_us": 1137.0,
                    "source": "profiles/r03_bench_13b_cfg4_world1.json (7.1 tokens per step, 9.5 inner iterations, 1 137 us overhead)"},
 }
-SCENARIOS = {"oneshot_done": (4.0, 10.0), "oneshot_alternating": (2.5, 6.0), "rccl": (10.0, 20.0)}
+SCENARIOS = {"gemm_exchange": (2.5, 6.0), "exchange_kernel_done": (5.5, 14.6), "rccl": (10.0, 20.0)}
 BCAST_US = (8.0, 20.0)            # one small RCCL broadcast, low / high; two per inner iteration and outer step at W > 1
 
 
@@ -95,7 +100,7 @@ def main():
             cfg["predictions"][scen] = preds
         out["configs"][name] = cfg
         md.append(f"**{name}** ({loop['tokens_per_step']} tokens per step, {loop['inner_iterations']} inner iterations)")
-        md.append("| W | per rank: target / retrieval verify / draft (us) | one-shot DONE: tokens/s (x W=1, eff.) | alternating | RCCL | dominant term |")
+        md.append("| W | per rank: target / retrieval verify / draft (us) | GEMM + exchange (shipped): tokens/s (x W=1, eff.) | exchange kernel + DONE | RCCL | dominant term |")
         md.append("|---|---|---|---|---|---|")
         for i, l in enumerate(rows):
             cells = []
@@ -107,7 +112,7 @@ def main():
                     cells.append(f"{p['high']['tokens_per_s']}-{p['low']['tokens_per_s']} "
                                  f"({p['high'].get('speedup_vs_w1', '-')}-{p['low'].get('speedup_vs_w1', '-')}x, "
                                  f"{p['high'].get('efficiency', '-')}-{p['low'].get('efficiency', '-')})")
-            dom = cfg["predictions"]["oneshot_done"][i]["high"]["dominant"]
+            dom = cfg["predictions"]["gemm_exchange"][i]["high"]["dominant"]
             md.append(f"| {l['emulated_world']} | {l['target_verify_us']:.0f} / {l['retrieval_verify_us']:.0f} / {l['draft_step_us']:.0f} | "
                       + " | ".join(cells) + f" | {dom} |")
         md.append("")

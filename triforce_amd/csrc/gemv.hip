@@ -95,7 +95,8 @@ static int64_t g_sg_ws_bytes[16] = {};
 // 7B TP-8 gate|up GEMM stays at 13.2 us with 258 workgroups instead of 86, q|k|v goes 9.1 -> 10.9 us: at 12-22 MB these
 // launches are made of fixed costs (dispatch, the norm prologue's dependent loads, merge, epilogue, drain), not of the
 // stream the extra CUs would shorten, and the hand-off adds a round trip.  Default off (0); tf_sg_tune key 3 turns it on.
-static int g_sg_ksplit_force = 0;          // > 1: that many K-splits across workgroups for EVERY P = 1 GEMM (tf_sg_tune key 4; A/B)
+static int g_sg_ksplit_force = 0;          // tf_sg_tune key 4 (A/B): > 1 that many K-splits across workgroups for EVERY P = 1 GEMM,
+                                           // 1 never split, 0 the rule in sg_pick_ksplit
 static int g_sg_ksplit_max_groups = 0;     // split K across workgroups below this many panel groups (tf_sg_tune key 3; 0 = never)
 
 __device__ __forceinline__ void sg_st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -714,6 +715,15 @@ static int sg_pick_ksplit(const SgArgs& a, SgKsplit& kx) {
     int ks;
     if (g_sg_ksplit_force > 1) {                       // A/B (tf_sg_tune key 4): this many workgroups per panel, any grid
         ks = g_sg_ksplit_force;
+    } else if (g_sg_ksplit_force == 1) {               // ... or never
+        return 1;
+    } else if (panels > 256 && panels <= 384 && nchunks >= 256) {
+        // The one regime where the split pays (profiles/r04_gemm_ksplit_force_ab.jsonl): a grid a little larger than the
+        // chip — 13B down_proj: 320 panels on 256 CUs, 64 CUs hold two workgroups and set the pace — with a LONG K
+        // (432 k-chunks, 141.6 MB).  Three K-splits (960 workgroups, even): 41.8 -> 34.8 us at 17 rows, 32.4 -> 28.5 at 8,
+        // 48.4 -> 39.8 at 32.  With a short K (13B o_proj, 160 k-chunks: 16.3 -> 19.2) or a grid that already fits
+        // (7B: 256 panels) it loses.
+        ks = 3;
     } else {
         if (groups >= g_sg_ksplit_max_groups) return 1;
         ks = (256 + groups - 1) / groups;
