@@ -35,6 +35,7 @@ VARIANTS = {"q2occ1": ["TF_ATTN_QT2_OCC=0"],
             # the many-split in-launch attention merge off, the retrieval scorer's round-3 grid rule
             "psplitblk": ["TF_BLOCK_P_SPLIT=1"], "draftps0": ["TF_DRAFT_P_SPLIT=0"],
             "bigmerge": ["FUSED_MERGE_BIG_SPLITS=64"], "rscoreceil": ["TF_RSCORE_CAP_CEIL=1"],
+            "sgtail0": ["SG_TAIL_BATCH=0"],          # K-loop tail one chunk at a time (round 3)
             "sgprol0": ["SG_PROLOGUE_ORDER=0"],      # norm-GEMM prologue in round 3's load order (weights first, x after the fold)
             "ring4ps1": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_RING_Q1=4", "TF_ATTN_RING_Q2=4", "TF_ATTN_QT2_OCC=1", "TF_ATTN_P_SPLIT=1"]}
 

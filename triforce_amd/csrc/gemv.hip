@@ -46,6 +46,9 @@
 #ifndef SG_U
 #define SG_U 4              // k-chunks (KiB of weights) in flight per wave
 #endif
+#ifndef SG_TAIL_BATCH
+#define SG_TAIL_BATCH 1         // 1: the last 1..U-1 k-chunks of a wave as one batch of loads (round 4); 0: one chunk at a time
+#endif
 #ifndef SG_PROLOGUE_ORDER
 #define SG_PROLOGUE_ORDER 1     // 1: norm partials, x rows, then weights (round 4); 0: weights first, x after the fold (round 3)
 #endif
@@ -95,6 +98,7 @@ static int64_t g_sg_ws_bytes[16] = {};
 // 7B TP-8 gate|up GEMM stays at 13.2 us with 258 workgroups instead of 86, q|k|v goes 9.1 -> 10.9 us: at 12-22 MB these
 // launches are made of fixed costs (dispatch, the norm prologue's dependent loads, merge, epilogue, drain), not of the
 // stream the extra CUs would shorten, and the hand-off adds a round trip.  Default off (0); tf_sg_tune key 3 turns it on.
+static int g_sg_few_panels = 200;          // panel counts up to this run 16 (one row tile) / 8 (two) waves per panel (tf_sg_tune key 5)
 static int g_sg_ksplit_force = 0;          // tf_sg_tune key 4 (A/B): > 1 that many K-splits across workgroups for EVERY P = 1 GEMM,
                                            // 1 never split, 0 the rule in sg_pick_ksplit
 static int g_sg_ksplit_max_groups = 0;     // split K across workgroups below this many panel groups (tf_sg_tune key 3; 0 = never)
@@ -441,23 +445,59 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
                     for (int aa = 0; aa < NA; ++aa)
                         acc[j][aa][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u][j][aa], b[u][t], acc[j][aa][t], 0, 0, 0);
     }
-    for (; c < c1; ++c) {
-        half8 a[P][NA];
+    if constexpr (NORM || !SG_TAIL_BATCH) {
+        // (norm-prologue forms: K = hidden, whose k-chunks divide evenly among the waves in every configuration that
+        //  matters; the batch below would only cost them registers — a wave per SIMD on the gate|up form)
+        for (; c < c1; ++c) {
+            half8 a[P][NA];
 #pragma unroll
-        for (int j = 0; j < P; ++j) {
-            a[j][0] = SG_LOAD(wa + j * pstride + (int64_t)c * 64);
-            if (GATEUP) a[j][NA - 1] = SG_LOAD(wu + j * pstride + (int64_t)c * 64);
+            for (int j = 0; j < P; ++j) {
+                a[j][0] = SG_LOAD(wa + j * pstride + (int64_t)c * 64);
+                if (GATEUP) a[j][NA - 1] = SG_LOAD(wu + j * pstride + (int64_t)c * 64);
+            }
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                half8 b = xok[t] ? load_half8(xr[t] + xcs * c) : zero8;
+                if (NORM) b = sg_normalise(b, load_half8(ln_w + 32 * c + 8 * g), inv[t]);
+#pragma unroll
+                for (int j = 0; j < P; ++j)
+#pragma unroll
+                    for (int aa = 0; aa < NA; ++aa)
+                        acc[j][aa][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j][aa], b, acc[j][aa][t], 0, 0, 0);
+            }
+        }
+    } else if (c < c1) {
+        // the last 1 .. U-1 k-chunks of this wave as ONE batch: every load issued before the first wait (one memory
+        // round trip; round 3 walked them one chunk — one round trip — at a time: 3 of them in a 7B down_proj wave, 43 =
+        // 10 x 4 + 3 chunks).  Loads past the end re-read the last chunk instead of being predicated: a conditional load
+        // makes the waitcnt pass wait for everything (compiler trap); its MFMAs are skipped.  Same
+        // chunk order, same accumulators: bit-identical to the chunk-by-chunk walk.
+        half8 a[U][P][NA], b[U][MT];
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u) {
+            const int cc = min(c + u, c1 - 1);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                a[u][j][0] = SG_LOAD(wa + j * pstride + (int64_t)cc * 64);
+                if (GATEUP) a[u][j][NA - 1] = SG_LOAD(wu + j * pstride + (int64_t)cc * 64);
+            }
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                b[u][t] = xok[t] ? load_half8(xr[t] + xcs * cc) : zero8;
+                if (NORM) b[u][t] = sg_normalise(b[u][t], load_half8(ln_w + 32 * cc + 8 * g), inv[t]);
+            }
         }
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            half8 b = xok[t] ? load_half8(xr[t] + xcs * c) : zero8;
-            if (NORM) b = sg_normalise(b, load_half8(ln_w + 32 * c + 8 * g), inv[t]);
+        for (int u = 0; u < U - 1; ++u)
+            if (c + u < c1) {
 #pragma unroll
-            for (int j = 0; j < P; ++j)
+                for (int t = 0; t < MT; ++t)
 #pragma unroll
-                for (int aa = 0; aa < NA; ++aa)
-                    acc[j][aa][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j][aa], b, acc[j][aa][t], 0, 0, 0);
-        }
+                    for (int j = 0; j < P; ++j)
+#pragma unroll
+                        for (int aa = 0; aa < NA; ++aa)
+                            acc[j][aa][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u][j][aa], b[u][t], acc[j][aa][t], 0, 0, 0);
+            }
     }
 
     // split-K merge across the waves; C layout: lane holds D[n = 4g + r][m = li]
@@ -772,6 +812,17 @@ static int launch_sg(const SgArgs& a, const SgRope& rp, hipStream_t st) {
         TF_LAUNCH_CHECK();
         return TF_OK;
     }
+    // few-panel grids (a tensor-parallel rank's q|k|v / gate|up shard: 86-192 panels): fewer workgroups than CUs, and each
+    // wave walks its K share as a chain of load -> wait -> MFMA round trips (4 KiB in flight per stream) — 8 of them at 4
+    // waves per panel and K = 4096.  More waves per panel shorten the chain with no cross-workgroup hand-off (the partial
+    // sums meet in LDS as always): 16 waves for one row tile, 8 for two (16 x 64 lanes leave 128 registers per lane; the
+    // two-tile norm forms need 140-156).  tf_sg_tune key 5 = largest panel count that takes this form (0: never).
+    if (MODE != SG_F32 && panels <= g_sg_few_panels && nchunks >= 32) {
+        if (a.M <= 16) launch_sg_w<1, MODE, NORM, 16, 1>(a, rp, st);
+        else launch_sg_w<2, MODE, NORM, 8, 1>(a, rp, st);
+        TF_LAUNCH_CHECK();
+        return TF_OK;
+    }
     // wide variant: few panels and enough k-chunks that every wave still gets >= 2 of them
     constexpr bool CAN_WIDE = MODE != SG_GATEUP;
     const bool wide = CAN_WIDE && panels <= SG_WIDE_MAX_PANELS && nchunks >= 2 * SG_WAVES_WIDE;
@@ -798,7 +849,7 @@ static bool sg_shape_ok(int M, int N, int K, const SgAct& xa) {
 // key 3 = panel-group count below which K is also split ACROSS workgroups (0 = never).  Returns the previous value, -1 for an unknown key.
 extern "C" int tf_sg_tune(int key, int value) {
     int* slot = key == 0 ? &g_sg_p2_rows : key == 1 ? &g_sg_p2_waves : key == 2 ? &g_sg_p2_groups
-                : key == 3 ? &g_sg_ksplit_max_groups : key == 4 ? &g_sg_ksplit_force : nullptr;
+                : key == 3 ? &g_sg_ksplit_max_groups : key == 4 ? &g_sg_ksplit_force : key == 5 ? &g_sg_few_panels : nullptr;
     if (!slot) return -1;
     const int old = *slot;
     if (key == 1 && value != 4 && value != 8) return old;
