@@ -98,7 +98,7 @@ static int64_t g_sg_ws_bytes[16] = {};
 // 7B TP-8 gate|up GEMM stays at 13.2 us with 258 workgroups instead of 86, q|k|v goes 9.1 -> 10.9 us: at 12-22 MB these
 // launches are made of fixed costs (dispatch, the norm prologue's dependent loads, merge, epilogue, drain), not of the
 // stream the extra CUs would shorten, and the hand-off adds a round trip.  Default off (0); tf_sg_tune key 3 turns it on.
-static int g_sg_few_panels = 200;          // panel counts up to this run 16 (one row tile) / 8 (two) waves per panel (tf_sg_tune key 5)
+static int g_sg_few_panels = 200;          // gate|up GEMMs of up to this many panels run 8 waves per panel at two row tiles (tf_sg_tune key 5)
 static int g_sg_ksplit_force = 0;          // tf_sg_tune key 4 (A/B): > 1 that many K-splits across workgroups for EVERY P = 1 GEMM,
                                            // 1 never split, 0 the rule in sg_pick_ksplit
 static int g_sg_ksplit_max_groups = 0;     // split K across workgroups below this many panel groups (tf_sg_tune key 3; 0 = never)
@@ -115,22 +115,24 @@ __device__ __forceinline__ float sg_ld_agent(const float* p) { return __hip_atom
 //   partial panel (fp16) -> own staging half (system-scope 8-byte stores), drained        [what the GEMM epilogue wrote anyway]
 //   flag[rank][panel] = epoch on every peer; wait for the peers' flags of this panel      [one hop, per panel]
 //   read the peers' panels, add in rank order (fp32), round, + residual, store, sums of squares   [one remote round trip]
-// Exchange e uses staging half e & 1 (the device-side epoch): rank B rewrites a panel's half at exchange e + 2, after its
-// exchange e + 1 of that panel, which waited for every peer's flag e + 1 — set after that peer's exchange e of the panel
-// had finished reading.  No DONE phase, no host-side half bookkeeping (producer and exchange are one kernel).  Same
+// Exchange e OF A PANEL uses staging half e & 1 (every panel counts its own exchanges on the device): rank B rewrites a
+// panel's half at that panel's exchange e + 2, after its exchange e + 1, which waited for every peer's flag e + 1 — set
+// after that peer's exchange e of the panel had finished reading.  No DONE phase, no host-side half bookkeeping (producer and exchange are one kernel).  Same
 // arithmetic as GEMM -> tf_allreduce_oneshot_add: fp16 partials, fp32 sum in rank order, one rounding, fp16 residual add.
 // Every spin is bounded; a time-out poisons the panel with NaN and sets the sticky error word (+ host mirror).
 #define XC_MAXP 512                          // panels (N / 16) an exchange GEMM may have
 #define XC_MAX_WORLD 8
 #define XC_SPIN_LIMIT (1u << 27)
-struct XcCtl {                               // head of a rank's control buffer (fine-grained memory); flags follow at +1024 B
-    unsigned epoch, ticket, error, pad;
-    unsigned long long mirror;               // 0 or a pinned host word that also receives error codes
+struct XcCtl {                               // head of a rank's control buffer (fine-grained memory); flags follow at +1024 B,
+    unsigned epoch, ticket, error, pad;      // then this rank's own per-panel epochs (XC_PEPOCH_OFF); epoch / ticket unused since
+    unsigned long long mirror;               // the epochs went per panel.  mirror: 0 or a pinned host word that also gets error codes
 };
+#define XC_PEPOCH_OFF (1024 + XC_MAX_WORLD * XC_MAXP * 4)
 struct SgXchg {
     h16* stage[XC_MAX_WORLD];                // every rank's staging buffer (2 halves), own entry = local pointer
     unsigned* pf[XC_MAX_WORLD];              // every rank's flag array [world][XC_MAXP]: pf[r][q * XC_MAXP + p] written by rank q
     XcCtl* ctl;                              // own control block
+    unsigned* pepoch;                        // own per-panel exchange counts [XC_MAXP] (no peer reads them)
     int64_t half_elems;
     int rank, world;
 };
@@ -371,7 +373,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
     unsigned xepoch = 0, xerr = 0;
     if constexpr (XCHG) {
         if (epi) {
-            xepoch = xc_ld(&xc.ctl->epoch) + 1u;     // bumped by the last workgroup to finish, i.e. after every read of it
+            // every panel counts its own exchanges (written at the end of this panel's previous exchange, an earlier
+            // launch of the stream): no grid-wide epoch, so no ticket and no last-workgroup tail at the end of the kernel
+            xepoch = xc_ld(&xc.pepoch[panel]) + 1u;
             xerr = xc_ld(&xc.ctl->error);
         }
     }
@@ -607,7 +611,10 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
                 if (mir) xc_st(mir, 1u);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                // system scope: nothing read below predates the flags
+        // No acquire FENCE: the peers' panels are read with system-scope (sc0 sc1) loads, which bypass this CU's caches —
+        // issued after the flag loads returned (the loop above consumed their values), and the producers drained their
+        // system-scope stores before flagging.  A system-scope buffer_inv here cost ~1.7 us per exchange (the first build).
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const bool rowv = t * 16 + li < M;
@@ -722,14 +729,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
         }
     }
     if constexpr (XCHG) {
-        // the last panel to finish advances the epoch: the next exchange launch (stream-ordered) reads epoch + 1
-        if (lane == 0) {
-            const unsigned tk = __hip_atomic_fetch_add(&xc.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tk == gridDim.x * P - 1) {
-                __hip_atomic_store(&xc.ctl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                xc_st(&xc.ctl->epoch, xepoch);
-            }
-        }
+        if (lane == 0) xc_st(&xc.pepoch[panel], xepoch);      // this panel's next exchange (a later launch) is epoch + 1
     }
 }
 
@@ -812,14 +812,14 @@ static int launch_sg(const SgArgs& a, const SgRope& rp, hipStream_t st) {
         TF_LAUNCH_CHECK();
         return TF_OK;
     }
-    // few-panel grids (a tensor-parallel rank's q|k|v / gate|up shard: 86-192 panels): fewer workgroups than CUs, and each
-    // wave walks its K share as a chain of load -> wait -> MFMA round trips (4 KiB in flight per stream) — 8 of them at 4
-    // waves per panel and K = 4096.  More waves per panel shorten the chain with no cross-workgroup hand-off (the partial
-    // sums meet in LDS as always): 16 waves for one row tile, 8 for two (16 x 64 lanes leave 128 registers per lane; the
-    // two-tile norm forms need 140-156).  tf_sg_tune key 5 = largest panel count that takes this form (0: never).
-    if (MODE != SG_F32 && panels <= g_sg_few_panels && nchunks >= 32) {
-        if (a.M <= 16) launch_sg_w<1, MODE, NORM, 16, 1>(a, rp, st);
-        else launch_sg_w<2, MODE, NORM, 8, 1>(a, rp, st);
+    // Few-panel gate|up GEMMs at two row tiles (a tensor-parallel rank's shard at 17-32 rows: 108 panel pairs at 13B TP 8)
+    // run 8 waves per panel like the other few-panel forms, not 4: 13B TP-8 retrieval verify 3 421 -> 3 215 us, target
+    // verify 5 492 -> 5 278 (profiles/r04_tp_shard_waves_tail_ab.jsonl).  At ONE row tile more waves per panel were
+    // measured and lose (16 waves: 7B TP-8 retrieval verify 1 877 -> 1 925 us; q|k|v 10.0 -> 10.9 us, gate|up 13.8 ->
+    // 13.9): those launches are not bound by the length of a wave's K chain.  tf_sg_tune key 5 = largest panel count that
+    // takes the form (0: never).
+    if (MODE == SG_GATEUP && a.M > 16 && panels <= g_sg_few_panels && nchunks >= 32) {
+        launch_sg_w<2, MODE, NORM, 8, 1>(a, rp, st);
         TF_LAUNCH_CHECK();
         return TF_OK;
     }
@@ -970,7 +970,7 @@ extern "C" int tf_skinny_qkv_rope(const void* wqkv_packed, const void* x, int64_
 // fine-grained) and control buffer (tf_xchg_ctl_bytes(), fine-grained, zero-filled once), own entries included, peers'
 // mapped through hipIpc.  The output block (out, its strides) and the staging halves share one activation layout; N / 16
 // <= 512 panels, M * N <= half_elems.  out may alias resid.  ss_out: per-panel sums of squares of the result rows.
-extern "C" int64_t tf_xchg_ctl_bytes(void) { return 1024 + (int64_t)XC_MAX_WORLD * XC_MAXP * 4; }
+extern "C" int64_t tf_xchg_ctl_bytes(void) { return XC_PEPOCH_OFF + (int64_t)XC_MAXP * 4; }
 
 extern "C" int tf_skinny_gemm_xchg(const void* w_packed, const void* x, int64_t xs_m, int64_t xs_k,
                                    void* const* peer_stage, void* const* peer_ctl, int rank, int world, int64_t half_elems,
@@ -993,6 +993,7 @@ extern "C" int tf_skinny_gemm_xchg(const void* w_packed, const void* x, int64_t 
         xc.pf[r] = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(peer_ctl[r]) + 1024);
     }
     xc.ctl = reinterpret_cast<XcCtl*>(peer_ctl[rank]);
+    xc.pepoch = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(peer_ctl[rank]) + XC_PEPOCH_OFF);
     xc.half_elems = half_elems, xc.rank = rank, xc.world = world;
     if ((const void*)out == (const void*)xc.stage[rank] || (const void*)resid == (const void*)xc.stage[rank]) return TF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
