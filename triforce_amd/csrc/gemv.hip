@@ -91,7 +91,24 @@ struct SgAct {
 struct SgKsplit {
     float* ws;            // [panel][KS][NA][MT][64][4] fp32
     unsigned* tickets;    // [SG_TICKETS], zero between launches
+    unsigned long long* stamps;   // -DSG_STAMPS=1 builds only (tools/gemm_stamps.py): 16 cycle stamps per workgroup
 };
+// Phase stamps of wave 0 of every workgroup (instrumented build only): 0 entry, 1 prologue loads issued, 2 norm scale known,
+// 3 first k-batch done, 4 K loop done, 5 waves merged, 6 exit; 8 / 9 = 100 MHz wall clock at entry / exit.
+#ifndef SG_STAMPS
+#define SG_STAMPS 0
+#endif
+#if SG_STAMPS
+#define SG_STAMP(i)                                                                                                      \
+    do {                                                                                                                 \
+        if (tid == 0 && kx.stamps) {                                                                                     \
+            kx.stamps[((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 16 + (i)] = __builtin_readcyclecounter();        \
+            if ((i) == 0 || (i) == 6) kx.stamps[((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 16 + 8 + (i) / 6] = wall_clock64(); \
+        }                                                                                                                \
+    } while (0)
+#else
+#define SG_STAMP(i) do { } while (0)
+#endif
 static void* g_sg_ws[16] = {};
 static int64_t g_sg_ws_bytes[16] = {};
 // Measured (profiles/r04_tp_shard_structural_ab.jsonl, r04_tp8_7b_kernel_timeline_after_splitk.json): NO gain in situ — the
@@ -189,6 +206,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
     const int panel0 = blockIdx.x * P;                       // this workgroup's P consecutive panels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
+    SG_STAMP(0);
     const int nchunks = K >> 5;
     // this workgroup's share of K (gridDim.y = KS workgroups per panel group), then its waves' shares of that
     const int KS = KSPLIT ? (int)gridDim.y : 1, ks = KSPLIT ? (int)blockIdx.y : 0;   // (own instantiation: the fold below
@@ -274,6 +292,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
     }
 #endif
 
+    SG_STAMP(1);
     float inv[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) inv[t] = 1.f;
@@ -365,6 +384,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
         for (int t = 0; t < MT; ++t) inv[t] = 1.0f / sqrtf(tot[t] / (float)K + eps);
     }
 
+    SG_STAMP(2);
     // Epilogue waves: wave j < P finishes panel panel0 + j.
     const bool epi = wave < P;
     const int panel = panel0 + (epi ? wave : 0);
@@ -448,7 +468,14 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
 #pragma unroll
                     for (int aa = 0; aa < NA; ++aa)
                         acc[j][aa][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u][j][aa], b[u][t], acc[j][aa][t], 0, 0, 0);
+#if SG_STAMPS
+        if (c == c0) {
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // let the batch's MFMAs issue before the stamp
+            SG_STAMP(3);
+        }
+#endif
     }
+    SG_STAMP(4);
     if constexpr (NORM || !SG_TAIL_BATCH) {
         // (norm-prologue forms: K = hidden, whose k-chunks divide evenly among the waves in every configuration that
         //  matters; the batch below would only cost them registers — a wave per SIMD on the gate|up form)
@@ -513,6 +540,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
             for (int t = 0; t < MT; ++t)
                 *reinterpret_cast<f32x4*>(&sm[wave][j * NA + aa][t][lane][0]) = acc[j][aa][t];
     __syncthreads();
+    SG_STAMP(5);
     if (!epi) return;
     float S[MT][4], S2[MT][4];
 #pragma unroll
@@ -731,6 +759,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
     if constexpr (XCHG) {
         if (lane == 0) xc_st(&xc.pepoch[panel], xepoch);      // this panel's next exchange (a later launch) is epoch + 1
     }
+    SG_STAMP(6);
 }
 
 struct SgArgs {                       // one GEMM call: operands with their layouts
@@ -747,7 +776,14 @@ struct SgArgs {                       // one GEMM call: operands with their layo
 // partials, and only while every wave of every workgroup still gets >= 2 k-chunks.
 template <int MT, int NA, int WAVES, int P>
 static int sg_pick_ksplit(const SgArgs& a, SgKsplit& kx) {
-    kx = SgKsplit{nullptr, nullptr};
+    kx = SgKsplit{nullptr, nullptr, nullptr};
+#if SG_STAMPS
+    {
+        int d0 = 0;
+        if (hipGetDevice(&d0) == hipSuccess && d0 >= 0 && d0 < 16 && g_sg_ws[d0] && g_sg_ws_bytes[d0] >= (6 << 20))
+            kx.stamps = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(g_sg_ws[d0]) + (4 << 20));
+    }
+#endif
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !g_sg_ws[dev]) return 1;
     const int panels = a.N / 16, groups = panels / P, nchunks = a.K >> 5;
@@ -780,7 +816,7 @@ static int sg_pick_ksplit(const SgArgs& a, SgKsplit& kx) {
 
 template <int MT, int MODE, bool NORM, int WAVES, int P>
 static void launch_sg_w(const SgArgs& a, const SgRope& rp, hipStream_t st) {
-    SgKsplit kx = {nullptr, nullptr};
+    SgKsplit kx = {nullptr, nullptr, nullptr};
     if constexpr (P == 1 && MODE != SG_F32) {                     // few-panel grids only: never the P = 2 form, never lm_head
         const int ks = sg_pick_ksplit<MT, (MODE == SG_GATEUP ? 2 : 1), WAVES, P>(a, kx);
         if (ks > 1) {
@@ -998,7 +1034,15 @@ extern "C" int tf_skinny_gemm_xchg(const void* w_packed, const void* x, int64_t 
     if ((const void*)out == (const void*)xc.stage[rank] || (const void*)resid == (const void*)xc.stage[rank]) return TF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const SgRope rp = {};
-    const SgKsplit kx = {nullptr, nullptr};
+    SgKsplit kx = {nullptr, nullptr, nullptr};
+#if SG_STAMPS
+    {
+        SgKsplit tmp;
+        SgArgs dummy = a;
+        sg_pick_ksplit<1, 1, 8, 1>(dummy, tmp);
+        kx.stamps = tmp.stamps;
+    }
+#endif
     const int nchunks = K >> 5;
     const bool wide = nchunks >= 2 * SG_WAVES_WIDE;
 #define XCHG_LAUNCH(MT_, W_)                                                                                                  \
