@@ -115,6 +115,7 @@ static int64_t g_sg_ws_bytes[16] = {};
 // 7B TP-8 gate|up GEMM stays at 13.2 us with 258 workgroups instead of 86, q|k|v goes 9.1 -> 10.9 us: at 12-22 MB these
 // launches are made of fixed costs (dispatch, the norm prologue's dependent loads, merge, epilogue, drain), not of the
 // stream the extra CUs would shorten, and the hand-off adds a round trip.  Default off (0); tf_sg_tune key 3 turns it on.
+static int g_sg_deep_panels = 200;         // grids of up to this many panels (and K >= 2048) keep twice the weights in flight per wave (key 6)
 static int g_sg_few_panels = 200;          // gate|up GEMMs of up to this many panels run 8 waves per panel at two row tiles (tf_sg_tune key 5)
 static int g_sg_ksplit_force = 0;          // tf_sg_tune key 4 (A/B): > 1 that many K-splits across workgroups for EVERY P = 1 GEMM,
                                            // 1 never split, 0 the rule in sg_pick_ksplit
@@ -189,7 +190,7 @@ __device__ __forceinline__ half8 sg_normalise(half8 xv, half8 wv, float inv) {
     return o;
 }
 
-template <int MT, int MODE, bool NORM, int WAVES, int P, bool KSPLIT, bool XCHG = false>
+template <int MT, int MODE, bool NORM, int WAVES, int P, bool KSPLIT, bool XCHG = false, int UX = 1>
 __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __restrict__ wp,
                                                                  const half8* __restrict__ wp_up,
                                                                  const h16* __restrict__ x, SgAct xa,
@@ -201,7 +202,11 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
     static_assert(!XCHG || (MODE == SG_PLAIN && P == 1 && !KSPLIT), "the exchange form is the plain one-panel GEMM");
     constexpr bool GATEUP = MODE == SG_GATEUP;
     constexpr int NA = GATEUP ? 2 : 1;                       // weight streams (accumulator sets) per panel
-    constexpr int U = (P * NA >= 2) ? (8 / (P * NA)) : SG_U;  // k-chunks in flight per wave: 8 KiB of weights (4 for P = NA = 1)
+    // k-chunks in flight per wave and weight stream: 8 KiB of weights per wave (4 for P = NA = 1) — times UX.  UX = 2 is the
+    // form of the FEW-PANEL grids (a tensor-parallel rank's shards): there a wave's K share is a chain of load -> wait ->
+    // MFMA round trips of ~0.9 us each — 7.5 of the 11.1 us a 7B TP-8 gate|up workgroup lives (tools/gemm_stamps.py,
+    // profiles/r04_gemm_phase_stamps.json) — with HBM at a quarter of its rate; twice the bytes per trip, half the trips.
+    constexpr int U = ((P * NA >= 2) ? (8 / (P * NA)) : SG_U) * UX;
     static_assert(P <= WAVES && U >= 1, "one epilogue wave per panel");
     const int panel0 = blockIdx.x * P;                       // this workgroup's P consecutive panels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -814,9 +819,17 @@ static int sg_pick_ksplit(const SgArgs& a, SgKsplit& kx) {
     return ks;
 }
 
-template <int MT, int MODE, bool NORM, int WAVES, int P>
+template <int MT, int MODE, bool NORM, int WAVES, int P, int UX = 1>
 static void launch_sg_w(const SgArgs& a, const SgRope& rp, hipStream_t st) {
     SgKsplit kx = {nullptr, nullptr, nullptr};
+    if constexpr (UX > 1) {
+        sg_pick_ksplit<MT, (MODE == SG_GATEUP ? 2 : 1), WAVES, P>(a, kx);      // (stamps pointer of the instrumented build)
+        kx.ws = nullptr, kx.tickets = nullptr;
+        hipLaunchKernelGGL((skinny_gemm_kernel<MT, MODE, NORM, WAVES, P, false, false, UX>), dim3(a.N / 16 / P), dim3(WAVES * 64),
+                           0, st, (const half8*)a.wp, (const half8*)a.wp_up, (const h16*)a.x, a.xa, (const h16*)a.ln_w, a.eps,
+                           (const h16*)a.resid, a.ra, a.y, a.ya, a.M, a.N, a.K, rp, a.ss_in, a.ss_out, kx, SgXchg{});
+        return;
+    }
     if constexpr (P == 1 && MODE != SG_F32) {                     // few-panel grids only: never the P = 2 form, never lm_head
         const int ks = sg_pick_ksplit<MT, (MODE == SG_GATEUP ? 2 : 1), WAVES, P>(a, kx);
         if (ks > 1) {
@@ -854,8 +867,17 @@ static int launch_sg(const SgArgs& a, const SgRope& rp, hipStream_t st) {
     // measured and lose (16 waves: 7B TP-8 retrieval verify 1 877 -> 1 925 us; q|k|v 10.0 -> 10.9 us, gate|up 13.8 ->
     // 13.9): those launches are not bound by the length of a wave's K chain.  tf_sg_tune key 5 = largest panel count that
     // takes the form (0: never).
+    constexpr bool CAN_DEEP = MODE != SG_F32;
+    const bool deep = CAN_DEEP && panels <= g_sg_deep_panels && nchunks >= 64;    // few panels, long K: UX = 2 (see the kernel)
     if (MODE == SG_GATEUP && a.M > 16 && panels <= g_sg_few_panels && nchunks >= 32) {
-        launch_sg_w<2, MODE, NORM, 8, 1>(a, rp, st);
+        launch_sg_w<2, MODE, NORM, 8, 1>(a, rp, st);              // (UX = 2 would spill here: 256 registers + 4)
+        TF_LAUNCH_CHECK();
+        return TF_OK;
+    }
+    if (deep) {
+        constexpr int DW = MODE == SG_GATEUP ? SG_WAVES : SG_WAVES_WIDE;
+        if (a.M <= 16) launch_sg_w<1, MODE, NORM, DW, 1, (CAN_DEEP ? 2 : 1)>(a, rp, st);
+        else launch_sg_w<2, MODE, NORM, SG_WAVES_WIDE, 1, ((CAN_DEEP && MODE != SG_GATEUP) ? 2 : 1)>(a, rp, st);
         TF_LAUNCH_CHECK();
         return TF_OK;
     }
@@ -885,7 +907,8 @@ static bool sg_shape_ok(int M, int N, int K, const SgAct& xa) {
 // key 3 = panel-group count below which K is also split ACROSS workgroups (0 = never).  Returns the previous value, -1 for an unknown key.
 extern "C" int tf_sg_tune(int key, int value) {
     int* slot = key == 0 ? &g_sg_p2_rows : key == 1 ? &g_sg_p2_waves : key == 2 ? &g_sg_p2_groups
-                : key == 3 ? &g_sg_ksplit_max_groups : key == 4 ? &g_sg_ksplit_force : key == 5 ? &g_sg_few_panels : nullptr;
+                : key == 3 ? &g_sg_ksplit_max_groups : key == 4 ? &g_sg_ksplit_force : key == 5 ? &g_sg_few_panels
+                : key == 6 ? &g_sg_deep_panels : nullptr;
     if (!slot) return -1;
     const int old = *slot;
     if (key == 1 && value != 4 && value != 8) return old;
@@ -1046,7 +1069,7 @@ extern "C" int tf_skinny_gemm_xchg(const void* w_packed, const void* x, int64_t 
     const int nchunks = K >> 5;
     const bool wide = nchunks >= 2 * SG_WAVES_WIDE;
 #define XCHG_LAUNCH(MT_, W_)                                                                                                  \
-    hipLaunchKernelGGL((skinny_gemm_kernel<MT_, SG_PLAIN, false, W_, 1, false, true>), dim3(N / 16), dim3(W_ * 64), 0, st,  \
+    hipLaunchKernelGGL((skinny_gemm_kernel<MT_, SG_PLAIN, false, W_, 1, false, true, 2>), dim3(N / 16), dim3(W_ * 64), 0, st, \
                        (const half8*)a.wp, (const half8*)nullptr, (const h16*)a.x, a.xa, (const h16*)nullptr, 0.f,          \
                        (const h16*)a.resid, a.ra, a.y, a.ya, a.M, a.N, a.K, rp, (const float*)nullptr, a.ss_out, kx, xc)
     if (M <= 16) {

@@ -91,6 +91,8 @@ def _ensure_sg_workspace(device):
         hip.check(hip.lib().tf_sg_workspace(_ptr(ws), ws.numel()), "tf_sg_workspace")
         if _os.environ.get("TRIFORCE_GEMM_KSPLIT", "0") == "1":          # measured: no gain (csrc/gemv.hip) — opt-in
             hip.lib().tf_sg_tune(3, 200)
+        if "TRIFORCE_GEMM_DEEP_PANELS" in _os.environ:                   # A/B: largest panel count that keeps 2x the weights in flight
+            hip.lib().tf_sg_tune(6, int(_os.environ["TRIFORCE_GEMM_DEEP_PANELS"]))
         if "TRIFORCE_GEMM_FEW_PANELS" in _os.environ:                    # A/B: largest panel count that runs 16 waves per panel
             hip.lib().tf_sg_tune(5, int(_os.environ["TRIFORCE_GEMM_FEW_PANELS"]))
     _SG_WS[device] = ws
