@@ -115,7 +115,11 @@ static int64_t g_sg_ws_bytes[16] = {};
 // 7B TP-8 gate|up GEMM stays at 13.2 us with 258 workgroups instead of 86, q|k|v goes 9.1 -> 10.9 us: at 12-22 MB these
 // launches are made of fixed costs (dispatch, the norm prologue's dependent loads, merge, epilogue, drain), not of the
 // stream the extra CUs would shorten, and the hand-off adds a round trip.  Default off (0); tf_sg_tune key 3 turns it on.
-static int g_sg_deep_panels = 200;         // grids of up to this many panels (and K >= 2048) keep twice the weights in flight per wave (key 6)
+// Measured (profiles/r04_gemm_deep_prefetch_ab.jsonl) and OFF: twice the bytes per trip halves the trips but not the time —
+// 7B TP-8 gate|up K loop 7.3 -> 6.4 us with the prologue 0.8 us longer, workgroup lifetime 11.0 us either way; retrieval verify
+// 1 671 -> 1 685 us, 13B TP 8 3 109 -> 3 200.  The K loop of a few-panel GEMM is bound by what ONE CU can pull (~37 GB/s:
+// 256 KiB in 7 us, whatever is in flight), not by the number of round trips.
+static int g_sg_deep_panels = 0;           // grids of up to this many panels (and K >= 2048) keep twice the weights in flight per wave (key 6)
 static int g_sg_few_panels = 200;          // gate|up GEMMs of up to this many panels run 8 waves per panel at two row tiles (tf_sg_tune key 5)
 static int g_sg_ksplit_force = 0;          // tf_sg_tune key 4 (A/B): > 1 that many K-splits across workgroups for EVERY P = 1 GEMM,
                                            // 1 never split, 0 the rule in sg_pick_ksplit
@@ -202,10 +206,10 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
     static_assert(!XCHG || (MODE == SG_PLAIN && P == 1 && !KSPLIT), "the exchange form is the plain one-panel GEMM");
     constexpr bool GATEUP = MODE == SG_GATEUP;
     constexpr int NA = GATEUP ? 2 : 1;                       // weight streams (accumulator sets) per panel
-    // k-chunks in flight per wave and weight stream: 8 KiB of weights per wave (4 for P = NA = 1) — times UX.  UX = 2 is the
-    // form of the FEW-PANEL grids (a tensor-parallel rank's shards): there a wave's K share is a chain of load -> wait ->
-    // MFMA round trips of ~0.9 us each — 7.5 of the 11.1 us a 7B TP-8 gate|up workgroup lives (tools/gemm_stamps.py,
-    // profiles/r04_gemm_phase_stamps.json) — with HBM at a quarter of its rate; twice the bytes per trip, half the trips.
+    // k-chunks in flight per wave and weight stream: 8 KiB of weights per wave (4 for P = NA = 1) — times UX.  UX = 2 was
+    // built for the FEW-PANEL grids (a tensor-parallel rank's shards), where a wave's K share looks like a chain of load ->
+    // wait -> MFMA round trips of ~0.9 us — 7.5 of the 11.1 us a 7B TP-8 gate|up workgroup lives (tools/gemm_stamps.py,
+    // profiles/r04_gemm_phase_stamps.json).  Measured: half the trips take as long (see g_sg_deep_panels) — off by default.
     constexpr int U = ((P * NA >= 2) ? (8 / (P * NA)) : SG_U) * UX;
     static_assert(P <= WAVES && U >= 1, "one epilogue wave per panel");
     const int panel0 = blockIdx.x * P;                       // this workgroup's P consecutive panels
@@ -1069,7 +1073,7 @@ extern "C" int tf_skinny_gemm_xchg(const void* w_packed, const void* x, int64_t 
     const int nchunks = K >> 5;
     const bool wide = nchunks >= 2 * SG_WAVES_WIDE;
 #define XCHG_LAUNCH(MT_, W_)                                                                                                  \
-    hipLaunchKernelGGL((skinny_gemm_kernel<MT_, SG_PLAIN, false, W_, 1, false, true, 2>), dim3(N / 16), dim3(W_ * 64), 0, st, \
+    hipLaunchKernelGGL((skinny_gemm_kernel<MT_, SG_PLAIN, false, W_, 1, false, true, 1>), dim3(N / 16), dim3(W_ * 64), 0, st, \
                        (const half8*)a.wp, (const half8*)nullptr, (const h16*)a.x, a.xa, (const h16*)nullptr, 0.f,          \
                        (const h16*)a.resid, a.ra, a.y, a.ya, a.M, a.N, a.K, rp, (const float*)nullptr, a.ss_out, kx, xc)
     if (M <= 16) {
