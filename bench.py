@@ -675,7 +675,7 @@ def main():
         result["value_note"] = (f"configured-acceptance scenario: synthetic weights {wlabel} SET the draft->retrieval and "
                                 "retrieval->target acceptance rates (models/aligned.py); tokens/s and avg_accepted_len follow "
                                 "from that dial — stage_latency_us, roofline* and random_weights do not depend on it; other "
-                                "operating points: profiles/r03_acceptance_sweep.json; not comparable to the reference's "
+                                "operating points: profiles/r04_acceptance_sweep.json; not comparable to the reference's "
                                 "trained-weights 2.2x")
     elif kind == "random":
         result["value_note"] = "random-init weights: acceptance ~0, the loop's worst case (gamma inner iterations per token)"

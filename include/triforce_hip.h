@@ -74,6 +74,11 @@ int tf_attn_decode_fused(const void* q, const void* k, const void* v, void* out,
 int tf_attn_decode_act(const void* q, const void* k, const void* v, void* out, int64_t out_sm, int64_t out_sk,
                        int64_t stride_t, int64_t stride_h, int sq, int sk, const int32_t* sk_dev, int H, int D,
                        float scale, int nsplit, float* ws, int64_t ws_floats, uint32_t* tickets, void* stream);
+/* tf_attn_tune(0, v): v = 0 (default) keeps the split merge of > 8 splits as a second launch; 1 lets small grids (H * nsplit
+ * <= 256, H <= 64, D = 128) merge inside the launch by a rendezvous of the head's workgroups (csrc/attn.hip; measured
+ * slower, profiles/r04_attn_rendezvous_merge_ab.jsonl).  Returns the previous value, -1 for an unknown key.  Bit-identical
+ * either way. */
+int tf_attn_tune(int key, int value);
 
 /* -------------------------------------------------------------------------------------------
  * Block attention: 1 <= sq <= 128 query rows in ONE pass over the keys.

@@ -163,6 +163,17 @@ def test_attn_decode_one_launch_merge_is_bit_identical_to_two_launches(sq, sk, H
     tf_attn_decode (split kernel + merge kernel): same arithmetic in the same order -> the same bits; repeated
     launches on one ticket row (the row must come back zero each time), and replayed from a hipGraph."""
     ops = _ops()
+    from triforce_amd import hip
+    # > 8 splits merge inside the launch only with the rendezvous form switched on (shipped off: it measured slower,
+    # profiles/r04_attn_rendezvous_merge_ab.jsonl) — on here so that the path stays checked
+    was = hip.lib().tf_attn_tune(0, 1)
+    try:
+        _one_launch_merge_case(ops, sq, sk, H, D, nsplit, monkeypatch)
+    finally:
+        hip.lib().tf_attn_tune(0, was)
+
+
+def _one_launch_merge_case(ops, sq, sk, H, D, nsplit, monkeypatch):
     scale = R.softmax_scale_for(D)
     q, k, v, kd, vd = _attn_inputs(sq, sk, H, D, seed=31 + sq + sk)
     qd = q.to(DEV)

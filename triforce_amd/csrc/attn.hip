@@ -47,19 +47,20 @@
 #define FUSED_MERGE_MAX_SPLITS 8   // = COMBINE_GROUPS: each split is then one chain, merged in registers by one workgroup
 // Round 4: the in-launch merge also for MANY splits when the grid is small — the 4 / 5 heads of a tensor-parallel rank run
 // 32-64 splits per head (one workgroup per CU), whose merge was a second launch: 6.0 us of attn_combine_kernel behind an
-// 8.9 us split kernel (profiles/r04_tp8_7b_kernel_timeline_before.json).  The last workgroup of a head folds all splits
-// with attn_combine_kernel's arithmetic (8 chains over s = g, g + 8, ..., summed in chain order: bit-identical).  Only
-// while H * nsplit <= FUSED_MERGE_BIG_MAX_WGS: with 512+ workgroups the parallel merge kernel wins (16 splits x 32
-// heads: 28.0 vs 21.1 us).
-// MEASURED AND SWITCHED OFF (profiles/r04_tp_shard_structural_ab.jsonl): one workgroup folding 32 splits x 7 rows x 128 d
-// takes longer than the 1024-thread-per-(row, head) merge kernel it replaces, launch included — 7B TP-8 shard attention
-// 8.9 + 6.0 us -> 19.3 us, retrieval verify 1 968 -> 2 147 us; 13B TP-8 (51 splits x 17 rows) 3 869 -> 4 997 us.  The
-// default (8 = FUSED_MERGE_MAX_SPLITS) never takes this path; -DFUSED_MERGE_BIG_SPLITS=64 rebuilds it.
+// 8.9 us split kernel (profiles/r04_tp8_7b_kernel_timeline_before.json).  First form — the last workgroup of a head folds
+// all splits — measured 2x SLOWER than the merge kernel (retrieval verify 1 968 -> 2 147 us: one workgroup's serial fold
+// against 28 x 1 024 threads).  Second form (this one): a RENDEZVOUS — all workgroups of a head wait for its last arrival,
+// then each folds its slice of the output, 8 threads per element = attn_combine_kernel's 8 chains (bit-identical).  Only
+// while every workgroup of the launch is resident: H * nsplit <= FUSED_MERGE_BIG_MAX_WGS, H <= 64.  Measured
+// (profiles/r04_attn_rendezvous_merge_ab.jsonl): it loses too, by less — 7B TP-8 retrieval verify 1 654 -> 1 742 us (+2.8 us
+// per layer), 7B TP 4 1 819 -> 2 040, 13B TP 8 3 007 -> 3 191: a poll of the head's counter across XCDs, the uncached
+// read-back of the partials and the second counter cost ~9 us where the merge kernel costs 6 with its launch.  OFF by
+// default (tf_attn_tune(0, 1) turns it on; the tests do, so the path stays checked).
 #ifndef FUSED_MERGE_BIG_SPLITS
-#define FUSED_MERGE_BIG_SPLITS 8
+#define FUSED_MERGE_BIG_SPLITS 64
 #endif
 #ifndef FUSED_MERGE_BIG_MAX_WGS
-#define FUSED_MERGE_BIG_MAX_WGS 320
+#define FUSED_MERGE_BIG_MAX_WGS 256
 #endif
 #ifndef TF_ATTN_EAGER_TILES
 #define TF_ATTN_EAGER_TILES 16 // splits of up to this many 16-key tiles per wave use the unconditional-prefetch loop
@@ -461,69 +462,99 @@ __device__ __forceinline__ void attn_split_body(
     if (tid == 0)
         s_last = __hip_atomic_fetch_add(&tickets[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nsplit - 1);
     __syncthreads();
-    if (!s_last) return;
     const int64_t hbase = (int64_t)h * nsplit * QR;
     if (D == 128 && nsplit > FUSED_MERGE_MAX_SPLITS) {
-        // ---- many splits (host-checked: <= FUSED_MERGE_BIG_SPLITS): weights per (row, split) through LDS first, then
-        // every thread folds its (row, 4 d) elements over the splits in attn_combine_kernel's order ----
-        float* sw = &sm_o[0][0][0];                                   // [QR][BIG]: m_s, then exp(m_s - mm); reuses the wave-merge buffer
-        float* sl2 = sw + QR * FUSED_MERGE_BIG_SPLITS;                // [QR][BIG]: l_s
-        float* sl = sl2 + QR * FUSED_MERGE_BIG_SPLITS;                // [QR]: sum_s l_s * w_s
-        static_assert(D != 128 || (size_t)2 * QR * FUSED_MERGE_BIG_SPLITS + QR <= (size_t)NW * 16 * (DH + 1), "merge scratch");
-        for (int e = tid; e < sq * nsplit; e += 64 * NW) {            // all (row, split) statistics in flight at once
-            const int r = e / nsplit, sp = e - r * nsplit;
-            sw[r * FUSED_MERGE_BIG_SPLITS + sp] = ld_agent(&ws_m[hbase + (int64_t)sp * QR + r]);
-            sl2[r * FUSED_MERGE_BIG_SPLITS + sp] = ld_agent(&ws_l[hbase + (int64_t)sp * QR + r]);
-        }
-        __syncthreads();
-        for (int r = tid; r < sq; r += 64 * NW) {
-            float mm = NEG_BIG;
-            for (int sp = 0; sp < nsplit; ++sp) mm = fmaxf(mm, sw[r * FUSED_MERGE_BIG_SPLITS + sp]);
-            float l = 0.f;
-            for (int sp = 0; sp < nsplit; ++sp) {
-                const float w = __expf(sw[r * FUSED_MERGE_BIG_SPLITS + sp] - mm);
-                sw[r * FUSED_MERGE_BIG_SPLITS + sp] = w;
-                const float lw = sl2[r * FUSED_MERGE_BIG_SPLITS + sp] * w;      // attn_combine_kernel: sm_l[s] *= w, then the sum
-                l += lw;
+        // ---- many splits, small grid (host-checked: every workgroup of the launch is resident): RENDEZVOUS merge ----
+        // All nsplit workgroups of the head wait for the head's last arrival, then each folds ITS slice of the output —
+        // elements e = split, split + nsplit, ... of the sq x D/4 float4 items — 8 threads per element, one per
+        // accumulation chain of attn_combine_kernel (chain g folds splits g, g + 8, ...; chains summed in order; the
+        // normaliser summed over the splits in order): the same bits as the merge kernel, without its launch, and the
+        // fold is spread over all the head's workgroups instead of one (the one-workgroup fold measured 2x slower than
+        // the merge kernel: profiles/r04_tp_shard_structural_ab.jsonl).  A second counter (tickets[64 + h]) counts the
+        // slices done; whoever finishes last leaves both words zero for the next launch.
+        if (tid == 0) {
+            for (unsigned spins = 0; spins < (1u << 24); ++spins) {
+                if (__hip_atomic_load(&tickets[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)nsplit) break;
+                __builtin_amdgcn_s_sleep(1);
             }
-            sl[r] = l;
         }
         __syncthreads();
-        for (int e = tid; e < sq * (D / 4); e += 64 * NW) {
+        const int E = sq * (D / 4);
+        const int cnt = (E - split + nsplit - 1) / nsplit;             // elements of this workgroup's slice (may be <= 0)
+        const int grp = tid >> 3, gch = tid & 7;                       // 32 elements per pass x 8 chains
+        for (int i0 = 0; i0 < cnt; i0 += 32) {
+            const int i = i0 + grp;
+            const bool on = i < cnt;
+            const int e = on ? split + i * nsplit : 0;
             const int r = e / (D / 4), d4 = e - r * (D / 4);
-            f32x4 ch[COMBINE_GROUPS];
+            // every load of this chain issued up front: <= 8 splits x (4 + 2) values
+            f32x4 px[FUSED_MERGE_BIG_SPLITS / 8];
+            float pm[FUSED_MERGE_BIG_SPLITS / 8], pl[FUSED_MERGE_BIG_SPLITS / 8];
 #pragma unroll
-            for (int gg = 0; gg < COMBINE_GROUPS; ++gg) ch[gg] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int s0 = 0; s0 < nsplit; s0 += COMBINE_GROUPS) {     // 8 splits' loads in flight, one per chain
-                f32x4 px[COMBINE_GROUPS];
-#pragma unroll
-                for (int gg = 0; gg < COMBINE_GROUPS; ++gg) {
-                    const int sp = min(s0 + gg, nsplit - 1);
+            for (int jj = 0; jj < FUSED_MERGE_BIG_SPLITS / 8; ++jj) {
+                const int sp = gch + 8 * jj;
+                if (on && sp < nsplit) {
                     const float* xp = ws_o + (hbase + (int64_t)sp * QR + r) * D + 4 * d4;
-                    px[gg] = f32x4{ld_agent(xp), ld_agent(xp + 1), ld_agent(xp + 2), ld_agent(xp + 3)};
+                    px[jj] = f32x4{ld_agent(xp), ld_agent(xp + 1), ld_agent(xp + 2), ld_agent(xp + 3)};
+                    pm[jj] = ld_agent(&ws_m[hbase + (int64_t)sp * QR + r]);
+                    pl[jj] = ld_agent(&ws_l[hbase + (int64_t)sp * QR + r]);
+                } else {
+                    px[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    pm[jj] = NEG_BIG;
+                    pl[jj] = 0.f;
                 }
-#pragma unroll
-                for (int gg = 0; gg < COMBINE_GROUPS; ++gg)
-                    if (s0 + gg < nsplit) {
-                        const float w = sw[r * FUSED_MERGE_BIG_SPLITS + s0 + gg];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) ch[gg][c] = fmaf(px[gg][c], w, ch[gg][c]);
-                    }
             }
-            const float l = sl[r];
-            half4 o4;
+            float mm = NEG_BIG;                                         // max over ALL splits: fmaxf is order-free
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float acc = 0.f;
+            for (int jj = 0; jj < FUSED_MERGE_BIG_SPLITS / 8; ++jj) mm = fmaxf(mm, pm[jj]);
+            mm = fmaxf(mm, __shfl_xor(mm, 1, 64));
+            mm = fmaxf(mm, __shfl_xor(mm, 2, 64));
+            mm = fmaxf(mm, __shfl_xor(mm, 4, 64));
+            f32x4 ch = {0.f, 0.f, 0.f, 0.f};
+            float lw[FUSED_MERGE_BIG_SPLITS / 8];
 #pragma unroll
-                for (int gg = 0; gg < COMBINE_GROUPS; ++gg) acc += ch[gg][c];
-                o4[c] = (h16)(acc / l);
+            for (int jj = 0; jj < FUSED_MERGE_BIG_SPLITS / 8; ++jj) {
+                const float w = (gch + 8 * jj < nsplit) ? __expf(pm[jj] - mm) : 0.f;
+                lw[jj] = pl[jj] * w;                                    // attn_combine_kernel: sm_l[s] *= w
+                if (gch + 8 * jj < nsplit) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ch[c] = fmaf(px[jj][c], w, ch[c]);
+                }
             }
-            *reinterpret_cast<half4*>(out + (int64_t)r * osm + (int64_t)((h * D + 4 * d4) >> 3) * osk + ((4 * d4) & 7)) = o4;
+            // normaliser: l = sum over s = 0 .. nsplit-1 IN ORDER of l_s w_s (s = 8 jj + chain) — gathered by shuffles
+            const int lane0 = (threadIdx.x & 63) & ~7;
+            float l = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < FUSED_MERGE_BIG_SPLITS / 8; ++jj)
+#pragma unroll
+                for (int gg = 0; gg < 8; ++gg) {
+                    const float v = __shfl(lw[jj], lane0 + gg, 64);
+                    if (8 * jj + gg < nsplit) l += v;
+                }
+            // chains summed in chain order
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int gg = 0; gg < 8; ++gg)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] += __shfl(ch[c], lane0 + gg, 64);
+            if (on && gch == 0) {
+                half4 o4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o4[c] = (h16)(acc[c] / l);
+                *reinterpret_cast<half4*>(out + (int64_t)r * osm + (int64_t)((h * D + 4 * d4) >> 3) * osk + ((4 * d4) & 7)) = o4;
+            }
         }
-        if (tid == 0) __hip_atomic_store(&tickets[h], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned dn = __hip_atomic_fetch_add(&tickets[64 + h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (dn == (unsigned)(nsplit - 1)) {
+                __hip_atomic_store(&tickets[64 + h], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&tickets[h], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         return;
     }
+    if (!s_last) return;
     // nsplit <= FUSED_MERGE_MAX_SPLITS: every load of an output element is issued up front — one memory
     // latency — and each split is its own accumulation chain of attn_combine_kernel
     for (int e = tid; e < sq * (D / 4); e += 64 * NW) {
@@ -1837,6 +1868,16 @@ extern "C" int64_t tf_attn_decode_ws_floats(int H, int sq, int D, int nsplit) {
 // as long as a workgroup keeps >= 8 key tiles (2 per wave); more splits only add partials for the merge kernel to
 // re-read, fewer leave CUs idle.  (The first rule — up to 4 workgroups per CU, >= 32 tiles each — was 5-25 % slower
 // on the TP-shard shapes: 16 heads x 130K keys 237 vs 206 us, 32 heads x 12 305 keys 66 vs 54 us.)
+// A/B switch of the rendezvous merge (many splits on a small grid, see FUSED_MERGE_BIG_SPLITS): 1 on, 0 (shipped: it
+// measured slower) the two-launch merge
+static int g_attn_rendezvous = 0;
+extern "C" int tf_attn_tune(int key, int value) {
+    if (key != 0) return -1;
+    const int old = g_attn_rendezvous;
+    g_attn_rendezvous = value ? 1 : 0;
+    return old;
+}
+
 extern "C" int tf_attn_decode_pick_nsplit(int H, int sk) {
     const int tiles = (sk + 15) / 16;
     if (H < 1) H = 1;
@@ -1861,7 +1902,8 @@ static int launch_attn(const void* q, const void* k, const void* v, void* out, i
     // many splits on a big grid: the parallel merge kernel wins; on a small grid (few heads) the last workgroup of a head
     // folds them inside the launch (see FUSED_MERGE_BIG_SPLITS)
     if (tickets && nsplit > FUSED_MERGE_MAX_SPLITS &&
-        (D != 128 || nsplit > FUSED_MERGE_BIG_SPLITS || (int64_t)nsplit * H > FUSED_MERGE_BIG_MAX_WGS || TF_ATTN_Q2_WAVES > 4))
+        (D != 128 || H > 64 || nsplit > FUSED_MERGE_BIG_SPLITS || (int64_t)nsplit * H > FUSED_MERGE_BIG_MAX_WGS ||
+         TF_ATTN_Q2_WAVES > 4 || !g_attn_rendezvous))
         tickets = nullptr;
     bool launched = false;
 #if TF_ATTN_DEEP_TILES > 0

@@ -21,6 +21,7 @@ SIGNATURES = {
                                     _vp]),
     "tf_attn_decode_act": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _i32, _i32, _f32, _i32, _vp,
                                   _i64, _vp, _vp]),
+    "tf_attn_tune": (_i32, [_i32, _i32]),
     "tf_attn_block_ws_floats": (_i64, [_i32, _i32, _i32]),
     "tf_attn_block_pick_nsplit": (_i32, [_i32, _i32, _i32]),
     "tf_attn_prefill_pick_nsplit": (_i32, [_i32, _i32, _i32]),

@@ -416,6 +416,8 @@ def _ws_floats(H, sq, D, nsplit):
 # stream that has launched attention (calls on one stream are ordered; two streams must not share a row).  Allocated
 # at the first call, never freed; every launch leaves its row zero.
 ATTN_FUSED_MERGE = _os.environ.get("TRIFORCE_ATTN_FUSED_MERGE", "1") != "0"
+if _os.environ.get("TRIFORCE_ATTN_RENDEZVOUS", "0") == "1":     # A/B: > 8 splits on a small grid merged inside the launch
+    hip.lib().tf_attn_tune(0, 1)
 _TICKET_ROWS, _TICKET_WORDS = 64, 128
 _tickets = {}
 
