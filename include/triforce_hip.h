@@ -196,6 +196,13 @@ int tf_kv_copy_rows(const void* src, int64_t src_stride_l, int64_t src_stride_t,
                     int src_t0, int dst_t0, int n, int L, int H, int D, void* stream);
 int tf_kv_shift_rows(void* cache, int64_t stride_l, int64_t stride_t, int64_t stride_h,
                      int src_t0, int dst_t0, int n, int L, int H, int D, void* stream);
+/* The same two movements for the K AND V tensors of one cache (equal strides and row ranges) in one launch — the two
+ * tail copies and the two window shifts every decode step ends with (cache.py:180-182,252-265). */
+int tf_kv_copy_rows_pair(const void* src_k, const void* src_v, int64_t src_stride_l, int64_t src_stride_t,
+                         int64_t src_stride_h, void* dst_k, void* dst_v, int64_t dst_stride_l, int64_t dst_stride_t,
+                         int64_t dst_stride_h, int src_t0, int dst_t0, int n, int L, int H, int D, void* stream);
+int tf_kv_shift_rows_pair(void* k_cache, void* v_cache, int64_t stride_l, int64_t stride_t, int64_t stride_h,
+                          int src_t0, int dst_t0, int n, int L, int H, int D, void* stream);
 
 /* tf_kv_gather_rows: rows offset+idx[j] -> offset+j (j < n) of K and V for L layers x H heads — the compaction of
  *                   the accepted tree nodes, DistributedSimpleCache.gather_kv_incremental (cache.py:333-343).
@@ -226,6 +233,14 @@ int tf_silu_mul(const void* gate_up, void* out, int rows, int I, void* stream);
  * out[m * out_sm + (k / 8) * out_sk + k % 8].  embed [vocab][hidden] fp16, ids [n] int64 (clamped to the vocabulary). */
 int tf_embed_rows(const void* embed, const int64_t* ids, void* out, int64_t out_sm, int64_t out_sk, int n, int hidden,
                   int vocab, void* stream);
+/* tf_set_tokens: the token ids, positions and length scalars of one decode forward in ONE launch; the ids (known on the
+ * host: the loop has just read its accept record) travel as kernel arguments.  dst[i] = host_vals[i] for i < n_vals,
+ * pad for n_vals <= i < n_dst (utils/decoding.py:94,177 — the verify / pass token rows padded with a filler id);
+ * pos[i] = pos0 + i for i < n_pos (position_ids, decoding.py:178); *slot = pos0, *sk = sk_val when given (the device-side
+ * lengths of a captured full-cache forward).  HOST pointer: host_vals; device pointers: dst, pos, slot, sk (each optional
+ * with its count 0 / NULL).  n_dst, n_vals <= 32, n_pos <= 64. */
+int tf_set_tokens(int64_t* dst, int n_dst, const int64_t* host_vals, int n_vals, int64_t pad, int64_t* pos, int n_pos,
+                  int64_t pos0, int32_t* slot, int32_t* sk, int32_t sk_val, void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Skinny (decode) GEMMs — nn.Linear / F.linear with M <= 32 activation rows (models/modeling_llama.py:

@@ -6,7 +6,8 @@ from oracle import ref_ops as R
 
 PATCHED = ["rmsnorm", "rope_append", "silu_mul", "attn_decode", "attn_prefill", "attn_rope_on_read", "retrieval_score",
            "retrieval_topk", "retrieval_gather", "kv_copy_rows", "kv_shift_rows", "sample_inverse_cdf",
-           "accept_chain", "middle_accept", "attn_block", "attn_tree", "kv_gather_rows", "tree_accept"]
+           "accept_chain", "middle_accept", "attn_block", "attn_tree", "kv_gather_rows", "tree_accept", "kv_copy_rows_pair",
+           "kv_shift_rows_pair", "set_tokens"]
 
 
 def rmsnorm(x, w, eps, residual=None, sum_out=None):
@@ -77,6 +78,30 @@ def kv_copy_rows(src, dst, src_t0, dst_t0, n):
 def kv_shift_rows(cache, src_t0, dst_t0, n):
     if n > 0 and src_t0 != dst_t0:
         cache[:, :, dst_t0:dst_t0 + n] = cache[:, :, src_t0:src_t0 + n].clone()
+
+
+def kv_copy_rows_pair(src_k, src_v, dst_k, dst_v, src_t0, dst_t0, n):
+    kv_copy_rows(src_k, dst_k, src_t0, dst_t0, n)
+    kv_copy_rows(src_v, dst_v, src_t0, dst_t0, n)
+
+
+def kv_shift_rows_pair(k_cache, v_cache, src_t0, dst_t0, n):
+    kv_shift_rows(k_cache, src_t0, dst_t0, n)
+    kv_shift_rows(v_cache, src_t0, dst_t0, n)
+
+
+def set_tokens(dst, vals, pad, pos=None, pos0=0, slot=None, sk=None, sk_val=0):
+    if dst is not None:
+        flat = dst.view(-1)
+        flat.fill_(pad)
+        if len(vals):
+            flat[:len(vals)] = torch.tensor([int(v) for v in vals], dtype=flat.dtype)
+    if pos is not None:
+        pos.view(-1).copy_(torch.arange(pos.numel(), dtype=pos.dtype) + int(pos0))
+    if slot is not None:
+        slot.fill_(int(pos0))
+    if sk is not None:
+        sk.fill_(int(sk_val))
 
 
 def sample_inverse_cdf(probs, u, token_out):

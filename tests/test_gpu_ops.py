@@ -891,3 +891,60 @@ def test_13b_down_proj_takes_the_three_way_split_by_rule(M):
     assert bool((d <= 2 * one.float().abs() * 2 ** -10 + 2e-3).all()) and float((d > 0).float().mean()) < 0.12
     want = res + R.linear(x, w)                                # fp16 residual add of the fp16 GEMM result
     ulp_report("13B down_proj, 3 K-splits across workgroups", a, want, max_ulp_frac=8e-2, ulps=2, atol=2e-3)
+
+
+def test_set_tokens_writes_ids_positions_and_lengths_in_one_launch():
+    """tf_set_tokens: the ids arrive as kernel arguments; padding, positions and the two length scalars of a captured
+    forward in the same launch; optional parts left untouched; graph-capturable arguments are by value (a replay repeats
+    the captured ids — which is why the decode loop launches it eagerly in front of the replays)."""
+    ops = _ops()
+    dst = torch.full((1, 9), -7, dtype=torch.long, device=DEV)
+    pos = torch.full((1, 7), -7, dtype=torch.long, device=DEV)
+    slot = torch.full((1,), -7, dtype=torch.int32, device=DEV)
+    sk = torch.full((1,), -7, dtype=torch.int32, device=DEV)
+    ops.set_tokens(dst[:, :8], [5, 31999, 0, 2 ** 40 + 3], 100, pos=pos, pos0=124928, slot=slot, sk=sk, sk_val=124936)
+    assert dst[0].tolist() == [5, 31999, 0, 2 ** 40 + 3, 100, 100, 100, 100, -7]
+    assert pos[0].tolist() == [124928 + i for i in range(7)]
+    assert slot.item() == 124928 and sk.item() == 124936
+    ops.set_tokens(dst[:, :3], [1], 100)                            # tokens only
+    assert dst[0].tolist()[:4] == [1, 100, 100, 2 ** 40 + 3] and pos[0, 0].item() == 124928
+    ops.set_tokens(None, (), 0, pos=pos, pos0=3, slot=slot, sk=sk, sk_val=10)   # lengths only
+    assert pos[0].tolist() == [3, 4, 5, 6, 7, 8, 9] and slot.item() == 3 and sk.item() == 10 and dst[0, 0].item() == 1
+    full = torch.zeros(32, dtype=torch.long, device=DEV)
+    ops.set_tokens(full, list(range(1000, 1032)), 100)
+    assert full.tolist() == list(range(1000, 1032))
+    with pytest.raises(AssertionError):
+        ops.set_tokens(torch.zeros(33, dtype=torch.long, device=DEV), [1], 100)
+
+
+def test_kv_row_copies_for_k_and_v_in_one_launch_match_the_single_tensor_entries():
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    L, H, T, D = 3, 5, 40, 128
+    sk_ = torch.randn(L, H, T, D, generator=g, device=DEV, dtype=torch.float16)
+    sv_ = torch.randn(L, H, T, D, generator=g, device=DEV, dtype=torch.float16)
+    dk = torch.randn(L, H, 64, D, generator=g, device=DEV, dtype=torch.float16)
+    dv = torch.randn(L, H, 64, D, generator=g, device=DEV, dtype=torch.float16)
+    wk, wv = dk.clone(), dv.clone()
+    ops.kv_copy_rows(sk_, wk, 3, 50, 11)
+    ops.kv_copy_rows(sv_, wv, 3, 50, 11)
+    ops.kv_copy_rows_pair(sk_, sv_, dk, dv, 3, 50, 11)
+    assert torch.equal(dk, wk) and torch.equal(dv, wv)
+    ops.kv_copy_rows_pair(sk_[1:2], sv_[1:2], dk[2:3], dv[2:3], 0, 0, 40)        # layer slices (strided views)
+    assert torch.equal(dk[2, :, :40], sk_[1]) and torch.equal(dv[2, :, :40], sv_[1]) and torch.equal(dk[:2], wk[:2])
+    with pytest.raises(IndexError):
+        ops.kv_copy_rows_pair(sk_, sv_, dk, dv, 30, 0, 11)
+    # different strides for K and V: falls back to two launches, same result
+    sv_wide = torch.randn(L, H, T + 8, D, generator=g, device=DEV, dtype=torch.float16)
+    ops.kv_copy_rows_pair(sk_, sv_wide[:, :, :T], dk, dv, 0, 0, 5)
+    assert torch.equal(dk[:, :, :5], sk_[:, :, :5]) and torch.equal(dv[:, :, :5], sv_wide[:, :, :5])
+    # shifts: overlapping, downwards
+    ck, cv = sk_.clone(), sv_.clone()
+    rk, rv = sk_.clone(), sv_.clone()
+    ops.kv_shift_rows(rk, 9, 2, 31)
+    ops.kv_shift_rows(rv, 9, 2, 31)
+    ops.kv_shift_rows_pair(ck, cv, 9, 2, 31)
+    assert torch.equal(ck, rk) and torch.equal(cv, rv)
+    assert torch.equal(ck[:, :, 2:33], sk_[:, :, 9:40]) and torch.equal(cv[:, :, 2:33], sv_[:, :, 9:40])
+    with pytest.raises(IndexError):
+        ops.kv_shift_rows_pair(ck, cv, 20, 2, 31)

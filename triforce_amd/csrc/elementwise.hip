@@ -174,3 +174,34 @@ extern "C" int tf_embed_rows(const void* embed, const int64_t* ids, void* out, i
     TF_LAUNCH_CHECK();
     return TF_OK;
 }
+
+// ---- token / position / length scalars of a decode forward in ONE launch -----------------------------------------------
+// The decode loop knows a step's token ids on the host (it has just read the accept record) and used to ship them as
+// tensor -> pinned staging -> device row -> static graph input, then set the positions and the two length scalars of the
+// captured forward with three more launches: six ~10 us host-bound launches in front of every target verify
+// (profiles/r04_gap_analysis_decode_steps.txt).  Here the ids travel as kernel arguments.
+struct TokArgs { int64_t v[32]; };
+__global__ __launch_bounds__(64) void set_tokens_kernel(int64_t* __restrict__ dst, int n_dst, TokArgs vals, int n_vals,
+                                                        int64_t pad, int64_t* __restrict__ pos, int n_pos, int64_t pos0,
+                                                        int32_t* __restrict__ slot, int32_t* __restrict__ sk, int32_t sk_val) {
+    const int i = threadIdx.x;
+    if (i < n_dst) dst[i] = i < n_vals ? vals.v[i] : pad;
+    if (pos && i < n_pos) pos[i] = pos0 + i;
+    if (i == 0) {
+        if (slot) slot[0] = (int32_t)pos0;
+        if (sk) sk[0] = sk_val;
+    }
+}
+
+extern "C" int tf_set_tokens(int64_t* dst, int n_dst, const int64_t* host_vals, int n_vals, int64_t pad, int64_t* pos,
+                             int n_pos, int64_t pos0, int32_t* slot, int32_t* sk, int32_t sk_val, void* stream) {
+    if (n_dst < 0 || n_dst > 32 || n_vals < 0 || n_vals > 32 || n_pos < 0 || n_pos > 64) return TF_EINVAL;
+    if ((n_dst > 0 && !dst) || (n_vals > 0 && !host_vals) || (n_pos > 0 && !pos)) return TF_EINVAL;
+    if (n_dst == 0 && n_pos == 0 && !slot && !sk) return TF_OK;
+    TokArgs a;
+    for (int i = 0; i < 32; ++i) a.v[i] = i < n_vals ? host_vals[i] : pad;
+    hipLaunchKernelGGL(set_tokens_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, n_dst, a, n_vals, pad,
+                       n_pos > 0 ? pos : nullptr, n_pos, pos0, slot, sk, sk_val);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}

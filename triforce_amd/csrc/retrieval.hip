@@ -196,13 +196,15 @@ __global__ __launch_bounds__(128) void retrieval_gather_kernel(
 }
 
 // ---- row copies -----------------------------------------------------------------------------
+// (blockIdx.z = 1: the second (src, dst) pair of the same geometry — K and V of one cache in one launch)
 __global__ __launch_bounds__(256) void kv_copy_rows_kernel(const h16* __restrict__ src, int64_t ssl, int64_t sst,
                                                            int64_t ssh, h16* __restrict__ dst, int64_t dsl,
                                                            int64_t dst_t, int64_t dsh, int src_t0, int dst_t0, int n,
-                                                           int H, int D) {
+                                                           int H, int D, const h16* __restrict__ src2,
+                                                           h16* __restrict__ dst2) {
     const int l = blockIdx.y / H, h = blockIdx.y % H;
-    const h16* s = src + (int64_t)l * ssl + (int64_t)h * ssh;
-    h16* d = dst + (int64_t)l * dsl + (int64_t)h * dsh;
+    const h16* s = (blockIdx.z ? src2 : src) + (int64_t)l * ssl + (int64_t)h * ssh;
+    h16* d = (blockIdx.z ? dst2 : dst) + (int64_t)l * dsl + (int64_t)h * dsh;
     const int vpr = D / 8;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * vpr; e += gridDim.x * blockDim.x) {
         const int r = e / vpr, dv = e - r * vpr;
@@ -213,9 +215,10 @@ __global__ __launch_bounds__(256) void kv_copy_rows_kernel(const h16* __restrict
 // In-place downward shift (dst_t0 <= src_t0), overlap allowed: one workgroup per (layer, head)
 // walks the rows in ascending blocks; inside a block every thread reads before anyone writes.
 __global__ __launch_bounds__(256) void kv_shift_rows_kernel(h16* __restrict__ cache, int64_t sl, int64_t st,
-                                                            int64_t sh, int src_t0, int dst_t0, int n, int H, int D) {
+                                                            int64_t sh, int src_t0, int dst_t0, int n, int H, int D,
+                                                            h16* __restrict__ cache2) {
     const int l = blockIdx.x / H, h = blockIdx.x % H;
-    h16* base = cache + (int64_t)l * sl + (int64_t)h * sh;
+    h16* base = (blockIdx.y ? cache2 : cache) + (int64_t)l * sl + (int64_t)h * sh;
     const int vpr = D / 8;
     const int rows_per_blk = 256 / vpr;
     const int r_in = threadIdx.x / vpr, dv = threadIdx.x % vpr;
@@ -345,9 +348,9 @@ extern "C" int tf_kv_gather_rows(void* k_cache, void* v_cache, int64_t stride_l,
     return TF_OK;
 }
 
-extern "C" int tf_kv_copy_rows(const void* src, int64_t src_stride_l, int64_t src_stride_t, int64_t src_stride_h,
-                               void* dst, int64_t dst_stride_l, int64_t dst_stride_t, int64_t dst_stride_h,
-                               int src_t0, int dst_t0, int n, int L, int H, int D, void* stream) {
+static int kv_copy_rows_launch(const void* src, const void* src2, int64_t src_stride_l, int64_t src_stride_t,
+                               int64_t src_stride_h, void* dst, void* dst2, int64_t dst_stride_l, int64_t dst_stride_t,
+                               int64_t dst_stride_h, int src_t0, int dst_t0, int n, int L, int H, int D, void* stream) {
     if (n == 0) return TF_OK;
     if (!src || !dst || n < 0 || L < 1 || H < 1 || (D % 8) || src_t0 < 0 || dst_t0 < 0) return TF_EINVAL;
     if ((src_stride_t % 8) || (src_stride_h % 8) || (src_stride_l % 8) || (dst_stride_t % 8) || (dst_stride_h % 8) ||
@@ -355,20 +358,48 @@ extern "C" int tf_kv_copy_rows(const void* src, int64_t src_stride_l, int64_t sr
         return TF_EINVAL;
     int gx = (n * (D / 8) + 255) / 256;
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(kv_copy_rows_kernel, dim3(gx, L * H), dim3(256), 0, (hipStream_t)stream, (const h16*)src,
-                       src_stride_l, src_stride_t, src_stride_h, (h16*)dst, dst_stride_l, dst_stride_t, dst_stride_h,
-                       src_t0, dst_t0, n, H, D);
+    hipLaunchKernelGGL(kv_copy_rows_kernel, dim3(gx, L * H, src2 ? 2 : 1), dim3(256), 0, (hipStream_t)stream,
+                       (const h16*)src, src_stride_l, src_stride_t, src_stride_h, (h16*)dst, dst_stride_l, dst_stride_t,
+                       dst_stride_h, src_t0, dst_t0, n, H, D, (const h16*)src2, (h16*)dst2);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}
+
+extern "C" int tf_kv_copy_rows(const void* src, int64_t src_stride_l, int64_t src_stride_t, int64_t src_stride_h,
+                               void* dst, int64_t dst_stride_l, int64_t dst_stride_t, int64_t dst_stride_h,
+                               int src_t0, int dst_t0, int n, int L, int H, int D, void* stream) {
+    return kv_copy_rows_launch(src, nullptr, src_stride_l, src_stride_t, src_stride_h, dst, nullptr, dst_stride_l,
+                               dst_stride_t, dst_stride_h, src_t0, dst_t0, n, L, H, D, stream);
+}
+
+// K and V rows of one cache pair in ONE launch (same strides and row ranges for both): the decode step's tail copies
+extern "C" int tf_kv_copy_rows_pair(const void* src_k, const void* src_v, int64_t src_stride_l, int64_t src_stride_t,
+                                    int64_t src_stride_h, void* dst_k, void* dst_v, int64_t dst_stride_l,
+                                    int64_t dst_stride_t, int64_t dst_stride_h, int src_t0, int dst_t0, int n, int L, int H,
+                                    int D, void* stream) {
+    if (n != 0 && (!src_v || !dst_v)) return TF_EINVAL;
+    return kv_copy_rows_launch(src_k, src_v, src_stride_l, src_stride_t, src_stride_h, dst_k, dst_v, dst_stride_l,
+                               dst_stride_t, dst_stride_h, src_t0, dst_t0, n, L, H, D, stream);
+}
+
+static int kv_shift_rows_launch(void* cache, void* cache2, int64_t stride_l, int64_t stride_t, int64_t stride_h,
+                                int src_t0, int dst_t0, int n, int L, int H, int D, void* stream) {
+    if (n == 0 || src_t0 == dst_t0) return TF_OK;
+    if (!cache || n < 0 || L < 1 || H < 1 || (D % 8) || D > 2048 || dst_t0 > src_t0 || dst_t0 < 0) return TF_EINVAL;
+    if ((stride_t % 8) || (stride_h % 8) || (stride_l % 8)) return TF_EINVAL;
+    hipLaunchKernelGGL(kv_shift_rows_kernel, dim3(L * H, cache2 ? 2 : 1), dim3(256), 0, (hipStream_t)stream, (h16*)cache,
+                       stride_l, stride_t, stride_h, src_t0, dst_t0, n, H, D, (h16*)cache2);
     TF_LAUNCH_CHECK();
     return TF_OK;
 }
 
 extern "C" int tf_kv_shift_rows(void* cache, int64_t stride_l, int64_t stride_t, int64_t stride_h, int src_t0,
                                 int dst_t0, int n, int L, int H, int D, void* stream) {
-    if (n == 0 || src_t0 == dst_t0) return TF_OK;
-    if (!cache || n < 0 || L < 1 || H < 1 || (D % 8) || D > 2048 || dst_t0 > src_t0 || dst_t0 < 0) return TF_EINVAL;
-    if ((stride_t % 8) || (stride_h % 8) || (stride_l % 8)) return TF_EINVAL;
-    hipLaunchKernelGGL(kv_shift_rows_kernel, dim3(L * H), dim3(256), 0, (hipStream_t)stream, (h16*)cache, stride_l,
-                       stride_t, stride_h, src_t0, dst_t0, n, H, D);
-    TF_LAUNCH_CHECK();
-    return TF_OK;
+    return kv_shift_rows_launch(cache, nullptr, stride_l, stride_t, stride_h, src_t0, dst_t0, n, L, H, D, stream);
+}
+
+extern "C" int tf_kv_shift_rows_pair(void* k_cache, void* v_cache, int64_t stride_l, int64_t stride_t, int64_t stride_h,
+                                     int src_t0, int dst_t0, int n, int L, int H, int D, void* stream) {
+    if (n != 0 && src_t0 != dst_t0 && !v_cache) return TF_EINVAL;
+    return kv_shift_rows_launch(k_cache, v_cache, stride_l, stride_t, stride_h, src_t0, dst_t0, n, L, H, D, stream);
 }

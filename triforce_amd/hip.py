@@ -35,6 +35,9 @@ SIGNATURES = {
     "tf_retrieval_gather": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "tf_kv_copy_rows": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "tf_kv_shift_rows": (_i32, [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "tf_kv_copy_rows_pair": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32,
+                                    _i32, _vp]),
+    "tf_kv_shift_rows_pair": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "tf_kv_gather_rows": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "tf_tree_accept": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp]),
     "tf_sample_without_replacement": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
@@ -42,6 +45,7 @@ SIGNATURES = {
     "tf_rope_append": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "tf_silu_mul": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "tf_embed_rows": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "tf_set_tokens": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _i32, _vp]),
     "tf_skinny_gemm": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "tf_skinny_gemm_ex": (_i32, [_vp, _vp, _i64, _vp, _f32, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
     "tf_skinny_gemm_swiglu_ex": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),

@@ -468,8 +468,8 @@ class DistributedLlama:
             else:
                 d = self._layer(idx, x, d, pos, kl, vl, S, S + q_len, q_len, retrieval_build=build, tree=tree)
             if tail is not None:                          # keep the generated rows on the device for the retrieval tail
-                ops.kv_copy_rows(kl.unsqueeze(0), tail.tail_k[idx:idx + 1], S, S - self.prefill_len, q_len)
-                ops.kv_copy_rows(vl.unsqueeze(0), tail.tail_v[idx:idx + 1], S, S - self.prefill_len, q_len)
+                ops.kv_copy_rows_pair(kl.unsqueeze(0), vl.unsqueeze(0), tail.tail_k[idx:idx + 1], tail.tail_v[idx:idx + 1],
+                                      S, S - self.prefill_len, q_len)
             if idx >= n_on:
                 done = torch.cuda.Event()
                 done.record(torch.cuda.current_stream(self.device))
@@ -786,8 +786,7 @@ class DistributedLlama:
             return out
         tail = self.retrieval_cache
         if tail is not None and S >= self.prefill_len:    # device mirror of the generated rows, all layers at once
-            ops.kv_copy_rows(kvc.k, tail.tail_k, S, S - self.prefill_len, q_len)
-            ops.kv_copy_rows(kvc.v, tail.tail_v, S, S - self.prefill_len, q_len)
+            ops.kv_copy_rows_pair(kvc.k, kvc.v, tail.tail_k, tail.tail_v, S, S - self.prefill_len, q_len)
         kvc.seq_len = S + q_len
         return out
 

@@ -172,8 +172,8 @@ class OffloadingFlashSimpleCache(Cache):
     def layer_done(self, layer_idx, slot, n):
         b = layer_idx % 2
         if self.tail_base is not None and slot >= self.tail_base:
-            ops.kv_copy_rows(self.buf_k[b].unsqueeze(0), self.tail_k[layer_idx:layer_idx + 1], slot, slot - self.tail_base, n)
-            ops.kv_copy_rows(self.buf_v[b].unsqueeze(0), self.tail_v[layer_idx:layer_idx + 1], slot, slot - self.tail_base, n)
+            ops.kv_copy_rows_pair(self.buf_k[b].unsqueeze(0), self.buf_v[b].unsqueeze(0), self.tail_k[layer_idx:layer_idx + 1],
+                                  self.tail_v[layer_idx:layer_idx + 1], slot, slot - self.tail_base, n)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.device))
         self.load_stream.wait_event(done)
@@ -238,8 +238,7 @@ class RetrievalCache(Cache):
         if g > self.max_budget:
             raise IndexError(f"generated tail ({g}) exceeds the retrieval budget ({self.max_budget})")
         src_k, src_v, t0 = kv_cache.tail_source(layers, self.prefill)
-        ops.kv_copy_rows(src_k, self.k[layers], t0, self.max_budget - g, g)
-        ops.kv_copy_rows(src_v, self.v[layers], t0, self.max_budget - g, g)
+        ops.kv_copy_rows_pair(src_k, src_v, self.k[layers], self.v[layers], t0, self.max_budget - g, g)
 
     def update_graph_cache(self, kv_cache=None):
         self._copy_tail(kv_cache, slice(0, self.layers))
@@ -322,13 +321,11 @@ class StreamingLLMEvictionCache(Cache):
         if self.seq_len + incoming <= self.start_size + self.recent_size:
             return
         size_keep = self.recent_size - incoming
-        ops.kv_shift_rows(self.k, self.seq_len - size_keep, self.start_size, size_keep)
-        ops.kv_shift_rows(self.v, self.seq_len - size_keep, self.start_size, size_keep)
+        ops.kv_shift_rows_pair(self.k, self.v, self.seq_len - size_keep, self.start_size, size_keep)
         self.seq_len = self.start_size + self.recent_size - incoming
 
     def evict_for_spec(self, current_seq_len):
-        ops.kv_shift_rows(self.k, current_seq_len - self.recent_size, self.start_size, self.recent_size)
-        ops.kv_shift_rows(self.v, current_seq_len - self.recent_size, self.start_size, self.recent_size)
+        ops.kv_shift_rows_pair(self.k, self.v, current_seq_len - self.recent_size, self.start_size, self.recent_size)
 
 
 # =============================================================================================
@@ -516,8 +513,7 @@ class DistributedRetrievalCache:
             return
         if g > self.max_budget:
             raise IndexError(f"generated tail ({g}) exceeds the retrieval budget ({self.max_budget})")
-        ops.kv_copy_rows(self.tail_k, self.k, 0, self.max_budget - g, g)
-        ops.kv_copy_rows(self.tail_v, self.v, 0, self.max_budget - g, g)
+        ops.kv_copy_rows_pair(self.tail_k, self.tail_v, self.k, self.v, 0, self.max_budget - g, g)
 
     def reset(self):
         self.k.zero_()

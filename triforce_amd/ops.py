@@ -253,6 +253,20 @@ def embed_rows(embed, ids, packed, out=None):
     return x
 
 
+def set_tokens(dst, vals, pad, pos=None, pos0=0, slot=None, sk=None, sk_val=0):
+    """dst (int64, <= 32 entries) = vals padded with ``pad``; pos (int64) = pos0 + arange; slot / sk (int32 scalars) =
+    pos0 / sk_val — one launch, the ids passed as kernel arguments (tf_set_tokens).  ``vals``: python ints."""
+    n_dst = 0 if dst is None else dst.numel()
+    n_vals = len(vals)
+    assert n_vals <= 32 and n_dst <= 32 and (dst is None or (dst.dtype == torch.int64 and dst.is_contiguous()))
+    assert pos is None or (pos.dtype == torch.int64 and pos.is_contiguous() and pos.numel() <= 64)
+    assert (slot is None or slot.dtype == torch.int32) and (sk is None or sk.dtype == torch.int32)
+    _dev(dst, pos, slot, sk)
+    host = (ctypes.c_int64 * max(n_vals, 1))(*[int(v) for v in vals])
+    hip.check(hip.lib().tf_set_tokens(_ptr(dst), n_dst, host, n_vals, int(pad), _ptr(pos), 0 if pos is None else pos.numel(),
+                                      int(pos0), _ptr(slot), _ptr(sk), int(sk_val), _stream()), "tf_set_tokens")
+
+
 def can_fuse(x, *ws):
     """True when the fused decode kernels apply: HIP tensors, <= 32 rows, every weight packed."""
     return (x.is_cuda and x.dim() == 2 and x.shape[0] <= SKINNY_MAX_ROWS and x.dtype == _HALF and x.stride(1) == 1
@@ -683,6 +697,45 @@ def kv_shift_rows(cache, src_t0, dst_t0, n):
     sl, st, sh = _lhtd(cache)
     hip.check(hip.lib().tf_kv_shift_rows(_ptr(cache), sl, st, sh, int(src_t0), int(dst_t0), int(n), L, H, D,
                                          _stream()), "tf_kv_shift_rows")
+
+
+def kv_copy_rows_pair(src_k, src_v, dst_k, dst_v, src_t0, dst_t0, n):
+    """kv_copy_rows for the K and the V tensor of one cache in ONE launch (same shapes / strides), else two."""
+    if n <= 0:
+        return
+    if not (src_k.shape == src_v.shape and dst_k.shape == dst_v.shape and _lhtd(src_k) == _lhtd(src_v)
+            and _lhtd(dst_k) == _lhtd(dst_v)):
+        kv_copy_rows(src_k, dst_k, src_t0, dst_t0, n)
+        kv_copy_rows(src_v, dst_v, src_t0, dst_t0, n)
+        return
+    _dev(src_k, src_v, dst_k, dst_v)
+    L, H, _, D = src_k.shape
+    assert dst_k.shape[0] == L and dst_k.shape[1] == H and dst_k.shape[3] == D
+    if src_t0 < 0 or dst_t0 < 0 or src_t0 + n > src_k.shape[2] or dst_t0 + n > dst_k.shape[2]:
+        raise IndexError(f"kv_copy_rows: rows [{src_t0}, {src_t0 + n}) of {src_k.shape[2]} -> [{dst_t0}, {dst_t0 + n}) of "
+                         f"{dst_k.shape[2]} leave the cache (the kernel does not bounds-check)")
+    ssl, sst, ssh = _lhtd(src_k)
+    dsl, dst_t, dsh = _lhtd(dst_k)
+    hip.check(hip.lib().tf_kv_copy_rows_pair(_ptr(src_k), _ptr(src_v), ssl, sst, ssh, _ptr(dst_k), _ptr(dst_v), dsl, dst_t,
+                                             dsh, int(src_t0), int(dst_t0), int(n), L, H, D, _stream()),
+              "tf_kv_copy_rows_pair")
+
+
+def kv_shift_rows_pair(k_cache, v_cache, src_t0, dst_t0, n):
+    """kv_shift_rows for the K and the V tensor of one cache in ONE launch (same shapes / strides), else two."""
+    if n <= 0 or src_t0 == dst_t0:
+        return
+    if not (k_cache.shape == v_cache.shape and _lhtd(k_cache) == _lhtd(v_cache)):
+        kv_shift_rows(k_cache, src_t0, dst_t0, n)
+        kv_shift_rows(v_cache, src_t0, dst_t0, n)
+        return
+    _dev(k_cache, v_cache)
+    L, H, T, D = k_cache.shape
+    if src_t0 < 0 or dst_t0 < 0 or src_t0 + n > T or dst_t0 + n > T:
+        raise IndexError(f"kv_shift_rows: rows [{src_t0}, {src_t0 + n}) -> [{dst_t0}, {dst_t0 + n}) leave the {T}-row cache")
+    sl, st, sh = _lhtd(k_cache)
+    hip.check(hip.lib().tf_kv_shift_rows_pair(_ptr(k_cache), _ptr(v_cache), sl, st, sh, int(src_t0), int(dst_t0), int(n),
+                                              L, H, D, _stream()), "tf_kv_shift_rows_pair")
 
 
 def kv_gather_rows(k_cache, v_cache, offset, idx, max_index=None):

@@ -130,7 +130,8 @@ class _SpecBuffers:
 
     def __init__(self, device, gamma, vocab, graph_engine=None, mailbox=False):
         tok_buf = getattr(graph_engine, "tok_buf", None)
-        if tok_buf is not None and tok_buf.shape[1] >= gamma + 1:
+        self.shared_inputs = tok_buf is not None and tok_buf.shape[1] >= gamma + 1
+        if self.shared_inputs:
             # the engine's graphs read their tokens / positions from these very buffers: no input copies per replay
             self.verify_tokens = tok_buf[:, :gamma + 1]
             self.positions = graph_engine.pos_buf
@@ -187,15 +188,21 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
     n = accepted = drafted = 0
     ids = [int(next_token)]
     vt = buffers.verify_tokens
-    vt.fill_(PAD_TOKEN)
-    vt[0, 0] = ids[0]
-    position_ids = torch.add(buffers.pos_base, S, out=buffers.positions)
+    # [next, PAD...] and the gamma + 1 positions S, S + 1, ... in one launch (the token id travels as a kernel argument)
+    position_ids = buffers.positions
+    ops.set_tokens(vt, ids, PAD_TOKEN, pos=position_ids, pos0=S)
     # the engines' graph replays can hand out their static output buffers (valid until the same graph replays again):
     # q_d and p are consumed by tf_middle_accept / the spec_rows copies before the next iteration asks for new ones
     noclone = dict(clone=False) if getattr(graph_engine, "static_outputs", False) else {}
+    # the draft / verify graphs read vt itself: replay without looking at the inputs (this call sits between the host's
+    # read of the previous accept record and the next launch — the one place where host time is GPU idle time)
+    replay_draft = getattr(graph_engine, "replay_draft", None) if (noclone and buffers.shared_inputs) else None
+    flat = vt.view(-1)
     while n < gamma:
-        q_d = graph_engine.graph_draft_inference(input_ids=vt[:, :n + 1], gamma_offset=n, **noclone)
-        flat = vt.view(-1)
+        if replay_draft is not None:
+            q_d = replay_draft(n)
+        else:
+            q_d = graph_engine.graph_draft_inference(input_ids=vt[:, :n + 1], gamma_offset=n, **noclone)
         u = rng.take(3)
         ops.sample_inverse_cdf(q_d, u[0:1], flat[n + 1:n + 2])               # d ~ q_d, written into verify_tokens
         if sync_record is not None:           # TP: rank 0's draft token is everyone's BEFORE the all-reduced verify runs
@@ -338,16 +345,23 @@ class TriForceRunner:
         self.inner_iters += int(round(g2 / (1.0 + acc_mid)))        # g2 = iterations + accepted drafts
 
         # target model verifies [next, t1..t_g2] against the full KV cache
-        verify_tokens = bufs.to_device(ids)
         rebuild = self.rebuild_every > 0 and (len(self.counts) + 1) % self.rebuild_every == 0
         self.rebuilds += int(rebuild)
         eager = self.eager_every > 0 and (len(self.counts) + 1) % self.eager_every == 0
-        if self.top_k <= 0 and hasattr(ge, "verify_probs"):          # one hipGraph: forward + temperature / top-p
-            probs = ge.verify_probs(verify_tokens, self.temperature, self.top_p, rebuild_retrieval=rebuild, eager=eager)
+        fast = None
+        if self.top_k <= 0 and not rebuild and not eager and hasattr(ge, "verify_probs_ids"):
+            # captured forward + temperature / top-p: ids, positions and lengths set by ONE launch (ids as kernel arguments)
+            fast = ge.verify_probs_ids(ids, self.temperature, self.top_p)
+        if fast is not None:
+            probs, verify_tokens = fast
         else:
-            logits = ge.inference(input_ids=verify_tokens, rebuild_retrieval=True) if rebuild \
-                else (ge.inference(input_ids=verify_tokens, eager=True) if eager else ge.inference(input_ids=verify_tokens))
-            probs = norm_logits(logits[0], temperature=self.temperature, top_k=self.top_k, top_p=self.top_p)
+            verify_tokens = bufs.to_device(ids)
+            if self.top_k <= 0 and hasattr(ge, "verify_probs"):      # one hipGraph: forward + temperature / top-p
+                probs = ge.verify_probs(verify_tokens, self.temperature, self.top_p, rebuild_retrieval=rebuild, eager=eager)
+            else:
+                logits = ge.inference(input_ids=verify_tokens, rebuild_retrieval=True) if rebuild \
+                    else (ge.inference(input_ids=verify_tokens, eager=True) if eager else ge.inference(input_ids=verify_tokens))
+                probs = norm_logits(logits[0], temperature=self.temperature, top_k=self.top_k, top_p=self.top_p)
         if getattr(bufs, "rows_generation", None) is not None:
             # spec_rows is a view of the retrieval-verify graph's static output: nothing may have replayed that graph
             # between Middle_Spec's return and this read (the target verify above is a different graph)
@@ -369,6 +383,25 @@ class TriForceRunner:
         self.last_reason = reason          # 0 rejection + resample, 1 everything accepted (bonus token), 2 accepted eos
 
         pass_tokens = [next_token] + generated[:count] + [PAD_TOKEN] * (g2 + 1 - count)
+        if reason != 2:
+            pass_tokens[count + 1] = pred             # the resampled (:111-118) or the bonus (:127-134) token
+
+        # Launch order (not the reference's statement order; the three pieces touch disjoint buffers): the 68M catch-up
+        # forward (:137-139) goes FIRST — ~120 us of device work behind which the host issues the tail copies, the window
+        # shift and the next iteration's first launches; issued last, each of those short launches was a host-bound gap
+        # (profiles/r04_gap_analysis_decode_steps.txt).
+        tok_buf = getattr(ge, "tok_buf", None)
+        if tok_buf is not None and tok_buf.shape[0] == 1 and tok_buf.shape[1] >= len(pass_tokens) and tok_buf.is_cuda:
+            # straight into the draft graphs' static input (the next Middle_Spec re-initialises it): one launch, no copies
+            row = tok_buf[:, :len(pass_tokens)]
+            ops.set_tokens(row, pass_tokens, PAD_TOKEN)
+            ge.graph_draft_inference(input_ids=row, gamma_offset=g2 + 1)
+        else:
+            ge.graph_draft_inference(input_ids=bufs.to_device(pass_tokens), gamma_offset=g2 + 1)
+
+        eng.kv_cache.seq_len -= (g2 - count)                              # rollback (:124)
+        ge.update_graph_cache()                                           # refresh the retrieval tail (:125)
+
         self.accepted_count += count
         self.n += count
         self.emitted += generated[:count]
@@ -378,28 +411,20 @@ class TriForceRunner:
         if reason == 0:                                                   # rejection -> residual resample (:111-118)
             self.resample_count += 1
             self.n += 1
-            pass_tokens[count + 1] = pred
             self.emitted.append(pred)
             if verbose:
                 spec_stream(pred, tokenizer, "red")
         elif reason == 2:                                                 # accepted eos (:108-110)
             self.draft_count -= g2 - count
-
-        eng.kv_cache.seq_len -= (g2 - count)                              # rollback (:124)
-        ge.update_graph_cache()                                           # refresh the retrieval tail (:125)
-
-        if reason == 1:                                                   # everything accepted -> bonus token (:127-134)
+        else:                                                             # everything accepted -> bonus token (:127-134)
             self.target_sample_count += 1
             self.n += 1
-            pass_tokens[count + 1] = pred
             self.emitted.append(pred)
             if verbose:
                 spec_stream(pred, tokenizer, "blue")
             count += 1
         self.counts.append(count)
 
-        # bring the 68M cache up to date (:137-139)
-        ge.graph_draft_inference(input_ids=bufs.to_device(pass_tokens), gamma_offset=g2 + 1)
         dc = eng.draft_cache
         dc.evict_for_spec(dc.start_size + dc.recent_size + count)
         self.next_token = pred

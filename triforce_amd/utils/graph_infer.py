@@ -12,6 +12,7 @@ from typing import Optional
 
 import torch
 
+from .. import ops
 from .sampling import norm_logits
 
 
@@ -280,14 +281,22 @@ class _TargetGraph:
         self.graph, (self.logits, self.out_probs) = _capture(run, (), mempool, n_warmups)
 
     def __call__(self, input_ids):
+        """input_ids: a (1, q_len) device tensor, or a python list of q_len ids (then they travel as kernel arguments)."""
         kvc = self.engine.kv_cache
         S = kvc.seq_len
         if S + self.q_len > kvc.max_budget:
             raise IndexError(f"FlashSimpleCache overflow: {S}+{self.q_len} > {kvc.max_budget}")
-        self.ids.copy_(input_ids)
-        torch.add(self.base, S, out=self.pos)
-        self.slot.fill_(S)
-        self.sk.fill_(S + self.q_len)
+        if isinstance(input_ids, (list, tuple)):
+            assert len(input_ids) == self.q_len
+            ops.set_tokens(self.ids, input_ids, 0, pos=self.pos, pos0=S, slot=self.slot, sk=self.sk, sk_val=S + self.q_len)
+        elif self.ids.is_cuda:
+            self.ids.copy_(input_ids)
+            ops.set_tokens(None, (), 0, pos=self.pos, pos0=S, slot=self.slot, sk=self.sk, sk_val=S + self.q_len)
+        else:
+            self.ids.copy_(input_ids)
+            torch.add(self.base, S, out=self.pos)
+            self.slot.fill_(S)
+            self.sk.fill_(S + self.q_len)
         self.graph.replay()
         kvc.seq_len = S + self.q_len
         return self.logits, self.out_probs
@@ -373,6 +382,17 @@ class GraphInferenceEngine:
         return norm_logits(logits[0], temperature=temperature, top_k=-1, top_p=top_p)
 
     @torch.inference_mode()
+    def verify_probs_ids(self, ids, temperature, top_p):
+        """``verify_probs`` for a python list of token ids when the captured target graph of that length exists with these
+        sampling settings: (probabilities, the graph's (1, q_len) device token row), else None (caller: tensor path).
+        One launch sets ids, positions and lengths (tf_set_tokens) in front of the replay."""
+        tg = self.target_graphs.get(len(ids))
+        if tg is None or tg.cache is not self.engine.kv_cache or not tg.probs or not tg.ids.is_cuda \
+                or (temperature, top_p) != (self.sampling["temperature"], self.sampling["top_p"]):
+            return None
+        return tg(list(ids))[1], tg.ids
+
+    @torch.inference_mode()
     def decode_step(self, input_ids):
         """One autoregressive step (q_len == 1, no retrieval build) over the full cache: the captured graph when there
         is one, else the eager forward the reference runs (decoding.py:28)."""
@@ -389,6 +409,16 @@ class GraphInferenceEngine:
     def graph_draft_inference(self, input_ids: torch.LongTensor, gamma_offset: int = 0, clone=True):
         fn = self.callables[gamma_offset]
         return fn(input_ids, clone=clone) if isinstance(fn, _GraphedCall) else fn(input_ids)
+
+    def replay_draft(self, gamma_offset):
+        """graph_draft_inference(tok_buf[:, :gamma_offset + 1], gamma_offset, clone=False) for a caller that has written
+        the tokens into ``tok_buf`` itself: the replay and nothing else."""
+        fn = self.callables[gamma_offset]
+        if not isinstance(fn, _GraphedCall):
+            return fn(self.tok_buf[:, :gamma_offset + 1])
+        fn.graph.replay()
+        fn.generation += 1
+        return fn.output
 
     @torch.inference_mode()
     def graph_verify(self, input_ids: torch.LongTensor, position_ids: torch.LongTensor, clone=True):
