@@ -37,6 +37,9 @@ VARIANTS = {"q2occ1": ["TF_ATTN_QT2_OCC=0"],
             "bigmerge": ["FUSED_MERGE_BIG_SPLITS=64"], "rscoreceil": ["TF_RSCORE_CAP_CEIL=1"],
             "sgtail0": ["SG_TAIL_BATCH=0"],          # K-loop tail one chunk at a time (round 3)
             "sgprol0": ["SG_PROLOGUE_ORDER=0"],      # norm-GEMM prologue in round 3's load order (weights first, x after the fold)
+            "sgprol1": ["SG_PROLOGUE_ORDER=1"],      # ... in round 4's first form (same order behind branches: the compiler threads it)
+            "lnpre": ["SG_LN_PRE=1"],                # the first batch's norm weights prefetched with the prologue (+16 registers)
+            "nopreload": ["!kernarg-preload"],       # built without -mllvm -amdgpu-kernarg-preload-count=14
             "ring4ps1": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_RING_Q1=4", "TF_ATTN_RING_Q2=4", "TF_ATTN_QT2_OCC=1", "TF_ATTN_P_SPLIT=1"]}
 
 if __name__ == "__main__":

@@ -8,8 +8,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtriforce_hip.so")
 SOURCES = ["attn.hip", "retrieval.hip", "elementwise.hip", "sampling.hip", "offload.hip", "gemv.hip", "allreduce.hip", "draft.hip", "abi.hip"]
+# -amdgpu-kernarg-preload-count: the leading pointer / scalar kernel arguments (up to 14 dwords) arrive in SGPRs with the
+# dispatch instead of through s_load + s_waitcnt at the top of every kernel (gfx950 hardware feature; the compiler keeps a
+# backward-compatible entry for firmware without it).  The decode kernels order their arguments for it (csrc/gemv.hip).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fno-gpu-rdc", "-Wno-unused-result"]
+         "-fno-gpu-rdc", "-Wno-unused-result", "-mllvm", "-amdgpu-kernarg-preload-count=14"]
 
 
 def hipcc_path():
@@ -35,7 +38,13 @@ def needs_build():
 def build_variant(name, defines, verbose=True):
     """Tuning builds (A/B of compile-time knobs): lib/libtriforce_hip_<name>.so, selected with TRIFORCE_HIP_LIB."""
     out = os.path.join(LIB_DIR, f"libtriforce_hip_{name}.so")
-    cmd = [hipcc_path()] + FLAGS + [f"-D{d}" for d in defines] + sources() + ["-o", out]
+    # "NAME=VALUE" -> -DNAME=VALUE; an entry that starts with "-" is a raw compiler flag, "!-flag" removes a default flag
+    drop = {d[1:] for d in defines if d.startswith("!")}
+    flags = [f for f in FLAGS if f not in drop]
+    if "kernarg-preload" in drop:                                # "!kernarg-preload": build without the preload flag pair
+        flags = [f for f in flags if f != "-mllvm" and not f.startswith("-amdgpu-kernarg-preload-count")]
+    cmd = [hipcc_path()] + flags + [d if d.startswith("-") else f"-D{d}" for d in defines if not d.startswith("!")] \
+        + sources() + ["-o", out]
     if verbose:
         print("[triforce_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -1556,6 +1556,17 @@ __global__ __launch_bounds__(D * COMBINE_GROUPS) void attn_combine_kernel(const 
     const float* ws_m = ws + (int64_t)H * nsplit * QR * D;
     const float* ws_l = ws_m + (int64_t)H * nsplit * QR;
     const int64_t base = (int64_t)h * nsplit * QR + qq;
+    // this thread's partial outputs (splits g, g + 8, ...) are requested TOGETHER with the split maxima — they do not
+    // depend on them; loaded after the weights were known they were a second dependent round trip (the partials come from
+    // other XCDs' workgroups: Infinity-Cache latency) in a 6 us kernel.  Unconditional loads (clamped split index): a
+    // predicated load makes the compiler branch and wait per load.
+    constexpr int CPT = COMBINE_MAX_SPLITS / COMBINE_GROUPS;
+    float ov[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int sc = min(g + i * COMBINE_GROUPS, nsplit - 1);
+        ov[i] = ws_o[(base + (int64_t)sc * QR) * D + d];
+    }
     if (tid < nsplit) {
         sm_w[tid] = ws_m[base + (int64_t)tid * QR];
         sm_l[tid] = ws_l[base + (int64_t)tid * QR];
@@ -1571,8 +1582,11 @@ __global__ __launch_bounds__(D * COMBINE_GROUPS) void attn_combine_kernel(const 
     }
     __syncthreads();
     float o = 0.f;
-#pragma unroll 4
-    for (int s = g; s < nsplit; s += COMBINE_GROUPS) o = fmaf(ws_o[(base + (int64_t)s * QR) * D + d], sm_w[s], o);
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {                                  // same splits in the same order as `for s = g; s += 8`
+        const int s = g + i * COMBINE_GROUPS;
+        if (s < nsplit) o = fmaf(ov[i], sm_w[s], o);
+    }
     sm_o[g][d] = o;
     __syncthreads();
     if (g == 0) {

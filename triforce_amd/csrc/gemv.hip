@@ -49,8 +49,14 @@
 #ifndef SG_TAIL_BATCH
 #define SG_TAIL_BATCH 1         // 1: the last 1..U-1 k-chunks of a wave as one batch of loads (round 4); 0: one chunk at a time
 #endif
+#ifndef SG_LN_PRE
+#define SG_LN_PRE 0             // 1: the first batch's norm weights are loaded with the prologue too (+16 registers: the one-tile
+                                // gate|up form drops from 4 to 3 waves per SIMD)
+#endif
 #ifndef SG_PROLOGUE_ORDER
-#define SG_PROLOGUE_ORDER 1     // 1: norm partials, x rows, then weights (round 4); 0: weights first, x after the fold (round 3)
+#define SG_PROLOGUE_ORDER 2     // 2: norm partials, x rows, norm weights, weights in ONE basic block (unconditional loads,
+                                // pinned in front of the fold); 1: the same order behind branches — which the compiler
+                                // threads into "partials, WAIT, fold, then the rest"; 0: weights first, x after the fold (round 3)
 #endif
 #ifndef TF_SG_RES_EARLY
 #define TF_SG_RES_EARLY 1   // residual epilogue operands fetched before the weight loop (0: at the tail, round 2's form)
@@ -195,14 +201,21 @@ __device__ __forceinline__ half8 sg_normalise(half8 xv, half8 wv, float inv) {
 }
 
 template <int MT, int MODE, bool NORM, int WAVES, int P, bool KSPLIT, bool XCHG = false, int UX = 1>
+// Argument order: what the PROLOGUE needs comes first, as plain pointers / scalars — weights, x and its two strides, the
+// norm partials and weights, K, M: 14 dwords, the most the hardware preloads into SGPRs with the dispatch (built with
+// -mllvm -amdgpu-kernarg-preload-count=14, triforce_amd/build.py): the first loads are issued without waiting for the
+// kernel-argument segment to arrive through the scalar cache; everything the epilogue needs follows (by-value structs end
+// the preloadable run).
 __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __restrict__ wp,
                                                                  const half8* __restrict__ wp_up,
-                                                                 const h16* __restrict__ x, SgAct xa,
-                                                                 const h16* __restrict__ ln_w, float eps,
-                                                                 const h16* resid, SgAct ra, void* yv, SgAct ya,
-                                                                 int M, int N, int K, SgRope rp,
+                                                                 const h16* __restrict__ x,
                                                                  const float* __restrict__ ss_in,
-                                                                 float* __restrict__ ss_out, SgKsplit kx, SgXchg xc) {
+                                                                 const h16* __restrict__ ln_w, int K, int M,
+                                                                 int xa_sm, int xa_sk, float eps, int N,
+                                                                 const h16* resid, SgAct ra, void* yv, SgAct ya,
+                                                                 SgRope rp, float* __restrict__ ss_out, SgKsplit kx,
+                                                                 SgXchg xc) {
+    const SgAct xa = {(int64_t)xa_sm, (int64_t)xa_sk};          // (32-bit in the argument list: two more preloaded dwords)
     static_assert(!XCHG || (MODE == SG_PLAIN && P == 1 && !KSPLIT), "the exchange form is the plain one-panel GEMM");
     constexpr bool GATEUP = MODE == SG_GATEUP;
     constexpr int NA = GATEUP ? 2 : 1;                       // weight streams (accumulator sets) per panel
@@ -258,9 +271,70 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
     constexpr int G = WAVES * 4;
     const int nparts = K >> 4;
     const int pg = tid >> 4, m16 = tid & 15;
-    float ssv[MT][SSB][8];
-    half8 a_pre[U][P][NA], b_pre[BPRE ? U : 1][MT];
+    float ssv[MT][SSB][8], part0[MT];
+    constexpr bool LNPRE = BPRE && SG_PROLOGUE_ORDER == 2 && SG_LN_PRE != 0;   // norm weights of the first batch fetched up front
+    half8 a_pre[U][P][NA], b_pre[BPRE ? U : 1][MT], ln_pre[LNPRE ? U : 1];
     const bool pre = NORM && (c0 + U <= c1);
+#if SG_PROLOGUE_ORDER == 2
+    if constexpr (NORM) {
+        // ONE basic block: every load below is unconditional (clamped index + select; a null ss_in reads the head of the
+        // weights instead — the values are not used), nothing between them can wait, and the block is pinned in front of
+        // the fold.  With the loads behind `if (ss_in)` / `if (pre)` / `p < nparts ? :` the compiler (a) branched around
+        // every partial load and sank the first addition into the first branch — `global_load; s_waitcnt vmcnt(0); v_add` at
+        // the very top of the kernel — and (b) threaded the two `if (ss_in)` regions together: partials, s_waitcnt
+        // vmcnt(0), the fold's additions, and only THEN the x rows and the first weights: two dependent memory round trips
+        // (Infinity Cache, then HBM) where the source asked for one.
+        const float* ssp = ss_in ? ss_in : reinterpret_cast<const float*>(wp);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int bb = 0; bb < SSB; ++bb)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int p = pg + bb * 8 * G + j * G;
+                    const float v = ssp[(int64_t)min(p, nparts - 1) * 32 + t * 16 + m16];
+                    ssv[t][bb][j] = (p < nparts) ? v : 0.f;
+                }
+        if constexpr (BPRE) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int cu = min(c0 + u, nchunks - 1);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const half8 v = load_half8(xr[t] + xcs * cu);
+                    b_pre[u][t] = xok[t] ? v : zero8;
+                }
+                if constexpr (LNPRE) ln_pre[u] = load_half8(ln_w + 32 * cu + 8 * g);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cu = min(c0 + u, nchunks - 1);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                a_pre[u][j][0] = SG_LOAD(wa + j * pstride + (int64_t)cu * 64);
+                if (GATEUP) a_pre[u][j][NA - 1] = SG_LOAD(wu + j * pstride + (int64_t)cu * 64);
+            }
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // the partials' first additions stay in THIS block (their loads can then not be sunk below the weights' loads into
+        // the fold's branch): they wait for the partials only — the x rows and the weights stay in flight behind them.
+        // Adding the zeros of the entries past nparts is the identity (the sums are non-negative): same bits as the
+        // guarded form.
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            float part = 0.f;
+#pragma unroll
+            for (int bb = 0; bb < SSB; ++bb)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) part += ssv[t][bb][j];
+            asm volatile("" : "+v"(part));                              // materialised HERE: nothing above may sink below
+            part0[t] = part;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #if SG_PROLOGUE_ORDER == 0
     if (pre) {                                               // round 3's order (A/B): weights first
 #pragma unroll
@@ -300,6 +374,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
             }
     }
 #endif
+#endif
 
     SG_STAMP(1);
     float inv[MT];
@@ -314,6 +389,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
             float* red = &sm[0][0][0][0][0];                            // reuse the merge buffer: [MT][G][16] floats
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
+#if SG_PROLOGUE_ORDER == 2
+                float part = part0[t];                                  // summed next to the loads (see there)
+#else
                 float part = 0.f;
 #pragma unroll
                 for (int bb = 0; bb < SSB; ++bb)                        // (same order of additions as the loop below)
@@ -321,6 +399,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
 #pragma unroll
                         for (int j = 0; j < 8; ++j) part += ssv[t][bb][j];
                     }
+#endif
                 for (int p0 = pg + SSB * 8 * G; p0 < nparts; p0 += 8 * G) {
                     float v[8];
 #pragma unroll
@@ -465,7 +544,12 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
             for (int t = 0; t < MT; ++t) {
                 if (BPRE && NORM && c == c0 && pre) b[u][t] = b_pre[BPRE ? u : 0][t];
                 else b[u][t] = xok[t] ? load_half8(xr[t] + xcs * (c + u)) : zero8;
-                if (NORM) b[u][t] = sg_normalise(b[u][t], load_half8(ln_w + 32 * (c + u) + 8 * g), inv[t]);
+                if (NORM) {
+                    half8 lw;
+                    if (LNPRE && c == c0 && pre) lw = ln_pre[LNPRE ? u : 0];
+                    else lw = load_half8(ln_w + 32 * (c + u) + 8 * g);
+                    b[u][t] = sg_normalise(b[u][t], lw, inv[t]);
+                }
             }
         }
 #pragma unroll
@@ -830,22 +914,23 @@ static void launch_sg_w(const SgArgs& a, const SgRope& rp, hipStream_t st) {
         sg_pick_ksplit<MT, (MODE == SG_GATEUP ? 2 : 1), WAVES, P>(a, kx);      // (stamps pointer of the instrumented build)
         kx.ws = nullptr, kx.tickets = nullptr;
         hipLaunchKernelGGL((skinny_gemm_kernel<MT, MODE, NORM, WAVES, P, false, false, UX>), dim3(a.N / 16 / P), dim3(WAVES * 64),
-                           0, st, (const half8*)a.wp, (const half8*)a.wp_up, (const h16*)a.x, a.xa, (const h16*)a.ln_w, a.eps,
-                           (const h16*)a.resid, a.ra, a.y, a.ya, a.M, a.N, a.K, rp, a.ss_in, a.ss_out, kx, SgXchg{});
+                           0, st, (const half8*)a.wp, (const half8*)a.wp_up, (const h16*)a.x, a.ss_in, (const h16*)a.ln_w, a.K, a.M,
+                           (int)a.xa.sm, (int)a.xa.sk, a.eps, a.N, (const h16*)a.resid, a.ra, a.y, a.ya, rp, a.ss_out, kx, SgXchg{});
         return;
     }
     if constexpr (P == 1 && MODE != SG_F32) {                     // few-panel grids only: never the P = 2 form, never lm_head
         const int ks = sg_pick_ksplit<MT, (MODE == SG_GATEUP ? 2 : 1), WAVES, P>(a, kx);
         if (ks > 1) {
             hipLaunchKernelGGL((skinny_gemm_kernel<MT, MODE, NORM, WAVES, P, true>), dim3(a.N / 16 / P, ks), dim3(WAVES * 64),
-                               0, st, (const half8*)a.wp, (const half8*)a.wp_up, (const h16*)a.x, a.xa, (const h16*)a.ln_w,
-                               a.eps, (const h16*)a.resid, a.ra, a.y, a.ya, a.M, a.N, a.K, rp, a.ss_in, a.ss_out, kx, SgXchg{});
+                               0, st, (const half8*)a.wp, (const half8*)a.wp_up, (const h16*)a.x, a.ss_in, (const h16*)a.ln_w, a.K, a.M,
+                               (int)a.xa.sm, (int)a.xa.sk, a.eps, a.N, (const h16*)a.resid, a.ra, a.y, a.ya, rp, a.ss_out, kx,
+                               SgXchg{});
             return;
         }
     }
     hipLaunchKernelGGL((skinny_gemm_kernel<MT, MODE, NORM, WAVES, P, false>), dim3(a.N / 16 / P), dim3(WAVES * 64), 0, st,
-                       (const half8*)a.wp, (const half8*)a.wp_up, (const h16*)a.x, a.xa, (const h16*)a.ln_w, a.eps,
-                       (const h16*)a.resid, a.ra, a.y, a.ya, a.M, a.N, a.K, rp, a.ss_in, a.ss_out, kx, SgXchg{});
+                       (const half8*)a.wp, (const half8*)a.wp_up, (const h16*)a.x, a.ss_in, (const h16*)a.ln_w, a.K, a.M,
+                       (int)a.xa.sm, (int)a.xa.sk, a.eps, a.N, (const h16*)a.resid, a.ra, a.y, a.ya, rp, a.ss_out, kx, SgXchg{});
 }
 
 template <int MODE, bool NORM>
@@ -903,7 +988,8 @@ static int launch_sg(const SgArgs& a, const SgRope& rp, hipStream_t st) {
 static bool sg_act_ok(const SgAct& s) { return s.sm > 0 && s.sk > 0 && (s.sm % 8) == 0 && (s.sk % 8) == 0; }
 
 static bool sg_shape_ok(int M, int N, int K, const SgAct& xa) {
-    return M >= 1 && M <= 32 && N >= 16 && (N % 16) == 0 && K >= 32 && (K % 32) == 0 && sg_act_ok(xa);
+    return M >= 1 && M <= 32 && N >= 16 && (N % 16) == 0 && K >= 32 && (K % 32) == 0 && sg_act_ok(xa) &&
+           xa.sm <= 0x7fffffff && xa.sk <= 0x7fffffff;     // (the kernel takes x's two strides as 32-bit arguments)
 }
 
 // A/B knobs of the launch rule (tools/gemm_layout_ab.py): key 0 = rows from which two panels per wave are used (33:
@@ -1074,8 +1160,9 @@ extern "C" int tf_skinny_gemm_xchg(const void* w_packed, const void* x, int64_t 
     const bool wide = nchunks >= 2 * SG_WAVES_WIDE;
 #define XCHG_LAUNCH(MT_, W_)                                                                                                  \
     hipLaunchKernelGGL((skinny_gemm_kernel<MT_, SG_PLAIN, false, W_, 1, false, true, 1>), dim3(N / 16), dim3(W_ * 64), 0, st, \
-                       (const half8*)a.wp, (const half8*)nullptr, (const h16*)a.x, a.xa, (const h16*)nullptr, 0.f,          \
-                       (const h16*)a.resid, a.ra, a.y, a.ya, a.M, a.N, a.K, rp, (const float*)nullptr, a.ss_out, kx, xc)
+                       (const half8*)a.wp, (const half8*)nullptr, (const h16*)a.x, (const float*)nullptr,              \
+                       (const h16*)nullptr, a.K, a.M, (int)a.xa.sm, (int)a.xa.sk, 0.f, a.N, (const h16*)a.resid, a.ra, a.y, a.ya, rp, a.ss_out, \
+                       kx, xc)
     if (M <= 16) {
         if (wide) XCHG_LAUNCH(1, SG_WAVES_WIDE);
         else XCHG_LAUNCH(1, SG_WAVES);
