@@ -31,7 +31,7 @@ def needs_build():
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "tree_mask.h"),
-                        os.path.join(HERE, "..", "include", "triforce_hip.h")]
+                        os.path.join(HERE, "..", "include", "triforce_hip.h"), os.path.abspath(__file__)]   # (flags live here)
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
