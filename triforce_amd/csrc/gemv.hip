@@ -53,6 +53,9 @@
 #define SG_LN_PRE 0             // 1: the first batch's norm weights are loaded with the prologue too (+16 registers: the one-tile
                                 // gate|up form drops from 4 to 3 waves per SIMD)
 #endif
+#ifndef SG_EPI_LATE
+#define SG_EPI_LATE 1           // forms without a norm prologue fetch their epilogue operands behind the first weight batch
+#endif
 #ifndef SG_PROLOGUE_ORDER
 #define SG_PROLOGUE_ORDER 2     // 2: norm partials, x rows, norm weights, weights in ONE basic block (unconditional loads,
                                 // pinned in front of the fold); 1: the same order behind branches — which the compiler
@@ -477,53 +480,56 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
     const bool epi = wave < P;
     const int panel = panel0 + (epi ? wave : 0);
 
-    // exchange form: this launch's epoch and the sticky error word, read now (uncached round trips) under the weight stream
+    // Operands of the epilogue, fetched early so that no dependent round trip is left at the tail of the kernel: the
+    // exchange's epoch and sticky error word (uncached), the RoPE tables (positions -> table: two dependent loads), this
+    // lane's residual values.  They need the TAIL of the argument list (not preloaded into SGPRs): the forms without a norm
+    // prologue run this after their first batch of weight loads has been issued (prefetch_epi below) — issued before, the
+    // wait for the argument segment stood in front of the first weight load of every o_proj / down_proj.
     unsigned xepoch = 0, xerr = 0;
-    if constexpr (XCHG) {
-        if (epi) {
-            // every panel counts its own exchanges (written at the end of this panel's previous exchange, an earlier
-            // launch of the stream): no grid-wide epoch, so no ticket and no last-workgroup tail at the end of the kernel
-            xepoch = xc_ld(&xc.pepoch[panel]) + 1u;
-            xerr = xc_ld(&xc.ctl->error);
-        }
-    }
-
-    // RoPE epilogue operands (epilogue waves only): cos / sin of this lane's 4 output columns, fetched now so that the
-    // positions -> table dependent loads do not sit at the tail of the kernel
-    half4 rope_cs[MT], rope_sn[MT];
-    if (MODE == SG_QKV && epi) {
-        const int H = rp.H, D = rp.D, pph = D >> 4;
-        const int sec = panel / (H * pph), pp = panel % pph;
-        const int d = 8 * pp + 4 * (g & 1) + ((g >= 2) ? (D >> 1) : 0);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const int m = t * 16 + li;
-            rope_cs[t] = half4{0, 0, 0, 0};
-            rope_sn[t] = half4{0, 0, 0, 0};
-            if (m < M && sec != 2 && (sec == 0 || rp.rotate_k)) {
-                const int64_t pos = rp.positions[m];
-                rope_cs[t] = *reinterpret_cast<const half4*>(rp.cosb + pos * D + d);
-                rope_sn[t] = *reinterpret_cast<const half4*>(rp.sinb + pos * D + d);
+    half4 rope_cs[MT], rope_sn[MT], res_pre[MT];
+    int64_t r_off = 0, y_off = 0;
+    bool res_early = false;
+    auto prefetch_epi = [&]() {
+        if constexpr (XCHG) {
+            if (epi) {
+                // every panel counts its own exchanges (written at the end of this panel's previous exchange, an earlier
+                // launch of the stream): no grid-wide epoch, so no ticket and no last-workgroup tail at the end of the kernel
+                xepoch = xc_ld(&xc.pepoch[panel]) + 1u;
+                xerr = xc_ld(&xc.ctl->error);
             }
         }
-    }
-
-    // residual epilogue operands (epilogue waves only): this lane's 4 residual values per row tile, fetched now — at the
-    // tail they would be one more exposed memory round trip between the split-K merge and the store.  (resid may alias
-    // y: every element is read and written by the same lane only.)
-    half4 res_pre[MT];
-    const int64_t r_off = (int64_t)(2 * panel + (g >> 1)) * ra.sk + 4 * (g & 1);   // this lane's 4 columns, piece form
-    const int64_t y_off = (int64_t)(2 * panel + (g >> 1)) * ya.sk + 4 * (g & 1);
-    const bool res_early = TF_SG_RES_EARLY && MODE == SG_PLAIN && resid != nullptr && epi && (ra.sm % 4) == 0 &&
-                           (ra.sk % 4) == 0 && (reinterpret_cast<uintptr_t>(resid) % 8) == 0;
-    if (res_early) {
+        if (MODE == SG_QKV && epi) {
+            const int H = rp.H, D = rp.D, pph = D >> 4;
+            const int sec = panel / (H * pph), pp = panel % pph;
+            const int d = 8 * pp + 4 * (g & 1) + ((g >= 2) ? (D >> 1) : 0);
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const int m = t * 16 + li;
-            res_pre[t] = half4{0, 0, 0, 0};
-            if (m < M) res_pre[t] = *reinterpret_cast<const half4*>(resid + (int64_t)m * ra.sm + r_off);
+            for (int t = 0; t < MT; ++t) {
+                const int m = t * 16 + li;
+                rope_cs[t] = half4{0, 0, 0, 0};
+                rope_sn[t] = half4{0, 0, 0, 0};
+                if (m < M && sec != 2 && (sec == 0 || rp.rotate_k)) {
+                    const int64_t pos = rp.positions[m];
+                    rope_cs[t] = *reinterpret_cast<const half4*>(rp.cosb + pos * D + d);
+                    rope_sn[t] = *reinterpret_cast<const half4*>(rp.sinb + pos * D + d);
+                }
+            }
         }
-    }
+        // (resid may alias y: every element is read and written by the same lane only.)
+        r_off = (int64_t)(2 * panel + (g >> 1)) * ra.sk + 4 * (g & 1);   // this lane's 4 columns, piece form
+        y_off = (int64_t)(2 * panel + (g >> 1)) * ya.sk + 4 * (g & 1);
+        res_early = TF_SG_RES_EARLY && MODE == SG_PLAIN && resid != nullptr && epi && (ra.sm % 4) == 0 &&
+                    (ra.sk % 4) == 0 && (reinterpret_cast<uintptr_t>(resid) % 8) == 0;
+        if (res_early) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int m = t * 16 + li;
+                res_pre[t] = half4{0, 0, 0, 0};
+                if (m < M) res_pre[t] = *reinterpret_cast<const half4*>(resid + (int64_t)m * ra.sm + r_off);
+            }
+        }
+    };
+    constexpr bool EPI_LATE = !NORM && SG_EPI_LATE != 0;         // prefetch_epi inside the first K batch
+    if (!EPI_LATE || !(c0 + U <= c1)) prefetch_epi();
 
     int c = c0;
     for (; c + U <= c1; c += U) {
@@ -551,6 +557,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
                     b[u][t] = sg_normalise(b[u][t], lw, inv[t]);
                 }
             }
+        }
+        if constexpr (EPI_LATE) {
+            if (c == c0) prefetch_epi();                             // (behind this batch's loads, in front of its MFMAs)
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
