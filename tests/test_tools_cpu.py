@@ -185,3 +185,23 @@ def test_kernel_timeline_groups_by_kernel_and_grid_and_measures_gaps(tmp_path):
     a, b = ks["gemm_a | grid 256 wg 0"], ks["gemm_a | grid 96 wg 0"]
     assert a["launches"] == 20 and abs(a["avg_us"] - 5.0) < 1e-6 and a["long_gaps"] == 19
     assert b["launches"] == 20 and abs(b["avg_us"] - 9.0) < 1e-6 and abs(b["avg_gap_before_us"] - 1.5) < 1e-6
+
+
+def test_build_variant_command_line(monkeypatch):
+    """triforce_amd.build.build_variant: "NAME=VALUE" -> -DNAME=VALUE, "-flag" passed through, "!kernarg-preload" builds
+    without the -mllvm -amdgpu-kernarg-preload-count pair; the default build carries the pair (csrc/gemv.hip orders its
+    kernel arguments for it)."""
+    from triforce_amd import build as tb
+    seen = []
+    monkeypatch.setattr(tb.subprocess, "run", lambda cmd, check=True: seen.append(list(cmd)))
+    monkeypatch.setattr(tb, "hipcc_path", lambda: "hipcc")
+    assert "-amdgpu-kernarg-preload-count=14" in tb.FLAGS and tb.FLAGS[tb.FLAGS.index("-amdgpu-kernarg-preload-count=14") - 1] == "-mllvm"
+    out = tb.build_variant("t1", ["SG_LN_PRE=1", "-save-temps"], verbose=False)
+    assert out.endswith("libtriforce_hip_t1.so")
+    cmd = seen[-1]
+    assert "-DSG_LN_PRE=1" in cmd and "-save-temps" in cmd and "-amdgpu-kernarg-preload-count=14" in cmd
+    assert cmd[-2:] == ["-o", out] and any(c.endswith("gemv.hip") for c in cmd)
+    tb.build_variant("t2", ["!kernarg-preload"], verbose=False)
+    cmd = seen[-1]
+    assert "-mllvm" not in cmd and not any(c.startswith("-amdgpu-kernarg-preload") for c in cmd)
+    assert "--offload-arch=gfx950" in cmd and not any(c.startswith("-D!") or c.startswith("!") for c in cmd)

@@ -39,6 +39,7 @@ VARIANTS = {"q2occ1": ["TF_ATTN_QT2_OCC=0"],
             "sgprol0": ["SG_PROLOGUE_ORDER=0"],      # norm-GEMM prologue in round 3's load order (weights first, x after the fold)
             "sgprol1": ["SG_PROLOGUE_ORDER=1"],      # ... in round 4's first form (same order behind branches: the compiler threads it)
             "lnpre": ["SG_LN_PRE=1"],                # the first batch's norm weights prefetched with the prologue (+16 registers)
+            "epilate0": ["SG_EPI_LATE=0"],           # plain GEMMs fetch their epilogue operands in front of the first weight batch
             "nopreload": ["!kernarg-preload"],       # built without -mllvm -amdgpu-kernarg-preload-count=14
             "ring4ps1": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_RING_Q1=4", "TF_ATTN_RING_Q2=4", "TF_ATTN_QT2_OCC=1", "TF_ATTN_P_SPLIT=1"]}
 
