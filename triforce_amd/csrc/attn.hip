@@ -601,21 +601,22 @@ __device__ __forceinline__ void attn_split_body(
 
 template <int D, int QT>
 __global__ ATTN_SPLIT_BOUNDS void attn_split_kernel(
-    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
-    int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
+    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, const int32_t* __restrict__ sk_dev,
+    int sq, int sk_host, int H, int nsplit, int stride_t, int stride_h, float scale,      // <- 14 dwords preloaded into SGPRs
     float* __restrict__ ws, unsigned* __restrict__ tickets, h16* __restrict__ out, int64_t osm, int64_t osk) {
-    attn_split_body<D, QT>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws, tickets, out, osm, osk);
+    attn_split_body<D, QT>(q, k, v, (int64_t)stride_t, (int64_t)stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws, tickets, out,
+                           osm, osk);
 }
 
 // The deep-prefetch form for short streams (one q-tile; see TF_ATTN_DEEP_TILES): one wave per SIMD, 512 registers.
 #if TF_ATTN_DEEP_TILES > 0
 template <int D>
 __global__ __launch_bounds__(256, 1) void attn_split_deep_kernel(
-    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
-    int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
+    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, const int32_t* __restrict__ sk_dev,
+    int sq, int sk_host, int H, int nsplit, int stride_t, int stride_h, float scale,      // <- 14 dwords preloaded into SGPRs
     float* __restrict__ ws, unsigned* __restrict__ tickets, h16* __restrict__ out, int64_t osm, int64_t osk) {
-    attn_split_body<D, 1, TF_ATTN_DEEP_TILES>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws, tickets,
-                                              out, osm, osk);
+    attn_split_body<D, 1, TF_ATTN_DEEP_TILES>(q, k, v, (int64_t)stride_t, (int64_t)stride_h, sq, sk_host, sk_dev, H, scale, nsplit,
+                                              ws, tickets, out, osm, osk);
 }
 #endif
 
@@ -628,10 +629,11 @@ __global__ __launch_bounds__(256, 1) void attn_split_deep_kernel(
 #if TF_ATTN_QT2_OCC > 0
 template <int D>
 __global__ __launch_bounds__(64 * TF_ATTN_Q2_WAVES, TF_ATTN_Q2_WAVES == 8 ? 2 : TF_ATTN_QT2_OCC) void attn_split_q2_kernel(
-    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, int64_t stride_t,
-    int64_t stride_h, int sq, int sk_host, const int32_t* __restrict__ sk_dev, int H, float scale, int nsplit,
+    const h16* __restrict__ q, const h16* __restrict__ k, const h16* __restrict__ v, const int32_t* __restrict__ sk_dev,
+    int sq, int sk_host, int H, int nsplit, int stride_t, int stride_h, float scale,      // <- 14 dwords preloaded into SGPRs
     float* __restrict__ ws, unsigned* __restrict__ tickets, h16* __restrict__ out, int64_t osm, int64_t osk) {
-    attn_split_body<D, 2, 0, TF_ATTN_Q2_WAVES>(q, k, v, stride_t, stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws, tickets, out, osm, osk);
+    attn_split_body<D, 2, 0, TF_ATTN_Q2_WAVES>(q, k, v, (int64_t)stride_t, (int64_t)stride_h, sq, sk_host, sk_dev, H, scale, nsplit, ws,
+                                               tickets, out, osm, osk);
 }
 #endif
 
@@ -1913,6 +1915,7 @@ static int launch_attn(const void* q, const void* k, const void* v, void* out, i
                        int64_t stride_t, int64_t stride_h, int sq, int sk, const int32_t* sk_dev, int H, float scale,
                        int nsplit, float* ws, unsigned* tickets, hipStream_t st) {
     dim3 grid(nsplit, H), block(256);
+    if (stride_t > 0x7fffffff || stride_h > 0x7fffffff) return TF_EINVAL;   // (the kernels take the two strides as 32-bit arguments)
     // many splits on a big grid: the parallel merge kernel wins; on a small grid (few heads) the last workgroup of a head
     // folds them inside the launch (see FUSED_MERGE_BIG_SPLITS)
     if (tickets && nsplit > FUSED_MERGE_MAX_SPLITS &&
@@ -1926,7 +1929,7 @@ static int launch_attn(const void* q, const void* k, const void* v, void* out, i
         const int ntiles = (sk + 15) / 16, tps = (ntiles + nsplit - 1) / nsplit, per_wave = (tps + 3) / 4;
         if (per_wave <= 2 * TF_ATTN_DEEP_TILES && (int64_t)nsplit * H <= 320) {      // short streams, <= ~1 workgroup per CU
             hipLaunchKernelGGL((attn_split_deep_kernel<D>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
-                               stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, (h16*)out, osm, osk);
+                               sk_dev, sq, sk, H, nsplit, (int)stride_t, (int)stride_h, scale, ws, tickets, (h16*)out, osm, osk);
             launched = true;
         }
     }
@@ -1934,12 +1937,12 @@ static int launch_attn(const void* q, const void* k, const void* v, void* out, i
 #if TF_ATTN_QT2_OCC > 0
     if constexpr (QT == 2)
         hipLaunchKernelGGL((attn_split_q2_kernel<D>), grid, dim3(64 * TF_ATTN_Q2_WAVES), 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
-                           stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, (h16*)out, osm, osk);
+                           sk_dev, sq, sk, H, nsplit, (int)stride_t, (int)stride_h, scale, ws, tickets, (h16*)out, osm, osk);
     else
 #endif
     if (!launched)
         hipLaunchKernelGGL((attn_split_kernel<D, QT>), grid, block, 0, st, (const h16*)q, (const h16*)k, (const h16*)v,
-                           stride_t, stride_h, sq, sk, sk_dev, H, scale, nsplit, ws, tickets, (h16*)out, osm, osk);
+                           sk_dev, sq, sk, H, nsplit, (int)stride_t, (int)stride_h, scale, ws, tickets, (h16*)out, osm, osk);
     TF_LAUNCH_CHECK();
     if (tickets) return TF_OK;
     hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(H, sq), dim3(D, COMBINE_GROUPS), 0, st, (const float*)ws,
