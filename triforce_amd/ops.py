@@ -93,6 +93,10 @@ def _ensure_sg_workspace(device):
             hip.lib().tf_sg_tune(3, 200)
         if "TRIFORCE_GEMM_DEEP_PANELS" in _os.environ:                   # A/B: largest panel count that keeps 2x the weights in flight
             hip.lib().tf_sg_tune(6, int(_os.environ["TRIFORCE_GEMM_DEEP_PANELS"]))
+        if "TRIFORCE_GEMM_P2_GROUPS" in _os.environ:                     # A/B: two panels per wave while panels / 2 >= this
+            hip.lib().tf_sg_tune(2, int(_os.environ["TRIFORCE_GEMM_P2_GROUPS"]))
+        if "TRIFORCE_GEMM_P2_WAVES" in _os.environ:                      # A/B: waves per workgroup of that form (4 | 8)
+            hip.lib().tf_sg_tune(1, int(_os.environ["TRIFORCE_GEMM_P2_WAVES"]))
         if "TRIFORCE_GEMM_FEW_PANELS" in _os.environ:                    # A/B: largest panel count that runs 16 waves per panel
             hip.lib().tf_sg_tune(5, int(_os.environ["TRIFORCE_GEMM_FEW_PANELS"]))
     _SG_WS[device] = ws
