@@ -289,7 +289,7 @@ class _TargetGraph:
         if isinstance(input_ids, (list, tuple)):
             assert len(input_ids) == self.q_len
             ops.set_tokens(self.ids, input_ids, 0, pos=self.pos, pos0=S, slot=self.slot, sk=self.sk, sk_val=S + self.q_len)
-        elif self.ids.is_cuda:
+        elif self.ids.is_cuda and os.environ.get("TRIFORCE_HOST_FAST", "1") != "0":
             self.ids.copy_(input_ids)
             ops.set_tokens(None, (), 0, pos=self.pos, pos0=S, slot=self.slot, sk=self.sk, sk_val=S + self.q_len)
         else:
