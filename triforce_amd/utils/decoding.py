@@ -22,7 +22,11 @@ from .sampling import UniformSource, norm_logits, sample
 PAD_TOKEN = 100            # filler id of verify_tokens / pass_tokens (decoding.py:94,177)
 # 0: round 3's host path between a record read and the next launch (ids through pinned staging, separate position / length
 #    launches, input checks on every draft replay) — kept for same-box A/B of DESIGN 13.6; 1 (default): ids as kernel arguments
-HOST_FAST = __import__("os").environ.get("TRIFORCE_HOST_FAST", "1") != "0"
+#    TRIFORCE_HOST_FAST_MASK selects pieces: 1 ids / positions of Middle_Spec, 2 check-free draft replay, 4 target verify,
+#    8 catch-up draft input
+_HF = __import__("os").environ
+HOST_FAST_MASK = 0 if _HF.get("TRIFORCE_HOST_FAST", "1") == "0" else int(_HF.get("TRIFORCE_HOST_FAST_MASK", "15"))
+HOST_FAST = HOST_FAST_MASK != 0
 
 
 def _sync(device):
@@ -192,7 +196,7 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
     ids = [int(next_token)]
     vt = buffers.verify_tokens
     # [next, PAD...] and the gamma + 1 positions S, S + 1, ... in one launch (the token id travels as a kernel argument)
-    if HOST_FAST:
+    if HOST_FAST_MASK & 1:
         position_ids = buffers.positions
         ops.set_tokens(vt, ids, PAD_TOKEN, pos=position_ids, pos0=S)
     else:
@@ -204,7 +208,7 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
     noclone = dict(clone=False) if getattr(graph_engine, "static_outputs", False) else {}
     # the draft / verify graphs read vt itself: replay without looking at the inputs (this call sits between the host's
     # read of the previous accept record and the next launch — the one place where host time is GPU idle time)
-    replay_draft = getattr(graph_engine, "replay_draft", None) if (HOST_FAST and noclone and buffers.shared_inputs) else None
+    replay_draft = getattr(graph_engine, "replay_draft", None) if ((HOST_FAST_MASK & 2) and noclone and buffers.shared_inputs) else None
     flat = vt.view(-1)
     while n < gamma:
         if replay_draft is not None:
@@ -357,7 +361,7 @@ class TriForceRunner:
         self.rebuilds += int(rebuild)
         eager = self.eager_every > 0 and (len(self.counts) + 1) % self.eager_every == 0
         fast = None
-        if HOST_FAST and self.top_k <= 0 and not rebuild and not eager and hasattr(ge, "verify_probs_ids"):
+        if (HOST_FAST_MASK & 4) and self.top_k <= 0 and not rebuild and not eager and hasattr(ge, "verify_probs_ids"):
             # captured forward + temperature / top-p: ids, positions and lengths set by ONE launch (ids as kernel arguments)
             fast = ge.verify_probs_ids(ids, self.temperature, self.top_p)
         if fast is not None:
@@ -399,7 +403,7 @@ class TriForceRunner:
         # shift and the next iteration's first launches; issued last, each of those short launches was a host-bound gap
         # (profiles/r04_gap_analysis_decode_steps.txt).
         tok_buf = getattr(ge, "tok_buf", None)
-        if HOST_FAST and tok_buf is not None and tok_buf.shape[0] == 1 and tok_buf.shape[1] >= len(pass_tokens) \
+        if (HOST_FAST_MASK & 8) and tok_buf is not None and tok_buf.shape[0] == 1 and tok_buf.shape[1] >= len(pass_tokens) \
                 and tok_buf.is_cuda:
             # straight into the draft graphs' static input (the next Middle_Spec re-initialises it): one launch, no copies
             row = tok_buf[:, :len(pass_tokens)]
