@@ -71,6 +71,14 @@ def Autoregressive(tokenizer, graph_engine, input_ids, max_len=256, top_k=-1, to
     return n / (time2 - time1)
 
 
+# The host waits for a decision record by polling pinned memory.  A poll loop that never yields can sit on the core a HIP
+# runtime thread needs (launch hand-off, completion signals): measured on 8-vCPU boxes, the hop between an accept kernel
+# and the next launch was 12 us in one process and 61 us in another for the same code (profiles/r04_host_path_ab.txt).
+# TRIFORCE_POLL_YIELD=1: sched_yield() per poll.
+_POLL_YIELD = __import__("os").environ.get("TRIFORCE_POLL_YIELD", "0") == "1"
+_sched_yield = getattr(__import__("os"), "sched_yield", lambda: None)
+
+
 class _Record:
     """A small int64 decision record written by a kernel and read by the host once per (inner / outer) step.
     mailbox=True: the record lives in PINNED HOST memory that the kernel writes directly (unified addressing); the host
@@ -99,6 +107,8 @@ class _Record:
         view, s, spins = self._np[:k], self.SENTINEL, 0
         while (view == s).any():
             spins += 1
+            if _POLL_YIELD:
+                _sched_yield()         # let the HIP runtime's own threads run if they share this core (see _POLL_YIELD)
             if spins > 50_000_000:
                 raise RuntimeError("decision record never arrived (kernel failed?)")
         return view.tolist()
