@@ -32,3 +32,39 @@ def test_attention_kernels_have_no_unguarded_asm_read_of_an_mfma_result(defines)
     text = isa_lint.compile_to_asm(os.path.join(CSRC, "attn.hip"), defines)
     findings = isa_lint.lint_asm(text)
     assert findings == [], findings[:3]
+
+
+def test_norm_gemm_prologue_issues_every_load_before_its_first_wait():
+    """Round 4: built with the library's flags, the norm-prologue forms of skinny_gemm_kernel must (a) get
+    their 14 leading argument dwords preloaded into SGPRs, (b) issue their first vector load without a scalar wait, and
+    (c) issue the norm partials, the x rows and the first weights — >= 24 loads — before the first vmcnt wait, which must
+    leave the later loads in flight (a count > 0).  Round 4's first build failed all three: `s_load x6; s_waitcnt
+    lgkmcnt(0)` at entry, then `global_load; s_waitcnt vmcnt(0); v_add`, the fold in front of the first weight load —
+    none of it visible in the source.  The synthetic text pins the parser."""
+    old = """
+\t.amdhsa_kernel _Zk
+\t\t.amdhsa_user_sgpr_kernarg_preload_length 0
+_Zk: ; @_Zk
+\ts_load_dwordx4 s[12:15], s[0:1], 0x0
+\ts_waitcnt lgkmcnt(0)
+\tglobal_load_dword v2, v2, s[26:27]
+\ts_waitcnt vmcnt(0)
+\tv_add_f32_e32 v23, 0, v2
+\tglobal_load_dwordx4 v[4:7], v[8:9], off
+\ts_endpgm
+"""
+    sh = isa_lint.prologue_shape(old)["_Zk"]
+    assert sh == dict(preload=0, scalar_wait_before_first_load=True, loads_before_first_wait=1, first_vmcnt=0)
+    from triforce_amd.build import FLAGS
+    extra = [f for f in FLAGS if f == "-mllvm" or f.startswith("-amdgpu-")]
+    assert extra, "the library is built with kernarg preload"
+    shapes = isa_lint.prologue_shape(isa_lint.compile_to_asm(os.path.join(CSRC, "gemv.hip"), extra=extra))
+    norm = {k: v for k, v in shapes.items() if k.startswith("_Z18skinny_gemm_kernelILi1E") and "ELb1ELi" in k[:40]
+            and v.get("loads_before_first_wait") is not None}
+    # one row tile, norm prologue, no K split across workgroups, UX = 1: q|k|v / gate|up / lm_head forms at 4 and 8 waves
+    hot = {k: v for k, v in norm.items() if "ELb0ELb0ELi1EE" in k}
+    assert len(hot) >= 8, sorted(norm)[:4]
+    for k, v in hot.items():
+        assert v.get("preload") == 14, (k, v)
+        assert v["scalar_wait_before_first_load"] is False, (k, v)
+        assert v["loads_before_first_wait"] >= 24 and v["first_vmcnt"] > 0, (k, v)

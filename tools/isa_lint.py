@@ -8,6 +8,7 @@ register (within one basic block) and adds up a LOWER bound of the cycles in bet
 for its passes), N + 1 per `s_nop N`, 1 per anything else.  Fewer than 11 is reported.
 
     python tools/isa_lint.py [file.hip ...]      exit code 1 on findings
+    python tools/isa_lint.py --prologue [file.hip ...]   per kernel: preloaded argument SGPRs, loads issued before the first wait
 """
 import os
 import re
@@ -16,6 +17,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 NEED = 11
 REG = re.compile(r"v\[(\d+):(\d+)\]|\bv(\d+)\b")
 
@@ -86,17 +88,79 @@ def lint_asm(text, window=40):
     return findings
 
 
-def compile_to_asm(src, defines=()):
+def compile_to_asm(src, defines=(), extra=()):
     hipcc = "/opt/rocm/bin/hipcc"
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only"] + \
-            [f"-D{x}" for x in defines] + ["-o", out, src]
+            [f"-D{x}" for x in defines] + list(extra) + ["-o", out, src]
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         return open(out).read()
 
 
+# ---- second check (round 4): the shape of a kernel's PROLOGUE ---------------------------------------------------------------
+# Two things the round-4 ISA reading found at the top of the decode kernels, both invisible in the source:
+#   * every kernel opened with `s_load_dwordx*; s_waitcnt lgkmcnt(0)` — the kernel-argument segment through the scalar cache
+#     — before its first address; the library is built with kernarg preload and the kernels order their arguments for it;
+#   * the norm-prologue GEMM's first vector-memory operation was `global_load; s_waitcnt vmcnt(0)` and the fold of the norm
+#     partials ran BEFORE the first weight load was issued (the compiler sank / threaded the conditional loads).
+# prologue_shape() reports, per kernel: the preloaded SGPR count, whether a scalar wait precedes the first vector load of the
+# real entry (behind the backward-compatible s_load + s_branch header), the number of vector loads issued before the first
+# vmcnt wait, and that wait's count (0 = everything outstanding is waited for: a serialisation when loads follow).
+def prologue_shape(text):
+    out, func, state, desc = {}, None, None, None
+    for line in text.split("\n"):
+        t = line.strip()
+        m = re.match(r"^\.amdhsa_kernel\s+(\S+)", t)
+        if m:
+            desc = m.group(1)
+            continue
+        m = re.match(r"^\.amdhsa_user_sgpr_kernarg_preload_length\s+(\d+)", t)
+        if m and desc is not None:
+            out.setdefault(desc, {})["preload"] = int(m.group(1))
+            continue
+        m = re.match(r"^([A-Za-z_]\w*):\s*(;.*)?$", line)
+        if m:                                               # a function label (local labels start with '.')
+            func = m.group(1)
+            state = dict(loads=0, scalar_wait=False, done=False)
+            out.setdefault(func, {}).update(loads_before_first_wait=None, first_vmcnt=None, scalar_wait_before_first_load=None)
+            continue
+        if func is None or state is None or state["done"] or not t or t[0] == ";":
+            continue
+        if re.match(r"^\.LBB\d+_0:", t):                    # real entry behind the kernarg-preload compatibility header
+            state.update(loads=0, scalar_wait=False)
+            continue
+        if t[0] == ".":
+            continue
+        if t.startswith("s_endpgm"):
+            state["done"] = True
+            continue
+        if t.startswith("s_waitcnt") and "lgkmcnt" in t and state["loads"] == 0:
+            state["scalar_wait"] = True
+        if re.match(r"(global_load|buffer_load|flat_load)", t):
+            if state["loads"] == 0:
+                out[func]["scalar_wait_before_first_load"] = state["scalar_wait"]
+            state["loads"] += 1
+        m = re.search(r"vmcnt\((\d+)\)", t) if t.startswith("s_waitcnt") else None
+        if m and state["loads"] > 0:
+            out[func]["loads_before_first_wait"] = state["loads"]
+            out[func]["first_vmcnt"] = int(m.group(1))
+            state["done"] = True
+    return out
+
+
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--prologue":           # table of prologue shapes, built like the library
+        from triforce_amd.build import FLAGS
+        extra = [f for f in FLAGS if f in ("-mllvm",) or f.startswith("-amdgpu-")]
+        for f in sys.argv[2:] or [os.path.join(ROOT, "triforce_amd", "csrc", "gemv.hip")]:
+            for func, sh in sorted(prologue_shape(compile_to_asm(f, extra=extra)).items()):
+                if sh.get("loads_before_first_wait") is not None:
+                    print(f"{func[:70]:70s} preload {sh.get('preload')}  scalar wait first: {sh['scalar_wait_before_first_load']}  "
+                          f"loads before first vmcnt wait: {sh['loads_before_first_wait']}  vmcnt({sh['first_vmcnt']})")
+        return 0
     files = sys.argv[1:] or [os.path.join(ROOT, "triforce_amd", "csrc", f) for f in ("attn.hip", "gemv.hip", "sampling.hip")]
     bad = 0
     for f in files:
