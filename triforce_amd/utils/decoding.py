@@ -23,9 +23,9 @@ PAD_TOKEN = 100            # filler id of verify_tokens / pass_tokens (decoding.
 # 0: round 3's host path between a record read and the next launch (ids through pinned staging, separate position / length
 #    launches, input checks on every draft replay) — kept for same-box A/B of DESIGN 13.6; 1 (default): ids as kernel arguments
 #    TRIFORCE_HOST_FAST_MASK selects pieces: 1 ids / positions of Middle_Spec, 2 check-free draft replay, 4 target verify,
-#    8 catch-up draft input
+#    8 catch-up draft input, 16 the remaining host -> device token lists (eager / rebuild steps) without an H2D copy
 _HF = __import__("os").environ
-HOST_FAST_MASK = 0 if _HF.get("TRIFORCE_HOST_FAST", "1") == "0" else int(_HF.get("TRIFORCE_HOST_FAST_MASK", "15"))
+HOST_FAST_MASK = 0 if _HF.get("TRIFORCE_HOST_FAST", "1") == "0" else int(_HF.get("TRIFORCE_HOST_FAST_MASK", "31"))
 HOST_FAST = HOST_FAST_MASK != 0
 
 
@@ -174,7 +174,11 @@ class _SpecBuffers:
         copy that read it."""
         n = len(ids)
         self._flip ^= 1
-        stage, row = self.stage[self._flip, :n], self.dev_tokens[self._flip, :n]
+        row = self.dev_tokens[self._flip, :n]
+        if (HOST_FAST_MASK & 16) and row.is_cuda and n <= 32:
+            ops.set_tokens(row, ids, PAD_TOKEN)                # ids as kernel arguments: no staging copy, no H2D copy
+            return row.unsqueeze(0)
+        stage = self.stage[self._flip, :n]
         stage.copy_(torch.tensor(ids, dtype=torch.long))
         row.copy_(stage, non_blocking=True)
         return row.unsqueeze(0)
