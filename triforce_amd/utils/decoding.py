@@ -76,7 +76,21 @@ def Autoregressive(tokenizer, graph_engine, input_ids, max_len=256, top_k=-1, to
 # and the next launch was 12 us in one process and 61 us in another for the same code (profiles/r04_host_path_ab.txt).
 # TRIFORCE_POLL_YIELD=1: sched_yield() per poll.
 _POLL_YIELD = __import__("os").environ.get("TRIFORCE_POLL_YIELD", "0") == "1"
+# The replay that follows a record read spends 36-69 us INSIDE hipGraphLaunch in the loop (tools/hop_trace.py) against ~9 us
+# from an idle, synchronised queue (tools/draft_launch_latency.py): the runtime retires the completed commands of the
+# 165-node verify graph at its next API call.  TRIFORCE_POLL_QUERY=1: hipStreamQuery every 16th poll, so that the
+# retirement happens while the host waits anyway.
+_POLL_QUERY = __import__("os").environ.get("TRIFORCE_POLL_QUERY", "0") == "1"
+# The record becomes visible a moment BEFORE its kernel completes; a hipGraphLaunch into a stream whose last command is still
+# in flight takes 35-56 us on the host here, into an idle stream ~9 us in all.  TRIFORCE_SYNC_AFTER_RECORD=1: wait for the
+# stream to drain (the kernel is ending anyway) before the replay.
+_SYNC_AFTER_RECORD = __import__("os").environ.get("TRIFORCE_SYNC_AFTER_RECORD", "0") == "1"
+_POLL_QUERY_MASK = int(__import__("os").environ.get("TRIFORCE_POLL_QUERY_EVERY", "16")) - 1
 _sched_yield = getattr(__import__("os"), "sched_yield", lambda: None)
+
+
+# TRIFORCE_HOP_TRACE=1: (ns from "record seen" to "replay called", ns inside the replay call) per inner hop, for tools
+_HOP_TRACE = [] if __import__("os").environ.get("TRIFORCE_HOP_TRACE", "0") == "1" else None
 
 
 class _Record:
@@ -105,8 +119,11 @@ class _Record:
         if not self.mailbox:
             return self.tensor[:k].tolist()
         view, s, spins = self._np[:k], self.SENTINEL, 0
+        query = torch.cuda.current_stream().query if _POLL_QUERY else None
         while (view == s).any():
             spins += 1
+            if query is not None and (spins & _POLL_QUERY_MASK) == 0:
+                query()                # lets the HIP runtime retire finished commands NOW (see _POLL_QUERY)
             if _POLL_YIELD:
                 _sched_yield()         # let the HIP runtime's own threads run if they share this core (see _POLL_YIELD)
             if spins > 50_000_000:
@@ -225,8 +242,12 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
     replay_draft = getattr(graph_engine, "replay_draft", None) if ((HOST_FAST_MASK & 2) and noclone and buffers.shared_inputs) else None
     flat = vt.view(-1)
     while n < gamma:
+        if _HOP_TRACE is not None and drafted:
+            _t_before = time.perf_counter_ns()
         if replay_draft is not None:
             q_d = replay_draft(n)
+            if _HOP_TRACE is not None and drafted:            # host pieces of the inner hop (TRIFORCE_HOP_TRACE=1, tools only)
+                _HOP_TRACE.append((_t_before - _t_seen, time.perf_counter_ns() - _t_before))
         else:
             q_d = graph_engine.graph_draft_inference(input_ids=vt[:, :n + 1], gamma_offset=n, **noclone)
         u = rng.take(3)
@@ -242,6 +263,10 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
             if n + 1 < flat.numel():
                 flat[n + 1:n + 3].copy_(_mid_tokens(rec.tensor, n, gamma, flat))
         acc, b, d = rec.read(3)                                               # the one host read of this step
+        if _HOP_TRACE is not None:
+            _t_seen = time.perf_counter_ns()                # (the drain below counts as part of the hop)
+        if _SYNC_AFTER_RECORD:
+            torch.cuda.current_stream().synchronize()       # the accept kernel is ending: launch from an IDLE stream (see there)
         if health is not None:                # TP: a timed-out exchange NaN-filled p — stop before its tokens are used
             health()
         rng.advance(3)
