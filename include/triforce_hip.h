@@ -303,6 +303,24 @@ int tf_skinny_qkv_rope_act(const void* wqkv_packed, const void* x, int64_t xs_m,
                            void* q_out, void* k_cache, void* v_cache, int64_t stride_t, int64_t stride_h, int slot0,
                            const int32_t* slot0_dev, int M, int H, int D, int K, int rotate_k, void* stream);
 int tf_sg_tune(int key, int value);
+/* NARROW-PANEL forms of the two norm GEMMs (round 5; csrc/gemv.hip skinny_gemm_n8_kernel) for the FEW-PANEL shards of a
+ * tensor-parallel rank (q|k|v: 3 * H/W * D rows, gate|up: I/W rows — 86-120 16-row panels at 8 ranks, on 256 CUs;
+ * models/tensor_op.py:140-142,353-357 on the shards of models/TP_layers.py:126-147): a workgroup owns 8 output rows, two
+ * 32-wide k-chunks stacked on the MFMA's 16 A rows and the matching x chunks on its 16 B columns, the two diagonal 8 x 8
+ * blocks summed — twice the workgroups, half the bytes each, no cross-workgroup hand-off.  Weights packed by
+ * triforce_amd.ops.pack_weight_n8 ([N/8][K/64][4][2][8][8]; q|k|v in triforce_amd.ops.rope_row_order_n8: every 8-row
+ * panel of the q and k sections = rows d0..d0+3 and d0+D/2..d0+D/2+3 of one head).  Same operands, layouts and rounding
+ * points as tf_skinny_gemm_swiglu_act / tf_skinny_qkv_rope_act; requires ln_w (norm prologue), M <= 24, K % 64 == 0,
+ * K >= 1024 — otherwise -EINVAL and the caller keeps the 16-row form.  Results agree with the 16-row form to fp32
+ * summation order (the K sum is taken even | odd chunk first), not bit for bit.  tf_sg_tune key 7: super-chunks per batch
+ * (0 = rule, 5, 8). */
+int tf_skinny_gemm_swiglu_n8(const void* gate_n8, const void* up_n8, const void* x, int64_t xs_m, int64_t xs_k,
+                             const void* ln_w, float eps, const float* ss_in, void* act, int64_t ys_m, int64_t ys_k,
+                             int M, int I, int K, void* stream);
+int tf_skinny_qkv_rope_n8(const void* wqkv_n8, const void* x, int64_t xs_m, int64_t xs_k, const void* ln_w, float eps,
+                          const float* ss_in, const void* cos, const void* sin, const int64_t* positions, void* q_out,
+                          void* k_cache, void* v_cache, int64_t stride_t, int64_t stride_h, int slot0,
+                          const int32_t* slot0_dev, int M, int H, int D, int K, int rotate_k, void* stream);
 /* Split-K workspace of the CURRENT device (csrc/gemv.hip, SgKsplit): GEMMs with few output panels — the q|k|v and
  * gate|up shards of a tensor-parallel rank — split K across up to 4 workgroups per panel; their partial sums meet in
  * `ws` (zero-filled device memory, first 16 KiB = per-panel tickets, left zero by every launch; 8 MiB covers every shape

@@ -727,7 +727,7 @@ def test_swiglu_norm_prologue(M, I, K):
 @pytest.mark.parametrize("kind,N,K,HD", [("qkv", 1536, 4096, (4, 128)), ("qkv", 1920, 5120, (5, 128)),
                                           ("swiglu", 1376, 4096, None), ("swiglu", 1728, 5120, None),
                                           ("plain", 3072, 4096, None), ("plain", 1024, 11008, None)])
-def test_gemm_split_across_workgroups(M, kind, N, K, HD):
+def test_gemm_split_across_workgroups(M, kind, N, K, HD, monkeypatch):
     """Few-panel GEMMs (the q|k|v / gate|up shards of a tensor-parallel rank: models/TP_layers.py:126-147) CAN split K
     across up to 4 workgroups per panel, the partial sums meeting through the registered workspace (csrc/gemv.hip
     SgKsplit) — built and measured in round 4, no gain in situ, so the launch rule leaves it off (tf_sg_tune key 3 = 0);
@@ -739,6 +739,7 @@ def test_gemm_split_across_workgroups(M, kind, N, K, HD):
     from triforce_amd import hip
     L = hip.lib()
     eps = 1e-5
+    monkeypatch.setattr(ops, "N8_ENABLED", False)             # (these shapes take the narrow-panel form since round 5)
     x = rnd(M, K, seed=400 + M).to(DEV)
     ln = (1 + 0.1 * rnd(K, seed=401).float()).half().to(DEV)
     ssx = ops.ss_buffer(K, DEV)
@@ -798,6 +799,101 @@ def test_gemm_split_across_workgroups(M, kind, N, K, HD):
         # spacings at that magnitude (1.6e-2) where the other forms get 2 ulp of the result
         tol = 2 * b.float().abs() * 2 ** -10 + (1.6e-2 if kind == "qkv" else 2e-3)
         assert bool((d <= tol).all()) and float((d > 0).float().mean()) < 0.12, (float(d.max()), float((d > 0).float().mean()))
+
+
+@pytest.mark.parametrize("M", [1, 7, 8, 9, 16, 17, 24, 25])
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("kind,N,K,HD", [("qkv", 1536, 4096, (4, 128)), ("qkv", 1920, 5120, (5, 128)), ("qkv", 768, 1024, (4, 64)),
+                                          ("swiglu", 1376, 4096, None), ("swiglu", 1728, 5120, None)])
+def test_narrow_panel_norm_gemms(M, packed, kind, N, K, HD, monkeypatch):
+    """Round 5: the q|k|v / gate|up shards of a tensor-parallel rank (models/TP_layers.py:126-147: 3 * H/W * D and I/W rows —
+    96 / 86 16-row panels at 7B with 8 ranks, 120 / 108 at 13B) run 8-ROW panels (csrc/gemv.hip skinny_gemm_n8_kernel: two
+    k-chunks stacked on the MFMA's 16 A rows, the diagonal 8 x 8 blocks summed) so that twice the workgroups stream half the
+    bytes each.  Checked (a) against the oracle pipeline norm -> linear -> RoPE / SwiGLU at the tolerances of the 16-row
+    tests (test_qkv_rope_fused, test_swiglu_norm_prologue), (b) against the 16-row kernel on the same device — same
+    rounding points, K summed in another order: <= 1 fp16 ulp before the epilogue —, (c) sum-of-squares hand-off == re-reading
+    x, (d) run to run and inside a hipGraph bit-identical, (e) 25 rows fall back to the 16-row form.  Row-major and
+    k-octet-major activations."""
+    ops = _ops()
+    eps = 1e-5
+    x = rnd(M, K, seed=500 + M)
+    ln = (1 + 0.1 * rnd(K, seed=501).float()).half()
+    xd, lnd = x.to(DEV), ln.to(DEV)
+    xin = ops.Act.from_rows(xd) if packed else xd
+    ssx = ops.ss_buffer(K, DEV)
+    ssx[:, :M] = xd.float().square().view(M, K // 16, 16).sum(-1).t()
+    if kind == "qkv":
+        H, D = HD
+        w = rnd(N, K, seed=502, scale=0.05)
+        cos, sin = R.rope_tables_yarn(D, 4096, 16.0, 256) if D == 128 else R.rope_tables_plain(D, 4096)
+        pos = torch.randint(0, 4096, (M,), generator=torch.Generator().manual_seed(M))
+        cd, sd, pd = cos.to(DEV), sin.to(DEV), pos.to(DEV)
+
+        def build():
+            return ops.PackedLinear(w.to(DEV), rope=(H, D))
+
+        def run(pl, ss_in=None):
+            k = torch.zeros(H, 64, D, dtype=torch.float16, device=DEV)
+            v = torch.zeros(H, 64, D, dtype=torch.float16, device=DEV)
+            q = ops.qkv_rope(xin, pl, lnd, eps, cd, sd, pd, k, v, 3, H, D, ss_in=ss_in)
+            assert k[:, :3].abs().sum() == 0 and k[:, 3 + M:].abs().sum() == 0
+            return q, k[:, 3:3 + M].permute(1, 0, 2).contiguous(), v[:, 3:3 + M].permute(1, 0, 2).contiguous()
+    else:
+        wgu = rnd(2 * N, K, seed=503, scale=0.05)
+
+        def build():
+            return ops.PackedLinear(wgu.to(DEV), split=2)
+
+        def run(pl, ss_in=None):
+            a = ops.mlp_act(xin, pl, ln=lnd, eps=eps, ss_in=ss_in)
+            return (a.rows() if packed else a,)
+    pl8 = build()
+    assert (pl8.wp_rope_n8 if kind == "qkv" else pl8.parts_n8) is not None, "narrow-panel copy was not packed"
+    monkeypatch.setattr(ops, "N8_ENABLED", False)
+    pl16 = build()
+    assert pl16.wp_rope_n8 is None and pl16.parts_n8 is None
+    got, got_ss, wide = run(pl8), run(pl8, ssx), run(pl16)
+    again = run(pl8)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        cap = run(pl8, ssx)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    for a, b, c, d in zip(got, again, cap, got_ss):
+        assert torch.equal(a, b), "run to run"
+        assert torch.equal(c, d), "captured == eager"
+    if M > ops.N8_MAX_ROWS:                                    # (e) 16-row form: bit-identical to the copy without n8
+        for a, b in zip(got, wide):
+            assert torch.equal(a, b)
+    h = R.rms_norm(x, ln, eps)
+    if kind == "qkv":
+        qkv = R.linear(h, w)
+        wq = R.apply_rope(qkv[:, :H * D].view(M, H, D), cos, sin, pos)
+        wk = R.apply_rope(qkv[:, H * D:2 * H * D].view(M, H, D), cos, sin, pos)
+        wv = qkv[:, 2 * H * D:].view(M, H, D)
+        for res in (got, got_ss):
+            ulp_report("n8 qkv_rope q", res[0], wq, max_ulp_frac=8e-2, ulps=2, atol=1e-3)
+            ulp_report("n8 qkv_rope k", res[1], wk, max_ulp_frac=8e-2, ulps=2, atol=1e-3)
+            ulp_report("n8 qkv_rope v", res[2], wv, max_ulp_frac=5e-2, ulps=1, atol=1e-4)
+        # vs the 16-row kernel: v is the bare GEMM (<= 1 ulp), rotated q / k add two such values (see the K-split test)
+        ulp_report("n8 vs 16-row v", got[2], wide[2], max_ulp_frac=5e-2, ulps=1, atol=1e-4)
+        for a, b in zip(got[:2], wide[:2]):
+            dq = (a.float() - b.float()).abs()
+            assert bool((dq <= 2 * b.float().abs() * 2 ** -10 + 1.6e-2).all()) and float((dq > 0).float().mean()) < 0.12
+    else:
+        gu = R.linear(h, wgu)
+        want = R.silu_mul(gu[:, :N], gu[:, N:])
+        for res in (got, got_ss):
+            dd = (res[0].float().cpu() - want.float()).abs()
+            tolw = 6 * want.float().abs() * 2 ** -10 + 4e-3
+            assert bool((dd <= tolw).all()) and dd.mean() < 5e-4, (float(dd.max()), float(dd.mean()))
+        dq = (got[0].float() - wide[0].float()).abs()
+        assert bool((dq <= 4 * wide[0].float().abs() * 2 ** -10 + 2e-3).all()) and float((dq > 0).float().mean()) < 8e-2
+    # (c) folding the producer's partials vs re-reading x: the sum of squares in another fp32 order
+    for a, b in zip(got, got_ss):
+        dq = (a.float() - b.float()).abs()
+        assert bool((dq <= 2 * b.float().abs() * 2 ** -10 + (1.6e-2 if kind == "qkv" else 2e-3)).all())
 
 
 def test_row_copy_wrappers_refuse_out_of_range_rows():

@@ -133,6 +133,8 @@ static int g_sg_few_panels = 200;          // gate|up GEMMs of up to this many p
 static int g_sg_ksplit_force = 0;          // tf_sg_tune key 4 (A/B): > 1 that many K-splits across workgroups for EVERY P = 1 GEMM,
                                            // 1 never split, 0 the rule in sg_pick_ksplit
 static int g_sg_ksplit_max_groups = 0;     // split K across workgroups below this many panel groups (tf_sg_tune key 3; 0 = never)
+static int g_sg_n8_u = 0;                  // narrow-panel form (skinny_gemm_n8_kernel), tf_sg_tune key 7 (A/B): 0 = the rule in
+                                           // launch_sg_n8, 5 / 8 = that many super-chunks per batch for every launch
 
 __device__ __forceinline__ void sg_st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float sg_ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -864,6 +866,341 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
     SG_STAMP(6);
 }
 
+// ---- NARROW panels (round 5): 8 weight rows per workgroup, for the FEW-PANEL norm GEMMs of a tensor-parallel rank ------
+// A rank's q|k|v / gate|up shard has 86-120 16-row panels (7B / 13B at 8 ranks): one workgroup per panel leaves 2/3 of the
+// 256 CUs idle, and the K loop of such a workgroup is bound by what ONE CU can pull (~37 GB/s whatever is in flight:
+// profiles/r04_gemm_phase_stamps.json, r04_gemm_deep_prefetch_ab.jsonl).  Splitting K across workgroups buys the CUs with a
+// ~4.7 us cross-workgroup hand-off (SgKsplit above: no gain).  This form splits N instead — no hand-off at all: a workgroup
+// owns 8 output rows and streams HALF the bytes; twice the workgroups.  The matrix core still does the K reduction: TWO
+// 32-wide k-chunks are stacked on the 16 A rows (rows 0-7: chunk 2c, rows 8-15: chunk 2c+1 of the same 8 weight rows) and
+// the matching two x chunks on the 16 B columns (columns 0-7: rows m of chunk 2c, columns 8-15: the same rows of chunk
+// 2c+1), so the two DIAGONAL 8 x 8 blocks of the 16 x 16 result hold the even / odd halves of the K sum (the off-diagonal
+// blocks are cross terms nobody reads); the epilogue adds the two.  Half the MFMA's flops are wasted — of a pipe that is
+// ~10 % busy.  Weights are packed for it once (ops.pack_weight_n8): per 8-row panel and 64-wide super-chunk one contiguous
+// KiB in operand order, so a wave's A load is still one 1 KiB run.  x rows come in tiles of 8 (MT tiles: <= 8 / 16 / 24
+// rows).  Same rounding points as skinny_gemm_kernel (fp32 accumulate, one fp16 rounding, the fused epilogues' fp16
+// arithmetic); the K sum is taken in another order (even | odd chunks, then the waves), so results agree with the 16-row
+// form to fp32-summation noise, not bit for bit — both are checked against the oracle at the same tolerance.
+// Every wave issues ALL loads of a batch up front; registers are not a constraint here (<= 1 workgroup per CU by design).
+template <int MT, int MODE, bool NORM, int WAVES, int U>
+__global__ __launch_bounds__(WAVES * 64) void skinny_gemm_n8_kernel(const half8* __restrict__ wp,
+                                                                    const half8* __restrict__ wp_up,
+                                                                    const h16* __restrict__ x,
+                                                                    const float* __restrict__ ss_in,
+                                                                    const h16* __restrict__ ln_w, int K, int M,
+                                                                    int xa_sm, int xa_sk, float eps, void* yv, SgAct ya,
+                                                                    SgRope rp) {
+    static_assert(MODE == SG_GATEUP || MODE == SG_QKV, "narrow panels: the two norm GEMMs of a decoder layer");
+    constexpr bool GATEUP = MODE == SG_GATEUP;
+    constexpr int NA = GATEUP ? 2 : 1;
+    constexpr int MT16 = (MT * 8 + 15) / 16;                    // 16-row tiles of the norm partials (producer's layout)
+    const int panel = blockIdx.x;                               // 8 output rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4, lr = li & 7, par = li >> 3;
+    const int nsc = K >> 6;                                     // 64-wide super-chunks
+    const int cpw = (nsc + WAVES - 1) / WAVES;
+    const int c0 = wave * cpw, c1 = min(nsc, c0 + cpw);
+
+    __shared__ float sm[WAVES][NA][MT][64][4];
+    __shared__ float red[MT16][WAVES * 4][16];
+    __shared__ float sm_ss[WAVES][MT * 8];
+
+    f32x4 acc[NA][MT];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t pstride = (int64_t)nsc * 64;                  // half8 pieces per 8-row panel
+    const half8* wa = wp + (int64_t)panel * pstride + lane;
+    const half8* wu = GATEUP ? (wp_up + (int64_t)panel * pstride + lane) : wa;
+    const int64_t sk = xa_sk, xcs = 8 * sk;                     // elements per super-chunk step of the B operand
+    const h16* xr[MT];
+    bool xok[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = t * 8 + lr;
+        xok[t] = m < M;
+        xr[t] = x + (int64_t)(xok[t] ? m : 0) * xa_sm + (int64_t)(4 * par + g) * sk;
+    }
+    const h16* lnp = NORM ? (ln_w + 32 * par + 8 * g) : nullptr;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // ---- prologue: every load of the norm partials and of the first batch in ONE basic block (see skinny_gemm_kernel) ----
+    constexpr int G = WAVES * 4;
+    constexpr int SSB = 2;
+    const int nparts = K >> 4;
+    const int pg = tid >> 4, m16 = tid & 15;
+    float ssv[MT16][SSB][8], part0[MT16];
+    half8 a[U][NA], b[U][MT], lw[U];
+    const int last = max(c1 - 1, 0);
+    {
+        const float* ssp = (NORM && ss_in) ? ss_in : reinterpret_cast<const float*>(wp);
+        if constexpr (NORM) {
+#pragma unroll
+            for (int t = 0; t < MT16; ++t)
+#pragma unroll
+                for (int bb = 0; bb < SSB; ++bb)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int p = pg + bb * 8 * G + j * G;
+                        const float v = ssp[(int64_t)min(p, nparts - 1) * 32 + t * 16 + m16];
+                        ssv[t][bb][j] = (p < nparts) ? v : 0.f;
+                    }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cu = min(c0 + u, last);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const half8 v = load_half8(xr[t] + xcs * cu);
+                b[u][t] = xok[t] ? v : zero8;
+            }
+            if constexpr (NORM) lw[u] = load_half8(lnp + 64 * cu);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cu = min(c0 + u, last);
+            a[u][0] = SG_LOAD(wa + (int64_t)cu * 64);
+            if (GATEUP) a[u][NA - 1] = SG_LOAD(wu + (int64_t)cu * 64);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NORM) {
+#pragma unroll
+            for (int t = 0; t < MT16; ++t) {
+                float part = 0.f;
+#pragma unroll
+                for (int bb = 0; bb < SSB; ++bb)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) part += ssv[t][bb][j];
+                asm volatile("" : "+v"(part));                  // the fold's first additions stay in front of everything else
+                part0[t] = part;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    float inv[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) inv[t] = 1.f;
+    if constexpr (NORM) {
+        float tot[MT];
+        if (ss_in) {
+            // per-panel sums of squares left by the producer of x (residual-epilogue GEMM / exchange): fold in a fixed order
+#pragma unroll
+            for (int t = 0; t < MT16; ++t) {
+                float part = part0[t];
+                for (int p0 = pg + SSB * 8 * G; p0 < nparts; p0 += 8 * G) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int p = p0 + j * G;
+                        v[j] = (p < nparts) ? ss_in[(int64_t)p * 32 + t * 16 + m16] : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) part += v[j];
+                }
+                red[t][pg][m16] = part;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int row = t * 8 + lr;
+                tot[t] = 0.f;
+                for (int j = 0; j < G; ++j) tot[t] += red[row >> 4][j][row & 15];
+            }
+        } else {
+            // no hand-off (layer 0): this wave's share of sum(x^2) over ALL of K, then across the waves
+            float ss[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) ss[t] = 0.f;
+            for (int cc = c0; cc < c1; cc += 4) {
+                half8 v[4][MT];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        const half8 q = load_half8(xr[t] + xcs * min(cc + j, last));
+                        v[j][t] = (xok[t] && cc + j < c1) ? q : zero8;
+                    }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float f = (float)v[j][t][e];
+                            ss[t] = fmaf(f, f, ss[t]);
+                        }
+            }
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                ss[t] += __shfl_xor(ss[t], 8, 64);              // the two stacked chunks
+                ss[t] += __shfl_xor(ss[t], 16, 64);             // the four k-octets
+                ss[t] += __shfl_xor(ss[t], 32, 64);
+                if (lane < 8) sm_ss[wave][t * 8 + lane] = ss[t];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                tot[t] = 0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) tot[t] += sm_ss[w][t * 8 + lr];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) inv[t] = 1.0f / sqrtf(tot[t] / (float)K + eps);
+    }
+
+    // RoPE tables of this lane's output columns (positions -> table: two dependent loads, fetched under the K loop)
+    const bool epi = wave == 0;
+    half4 rope_cs[MT], rope_sn[MT];
+    if (MODE == SG_QKV && epi) {
+        const int H = rp.H, D = rp.D, pph = D >> 3;
+        const int sec = panel / (H * pph), pp = panel % pph;
+        const int d = 4 * pp + ((g & 1) ? (D >> 1) : 0);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int m = t * 8 + lr;
+            rope_cs[t] = half4{0, 0, 0, 0};
+            rope_sn[t] = half4{0, 0, 0, 0};
+            if (m < M && sec != 2 && (sec == 0 || rp.rotate_k)) {
+                const int64_t pos = rp.positions[m];
+                rope_cs[t] = *reinterpret_cast<const half4*>(rp.cosb + pos * D + d);
+                rope_sn[t] = *reinterpret_cast<const half4*>(rp.sinb + pos * D + d);
+            }
+        }
+    }
+
+    auto compute = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c + u < c1) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const half8 bn = NORM ? sg_normalise(b[u][t], lw[u], inv[t]) : b[u][t];
+#pragma unroll
+                    for (int aa = 0; aa < NA; ++aa)
+                        acc[aa][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u][aa], bn, acc[aa][t], 0, 0, 0);
+                }
+            }
+        }
+    };
+    compute(c0);                                                // the batch the prologue issued (straight-line: no join)
+    for (int c = c0 + U; c < c1; c += U) {
+        // (loads past the end re-read the wave's last super-chunk instead of being predicated: a conditional load makes
+        //  the waitcnt pass wait for everything; their MFMAs are skipped)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cu = min(c + u, last);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const half8 v = load_half8(xr[t] + xcs * cu);
+                b[u][t] = xok[t] ? v : zero8;
+            }
+            if constexpr (NORM) lw[u] = load_half8(lnp + 64 * cu);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cu = min(c + u, last);
+            a[u][0] = SG_LOAD(wa + (int64_t)cu * 64);
+            if (GATEUP) a[u][NA - 1] = SG_LOAD(wu + (int64_t)cu * 64);
+        }
+        compute(c);
+    }
+
+    // merge across the waves; C layout: lane holds D[n = 4g + r][m = li].  Valid blocks: (g < 2, li < 8) = even chunks,
+    // (g >= 2, li >= 8) = odd chunks of the same (weight row 4 (g & 1) + r, x row li & 7): lane + 40.
+#pragma unroll
+    for (int aa = 0; aa < NA; ++aa)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) *reinterpret_cast<f32x4*>(&sm[wave][aa][t][lane][0]) = acc[aa][t];
+    __syncthreads();
+    if (!epi) return;
+    const bool vl = g < 2 && li < 8;                            // lanes that own outputs (all 64 run the sums: no divergence)
+    const int lo = vl ? lane : 0, hi_l = vl ? lane + 40 : 40;
+    float S[MT][4], S2[MT][4];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            S[t][r] = 0.f;
+            S2[t][r] = 0.f;
+        }
+#pragma unroll 2
+        for (int w = 0; w < WAVES; ++w) {                       // (fully unrolled the reads of all waves and tiles are hoisted: spills)
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(&sm[w][0][t][lo][0]);
+            const f32x4 o0 = *reinterpret_cast<const f32x4*>(&sm[w][0][t][hi_l][0]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[t][r] += e0[r] + o0[r];
+            if (GATEUP) {
+                const f32x4 e1 = *reinterpret_cast<const f32x4*>(&sm[w][NA - 1][t][lo][0]);
+                const f32x4 o1 = *reinterpret_cast<const f32x4*>(&sm[w][NA - 1][t][hi_l][0]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S2[t][r] += e1[r] + o1[r];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = t * 8 + lr;
+        if (MODE == SG_QKV) {
+            // 8-row panel -> (section, head, 4-wide rotary block): q and k panels hold rows d0..d0+3 | d0+D/2..d0+D/2+3
+            const int H = rp.H, D = rp.D, half = D >> 1, pph = D >> 3;
+            const int sec = panel / (H * pph), hd = (panel / pph) % H, pp = panel % pph;
+            h16 val[4], oth[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                val[r] = (h16)S[t][r];
+                oth[r] = (h16)__shfl_xor((float)val[r], 16, 64);         // rotary partner: lane g <-> g ^ 1 (exact)
+            }
+            if (!vl || m >= M) continue;
+            const int slot = (rp.slot0_dev ? *rp.slot0_dev : rp.slot0) + m;
+            half4 out;
+            if (sec == 2) {                                              // v: natural row order
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[r] = val[r];
+                h16* dst = rp.v_cache + (int64_t)slot * rp.stride_t + (int64_t)hd * rp.stride_h + 8 * pp + 4 * g;
+                *reinterpret_cast<half4*>(dst) = out;
+                continue;
+            }
+            const bool hi = g == 1;
+            const int d = 4 * pp + (hi ? half : 0);
+            if (sec == 0 || rp.rotate_k) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const h16 cs = rope_cs[t][r], sn = rope_sn[t][r];
+                    const h16 rh = hi ? oth[r] : (h16)(-(float)oth[r]);
+                    out[r] = hadd_rn(hmul_rn(val[r], cs), hmul_rn(rh, sn));
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[r] = val[r];
+            }
+            h16* dst = (sec == 0) ? rp.q_out + ((int64_t)m * H + hd) * D + d
+                                  : rp.k_cache + (int64_t)slot * rp.stride_t + (int64_t)hd * rp.stride_h + d;
+            *reinterpret_cast<half4*>(dst) = out;
+        } else {
+            if (!vl || m >= M) continue;
+            half4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const h16 gt = (h16)S[t][r], up = (h16)S2[t][r];
+                const float gf = (float)gt;
+                const h16 act = (h16)(gf / (1.0f + expf(-gf)));
+                o[r] = hmul_rn(act, up);
+            }
+            h16* dst = (h16*)yv + (int64_t)m * ya.sm + (int64_t)panel * ya.sk + 4 * g;   // columns 8 panel + 4 g + r
+            if (((ya.sm | ya.sk) % 4) == 0 && (reinterpret_cast<uintptr_t>(yv) % 8) == 0) {
+                *reinterpret_cast<half4*>(dst) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[r] = o[r];
+            }
+        }
+    }
+}
+
 struct SgArgs {                       // one GEMM call: operands with their layouts
     const void *wp, *wp_up, *x, *ln_w, *resid;
     void* y;
@@ -1007,10 +1344,11 @@ static bool sg_shape_ok(int M, int N, int K, const SgAct& xa) {
 extern "C" int tf_sg_tune(int key, int value) {
     int* slot = key == 0 ? &g_sg_p2_rows : key == 1 ? &g_sg_p2_waves : key == 2 ? &g_sg_p2_groups
                 : key == 3 ? &g_sg_ksplit_max_groups : key == 4 ? &g_sg_ksplit_force : key == 5 ? &g_sg_few_panels
-                : key == 6 ? &g_sg_deep_panels : nullptr;
+                : key == 6 ? &g_sg_deep_panels : key == 7 ? &g_sg_n8_u : nullptr;
     if (!slot) return -1;
     const int old = *slot;
     if (key == 1 && value != 4 && value != 8) return old;
+    if (key == 7 && value != 0 && value != 5 && value != 8) return old;
     *slot = value;
     return old;
 }
@@ -1120,6 +1458,85 @@ extern "C" int tf_skinny_qkv_rope(const void* wqkv_packed, const void* x, int64_
                                   void* stream) {
     return tf_skinny_qkv_rope_act(wqkv_packed, x, ldx, 8, ln_w, eps, ss_in, cosb, sinb, positions, q_out, k_cache,
                                   v_cache, stride_t, stride_h, slot0, slot0_dev, M, H, D, K, rotate_k, stream);
+}
+
+// ---- narrow-panel entry points (skinny_gemm_n8_kernel) ----
+// Weights packed by ops.pack_weight_n8: [N/8 panels][K/64 super-chunks][4 (g)][2 (chunk parity)][8 rows][8]; the q|k|v
+// weight additionally in the 8-row rotary order (ops.rope_row_order_n8: every panel of the q and k sections holds rows
+// d0..d0+3 and their partners d0+D/2..d0+D/2+3 of one head).  Applies to <= 24 rows with a norm prologue (ln_w) and
+// K a multiple of 64 with >= 2 super-chunks per wave; anything else returns TF_EINVAL — the caller keeps the 16-row form.
+#define SG_N8_WAVES 8
+
+static bool sg_n8_ok(int M, int N, int K, const SgAct& xa) {
+    return M >= 1 && M <= 24 && N >= 8 && (N % 8) == 0 && K >= 64 * 2 * SG_N8_WAVES && (K % 64) == 0 && sg_act_ok(xa) &&
+           xa.sm <= 0x7fffffff && xa.sk <= 0x7fffffff;
+}
+
+template <int MODE>
+static int launch_sg_n8(const SgArgs& a, const SgRope& rp, hipStream_t st) {
+    const int nsc = a.K >> 6, cpw = (nsc + SG_N8_WAVES - 1) / SG_N8_WAVES;
+    // batch = super-chunks a wave keeps in flight (x NA weight streams): its whole share when that is <= 8 (7B: 8 — one
+    // round trip per wave), else the even split of 10 (13B: 5 + 5)
+    const bool u5 = g_sg_n8_u ? (g_sg_n8_u == 5) : (cpw > 8 && (cpw % 5) == 0);
+#define N8_LAUNCH(MT_, U_)                                                                                                   \
+    hipLaunchKernelGGL((skinny_gemm_n8_kernel<MT_, MODE, true, SG_N8_WAVES, U_>), dim3(a.N / 8), dim3(SG_N8_WAVES * 64), 0,  \
+                       st, (const half8*)a.wp, (const half8*)a.wp_up, (const h16*)a.x, a.ss_in, (const h16*)a.ln_w, a.K,    \
+                       a.M, (int)a.xa.sm, (int)a.xa.sk, a.eps, a.y, a.ya, rp)
+    // (the gate|up form holds two weight streams: from two row tiles up a batch of 4 keeps it inside 256 registers)
+    if (a.M <= 8) {
+        if (u5) N8_LAUNCH(1, 5); else N8_LAUNCH(1, 8);
+    } else if constexpr (MODE == SG_GATEUP) {
+        if (a.M <= 16) N8_LAUNCH(2, 4); else N8_LAUNCH(3, 4);
+    } else if (a.M <= 16) {
+        if (u5) N8_LAUNCH(2, 5); else N8_LAUNCH(2, 8);
+    } else {
+        N8_LAUNCH(3, 5);
+    }
+#undef N8_LAUNCH
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}
+
+extern "C" int tf_skinny_gemm_swiglu_n8(const void* gate_n8, const void* up_n8, const void* x, int64_t xs_m, int64_t xs_k,
+                                        const void* ln_w, float eps, const float* ss_in, void* act, int64_t ys_m,
+                                        int64_t ys_k, int M, int I, int K, void* stream) {
+    SgArgs a = {};
+    a.wp = gate_n8, a.wp_up = up_n8, a.x = x, a.ln_w = ln_w, a.y = act;
+    a.xa = SgAct{xs_m, xs_k}, a.ya = SgAct{ys_m, ys_k}, a.ra = SgAct{8, 8};
+    a.eps = eps, a.M = M, a.N = I, a.K = K, a.ss_in = ss_in;
+    if (!gate_n8 || !up_n8 || !x || !act || !ln_w || !sg_n8_ok(M, I, K, a.xa)) return TF_EINVAL;
+    if (ys_m <= 0 || ys_k <= 0) return TF_EINVAL;
+    const SgRope rp = {};
+    return launch_sg_n8<SG_GATEUP>(a, rp, (hipStream_t)stream);
+}
+
+extern "C" int tf_skinny_qkv_rope_n8(const void* wqkv_n8, const void* x, int64_t xs_m, int64_t xs_k, const void* ln_w,
+                                     float eps, const float* ss_in, const void* cosb, const void* sinb,
+                                     const int64_t* positions, void* q_out, void* k_cache, void* v_cache, int64_t stride_t,
+                                     int64_t stride_h, int slot0, const int32_t* slot0_dev, int M, int H, int D, int K,
+                                     int rotate_k, void* stream) {
+    if (!wqkv_n8 || !x || !ln_w || !cosb || !sinb || !positions || !q_out || !k_cache || !v_cache) return TF_EINVAL;
+    SgArgs a = {};
+    a.wp = wqkv_n8, a.x = x, a.ln_w = ln_w;
+    a.xa = SgAct{xs_m, xs_k}, a.ra = SgAct{8, 8}, a.ya = SgAct{8, 8};
+    a.eps = eps, a.M = M, a.N = 3 * H * D, a.K = K, a.ss_in = ss_in;
+    if (H < 1 || D < 32 || (D % 32) || !sg_n8_ok(M, a.N, K, a.xa)) return TF_EINVAL;
+    if ((stride_t % 4) || (stride_h % 4)) return TF_EINVAL;                          // 8-byte epilogue stores
+    SgRope rp;
+    rp.cosb = (const h16*)cosb;
+    rp.sinb = (const h16*)sinb;
+    rp.positions = positions;
+    rp.q_out = (h16*)q_out;
+    rp.k_cache = (h16*)k_cache;
+    rp.v_cache = (h16*)v_cache;
+    rp.stride_t = stride_t;
+    rp.stride_h = stride_h;
+    rp.slot0_dev = slot0_dev;
+    rp.slot0 = slot0;
+    rp.H = H;
+    rp.D = D;
+    rp.rotate_k = rotate_k;
+    return launch_sg_n8<SG_QKV>(a, rp, (hipStream_t)stream);
 }
 
 // y = resid + all_reduce(x . W^T) over `world` ranks, GEMM and exchange in ONE launch (see SgXchg above): replaces

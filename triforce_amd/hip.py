@@ -57,6 +57,9 @@ SIGNATURES = {
     "tf_skinny_gemm_swiglu_act": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _f32, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "tf_skinny_qkv_rope_act": (_i32, [_vp, _vp, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32,
                                       _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "tf_skinny_gemm_swiglu_n8": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _f32, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "tf_skinny_qkv_rope_n8": (_i32, [_vp, _vp, _i64, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32,
+                                     _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "tf_sg_tune": (_i32, [_i32, _i32]),
     "tf_sg_workspace": (_i32, [_vp, _i64]),
     "tf_topp_probs": (_i32, [_vp, _vp, _i32, _i32, _f32, _f32, _vp]),

@@ -73,6 +73,41 @@ def rope_row_order(H, D, device=None):
     return torch.cat([qk, torch.arange(2 * H * D, 3 * H * D, device=device)])
 
 
+# ---- narrow panels (round 5; csrc/gemv.hip skinny_gemm_n8_kernel) ----------------------------------------------------
+# The q|k|v / gate|up shards of a tensor-parallel rank have 86-120 16-row panels: one workgroup per panel leaves 2/3 of the
+# 256 CUs idle and each workgroup is bound by what one CU can pull.  Weights with at most N8_MAX_PANELS 16-row panels per
+# weight stream get a SECOND packed copy in 8-row panels (twice the workgroups, half the bytes each, no hand-off) that the
+# two norm GEMMs use for blocks of <= 24 rows.  TRIFORCE_GEMM_N8 = 0 disables, TRIFORCE_GEMM_N8_MAX_PANELS sets the limit.
+N8_ENABLED = _os.environ.get("TRIFORCE_GEMM_N8", "1") != "0"
+N8_MAX_PANELS = int(_os.environ.get("TRIFORCE_GEMM_N8_MAX_PANELS", "128"))
+N8_MAX_ROWS = 24
+N8_MIN_K = 1024
+
+
+def pack_weight_n8(w):
+    """[N, K] fp16 -> narrow-panel operand order [N/8][K/64][4 (g)][2 (chunk parity)][8 (row)][8]: per 8-row panel and
+    64-wide super-chunk one contiguous KiB whose 64 16-byte pieces are the A operand of ONE 16x16x32 MFMA — rows 0-7 of
+    the operand = the panel's rows over the even 32-wide chunk, rows 8-15 = the same rows over the odd chunk."""
+    N, K = w.shape
+    assert N % 8 == 0 and K % 64 == 0 and w.dtype == _HALF
+    return w.view(N // 8, 8, K // 64, 2, 4, 8).permute(0, 2, 4, 3, 1, 5).contiguous()
+
+
+def rope_row_order_n8(H, D, device=None):
+    """rope_row_order for 8-row panels: every panel of the q and k sections holds rows d0..d0+3 and their rotary partners
+    d0+D/2..d0+D/2+3 of one head; v rows keep their order."""
+    assert D % 32 == 0
+    d = torch.arange(D // 2, device=device).view(D // 8, 4)
+    per_head = torch.cat([d, d + D // 2], dim=1).reshape(-1)                     # (D,)
+    qk = (torch.arange(2 * H, device=device).view(-1, 1) * D + per_head.view(1, -1)).reshape(-1)
+    return torch.cat([qk, torch.arange(2 * H * D, 3 * H * D, device=device)])
+
+
+def n8_applies(N_stream, K):
+    """Does a weight stream of N_stream rows x K get (and use) the narrow-panel copy?"""
+    return (N8_ENABLED and N_stream % 16 == 0 and N_stream // 16 <= N8_MAX_PANELS and K % 64 == 0 and K >= N8_MIN_K)
+
+
 # Split-K workspace of the skinny GEMM (csrc/gemv.hip SgKsplit, tf_sg_workspace): one zero-filled 8 MiB block per device,
 # registered when the first weight is packed there (i.e. before any hipGraph capture) and never freed.  Few-panel GEMMs
 # (the q|k|v / gate|up shards of a tensor-parallel rank) can then split K across up to 4 workgroups per panel —
@@ -122,6 +157,12 @@ class PackedLinear:
         self.wp_rope = None
         if ok and rope is not None and rope[1] % 32 == 0 and self.N == 3 * rope[0] * rope[1]:
             self.wp_rope = pack_weight(w[rope_row_order(rope[0], rope[1], w.device)])
+        # narrow-panel copies (few-panel shards only): gate|up streams, and the q|k|v weight in its 8-row rotary order
+        self.parts_n8 = self.wp_rope_n8 = None
+        if ok and w.is_cuda and split == 2 and n8_applies(self.N // split, self.K):
+            self.parts_n8 = [pack_weight_n8(b) for b in w.chunk(split, dim=0)]
+        if self.wp_rope is not None and w.is_cuda and n8_applies(self.N, self.K):
+            self.wp_rope_n8 = pack_weight_n8(w[rope_row_order_n8(rope[0], rope[1], w.device)])
 
     def refresh_(self):
         """Re-pack IN PLACE after ``self.w`` was modified in place (captured hipGraphs keep their pointers)."""
@@ -130,6 +171,11 @@ class PackedLinear:
                 dst.copy_(pack_weight(blk))
         if self.wp_rope is not None:
             self.wp_rope.copy_(pack_weight(self.w[rope_row_order(self.rope[0], self.rope[1], self.w.device)]))
+        if self.parts_n8 is not None:
+            for dst, blk in zip(self.parts_n8, self.w.chunk(self.split, dim=0)):
+                dst.copy_(pack_weight_n8(blk))
+        if self.wp_rope_n8 is not None:
+            self.wp_rope_n8.copy_(pack_weight_n8(self.w[rope_row_order_n8(self.rope[0], self.rope[1], self.w.device)]))
         return self
 
 
@@ -335,6 +381,11 @@ def mlp_act(h, wgu, ln=None, eps=0.0, ss_in=None):
         act = Act.empty(M, I, h.device) if isinstance(h, Act) else torch.empty(M, I, dtype=_HALF, device=h.device)
         hp, hsm, hsk = _lay(h)
         ap, asm, ask = _lay(act)
+        if wgu.parts_n8 is not None and ln is not None and M <= N8_MAX_ROWS:        # few-panel shard: 8-row panels
+            hip.check(hip.lib().tf_skinny_gemm_swiglu_n8(_ptr(wgu.parts_n8[0]), _ptr(wgu.parts_n8[1]), hp, hsm, hsk, _ptr(ln),
+                                                         float(eps), _ptr(ss_in), ap, asm, ask, M, I, wgu.K, _stream()),
+                      "tf_skinny_gemm_swiglu_n8")
+            return act
         hip.check(hip.lib().tf_skinny_gemm_swiglu_act(_ptr(wgu.parts[0]), _ptr(wgu.parts[1]), hp, hsm, hsk, _ptr(ln),
                                                       float(eps), _ptr(ss_in), ap, asm, ask, M, I, wgu.K, _stream()),
                   "tf_skinny_gemm_swiglu_act")
@@ -363,6 +414,12 @@ def qkv_rope(x, wqkv, ln, eps, cos, sin, positions, k_layer, v_layer, slot0, H, 
     assert _kv(v_layer) == (st, sh)
     q = torch.empty(rows, H, D, dtype=_HALF, device=x.device)
     xp, xsm, xsk = _lay(x)
+    if wqkv.wp_rope_n8 is not None and ln is not None and rows <= N8_MAX_ROWS:      # few-panel shard: 8-row panels
+        hip.check(hip.lib().tf_skinny_qkv_rope_n8(_ptr(wqkv.wp_rope_n8), xp, xsm, xsk, _ptr(ln), float(eps), _ptr(ss_in),
+                                                  _ptr(cos), _ptr(sin), _ptr(positions), _ptr(q), _ptr(k_layer),
+                                                  _ptr(v_layer), st, sh, int(slot0), _ptr(slot0_dev), rows, H, D, wqkv.K,
+                                                  1 if rotate_k else 0, _stream()), "tf_skinny_qkv_rope_n8")
+        return q
     hip.check(hip.lib().tf_skinny_qkv_rope_act(_ptr(wqkv.wp_rope), xp, xsm, xsk, _ptr(ln), float(eps), _ptr(ss_in),
                                                _ptr(cos), _ptr(sin), _ptr(positions), _ptr(q), _ptr(k_layer),
                                                _ptr(v_layer), st, sh, int(slot0), _ptr(slot0_dev), rows, H, D, wqkv.K,
