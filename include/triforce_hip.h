@@ -355,6 +355,22 @@ int tf_accept_chain(const float* p, const float* q, const int64_t* tokens, const
                     int g2, int V, int inclusive, int64_t eos_token_id, int64_t* out, void* stream);
 int tf_middle_accept(const float* p, const float* q_d, int64_t* tokens, const float* uniforms,
                      int n, int gamma, int V, int64_t* out, void* stream);
+/* The same three kernels with their uniforms behind a DEVICE CURSOR (round 5): u_k = ubuf[*cursor + k] — the form that
+ * can sit INSIDE a captured hipGraph (frozen arguments, fresh numbers at every replay), which is how the inner loop of
+ * utils/decoding.py:163-223 becomes ONE graph launch per iteration (draft forward, draw, retrieval verify, accept test).
+ *   tf_sample_inverse_cdf_cur: u = ubuf[*cursor + off]; the cursor is left alone.
+ *   tf_middle_accept_cur     : accept test with ubuf[*cursor + 1], follow-up sample with ubuf[*cursor + 2]; *cursor += 3;
+ *                              out[3] = the cursor value the decision started from (the host checks its mirror).
+ *   tf_accept_chain_cur      : the chain over ubuf[*cursor ...]; *cursor += out[3].
+ * In ALL forms (cursor or not) what the kernel leaves for the next chain of launches on the device — the token id in
+ * `tokens`, the cursor — is stored write-through (agent scope) and drained BEFORE the record `out` is stored: a host that
+ * polls `out` in pinned memory may launch the next chain on ANOTHER stream the moment it sees the record. */
+int tf_sample_inverse_cdf_cur(const float* probs, const float* ubuf, const int64_t* cursor, int off, int64_t* token_out,
+                              int V, void* stream);
+int tf_middle_accept_cur(const float* p, const float* q_d, int64_t* tokens, const float* ubuf, int64_t* cursor, int n,
+                         int gamma, int V, int64_t* out, void* stream);
+int tf_accept_chain_cur(const float* p, const float* q, const int64_t* tokens, const float* ubuf, int64_t* cursor, int g2,
+                        int V, int inclusive, int64_t eos_token_id, int64_t* out, void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Sequoia tree verification (utils/SpecTree_TP.py:147-199: accept_step + the walk in verify()).

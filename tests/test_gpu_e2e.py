@@ -570,6 +570,48 @@ def test_static_verify_rows_equal_per_step_copies_and_lifetime_is_guarded():
     assert ge.verify_generation() != bufs.rows_generation   # ... is what TriForceRunner.step's assert compares
 
 
+@pytest.mark.parametrize("temperature,top_p", [(0.8, 0.95), (1.0, 1e-9)])
+def test_one_launch_inner_iterations_on_two_lanes_emit_the_identical_stream(temperature, top_p, monkeypatch):
+    """Round 5: an inner iteration of Middle_Spec (reference decoding.py:182-220) is ONE hipGraph — draft step,
+    draw, retrieval verify, accept test, with the uniforms behind a device cursor — and consecutive chains of launches
+    alternate between two streams, ordered only by the decision record the host polls.  Nothing about the arithmetic
+    changes, so against rounds 2-4's form (two replays + two eager kernels per iteration on one stream) the emitted tokens,
+    the per-step accept counts and the consumed uniforms must be IDENTICAL — over a run long enough (>= 150 outer steps,
+    ~600 record-ordered stream switches) that a token id or cursor value read before it was visible would show as a
+    diverged stream.  Also: lanes without the inner graphs, and a second runner on the same engine (re-capture)."""
+    from triforce_amd.utils import decoding as Dm
+    from triforce_amd.utils.decoding import TriForce
+    from triforce_amd.utils.sampling import UniformSource
+    g = dict(Hh.load_golden("small_gamma6"), gen_len=260, budget=320)     # room for a long run (tail <= retrieval budget)
+    ge = Hh.build_product(g, DEV, temperature=temperature, top_p=top_p, graphs=True)
+    prompt, tok = Hh.prompt_of(g).to(DEV), Hh.FakeTokenizer()
+    vals = Hh.fixed_uniforms(n=4096, seed=901)
+    max_len = 230
+    out = {}
+    for mode, (inner, lanes) in {"r04": (False, False), "lanes": (False, True), "inner+lanes": (True, True),
+                                 "inner": (True, False), "inner+lanes again": (True, True)}.items():
+        monkeypatch.setattr(Dm, "INNER_GRAPH", inner)
+        monkeypatch.setattr(Dm, "LANES", lanes)
+        if hasattr(ge, "_tf_spec_buffers"):
+            del ge._tf_spec_buffers                   # (the lanes live in the per-engine buffers)
+        rng = UniformSource(DEV, values=vals)
+        res = TriForce(tok, ge, prompt, gamma=g["gamma"], max_len=max_len, top_k=-1, top_p=top_p, temperature=temperature,
+                       rng=rng, return_details=True)
+        out[mode] = (res["tokens"], res["counts"], rng.pos)
+        b = ge._tf_spec_buffers
+        assert (b.lanes is not None) == lanes
+        if lanes:
+            assert not b.lanes.active and b.lanes.flips >= len(res["counts"]), "lanes were not flipped at the record reads"
+        assert torch.cuda.current_stream() == torch.cuda.default_stream() or not lanes
+    ref = out["r04"]
+    assert len(ref[1]) >= 30
+    for mode, got in out.items():
+        assert got[0] == ref[0], f"{mode}: tokens diverge at {Hh.common_prefix(got[0], ref[0])} of {len(ref[0])}"
+        assert got[1] == ref[1] and got[2] == ref[2], f"{mode}: accept counts / uniform position differ"
+    Hh.note(f"inner-iteration graphs + lanes: {len(ref[0])} tokens / {len(ref[1])} steps identical to the four-launch form "
+            f"(T={temperature}, top_p={top_p})")
+
+
 def test_draft_prefill_graph_equals_eager(monkeypatch):
     """The 68M draft's prompt pass replays ONE captured steady-state step (shift the StreamingLLM window by 64 rows, run 64
     rows) per full chunk once the window is full; the result must equal the all-eager pass bit for bit: returned logits,

@@ -836,7 +836,8 @@ def test_narrow_panel_norm_gemms(M, packed, kind, N, K, HD, monkeypatch):
             k = torch.zeros(H, 64, D, dtype=torch.float16, device=DEV)
             v = torch.zeros(H, 64, D, dtype=torch.float16, device=DEV)
             q = ops.qkv_rope(xin, pl, lnd, eps, cd, sd, pd, k, v, 3, H, D, ss_in=ss_in)
-            assert k[:, :3].abs().sum() == 0 and k[:, 3 + M:].abs().sum() == 0
+            if not torch.cuda.is_current_stream_capturing():
+                assert k[:, :3].abs().sum() == 0 and k[:, 3 + M:].abs().sum() == 0
             return q, k[:, 3:3 + M].permute(1, 0, 2).contiguous(), v[:, 3:3 + M].permute(1, 0, 2).contiguous()
     else:
         wgu = rnd(2 * N, K, seed=503, scale=0.05)
@@ -894,6 +895,52 @@ def test_narrow_panel_norm_gemms(M, packed, kind, N, K, HD, monkeypatch):
     for a, b in zip(got, got_ss):
         dq = (a.float() - b.float()).abs()
         assert bool((dq <= 2 * b.float().abs() * 2 ** -10 + (1.6e-2 if kind == "qkv" else 2e-3)).all())
+
+
+def test_cursor_forms_of_the_sampling_kernels_equal_the_pointer_forms():
+    """Round 5: inside the inner-iteration hipGraphs the draw / accept kernels read their uniforms as ubuf[cursor + k]
+    (tf_*_cur; utils/decoding.py:163-223 as one launch per iteration) and advance the device cursor themselves.  Same
+    kernels, same numbers: records, written tokens and sampled ids must equal the pointer forms bit for bit, and the cursor
+    must move by exactly what each decision consumed."""
+    ops = _ops()
+    V, gamma = 32000, 6
+    g = torch.Generator().manual_seed(77)
+    ubuf = torch.rand(512, generator=g).to(DEV)
+    for trial in range(6):
+        p = torch.softmax(torch.randn(gamma + 2, V, generator=g) * 2, -1).to(DEV)
+        q = torch.softmax(torch.randn(gamma + 1, V, generator=g) * 2, -1).to(DEV)
+        if trial % 2:                                             # near-identical rows: accepted drafts, long chains
+            q = (p[:gamma + 1] * 0.98 + 0.02 / V).contiguous()
+        base = 5 + 17 * trial
+        cur = torch.tensor([base], dtype=torch.int64, device=DEV)
+        # draw
+        t_ptr = torch.zeros(1, dtype=torch.int64, device=DEV)
+        t_cur = torch.zeros(1, dtype=torch.int64, device=DEV)
+        ops.sample_inverse_cdf(q[0], ubuf[base:base + 1], t_ptr)
+        ops.sample_inverse_cdf_cur(q[0], ubuf, cur, 0, t_cur)
+        assert torch.equal(t_ptr, t_cur) and int(cur) == base
+        # inner accept at every position n
+        for n in range(gamma):
+            toks = torch.randint(0, V, (gamma + 1,), generator=g).to(DEV)
+            toks[n + 1] = int(torch.multinomial(q[n].cpu(), 1))
+            ta, tb = toks.clone(), toks.clone()
+            ra = torch.full((4,), -1, dtype=torch.int64, device=DEV)
+            rb = torch.full((4,), -1, dtype=torch.int64, device=DEV)
+            cur.fill_(base)
+            ops.middle_accept(p, q[n], ta, ubuf[base + 1:base + 3], n, gamma, ra)
+            ops.middle_accept_cur(p, q[n], tb, ubuf, cur, n, gamma, rb)
+            assert torch.equal(ra[:3], rb[:3]) and torch.equal(ta, tb), (trial, n)
+            assert int(rb[3]) == base and int(cur) == base + 3
+        # outer chain
+        for g2 in (gamma, gamma + 1):
+            toks = torch.stack([torch.multinomial(q[i].cpu(), 1)[0] for i in range(g2)]).to(DEV)
+            ra = torch.zeros(4, dtype=torch.int64, device=DEV)
+            rb = torch.zeros(4, dtype=torch.int64, device=DEV)
+            cur.fill_(base)
+            ops.accept_chain(p, q, toks, ubuf[base:base + g2 + 1], g2, False, 2, ra)
+            ops.accept_chain_cur(p, q, toks, ubuf, cur, g2, False, 2, rb)
+            assert torch.equal(ra, rb), (trial, g2, ra.tolist(), rb.tolist())
+            assert int(cur) == base + int(rb[3])
 
 
 def test_row_copy_wrappers_refuse_out_of_range_rows():

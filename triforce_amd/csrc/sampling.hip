@@ -113,20 +113,40 @@ __device__ int block_sample(const float* __restrict__ p, const float* __restrict
     return r;
 }
 
+// Uniforms behind a DEVICE CURSOR (round 5): `uniforms` is then the base of the stream's buffer and u_k = uniforms[*cursor + k],
+// so that a kernel captured inside a hipGraph (its arguments are frozen) consumes fresh numbers at every replay; the kernel
+// that closes a decision advances the cursor itself by what the decision consumed (utils.sampling.UniformSource mirrors the
+// position on the host).  cursor == NULL: `uniforms` points at u_0 (the eager form).
+__device__ __forceinline__ const float* cur_uniforms(const float* uniforms, const int64_t* cursor, int64_t* at) {
+    const int64_t c = cursor ? __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    *at = c;
+    return uniforms + c;
+}
+// What a record kernel leaves for the NEXT chain of launches (token ids in the shared token buffer, the cursor) is stored
+// write-through (agent scope) and drained BEFORE the record store: the host launches the next chain — on another stream,
+// so ordered by the record alone, not by this kernel's completion (utils/decoding.py, lanes) — as soon as it sees the record.
+__device__ __forceinline__ void st_agent_i64(int64_t* p, int64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(const float* __restrict__ probs,
-                                                              const float* __restrict__ u,
+                                                              const float* __restrict__ u, const int64_t* cursor, int off,
                                                               int64_t* __restrict__ token_out, int V) {
     __shared__ SampleShared sh;
-    const int t = block_sample<false>(probs, nullptr, V, *u, &sh);
+    int64_t at;
+    const float* uu = cur_uniforms(u, cursor, &at) + off;
+    const int t = block_sample<false>(probs, nullptr, V, *uu, &sh);
     if (threadIdx.x == 0) *token_out = (int64_t)t;
 }
 
 __global__ __launch_bounds__(SAMP_THREADS) void accept_chain_kernel(
     const float* __restrict__ p, const float* __restrict__ q, const int64_t* __restrict__ tokens,
-    const float* __restrict__ uniforms, int g2, int V, int inclusive, int64_t eos, int64_t* __restrict__ out) {
+    const float* __restrict__ uniforms_base, int64_t* cursor, int g2, int V, int inclusive, int64_t eos,
+    int64_t* __restrict__ out) {
     __shared__ SampleShared sh;
     __shared__ int s_count, s_reason;
     const int tid = threadIdx.x;
+    int64_t at;
+    const float* uniforms = cur_uniforms(uniforms_base, cursor, &at);
     if (tid < 64) {
         bool f = false, is_eos = false;
         if (tid < g2) {
@@ -162,27 +182,38 @@ __global__ __launch_bounds__(SAMP_THREADS) void accept_chain_kernel(
         next = block_sample<false>(p + (int64_t)g2 * V, nullptr, V, uniforms[examined], &sh);
     }
     if (tid == 0) {
+        const int consumed = examined + (reason != 2 ? 1 : 0);
+        if (cursor) {
+            st_agent_i64(cursor, at + consumed);
+            drain_stores();
+        }
         out[0] = count;
         out[1] = next;
         out[2] = reason;
-        out[3] = examined + (reason != 2 ? 1 : 0);
+        out[3] = consumed;
     }
 }
 
 __global__ __launch_bounds__(SAMP_THREADS) void middle_accept_kernel(
     const float* __restrict__ p, const float* __restrict__ q_d, int64_t* __restrict__ tokens,
-    const float* __restrict__ uniforms, int n, int gamma, int V, int64_t* __restrict__ out) {
+    const float* __restrict__ uniforms_base, int64_t* cursor, int uoff, int n, int gamma, int V, int64_t* __restrict__ out) {
     __shared__ SampleShared sh;
+    int64_t at;
+    const float* uniforms = cur_uniforms(uniforms_base, cursor, &at) + uoff;
     const int64_t d = tokens[n + 1];
     const float ratio = p[(int64_t)n * V + d] / q_d[d];
     const float m = (ratio != ratio) ? ratio : fminf(1.0f, ratio);
     const int acc = (uniforms[0] < m) ? 1 : 0;
     const int b = block_sample<false>(p + (int64_t)(n + acc) * V, nullptr, V, uniforms[1], &sh);
     if (threadIdx.x == 0) {
+        // first what the next chain reads on the device (write-through, drained), then the record the host waits for
+        if (n + 1 + acc <= gamma) st_agent_i64(&tokens[n + 1 + acc], (int64_t)b);
+        if (cursor) st_agent_i64(cursor, at + uoff + 2);
+        drain_stores();
         out[0] = acc;
         out[1] = b;
         out[2] = d;
-        if (n + 1 + acc <= gamma) tokens[n + 1 + acc] = b;
+        if (cursor) out[3] = at;             // where this decision's numbers began (the host checks its mirror)
     }
 }
 
@@ -469,7 +500,8 @@ extern "C" int tf_sample_without_replacement(const float* logits, const void* ra
 
 extern "C" int tf_sample_inverse_cdf(const float* probs, const float* u, int64_t* token_out, int V, void* stream) {
     if (!probs || !u || !token_out || V < 1) return TF_EINVAL;
-    hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(SAMP_THREADS), 0, (hipStream_t)stream, probs, u, token_out, V);
+    hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(SAMP_THREADS), 0, (hipStream_t)stream, probs, u, (const int64_t*)nullptr, 0,
+                       token_out, V);
     TF_LAUNCH_CHECK();
     return TF_OK;
 }
@@ -478,7 +510,7 @@ extern "C" int tf_accept_chain(const float* p, const float* q, const int64_t* to
                                int V, int inclusive, int64_t eos_token_id, int64_t* out, void* stream) {
     if (!p || !q || !tokens || !uniforms || !out || g2 < 1 || g2 > 63 || V < 1) return TF_EINVAL;
     hipLaunchKernelGGL(accept_chain_kernel, dim3(1), dim3(SAMP_THREADS), 0, (hipStream_t)stream, p, q, tokens,
-                       uniforms, g2, V, inclusive, eos_token_id, out);
+                       uniforms, (int64_t*)nullptr, g2, V, inclusive, eos_token_id, out);
     TF_LAUNCH_CHECK();
     return TF_OK;
 }
@@ -487,7 +519,39 @@ extern "C" int tf_middle_accept(const float* p, const float* q_d, int64_t* token
                                 int gamma, int V, int64_t* out, void* stream) {
     if (!p || !q_d || !tokens || !uniforms || !out || n < 0 || n >= gamma || V < 1) return TF_EINVAL;
     hipLaunchKernelGGL(middle_accept_kernel, dim3(1), dim3(SAMP_THREADS), 0, (hipStream_t)stream, p, q_d, tokens,
-                       uniforms, n, gamma, V, out);
+                       uniforms, (int64_t*)nullptr, 0, n, gamma, V, out);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}
+
+// The same three kernels with their uniforms behind a device cursor (see cur_uniforms): u_k = ubuf[*cursor + k].
+//   tf_sample_inverse_cdf_cur : token = sample(probs) with u = ubuf[*cursor + off]; the cursor is left alone
+//   tf_middle_accept_cur      : accept test with ubuf[*cursor + 1], follow-up sample with ubuf[*cursor + 2] (the draw of the
+//                               drafted token used + 0); cursor += 3; out[3] = the cursor value the decision started from
+//   tf_accept_chain_cur       : accept chain over ubuf[*cursor ...]; cursor += out[3] (the numbers it consumed)
+// In all of them the device-visible results (token ids, cursor) are stored write-through and drained before the record.
+extern "C" int tf_sample_inverse_cdf_cur(const float* probs, const float* ubuf, const int64_t* cursor, int off,
+                                         int64_t* token_out, int V, void* stream) {
+    if (!probs || !ubuf || !cursor || !token_out || V < 1 || off < 0) return TF_EINVAL;
+    hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(SAMP_THREADS), 0, (hipStream_t)stream, probs, ubuf, cursor, off, token_out, V);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}
+
+extern "C" int tf_middle_accept_cur(const float* p, const float* q_d, int64_t* tokens, const float* ubuf, int64_t* cursor,
+                                    int n, int gamma, int V, int64_t* out, void* stream) {
+    if (!p || !q_d || !tokens || !ubuf || !cursor || !out || n < 0 || n >= gamma || V < 1) return TF_EINVAL;
+    hipLaunchKernelGGL(middle_accept_kernel, dim3(1), dim3(SAMP_THREADS), 0, (hipStream_t)stream, p, q_d, tokens, ubuf, cursor,
+                       1, n, gamma, V, out);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}
+
+extern "C" int tf_accept_chain_cur(const float* p, const float* q, const int64_t* tokens, const float* ubuf, int64_t* cursor,
+                                   int g2, int V, int inclusive, int64_t eos_token_id, int64_t* out, void* stream) {
+    if (!p || !q || !tokens || !ubuf || !cursor || !out || g2 < 1 || g2 > 63 || V < 1) return TF_EINVAL;
+    hipLaunchKernelGGL(accept_chain_kernel, dim3(1), dim3(SAMP_THREADS), 0, (hipStream_t)stream, p, q, tokens, ubuf, cursor,
+                       g2, V, inclusive, eos_token_id, out);
     TF_LAUNCH_CHECK();
     return TF_OK;
 }

@@ -894,6 +894,44 @@ def middle_accept(p, q_d, tokens, uniforms, n, gamma, out):
                                          _ptr(out), _stream()), "tf_middle_accept")
 
 
+# ---- the same three kernels with their uniforms behind a device cursor: u_k = ubuf[cursor[0] + k] (capturable) -------------
+def sample_inverse_cdf_cur(probs, ubuf, cursor, off, token_out):
+    """token_out[0] <- sample(probs) with u = ubuf[cursor[0] + off]; the cursor is left alone."""
+    _dev(probs, ubuf, cursor)
+    _dev_or_pinned(token_out)
+    assert probs.dtype == torch.float32 and probs.is_contiguous() and probs.dim() == 1
+    assert ubuf.dtype == torch.float32 and cursor.dtype == torch.int64 and token_out.dtype == torch.int64
+    hip.check(hip.lib().tf_sample_inverse_cdf_cur(_ptr(probs), _ptr(ubuf), _ptr(cursor), int(off), _ptr(token_out),
+                                                  probs.numel(), _stream()), "tf_sample_inverse_cdf_cur")
+
+
+def middle_accept_cur(p, q_d, tokens, ubuf, cursor, n, gamma, out):
+    """middle_accept over ubuf[cursor + 1], ubuf[cursor + 2]; cursor += 3; out[4] <- (accepted, follow-up, drafted, cursor
+    value the decision started from)."""
+    _dev(p, q_d, tokens, ubuf, cursor)
+    _dev_or_pinned(out)
+    V = p.shape[-1]
+    assert p.dtype == torch.float32 and p.is_contiguous() and q_d.dtype == torch.float32 and q_d.numel() == V
+    assert tokens.dtype == torch.int64 and tokens.numel() >= gamma + 1 and out.numel() >= 4
+    assert ubuf.dtype == torch.float32 and cursor.dtype == torch.int64
+    hip.check(hip.lib().tf_middle_accept_cur(_ptr(p), _ptr(q_d), _ptr(tokens), _ptr(ubuf), _ptr(cursor), int(n), int(gamma), V,
+                                             _ptr(out), _stream()), "tf_middle_accept_cur")
+
+
+def accept_chain_cur(p, q, tokens, ubuf, cursor, g2, inclusive, eos_token_id, out):
+    """accept_chain over ubuf[cursor ...]; cursor += the numbers consumed (out[3])."""
+    _dev(p, q, tokens, ubuf, cursor)
+    _dev_or_pinned(out)
+    V = p.shape[-1]
+    assert p.dtype == torch.float32 and p.is_contiguous() and p.shape[0] >= g2 + 1
+    assert q.dtype == torch.float32 and q.is_contiguous() and q.shape[0] >= g2 and q.shape[-1] == V
+    assert tokens.dtype == torch.int64 and tokens.numel() >= g2 and out.dtype == torch.int64 and out.numel() >= 4
+    assert ubuf.dtype == torch.float32 and cursor.dtype == torch.int64
+    hip.check(hip.lib().tf_accept_chain_cur(_ptr(p), _ptr(q), _ptr(tokens), _ptr(ubuf), _ptr(cursor), int(g2), V,
+                                            1 if inclusive else 0, int(eos_token_id), _ptr(out), _stream()),
+              "tf_accept_chain_cur")
+
+
 def kv_h2d_async(dst_dev, src_host, n_tokens, stream):
     """Pinned host (H,T,D) -> device (H,T',D): tokens [0, n_tokens) of every head, on `stream` (a torch Stream)."""
     _dev(dst_dev)

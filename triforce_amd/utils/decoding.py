@@ -131,6 +131,52 @@ class _Record:
         return view.tolist()
 
 
+# Two-lane launching (round 5).  The host learns that a chain of launches has EXECUTED by seeing its
+# decision record in pinned memory — 35-50 us before the record kernel's completion is visible to the runtime; a launch into
+# the same stream spends that time inside hipGraphLaunch (profiles/r04_hop_trace.txt).  So everything launched between two
+# record reads goes to ONE stream ("lane") and the lane is flipped at every read: the next chain enters a stream whose last
+# command completed long ago, ordered after the previous chain by the record itself.  What makes that sound: a record is the
+# LAST store of the last kernel of its chain, and what that kernel leaves for later chains on the device (token ids, the
+# uniform cursor) is written through and drained before the record (csrc/sampling.hip); everything earlier in the chain
+# completed at a kernel boundary.  TRIFORCE_LANES=0: one stream (rounds 1-4).
+LANES = __import__("os").environ.get("TRIFORCE_LANES", "1") != "0"
+# One hipGraph per inner iteration (draft step, draw, retrieval verify, accept test: utils/graph_infer._InnerGraphs) instead
+# of two replays + two eager kernels.  TRIFORCE_INNER_GRAPH=0: rounds 2-4's four launches.
+INNER_GRAPH = __import__("os").environ.get("TRIFORCE_INNER_GRAPH", "1") != "0"
+
+
+class _Lanes:
+    def __init__(self, device):
+        self.streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+        self.i, self.home, self.flips = 0, None, 0
+
+    @property
+    def active(self):
+        return self.home is not None
+
+    def enter(self):
+        """Move launching from the caller's stream onto the current lane (ordered after everything the caller enqueued)."""
+        if self.home is None:
+            self.home = torch.cuda.current_stream()
+            lane = self.streams[self.i]
+            lane.wait_stream(self.home)
+            torch.cuda.set_stream(lane)
+
+    def flip(self):
+        """ONLY right after a record read: every launch so far has executed, the other lane has long been idle."""
+        if self.home is not None:
+            self.i ^= 1
+            self.flips += 1
+            torch.cuda.set_stream(self.streams[self.i])
+
+    def leave(self):
+        """Back to the caller's stream, ordered after the current lane's tail (all earlier chains were seen to finish)."""
+        if self.home is not None:
+            self.home.wait_stream(self.streams[self.i])
+            torch.cuda.set_stream(self.home)
+            self.home = None
+
+
 _MAILBOX_OK = {}
 
 
@@ -177,6 +223,8 @@ class _SpecBuffers:
         mailbox = bool(mailbox) and _mailbox_supported(device)
         self.mid_out = _Record(device, 4, mailbox)
         self.chain_out = _Record(device, 4, mailbox)
+        # two launch lanes, only with mailbox records (a record read is what licenses a flip) — see _Lanes
+        self.lanes = _Lanes(device) if (LANES and mailbox and torch.device(device).type == "cuda") else None
         self.pos_base = torch.arange(gamma + 1, dtype=torch.long, device=device).unsqueeze(0)
         # host -> device token lists go through one pinned staging row (a pageable source makes the copy synchronous)
         cuda = torch.device(device).type == "cuda"
@@ -222,6 +270,11 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
     rng = rng or UniformSource(device)
     if buffers is None:
         buffers = _buffers(graph_engine, gamma, eng.model.config.vocab_size, device, mailbox=sync_record is None)
+    lanes = buffers.lanes if (buffers.lanes is not None and buffers.lanes.active) else None
+    inner = None
+    if INNER_GRAPH and sync_record is None and buffers.mid_out.mailbox and buffers.shared_inputs \
+            and hasattr(graph_engine, "inner_graphs"):
+        inner = graph_engine.inner_graphs(gamma, rng, buffers.mid_out.tensor, capture=False)   # (the runner captured them)
     S = eng.kv_cache.seq_len
     n = accepted = drafted = 0
     ids = [int(next_token)]
@@ -241,6 +294,32 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
     # read of the previous accept record and the next launch — the one place where host time is GPU idle time)
     replay_draft = getattr(graph_engine, "replay_draft", None) if ((HOST_FAST_MASK & 2) and noclone and buffers.shared_inputs) else None
     flat = vt.view(-1)
+    while inner is not None and n < gamma:
+        # one launch, one read: [draft step n, draw, retrieval verify, accept test + follow-up draw] is ONE hipGraph whose
+        # kernels take their three uniforms from the stream's device cursor and advance it
+        rng.cursor_tensor(3)
+        rec = buffers.mid_out
+        rec.arm(4)
+        p = inner.replay(n)
+        acc, b, d, at = rec.read(4)                                           # the one host read of this step
+        if lanes is not None:
+            lanes.flip()
+        rng.advanced_on_device(3, at)
+        drafted += 1
+        if acc:                                                               # decoding.py:193-209
+            ids += [d, b]
+            accepted += 1
+            n += 2
+        else:                                                                 # decoding.py:211-220
+            ids.append(b)
+            n += 1
+        if verbose:
+            for t, colour in (((d, "green"), (b, "blue")) if acc else ((b, "red"),)):
+                spec_stream(t, tokenizer, colour)
+    if inner is not None:
+        # row i of the LAST replay's static output is the retrieval model's distribution after tokens 0..i (see below)
+        buffers.rows_generation = graph_engine.verify_generation()
+        return ids, p[:len(ids) - 1], accepted / drafted
     while n < gamma:
         if _HOP_TRACE is not None and drafted:
             _t_before = time.perf_counter_ns()
@@ -263,6 +342,8 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
             if n + 1 < flat.numel():
                 flat[n + 1:n + 3].copy_(_mid_tokens(rec.tensor, n, gamma, flat))
         acc, b, d = rec.read(3)                                               # the one host read of this step
+        if lanes is not None and sync_record is None:
+            lanes.flip()
         if _HOP_TRACE is not None:
             _t_seen = time.perf_counter_ns()                # (the drain below counts as part of the hop)
         if _SYNC_AFTER_RECORD:
@@ -338,6 +419,10 @@ class TriForceRunner:
         self.eos = _eos(tokenizer)
         self.bufs = _buffers(graph_engine, gamma, self.eng.model.config.vocab_size, self.device,
                              mailbox=sync_record is None)
+        self.inner = None
+        if INNER_GRAPH and sync_record is None and self.bufs.mid_out.mailbox and self.bufs.shared_inputs \
+                and hasattr(graph_engine, "inner_graphs"):
+            self.inner = graph_engine.inner_graphs(gamma, self.rng, self.bufs.mid_out.tensor)   # captured here, not in a step
         self.resample_count = self.accepted_count = self.target_sample_count = self.draft_count = 0
         self.n = 0
         self.inner_iters = 0          # Middle_Spec iterations = 68M draft calls = retrieval-verify replays
@@ -381,6 +466,16 @@ class TriForceRunner:
     def step(self):
         """One outer iteration: Middle_Spec drafting, target verify over the full KV, device-side
         accept/rollback, cache fix-ups.  Returns the number of tokens emitted."""
+        lanes = self.bufs.lanes
+        if lanes is None or self.sync_record is not None:
+            return self._step()
+        lanes.enter()                       # launches alternate between two streams, flipped at every record read
+        try:
+            return self._step()
+        finally:
+            lanes.leave()
+
+    def _step(self):
         eng, ge, gamma, device, bufs, rng = self.eng, self.ge, self.gamma, self.device, self.bufs, self.rng
         tokenizer, verbose = self.tokenizer, self.verbose
         next_token = self.next_token
@@ -419,18 +514,30 @@ class TriForceRunner:
             assert ge.verify_generation() == bufs.rows_generation, "retrieval-verify graph replayed before its rows were consumed"
         rec = bufs.chain_out
         rec.arm(4)
-        ops.accept_chain(probs, spec_rows, verify_tokens.view(-1)[1:], rng.take(g2 + 1), g2, self.inclusive_accept,
-                         self.eos, rec.tensor)
+        on_cursor = self.inner is not None and self.sync_record is None and not self.inclusive_accept
+        if on_cursor:
+            # the uniform stream's device cursor is live (the inner-iteration graphs advance it): the chain reads its numbers
+            # behind it and advances it by what it consumed, so no step ever has to re-synchronise the device copy
+            ops.accept_chain_cur(probs, spec_rows, verify_tokens.view(-1)[1:], rng.buf, rng.cursor_tensor(g2 + 1), g2,
+                                 self.inclusive_accept, self.eos, rec.tensor)
+        else:
+            ops.accept_chain(probs, spec_rows, verify_tokens.view(-1)[1:], rng.take(g2 + 1), g2, self.inclusive_accept,
+                             self.eos, rec.tensor)
         if self.sync_record is not None:
             self.sync_record(rec.tensor)
         count, pred, reason, consumed = rec.read(4)                      # the one host read of the outer step
+        if bufs.lanes is not None and self.sync_record is None:
+            bufs.lanes.flip()
         if self.health is not None:
             self.health()
         if self.inclusive_accept and reason == 1 and generated[g2 - 1] == self.eos:
             # TP loop only: an eos accepted as the LAST drafted token ends the loop before the bonus sample
             # (decoding.py:357-360,382-383); the on-chip loop — and tf_accept_chain — go on to the bonus token (:127)
             reason, pred, consumed = 2, self.eos, consumed - 1
-        rng.advance(consumed)
+        if on_cursor:
+            rng.advanced_on_device(consumed)
+        else:
+            rng.advance(consumed)
         self.last_reason = reason          # 0 rejection + resample, 1 everything accepted (bonus token), 2 accepted eos
 
         pass_tokens = [next_token] + generated[:count] + [PAD_TOKEN] * (g2 + 1 - count)

@@ -228,6 +228,47 @@ class _GraphedCall:
         return self.output.clone() if clone else self.output
 
 
+class _InnerGraphs:
+    """ONE hipGraph per inner position n of Middle_Spec (reference decoding.py:182-220): 68M draft step over n + 1 tokens ->
+    draw d ~ q_d into the token buffer -> retrieval-cache verify of the gamma + 1 tokens -> accept test of d + follow-up
+    draw, which also writes the follow-up token and the decision record (round 5).  The reference
+    issues these as two graph replays with host-side sampling and three blocking reads in between; rounds 2-4 as two
+    replays + two eager kernels + one record read.  Here an inner iteration is one launch and one record read: the draw /
+    accept kernels sit inside the graph with their uniforms behind the stream's device cursor (ops.*_cur), the record is
+    the LAST store of the graph's last kernel, so a host that sees it may launch the next iteration on another stream."""
+
+    def __init__(self, ge, gamma, rng, record):
+        eng, kw = ge.engine, ge.sampling
+        assert kw["probs"] and ge.tok_buf is not None and record.numel() >= 4
+        self.key = _InnerGraphs.key_of(ge, gamma, rng, record)
+        self.generation = 0
+        self.graphs, self.p = [], []
+        flat = ge.tok_buf.view(-1)
+        ge.tok_buf.fill_(0)                                    # valid token ids for the warm-up passes
+        for n in range(gamma):
+            def run(n=n):
+                q_d = eng.draft_run(input_ids=ge.tok_buf[:, :n + 1], gamma_offset=n, **kw)
+                ops.sample_inverse_cdf_cur(q_d, rng.buf, rng.cursor, 0, flat[n + 1:n + 2])
+                p = eng.model_verify(input_ids=ge.tok_buf[:, :gamma + 1], position_ids=ge.pos_buf, **kw)
+                ops.middle_accept_cur(p, q_d, flat, rng.buf, rng.cursor, n, gamma, record)
+                return p
+            graph, p = _capture(run, (), ge.mempool, 2)
+            self.graphs.append(graph)
+            self.p.append(p)
+        torch.cuda.synchronize()
+        rng.device_cursor = False                              # the warm-up passes advanced the device copy
+
+    @staticmethod
+    def key_of(ge, gamma, rng, record):
+        return (gamma, id(rng), rng.buf.data_ptr(), rng.cursor.data_ptr(), record.data_ptr(), ge.tok_buf.data_ptr(),
+                id(ge.engine.kv_cache), id(ge.engine.graph_cache), id(ge.engine.draft_cache))
+
+    def replay(self, n):
+        self.graphs[n].replay()
+        self.generation += 1
+        return self.p[n]
+
+
 def draft_run_capture_graph(engine: InferenceEngine, gamma_offset: int = 0, mempool=None, n_warmups: int = 3, probs=False,
                             temperature=0.6, top_p=0.9, verbose=True, ids=None):
     """One 68M draft step over ``gamma_offset + 1`` tokens (reference graph_infer.py:74-97).  ``ids``: static input
@@ -313,6 +354,7 @@ class GraphInferenceEngine:
         self.target_graphs = {}                    # q_len -> _TargetGraph (full-cache forward, device-resident lengths)
         self.static_outputs = True                 # graph_draft_inference / graph_verify accept clone=False
         self.tok_buf = self.pos_buf = None         # shared static inputs of the draft / verify graphs (graphs only)
+        self._inner = {}                           # inner-iteration graphs per (rng, record): see inner_graphs()
         self.mempool = None
         self.sampling = dict(probs=False, temperature=0.6, top_p=0.9)
 
@@ -328,6 +370,7 @@ class GraphInferenceEngine:
         # retrieval-verify graph (its first gamma + 1): the decode loop writes drafted tokens straight into it (the
         # sampling / accept kernels do) and no per-replay input copy is left.  Same for the verify positions.
         dev = self.engine.model.device
+        self._inner = {}
         self.tok_buf = torch.zeros((1, gamma + 3), dtype=torch.long, device=dev)
         self.pos_buf = torch.arange(gamma + 1, device=dev).unsqueeze(0).clone()
         self.callables = {off: draft_run_capture_graph(gamma_offset=off, ids=self.tok_buf[:, :off + 1], **common)
@@ -426,10 +469,32 @@ class GraphInferenceEngine:
         return fn(input_ids, position_ids, clone=clone) if isinstance(fn, _GraphedCall) else fn(input_ids, position_ids)
 
     def verify_generation(self):
-        """Replay count of the retrieval-verify graph (None when it is not a captured graph): the lifetime token of the
-        static probability rows ``graph_verify(..., clone=False)`` hands out."""
+        """Replay count of the retrieval-verify graph(s) (None when not captured): the lifetime token of the static
+        probability rows ``graph_verify(..., clone=False)`` / an inner-iteration graph hands out."""
         fn = self.callable_model_verify
-        return fn.generation if isinstance(fn, _GraphedCall) else None
+        if not isinstance(fn, _GraphedCall):
+            return None
+        return fn.generation + sum(g.generation for g in self._inner.values())
+
+    def inner_graphs(self, gamma, rng, record, capture=True):
+        """The per-position inner-iteration graphs (``_InnerGraphs``) over this engine's token buffer, ``rng``'s buffer /
+        cursor and the pinned decision ``record`` — captured at the first request (outside any timed region: the decode
+        runner asks for them when it is built), cached per (rng, record); None when the engine cannot provide them
+        (eager engine, logits instead of probabilities, CPU, TRIFORCE_INNER_GRAPH=0)."""
+        if os.environ.get("TRIFORCE_INNER_GRAPH", "1") == "0" or self.tok_buf is None or not self.tok_buf.is_cuda \
+                or not self.sampling.get("probs") or not isinstance(self.callable_model_verify, _GraphedCall) \
+                or self.tok_buf.shape[1] < gamma + 3 or record.numel() < 4 or record.is_cuda \
+                or torch.cuda.is_current_stream_capturing():
+            return None
+        key = _InnerGraphs.key_of(self, gamma, rng, record)
+        got = self._inner.get(key)
+        if got is None and not capture:                        # (Middle_Spec only uses what its runner captured)
+            return None
+        if got is None:
+            if len(self._inner) >= 2:                          # a runner per prompt / per seed: keep the two most recent sets
+                self._inner.pop(next(iter(self._inner)))
+            got = self._inner[key] = _InnerGraphs(self, gamma, rng, record)
+        return got
 
     def init_graph_cache(self):
         self.engine.graph_cache.init_graph_cache(kv_cache=self.engine.kv_cache)

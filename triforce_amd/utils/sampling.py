@@ -61,6 +61,13 @@ class UniformSource:
         self.block = block
         self.pos = 0
         self._fixed = values is not None
+        # Round 5: the buffer is allocated ONCE and refilled in place, and ``cursor`` is a device-resident int64 copy of
+        # ``pos`` — kernels captured inside a hipGraph read their numbers as buf[cursor + k] and the kernel that closes a
+        # decision advances the cursor itself (ops.*_cur); the host mirrors it with advance().  ``device_cursor`` says
+        # whether the device copy is current: the plain take() / advance() users (eager kernels that get a pointer) leave it
+        # stale, cursor_tensor() brings it up to date with one fill when it is.
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.device_cursor = True
         if self._fixed:
             v = torch.as_tensor(values, dtype=torch.float32).flatten()
             reps = (block + self.MAX_TAKE + v.numel() - 1) // v.numel() + 1
@@ -74,17 +81,38 @@ class UniformSource:
                 self.gen.seed()
             self.buf = torch.rand(block + self.MAX_TAKE, generator=self.gen, device=self.device)
 
-    def take(self, n):
+    def _room(self, n):
+        """Make sure buf[pos : pos + n] exists (refill / wrap, in place: captured graphs keep the buffer's address)."""
         assert n <= self.MAX_TAKE
         if self.pos + n > self.block:
             if self._fixed:
                 self.pos %= self._period
             else:
-                self.buf = torch.rand(self.block + self.MAX_TAKE, generator=self.gen, device=self.device)
+                self.buf.copy_(torch.rand(self.block + self.MAX_TAKE, generator=self.gen, device=self.device))
                 self.pos = 0
+            self.device_cursor = False
+
+    def take(self, n):
+        self._room(n)
         return self.buf[self.pos:self.pos + n]
 
     def advance(self, k):
+        """Consume k numbers on the host side only (an eager kernel got them through take())."""
+        self.pos += int(k)
+        self.device_cursor = False
+
+    def cursor_tensor(self, n):
+        """The device cursor, current and with room for n numbers: for kernels that read buf[cursor + k] (ops.*_cur)."""
+        self._room(n)
+        if not self.device_cursor:
+            self.cursor.fill_(self.pos)
+            self.device_cursor = True
+        return self.cursor
+
+    def advanced_on_device(self, k, at=None):
+        """A *_cur kernel consumed k numbers and advanced the device cursor itself; ``at``: the cursor value it reported."""
+        if at is not None and int(at) != self.pos:
+            raise RuntimeError(f"uniform stream out of step: device cursor {int(at)} != host position {self.pos}")
         self.pos += int(k)
 
 
