@@ -472,6 +472,16 @@ int tf_skinny_gemm_xchg(const void* w_packed, const void* x, int64_t xs_m, int64
                         void* stream);
 int tf_xchg_error(const void* ctl);
 int tf_xchg_set_error(void* ctl, int code, void* host_mirror, int set_mirror);
+/* tf_xchg_tune: key 0 = FENCED form of the exchange (1: system-scope release before the flag stores and acquire behind the
+ *   flag wait, the pair the first build had, ~1.7 us each; 0, default: s_waitcnt vmcnt(0) + system-scope accesses in issue
+ *   order) — selected by the engine's start-up litmus on the real group (utils/oneshot_ar.GemmExchange.litmus) when the
+ *   fence-free form shows a single mismatch, or forced with TRIFORCE_XCHG_FENCE=1; key 1 = wall-clock limit of one flag wait
+ *   in milliseconds (default 5000: a dead or starved peer is reported in seconds, not after 2^27 polls).  Returns the
+ *   previous value (a value outside the key's range only reads), -1 for an unknown key.
+ * tf_xchg_reset: control block back to its freshly allocated state (peer flags, per-panel exchange counts, error word; the
+ *   host mirror stays registered).  COLLECTIVE by contract: all ranks, between two barriers, nothing in flight. */
+int tf_xchg_tune(int key, int value);
+int tf_xchg_reset(void* ctl);
 /* Message-passing litmus around the exchange (tools/xgmi_litmus.py): tf_ar_litmus_stage advances the device counter
  * *it_dev and then writes, with PLAIN stores from an ordinary kernel (the role of the o_proj / down_proj epilogue), the
  * pattern v_rank[i] = (7 i + 13 it + 101 rank) mod 509 into `staging` (n fp16 values); after an all-reduce of those

@@ -94,7 +94,7 @@ def test_ops_refuse_cpu_tensors():
 _QUERIES = {"tf_abi_version", "tf_attn_block_pick_nsplit", "tf_attn_block_ws_floats", "tf_attn_decode_pick_nsplit",
             "tf_attn_prefill_pick_nsplit", "tf_attn_prefill_ws_floats", "tf_draft_forward_ws_bytes",
             "tf_attn_decode_ws_floats", "tf_ar_flags_bytes", "tf_ar_ipc_handle_bytes",
-            "tf_sg_tune", "tf_sg_workspace", "tf_xchg_ctl_bytes", "tf_attn_tune"}   # launch-rule knob / workspace registration: nothing launched (NULL = remove)
+            "tf_sg_tune", "tf_sg_workspace", "tf_xchg_ctl_bytes", "tf_attn_tune", "tf_xchg_tune"}   # launch-rule knob / workspace registration: nothing launched (NULL = remove)
 
 
 @pytest.mark.parametrize("fill", [1, 8, -1])

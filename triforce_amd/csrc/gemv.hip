@@ -155,7 +155,17 @@ __device__ __forceinline__ float sg_ld_agent(const float* p) { return __hip_atom
 // Every spin is bounded; a time-out poisons the panel with NaN and sets the sticky error word (+ host mirror).
 #define XC_MAXP 512                          // panels (N / 16) an exchange GEMM may have
 #define XC_MAX_WORLD 8
-#define XC_SPIN_LIMIT (1u << 27)
+#define XC_SPIN_LIMIT (1u << 27)            // hard cap on polls; the wall-clock limit below ends a wait long before it
+#define XC_WALL_HZ 100000000ull              // wall_clock64(): 100 MHz
+// A peer that never flags (dead rank; virtual ranks of one device that do not fit the chip together and starve each other)
+// is reported after g_xc_timeout_ms of WALL time — every poll is an uncached round trip of ~1-2 us, so a poll count alone
+// stood for minutes (advisor, round 4).  tf_xchg_tune key 1.
+static int g_xc_timeout_ms = 5000;
+// 1: the exchange runs with the release / acquire FENCES the first build had (system-scope release before the flag stores,
+// system-scope acquire = buffer_inv sc0 sc1 behind the flag wait, ~1.7 us each) instead of relying on s_waitcnt vmcnt(0) +
+// system-scope (sc0 sc1) accesses in issue order.  The engine's start-up litmus (utils/oneshot_ar.GemmExchange.litmus)
+// runs both forms on the REAL group and selects this one on any mismatch of the fence-free form.  tf_xchg_tune key 0.
+static int g_xc_fence = 0;
 struct XcCtl {                               // head of a rank's control buffer (fine-grained memory); flags follow at +1024 B,
     unsigned epoch, ticket, error, pad;      // then this rank's own per-panel epochs (XC_PEPOCH_OFF); epoch / ticket unused since
     unsigned long long mirror;               // the epochs went per panel.  mirror: 0 or a pinned host word that also gets error codes
@@ -168,6 +178,8 @@ struct SgXchg {
     unsigned* pepoch;                        // own per-panel exchange counts [XC_MAXP] (no peer reads them)
     int64_t half_elems;
     int rank, world;
+    int fence;                               // see g_xc_fence
+    unsigned long long timeout_ticks;        // wall-clock budget of one flag wait
 };
 __device__ __forceinline__ unsigned xc_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void xc_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -724,6 +736,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
             if (ok && t * 16 + li < M) xc_st8(xc.stage[xc.rank] + hb + (int64_t)(t * 16 + li) * ya.sm + y_off, part[t]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the partial has left this CU before any flag says so
+        if (xc.fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // (fenced form: system-scope release as well)
         if (ok) {
             const bool peer = lane < xc.world && lane != xc.rank;
             if (peer) xc_st(xc.pf[lane] + xc.rank * XC_MAXP + panel, xepoch);
@@ -731,12 +744,15 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(const half8* __
             if (peer) {
                 seen = false;
                 const unsigned* slot = xc.pf[xc.rank] + lane * XC_MAXP + panel;
+                const unsigned long long t0 = wall_clock64();
                 for (unsigned spins = 0; spins < XC_SPIN_LIMIT; ++spins) {
                     if ((int)(xc_ld(slot) - xepoch) >= 0) { seen = true; break; }
                     __builtin_amdgcn_s_sleep(1);
+                    if ((spins & 63u) == 63u && wall_clock64() - t0 > xc.timeout_ticks) break;
                 }
             }
             ok = __builtin_amdgcn_ballot_w64(!seen) == 0ull;
+            if (xc.fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // (fenced form: buffer_inv sc0 sc1 behind the wait)
             if (!ok && lane == 0) {
                 xc_st(&xc.ctl->error, 1u);
                 unsigned* mir = reinterpret_cast<unsigned*>(xc.ctl->mirror);
@@ -1465,7 +1481,9 @@ extern "C" int tf_skinny_qkv_rope(const void* wqkv_packed, const void* x, int64_
 // weight additionally in the 8-row rotary order (ops.rope_row_order_n8: every panel of the q and k sections holds rows
 // d0..d0+3 and their partners d0+D/2..d0+D/2+3 of one head).  Applies to <= 24 rows with a norm prologue (ln_w) and
 // K a multiple of 64 with >= 2 super-chunks per wave; anything else returns TF_EINVAL — the caller keeps the 16-row form.
-#define SG_N8_WAVES 8
+#ifndef SG_N8_WAVES
+#define SG_N8_WAVES 8          // waves per 8-row panel (A/B: variant build with SG_N8_WAVES=4)
+#endif
 
 static bool sg_n8_ok(int M, int N, int K, const SgAct& xa) {
     return M >= 1 && M <= 24 && N >= 8 && (N % 8) == 0 && K >= 64 * 2 * SG_N8_WAVES && (K % 64) == 0 && sg_act_ok(xa) &&
@@ -1570,6 +1588,8 @@ extern "C" int tf_skinny_gemm_xchg(const void* w_packed, const void* x, int64_t 
     xc.ctl = reinterpret_cast<XcCtl*>(peer_ctl[rank]);
     xc.pepoch = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(peer_ctl[rank]) + XC_PEPOCH_OFF);
     xc.half_elems = half_elems, xc.rank = rank, xc.world = world;
+    xc.fence = g_xc_fence;
+    xc.timeout_ticks = (unsigned long long)(g_xc_timeout_ms > 0 ? g_xc_timeout_ms : 1) * (XC_WALL_HZ / 1000ull);
     if ((const void*)out == (const void*)xc.stage[rank] || (const void*)resid == (const void*)xc.stage[rank]) return TF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const SgRope rp = {};
@@ -1599,6 +1619,38 @@ extern "C" int tf_skinny_gemm_xchg(const void* w_packed, const void* x, int64_t 
 #undef XCHG_LAUNCH
     TF_LAUNCH_CHECK();
     return TF_OK;
+}
+
+// Knobs of the fused exchange: key 0 = fenced form (0 / 1, see g_xc_fence), key 1 = wall-clock limit of one flag wait in
+// milliseconds.  Returns the previous value, -1 for an unknown key.  Applies to launches (and captures) made afterwards.
+extern "C" int tf_xchg_tune(int key, int value) {
+    int* slot = key == 0 ? &g_xc_fence : key == 1 ? &g_xc_timeout_ms : nullptr;
+    if (!slot) return -1;
+    const int old = *slot;
+    if (key == 0 && value != 0 && value != 1) return old;
+    if (key == 1 && value < 1) return old;
+    *slot = value;
+    return old;
+}
+
+// Back to the state of a freshly allocated control buffer: every peer flag, this rank's per-panel exchange counts and the
+// sticky error word zeroed (the host mirror pointer is kept, its word cleared).  COLLECTIVE by contract: every rank of the
+// group resets between two barriers with no exchange in flight — the per-panel counts of the ranks must leave together
+// (after a time-out they have drifted apart and nothing else can bring them back: advisor, round 4).  Blocking.
+extern "C" int tf_xchg_reset(void* ctl) {
+    if (!ctl) return TF_EINVAL;
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return (int)e;
+    XcCtl c;
+    e = hipMemcpy(&c, ctl, sizeof(c), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
+    const unsigned long long mirror = c.mirror;
+    e = hipMemset(ctl, 0, (size_t)tf_xchg_ctl_bytes());
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpy(&reinterpret_cast<XcCtl*>(ctl)->mirror, &mirror, sizeof(mirror), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return (int)e;
+    if (mirror) *reinterpret_cast<volatile unsigned*>(mirror) = 0u;
+    return (int)hipDeviceSynchronize();
 }
 
 // error word / epoch of an exchange control buffer (blocking host reads), fault injection, host mirror — the counterparts

@@ -90,6 +90,8 @@ SIGNATURES = {
                                    _i32, _i32, _i32, _vp]),
     "tf_xchg_error": (_i32, [_vp]),
     "tf_xchg_set_error": (_i32, [_vp, _i32, _vp, _i32]),
+    "tf_xchg_tune": (_i32, [_i32, _i32]),
+    "tf_xchg_reset": (_i32, [_vp]),
     "tf_ar_error": (_i32, [_vp]),
     "tf_ar_epoch": (_i64, [_vp]),
     "tf_ar_set_error_mirror": (_i32, [_vp, _vp]),

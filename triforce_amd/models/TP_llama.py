@@ -15,6 +15,7 @@ reference's two device-wide synchronize() per layer (TP_llama.py:222,228).
 """
 import math
 import os
+import socket
 
 import torch
 import torch.distributed as dist
@@ -227,6 +228,23 @@ class DistributedLlama:
             xc = GemmExchange(self.local_rank, self.world_size, self.device, self.ONESHOT_MAX_ROWS * self.hidden_size,
                               connect=False)
 
+        # Ranks that SHARE a device (bench.py --share-device, the two-process tests) run their exchange kernels side by side:
+        # every workgroup of the fused form spins on its peers' workgroup for the same panel, so all world x hidden / 16
+        # workgroups (8 waves each) must be co-resident or the spinners starve the peers they wait for (advisor, round 4).
+        # Up to 768 workgroups fit with margin (256 CUs x 4 of 8 waves); beyond that the two-launch form stays (its exchange
+        # kernel caps itself at 64 workgroups).
+        try:
+            mine = (socket.gethostname(), str(getattr(torch.cuda.get_device_properties(self.device), "uuid", self.device.index)))
+        except Exception:
+            mine = (socket.gethostname(), str(self.device.index))
+        everyone = [None] * self.world_size
+        dist.all_gather_object(everyone, mine)
+        sharing = max(everyone.count(e) for e in everyone)
+        self.ranks_per_device = sharing
+        if sharing > 1 and sharing * (self.hidden_size // 16) > 768 and os.environ.get("TRIFORCE_XCHG_SHARED_DEVICE", "0") != "1":
+            why.append(f"GEMM+exchange: {sharing} ranks share one device x {self.hidden_size // 16} panels do not fit the chip "
+                       "together - two-launch form kept")
+            return False
         ok = stage(alloc, "GEMM+exchange allocation")
         ok = ok and stage(lambda: xc.connect(), "GEMM+exchange handle exchange")
         if ok:
@@ -254,10 +272,57 @@ class DistributedLlama:
 
             ok = stage(selftest, "GEMM+exchange self-test")
         if ok:
+            ok = self._xchg_litmus(xc, stage, why)
+        if ok:
             self._xchg = xc
         elif xc is not None:
             xc.close()
         return ok
+
+    def _xchg_litmus(self, xc, stage, why):
+        """Which form of the fused exchange this GROUP can trust (verdict round 4, item 4): the fence-free form (default) is
+        run through GemmExchange.litmus on the real ranks — TRIFORCE_XCHG_LITMUS_ITERS iterations (default 100 000, 0 skips),
+        one rank delayed now and then; a single mismatched element or a time-out on ANY rank switches every rank to the
+        fenced form (control blocks reset collectively), which is then run through the same litmus; if that fails too the
+        fused form is not used at all.  TRIFORCE_XCHG_FENCE=1 starts with the fenced form.  The verdict goes into
+        ``allreduce_note`` / ``xchg_form``."""
+        from ..utils.graph_infer import _capture_error_mode
+        # (ranks sharing one device — functional runs on a one-GPU box — take turns on the chip: a fifth of the iterations)
+        iters = int(os.environ.get("TRIFORCE_XCHG_LITMUS_ITERS", "20000" if getattr(self, "ranks_per_device", 1) > 1 else "100000"))
+        forced = os.environ.get("TRIFORCE_XCHG_FENCE", "0") == "1"
+        xc.set_fenced(forced)
+        self.xchg_form = "fenced (TRIFORCE_XCHG_FENCE=1)" if forced else "fence-free"
+        self.xchg_litmus = []
+        if iters <= 0:
+            self.xchg_form += ", litmus skipped"
+            return True
+        for attempt in (0, 1):
+            res = {}
+
+            def run():
+                res.update(xc.litmus(iters=iters, capture_mode=_capture_error_mode()))
+                if res["mismatched_elements"] or res["error_word"]:
+                    raise RuntimeError(f"litmus: {res['mismatched_elements']} mismatched elements, error word {res['error_word']} "
+                                       f"in {res['iterations']} iterations ({'fenced' if res['fenced'] else 'fence-free'} form)")
+            good = stage(run, "GEMM+exchange litmus")
+            self.xchg_litmus.append(dict(res, ok=good))
+            if good:
+                self.xchg_form += f", litmus {res.get('iterations', 0)} iterations clean"
+                return True
+            if forced or attempt == 1:
+                break
+            # fence-free form failed somewhere: everyone resets and retries with the fences
+            dist.barrier()
+            xc.reset()
+            dist.barrier()
+            xc.set_fenced(True)
+            forced = True
+            self.xchg_form = "fenced (selected by the litmus: the fence-free form mismatched)"
+        dist.barrier()
+        xc.reset()
+        dist.barrier()
+        self.xchg_form = "off (litmus failed in both forms)"
+        return False
 
     def check_exchange(self, where=""):
         """Raise if the one-shot all-reduce ever timed out (its outputs are NaN-filled from then on).  Called once per

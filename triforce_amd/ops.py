@@ -132,6 +132,8 @@ def _ensure_sg_workspace(device):
             hip.lib().tf_sg_tune(2, int(_os.environ["TRIFORCE_GEMM_P2_GROUPS"]))
         if "TRIFORCE_GEMM_P2_WAVES" in _os.environ:                      # A/B: waves per workgroup of that form (4 | 8)
             hip.lib().tf_sg_tune(1, int(_os.environ["TRIFORCE_GEMM_P2_WAVES"]))
+        if "TRIFORCE_GEMM_N8_U" in _os.environ:                          # A/B: super-chunks per batch of the narrow-panel form (5 | 8)
+            hip.lib().tf_sg_tune(7, int(_os.environ["TRIFORCE_GEMM_N8_U"]))
         if "TRIFORCE_GEMM_FEW_PANELS" in _os.environ:                    # A/B: largest panel count that runs 16 waves per panel
             hip.lib().tf_sg_tune(5, int(_os.environ["TRIFORCE_GEMM_FEW_PANELS"]))
     _SG_WS[device] = ws

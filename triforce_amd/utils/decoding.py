@@ -86,6 +86,8 @@ _POLL_QUERY = __import__("os").environ.get("TRIFORCE_POLL_QUERY", "0") == "1"
 # stream to drain (the kernel is ending anyway) before the replay.
 _SYNC_AFTER_RECORD = __import__("os").environ.get("TRIFORCE_SYNC_AFTER_RECORD", "0") == "1"
 _POLL_QUERY_MASK = int(__import__("os").environ.get("TRIFORCE_POLL_QUERY_EVERY", "16")) - 1
+if (_POLL_QUERY_MASK + 1) & _POLL_QUERY_MASK or _POLL_QUERY_MASK < 0:
+    raise ValueError("TRIFORCE_POLL_QUERY_EVERY must be a power of two (it is used as a mask)")
 _sched_yield = getattr(__import__("os"), "sched_yield", lambda: None)
 
 
@@ -280,7 +282,7 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
     ids = [int(next_token)]
     vt = buffers.verify_tokens
     # [next, PAD...] and the gamma + 1 positions S, S + 1, ... in one launch (the token id travels as a kernel argument)
-    if HOST_FAST_MASK & 1:
+    if (HOST_FAST_MASK & 1) and vt.numel() <= 32 and buffers.positions.numel() <= 64:      # (tf_set_tokens' limits)
         position_ids = buffers.positions
         ops.set_tokens(vt, ids, PAD_TOKEN, pos=position_ids, pos0=S)
     else:
@@ -300,8 +302,14 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
         rng.cursor_tensor(3)
         rec = buffers.mid_out
         rec.arm(4)
+        if _HOP_TRACE is not None and drafted:
+            _t_before = time.perf_counter_ns()
         p = inner.replay(n)
+        if _HOP_TRACE is not None and drafted:                                # host pieces of the inner hop (tools/hop_trace.py)
+            _HOP_TRACE.append((_t_before - _t_seen, time.perf_counter_ns() - _t_before))
         acc, b, d, at = rec.read(4)                                           # the one host read of this step
+        if _HOP_TRACE is not None:
+            _t_seen = time.perf_counter_ns()
         if lanes is not None:
             lanes.flip()
         rng.advanced_on_device(3, at)
@@ -480,10 +488,11 @@ class TriForceRunner:
         tokenizer, verbose = self.tokenizer, self.verbose
         next_token = self.next_token
         n0 = self.n
+        # health (TP): a plain load of the pinned mirror of the exchange's error word after EVERY inner record read — after a
+        # timed-out exchange the probabilities are NaN-filled, and without the check up to gamma more iterations would draft,
+        # append draft KV and write token ids from them before the outer step noticed (advisor, round 4)
         ids, spec_rows, acc_mid = Middle_Spec(next_token, ge, gamma, False, tokenizer, rng=rng, buffers=bufs,
-                                              sync_record=self.sync_record)
-        # (the exchange health poll — a blocking copy of the control block — runs once per OUTER step, below: nothing an
-        #  inner iteration computes is emitted before the outer accept record has been read)
+                                              sync_record=self.sync_record, health=self.health)
         self.acc_rate_middle_list.append(acc_mid)
         generated = ids[1:]
         g2 = len(generated)
@@ -495,7 +504,8 @@ class TriForceRunner:
         self.rebuilds += int(rebuild)
         eager = self.eager_every > 0 and (len(self.counts) + 1) % self.eager_every == 0
         fast = None
-        if (HOST_FAST_MASK & 4) and self.top_k <= 0 and not rebuild and not eager and hasattr(ge, "verify_probs_ids"):
+        if (HOST_FAST_MASK & 4) and self.top_k <= 0 and not rebuild and not eager and hasattr(ge, "verify_probs_ids") \
+                and len(ids) <= 32:
             # captured forward + temperature / top-p: ids, positions and lengths set by ONE launch (ids as kernel arguments)
             fast = ge.verify_probs_ids(ids, self.temperature, self.top_p)
         if fast is not None:
@@ -550,7 +560,7 @@ class TriForceRunner:
         # (profiles/r04_gap_analysis_decode_steps.txt).
         tok_buf = getattr(ge, "tok_buf", None)
         if (HOST_FAST_MASK & 8) and tok_buf is not None and tok_buf.shape[0] == 1 and tok_buf.shape[1] >= len(pass_tokens) \
-                and tok_buf.is_cuda:
+                and tok_buf.is_cuda and len(pass_tokens) <= 32:
             # straight into the draft graphs' static input (the next Middle_Spec re-initialises it): one launch, no copies
             row = tok_buf[:, :len(pass_tokens)]
             ops.set_tokens(row, pass_tokens, PAD_TOKEN)

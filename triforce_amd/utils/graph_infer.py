@@ -328,9 +328,9 @@ class _TargetGraph:
         if S + self.q_len > kvc.max_budget:
             raise IndexError(f"FlashSimpleCache overflow: {S}+{self.q_len} > {kvc.max_budget}")
         if isinstance(input_ids, (list, tuple)):
-            assert len(input_ids) == self.q_len
+            assert len(input_ids) == self.q_len <= 32
             ops.set_tokens(self.ids, input_ids, 0, pos=self.pos, pos0=S, slot=self.slot, sk=self.sk, sk_val=S + self.q_len)
-        elif self.ids.is_cuda and os.environ.get("TRIFORCE_HOST_FAST", "1") != "0":
+        elif self.ids.is_cuda and self.q_len <= 64 and os.environ.get("TRIFORCE_HOST_FAST", "1") != "0":   # (tf_set_tokens: <= 64 positions)
             self.ids.copy_(input_ids)
             ops.set_tokens(None, (), 0, pos=self.pos, pos0=S, slot=self.slot, sk=self.sk, sk_val=S + self.q_len)
         else:
@@ -476,6 +476,7 @@ class GraphInferenceEngine:
             return None
         return fn.generation + sum(g.generation for g in self._inner.values())
 
+    @torch.inference_mode()
     def inner_graphs(self, gamma, rng, record, capture=True):
         """The per-position inner-iteration graphs (``_InnerGraphs``) over this engine's token buffer, ``rng``'s buffer /
         cursor and the pinned decision ``record`` — captured at the first request (outside any timed region: the decode

@@ -338,6 +338,77 @@ class GemmExchange:
     def inject_error(self, code):
         hip.check(hip.lib().tf_xchg_set_error(ctypes.c_void_p(self.ctl_ptr), int(code), None, 0), "tf_xchg_set_error")
 
+    # ---- hardening (round 5; advisor round 4, verdict item 4) -------------------------------------------------------------
+    @staticmethod
+    def set_fenced(on):
+        """Process-wide: later launches (and captures) of the fused exchange use the release / acquire FENCES (True) instead
+        of s_waitcnt + system-scope accesses in issue order (False, the default).  Returns the previous setting."""
+        return bool(hip.lib().tf_xchg_tune(0, 1 if on else 0))
+
+    @staticmethod
+    def set_timeout_ms(ms):
+        return hip.lib().tf_xchg_tune(1, int(ms))
+
+    def reset(self):
+        """Zero this rank's control block (peer flags, per-panel exchange counts, error word).  COLLECTIVE by contract:
+        every rank calls it between two barriers with no exchange in flight (after a time-out the per-panel counts of the
+        ranks have drifted apart; nothing else brings them back together)."""
+        hip.check(hip.lib().tf_xchg_reset(ctypes.c_void_p(self.ctl_ptr)), "tf_xchg_reset")
+
+    def litmus(self, iters=100_000, rows=7, per_graph=100, delay_every=17, capture_mode="thread_local"):
+        """Message-passing litmus of THIS kernel on THIS group (the staged exchange kernel has its own:
+        tools/xgmi_litmus.py): every iteration an ordinary kernel writes a fresh integer pattern as the activation
+        (tf_ar_litmus_stage), tf_skinny_gemm_xchg multiplies it by an identity weight and exchanges the panels, and
+        tf_ar_litmus_check compares every element of the sum with the value the SAME iteration's patterns give — a flag that
+        overtook its panel, a stale or torn peer read shows up as a COUNT, not a hang.  ``per_graph`` iterations are captured
+        as one hipGraph and replayed (no host synchronisation inside; this rank is delayed now and then so the peers run
+        ahead as far as the protocol lets them).  Collective: every rank passes the same arguments.  Returns a dict."""
+        from .. import ops
+        L, dev = hip.lib(), self.device
+        hidden = self.max_elems // 32
+        rows = min(rows, 32)
+        eye = ops.PackedLinear(torch.eye(hidden, dtype=torch.float16, device=dev))
+        a = torch.zeros(rows, hidden, dtype=torch.float16, device=dev)
+        out = torch.zeros(rows, hidden, dtype=torch.float16, device=dev)
+        ss = ops.ss_buffer(hidden, dev)
+        it_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        bad = torch.zeros(1, dtype=torch.int64, device=dev)
+        n = rows * hidden
+
+        def vp(t):
+            return ctypes.c_void_p(t.data_ptr())
+
+        def one():
+            st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            hip.check(L.tf_ar_litmus_stage(vp(a), n, self.rank, vp(it_dev), st), "tf_ar_litmus_stage")
+            hip.check(L.tf_skinny_gemm_xchg(ops._ptr(eye.wp), vp(a), hidden, 8, self._stage, self._ctl, self.rank, self.world,
+                                            self.max_elems, None, 8, 8, vp(out), hidden, 8, vp(ss), rows, hidden, hidden, st),
+                      "tf_skinny_gemm_xchg")
+            hip.check(L.tf_ar_litmus_check(vp(out), n, self.world, vp(it_dev), vp(bad), st), "tf_ar_litmus_check")
+
+        for _ in range(2):                                     # eager warm-up (module load, first-touch), also checked
+            one()
+        torch.cuda.synchronize(dev)
+        per = max(1, int(per_graph))
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side, capture_error_mode=capture_mode):
+                for _ in range(per):
+                    one()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        replays = max(1, int(iters) // per)
+        for j in range(replays):
+            if delay_every and j % delay_every == 0 and (j // delay_every) % self.world == self.rank:
+                torch.cuda._sleep(200_000)                     # ~0.1 ms: the peers run ahead as far as the protocol allows
+            graph.replay()
+        torch.cuda.synchronize(dev)
+        res = {"iterations": 2 + replays * per, "mismatched_elements": int(bad.item()), "error_word": self.error_device(),
+               "rows": rows, "hidden": hidden, "fenced": bool(L.tf_xchg_tune(0, -1))}
+        del graph
+        return res
+
     def check(self, where=""):
         e = self.error()
         if e:
