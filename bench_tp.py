@@ -75,6 +75,140 @@ def offload_report(llm, args, tcfg, world, device):
     return out
 
 
+def predicted_for(label, world, path=None):
+    """This configuration's row of the tracked scaling prediction (tools/predict_scaling.py -> profiles/r05_predicted_scaling.json):
+    per-rank stage latencies measured on ONE GPU + the low / high step the model composes from them; None when absent."""
+    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_predicted_scaling.json")
+    try:
+        cfgs = json.load(open(path))["configs"]
+    except Exception:
+        return None
+    key = next((k for k in cfgs if k in label), None)           # "BASELINE configs[1] shapes sharded TP=8" -> "configs[1]"
+    if key is None:
+        return None
+    c = cfgs[key]
+    rank_us = next((m for m in c["measured_per_rank_us"] if m["emulated_world"] == world), None)
+    pred = next((p for p in c["predictions"]["gemm_exchange"] if p["world"] == world), None)
+    if rank_us is None or pred is None:
+        return None
+    return {"source": os.path.relpath(path, os.path.dirname(os.path.abspath(__file__))), "config": key, "world": world,
+            "loop": c["loop"], "per_rank_us": {k: rank_us[k] for k in ("draft_step_us", "retrieval_verify_us", "target_verify_us")},
+            "exchange_form": "gemm_exchange", "low": pred["low"], "high": pred["high"]}
+
+
+def stage_latencies_lockstep(llm, args, device, timed):
+    """Per-rank latency (us) of the three model calls of a step — EVERY rank runs the same forwards the same number of
+    times, in the same order, after the timed region (the target and retrieval verifies contain the exchanges: a rank
+    cannot run them alone), HIP events on the launch stream.  The reference prints its per-stage latencies from every
+    configuration (test/offloading_TP.py:104-119); the predicted scaling table is written in exactly these quantities."""
+    S_now, g = llm.kv_cache.seq_len, args.gamma
+    ids = torch.full((1, g + 2), 100, dtype=torch.long, device=device)
+    pos = torch.arange(S_now, S_now + g + 1, device=device).unsqueeze(0)
+
+    def tv():
+        llm.inference(input_ids=ids)
+        llm.kv_cache.seq_len = S_now
+    return {"draft_step_us": round(timed(lambda: llm.draft_run(ids[:, :3], gamma_offset=2), 5), 1),
+            "retrieval_verify_us": round(timed(lambda: llm.retrieval_verify(ids[:, :g + 1], pos, args.temp, args.top_p), 5), 1),
+            "target_verify_us": round(timed(tv, 3), 1)}
+
+
+def exchange_cost_lockstep(llm, args, device, per_graph=64, replays=5):
+    """What ONE exchange costs this rank on this group (us): the o_proj-shaped GEMM of the decode layer with its exchange
+    (the form the engine selected: inside the GEMM, or GEMM -> staging -> exchange kernel, or GEMM + RCCL all-reduce)
+    against the SAME GEMM with the single-rank residual epilogue, each as a hipGraph of ``per_graph`` back-to-back calls —
+    all ranks in lock-step.  None when the engine has a single rank or the probe fails on any rank (agreed collectively)."""
+    from triforce_amd import ops
+    from triforce_amd.utils.graph_infer import _capture_error_mode
+    if llm.world_size == 1 or device.type != "cuda":
+        return None
+    rows, hid, W = args.gamma + 1, llm.hidden_size, llm.weights
+    out, ok = {}, True
+    try:
+        packed = ops.act_packed(rows)
+        a0 = torch.randn(rows, W.wo[0].K, device=device).to(torch.float16) * 0.05
+        x0 = torch.zeros(rows, hid, dtype=torch.float16, device=device)
+        a = ops.Act.from_rows(a0) if packed else a0
+        x = ops.Act.from_rows(x0) if packed else x0
+        ss = ops.ss_buffer(hid, device)
+
+        def with_exchange():
+            if llm._xchg is not None:
+                llm._xchg.linear_reduce(a, W.wo[0], x, ss)
+            elif llm._ar is not None:
+                llm._ar.reduce(ops.linear(a, W.wo[0], out=llm._ar.staging(rows, hid, packed=packed)), x, resid=x, ss_out=ss)
+            else:
+                part = ops.linear(a0, W.wo[0])
+                dist.all_reduce(part, dist.ReduceOp.SUM)
+                x0.add_(part)
+
+        def without():
+            ops.linear(a, W.wo[0], resid=x, out=x, ss_out=ss)
+
+        def graph_us(fn):
+            fn()
+            torch.cuda.synchronize(device)
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side, capture_error_mode=_capture_error_mode()):
+                    for _ in range(per_graph):
+                        fn()
+            torch.cuda.current_stream(device).wait_stream(side)
+            graph.replay()
+            torch.cuda.synchronize(device)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(replays):
+                graph.replay()
+            e.record()
+            torch.cuda.synchronize(device)
+            return s.elapsed_time(e) / (replays * per_graph) * 1e3
+        dist.barrier()
+        out["gemm_with_exchange_us"] = round(graph_us(with_exchange), 2)
+        dist.barrier()
+        out["gemm_alone_us"] = round(graph_us(without), 2)
+        out["per_exchange_us"] = round(out["gemm_with_exchange_us"] - out["gemm_alone_us"], 2)
+        out["shape"] = f"{rows} rows x K {W.wo[0].K} -> hidden {hid} (o_proj shard), {per_graph} calls per hipGraph x {replays} replays"
+    except Exception as ex:                                    # a probe must never cost the bench line
+        ok, out = False, {"failed": f"{type(ex).__name__}: {ex}"[:300]}
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, dist.ReduceOp.MIN)
+    if not int(flag.item()) and ok:
+        out = {"failed": "a peer rank failed the probe"}
+    return out
+
+
+def multi_rank_report(per_rank, args, tcfg, world, loop, exchange_form, predicted=None):
+    """The part of the N > 1 bench line the prediction is written in (pure function of gathered numbers; schema pinned by
+    tests/test_host_edges_cpu.py): per-rank stage latencies, the slowest rank's figures, exchanges per forward / step, the
+    measured per-exchange time, and — when profiles/r05_predicted_scaling.json has this configuration and world size — the
+    predicted step next to the measured one, term by term."""
+    L = tcfg.num_hidden_layers
+    k = loop["inner_iterations_per_step"]
+    slow = {key: max(r["stages"][key] for r in per_rank if r.get("stages")) for key in
+            ("draft_step_us", "retrieval_verify_us", "target_verify_us")} if all(r.get("stages") for r in per_rank) else None
+    rep = {"stage_latency_us_per_rank": [dict(rank=r["rank"], **(r.get("stages") or {})) for r in per_rank],
+           "stage_latency_us_slowest_rank": slow,
+           "exchange": {"form": exchange_form, "per_forward": 2 * L, "per_step": round(2 * L * (1 + k), 1),
+                        "per_rank": [dict(rank=r["rank"], **(r.get("exchange") or {})) for r in per_rank]}}
+    if slow is not None:
+        modelled = slow["target_verify_us"] + k * slow["retrieval_verify_us"] + (k + 1) * slow["draft_step_us"]
+        rep["measured_step_terms_us"] = {"target_verify": slow["target_verify_us"], "retrieval_verify": round(k * slow["retrieval_verify_us"], 1),
+                                         "draft": round((k + 1) * slow["draft_step_us"], 1),
+                                         "host_and_broadcasts": round(max(0.0, loop["ms_per_step"] * 1e3 - modelled), 1),
+                                         "note": "exchange time is INSIDE the verify latencies here (the forwards ran on the real "
+                                                 "group); the prediction lists it as its own term on top of one-GPU shard latencies"}
+    if predicted is not None:
+        rep["predicted"] = predicted
+        if slow is not None and predicted.get("per_rank_us"):
+            pr = predicted["per_rank_us"]
+            rep["measured_minus_predicted_us"] = {
+                key: round(slow[key] - pr[key], 1) for key in ("target_verify_us", "retrieval_verify_us", "draft_step_us") if key in pr}
+    return rep
+
+
 def _emit(line):
     """The one JSON line, on the process's ORIGINAL stdout (see run_tp)."""
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (line + "\n").encode())
@@ -232,6 +366,13 @@ def run_tp(args, rank, world, local):
     seconds = float(elapsed.item())
     tokens = run.n - n0
     accepted, drafted = run.accepted_count - acc0, run.draft_count - dr0
+    # ---- what the scaling prediction is written in, measured on THIS group by every rank in lock-step ----
+    my_stages = my_exchange = None
+    if offload is None and on_gpu:
+        my_stages = stage_latencies_lockstep(llm, args, device, _timed)
+        my_exchange = exchange_cost_lockstep(llm, args, device)
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, {"rank": rank, "stages": my_stages, "exchange": my_exchange})
     if rank == 0:
         # per-rank roofline: this rank's heads only (H / world), against ONE GPU's HBM peak
         roof = attn_roofline(timer, args.budget + args.gamma + 1, tcfg.num_attention_heads // world, tcfg.head_dim)
@@ -241,27 +382,15 @@ def run_tp(args, rank, world, local):
         inner_per_step = (run.inner_iters - in0) / max(args.steps, 1)
         label = baseline_config_label(args.target, args.prefill, args.budget, args.gamma, args.on_chip,
                                       tcfg.num_hidden_layers, world)
-        # stage rooflines of THIS rank's shard (graph replays, HIP events), after the timed region
-        stages, stage_rows = None, None
-        if offload is None:
-            S_now = llm.kv_cache.seq_len
-            g = args.gamma
-            ids = torch.full((1, g + 2), 100, dtype=torch.long, device=device)
-            pos = torch.arange(S_now, S_now + g + 1, device=device).unsqueeze(0)
-            solo = world == 1                                   # other ranks are past their timed loop: only a one-rank
-            if solo:                                            # engine can run extra forwards without its peers
-
-                def tv():
-                    llm.inference(input_ids=ids)
-                    llm.kv_cache.seq_len = S_now
-                stages = {"draft_step_us": round(_timed(lambda: llm.draft_run(ids[:, :3], gamma_offset=2), 5), 1),
-                          "retrieval_verify_us": round(_timed(lambda: llm.retrieval_verify(ids[:, :g + 1], pos, args.temp, args.top_p), 5), 1),
-                          "target_verify_us": round(_timed(tv, 3), 1)}
-                rvb, wl, rkv = forward_bytes(tcfg, args.budget + g + 1, world)
-                tvb, _, tkv = forward_bytes(tcfg, S_now + g + 2, world)
-                how = "HIP events around the engine's forwards (hipGraph replays where captured)"
-                stage_rows = [_stage_row("retrieval_verify forward (this rank's shard)", rvb, stages["retrieval_verify_us"], how),
-                              _stage_row("target_verify forward (this rank's shard)", tvb, stages["target_verify_us"], how)]
+        # stage rooflines of THIS rank's shard (graph replays, HIP events): measured by ALL ranks in lock-step below
+        stages, stage_rows = my_stages, None
+        if stages is not None:
+            S_now, g = llm.kv_cache.seq_len, args.gamma
+            rvb, wl, rkv = forward_bytes(tcfg, args.budget + g + 1, world)
+            tvb, _, tkv = forward_bytes(tcfg, S_now + g + 2, world)
+            how = "HIP events around the engine's forwards (hipGraph replays where captured), all ranks in lock-step"
+            stage_rows = [_stage_row("retrieval_verify forward (this rank's shard)", rvb, stages["retrieval_verify_us"], how),
+                          _stage_row("target_verify forward (this rank's shard)", tvb, stages["target_verify_us"], how)]
         cpu = None
         if not args.no_cpu_baseline:
             try:
@@ -301,6 +430,14 @@ def run_tp(args, rank, world, local):
             "allreduce_requested": getattr(args, "allreduce", "auto"),
             "allreduce_note": getattr(llm, "allreduce_note", "") or None,
             "inner_iterations_per_step": round(inner_per_step, 3), "stage_latency_us": stages,
+            "multi_rank": multi_rank_report(
+                per_rank, args, tcfg, world,
+                {"inner_iterations_per_step": inner_per_step, "ms_per_step": seconds / args.steps * 1e3},
+                ("inside the o_proj / down_proj GEMMs (tf_skinny_gemm_xchg, " + getattr(llm, "xchg_form", "fence-free") + ")"
+                 if getattr(llm, "_xchg", None) is not None else
+                 "GEMM -> staging -> tf_allreduce_oneshot" if getattr(llm, "_ar", None) is not None else
+                 ("GEMM -> RCCL all-reduce" if world > 1 else "none (one rank)")),
+                predicted_for(label, world)),
             "roofline": roof, "roofline_stages": stage_rows,
             "roofline_note": None if roof else "no eager target verify was sampled (--roofline-every 0, or no target "
             "graph): no per-launch HIP events on this run", "cpu_baseline": cpu}))

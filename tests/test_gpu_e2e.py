@@ -571,16 +571,17 @@ def test_static_verify_rows_equal_per_step_copies_and_lifetime_is_guarded():
 
 
 @pytest.mark.parametrize("temperature,top_p", [(0.8, 0.95), (1.0, 1e-9)])
-def test_one_launch_inner_iterations_on_two_lanes_emit_the_identical_stream(temperature, top_p, monkeypatch):
+def test_one_launch_inner_iterations_emit_the_identical_stream(temperature, top_p, monkeypatch):
     """Round 5: an inner iteration of Middle_Spec (reference decoding.py:182-220) is ONE hipGraph — draft step,
-    draw, retrieval verify, accept test, with the uniforms behind a device cursor — and consecutive chains of launches
-    alternate between two streams, ordered only by the decision record the host polls.  Nothing about the arithmetic
-    changes, so against rounds 2-4's form (two replays + two eager kernels per iteration on one stream) the emitted tokens,
-    the per-step accept counts and the consumed uniforms must be IDENTICAL — over a run long enough (>= 150 outer steps,
-    ~600 record-ordered stream switches) that a token id or cursor value read before it was visible would show as a
-    diverged stream.  Also: lanes without the inner graphs, and a second runner on the same engine (re-capture)."""
+    draw, retrieval verify, accept test, with the uniforms behind a device cursor the kernels advance themselves.  Nothing
+    about the arithmetic changes, so against rounds 2-4's form (two replays + two eager kernels per iteration) the emitted
+    tokens, the per-step accept counts and the consumed uniforms must be IDENTICAL — over a run long enough (>= 150 outer
+    steps at T = 0.8, ~600 inner iterations) that a token id, a probability row or a cursor value consumed before it was
+    visible, or a cursor out of step with the host's mirror, would show as a diverged stream (the two-stream form built
+    first did exactly that, at the first drafted token).  Also: a second runner with a fresh uniform stream on the same engine
+    (re-capture against the new buffers), and the cursor check itself (a host mirror pushed out of step must raise)."""
     from triforce_amd.utils import decoding as Dm
-    from triforce_amd.utils.decoding import TriForce
+    from triforce_amd.utils.decoding import TriForce, TriForceRunner
     from triforce_amd.utils.sampling import UniformSource
     g = dict(Hh.load_golden("small_gamma6"), gen_len=260, budget=320)     # room for a long run (tail <= retrieval budget)
     ge = Hh.build_product(g, DEV, temperature=temperature, top_p=top_p, graphs=True)
@@ -588,28 +589,28 @@ def test_one_launch_inner_iterations_on_two_lanes_emit_the_identical_stream(temp
     vals = Hh.fixed_uniforms(n=4096, seed=901)
     max_len = 230
     out = {}
-    for mode, (inner, lanes) in {"r04": (False, False), "lanes": (False, True), "inner+lanes": (True, True),
-                                 "inner": (True, False), "inner+lanes again": (True, True)}.items():
+    for mode, inner in {"four launches": False, "one graph": True, "one graph, second runner": True}.items():
         monkeypatch.setattr(Dm, "INNER_GRAPH", inner)
-        monkeypatch.setattr(Dm, "LANES", lanes)
-        if hasattr(ge, "_tf_spec_buffers"):
-            del ge._tf_spec_buffers                   # (the lanes live in the per-engine buffers)
         rng = UniformSource(DEV, values=vals)
         res = TriForce(tok, ge, prompt, gamma=g["gamma"], max_len=max_len, top_k=-1, top_p=top_p, temperature=temperature,
                        rng=rng, return_details=True)
         out[mode] = (res["tokens"], res["counts"], rng.pos)
-        b = ge._tf_spec_buffers
-        assert (b.lanes is not None) == lanes
-        if lanes:
-            assert not b.lanes.active and b.lanes.flips >= len(res["counts"]), "lanes were not flipped at the record reads"
-        assert torch.cuda.current_stream() == torch.cuda.default_stream() or not lanes
-    ref = out["r04"]
+        assert bool(ge._inner) == inner or mode.endswith("second runner")
+    ref = out["four launches"]
     assert len(ref[1]) >= 30
     for mode, got in out.items():
         assert got[0] == ref[0], f"{mode}: tokens diverge at {Hh.common_prefix(got[0], ref[0])} of {len(ref[0])}"
         assert got[1] == ref[1] and got[2] == ref[2], f"{mode}: accept counts / uniform position differ"
-    Hh.note(f"inner-iteration graphs + lanes: {len(ref[0])} tokens / {len(ref[1])} steps identical to the four-launch form "
+    Hh.note(f"inner-iteration graphs: {len(ref[0])} tokens / {len(ref[1])} steps identical to the four-launch form "
             f"(T={temperature}, top_p={top_p})")
+    # the device cursor and the host's mirror are compared at every record: a mirror pushed out of step raises
+    run = TriForceRunner(tok, ge, g["gamma"], top_k=-1, top_p=top_p, temperature=temperature, rng=UniformSource(DEV, values=vals))
+    assert run.inner is not None
+    run.prefill(prompt)
+    run.step()
+    run.rng.pos += 1                                   # (the device copy is current: nothing refreshes it)
+    with pytest.raises(RuntimeError, match="out of step"):
+        run.step()
 
 
 def test_draft_prefill_graph_equals_eager(monkeypatch):

@@ -788,6 +788,19 @@ def test_bench_tp_line_reports_allreduce_state_and_fails_loudly_on_a_timeout():
     assert j["config"]["world_size_observed"] == 2 and j["value"] > 0
     assert j["roofline"] is not None and j["roofline"]["launches"] >= 1, "no eager target verify was sampled"
     assert j["config"]["workload"].startswith("custom")
+    # round 5: the N > 1 line carries what the scaling prediction is written in — per-rank stage latencies measured by all
+    # ranks in lock-step, the exchange form selected (with its litmus verdict), exchanges per step, a measured per-exchange time
+    mr = j["multi_rank"]
+    assert [r["rank"] for r in mr["stage_latency_us_per_rank"]] == [0, 1]
+    for r in mr["stage_latency_us_per_rank"]:
+        assert r["draft_step_us"] > 0 and r["retrieval_verify_us"] > 0 and r["target_verify_us"] > 0
+    assert mr["stage_latency_us_slowest_rank"]["target_verify_us"] == max(r["target_verify_us"] for r in mr["stage_latency_us_per_rank"])
+    ex = mr["exchange"]
+    assert ex["per_forward"] == 4 and ex["per_step"] > 4 and "tf_skinny_gemm_xchg" in ex["form"] and "litmus" in ex["form"]
+    for r in ex["per_rank"]:
+        assert r["gemm_with_exchange_us"] > 0 and r["gemm_alone_us"] > 0 and "per_exchange_us" in r, r
+    assert set(mr["measured_step_terms_us"]) >= {"target_verify", "retrieval_verify", "draft", "host_and_broadcasts"}
+    assert j["stage_latency_us"] == {k: v for k, v in mr["stage_latency_us_per_rank"][0].items() if k != "rank"}
     rc, lines, err = _bench_tp2({"TRIFORCE_BENCH_INJECT_AR_ERROR": "1"}, ("--allreduce", "oneshot"))
     assert rc != 0, "a timed-out all-reduce must fail the bench"
     bad = [ln for ln in lines if ln.get("failed")]

@@ -1,5 +1,6 @@
 """Edge cases of the host logic on CPU (oracle-backed ops): EOS inside the accepted chain, capacity limits the
 reference enforces by crashing, config validation, the uniform stream, synthetic data."""
+import os
 import pytest
 import torch
 
@@ -241,6 +242,56 @@ def test_bench_self_launches_for_more_than_one_gpu():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
                          text=True, timeout=120, env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), cwd=root)
     assert bad.returncode != 0 and "WORLD_SIZE=4" in (bad.stderr + bad.stdout)
+
+
+def test_multi_rank_report_schema_and_prediction_lookup(tmp_path):
+    """The part of the N > 1 bench line the scaling prediction is written in (bench_tp.multi_rank_report; reference
+    test/offloading_TP.py:104-119 prints its latencies from every configuration): schema pinned here on fake numbers, the
+    prediction looked up from a tools/predict_scaling.py file by configuration label and world size."""
+    import json
+    import subprocess
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench_tp
+    shards = tmp_path / "shards.jsonl"
+    with open(shards, "w") as f:
+        for W, (tv, rv, dr) in {1: (13400.0, 3280.0, 115.0), 2: (7600.0, 2300.0, 126.0), 8: (2760.0, 1440.0, 132.0)}.items():
+            f.write(json.dumps({"target": "llama-7B-128K", "emulated_world": W, "heads_per_rank": 32 // W, "layers": 32,
+                                "prefill": 124928, "budget": 4096, "gamma": 6, "draft_step_us": dr, "retrieval_verify_us": rv,
+                                "target_verify_us": tv, "decode_layer": "fused (6 launches)", "exchange": "x"}) + "\n")
+    bench_line = tmp_path / "bench.json"
+    bench_line.write_text(json.dumps({"n_gpus": 1, "value": 216.0, "tokens_per_step": 5.85, "inner_iterations_per_step": 3.9,
+                                      "step_overhead_us": 300.0, "stage_latency_us": {"draft_step_us": 110.0, "retrieval_verify_us": 3250.0,
+                                                                                     "target_verify_us": 13300.0}}) + "\n")
+    out = tmp_path / "pred.json"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "predict_scaling.py"), "--shards", str(shards), "--out", str(out),
+                        "--bench", f"configs[1]={bench_line}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    pj = json.load(open(out))["configs"]["configs[1]"]
+    assert pj["measured_per_rank_us"][0]["decode_layer"].startswith("single-GPU graph engine")     # W = 1 row = the product
+    assert pj["loop"]["host_overhead_us"] == 300.0 and "bench.json" in pj["loop"]["source"]
+    pred = bench_tp.predicted_for("BASELINE configs[1] shapes sharded TP=8", 8, path=str(out))
+    assert pred["world"] == 8 and pred["per_rank_us"]["retrieval_verify_us"] == 1440.0
+    assert pred["low"]["tokens_per_s"] > pred["high"]["tokens_per_s"] > 0
+    assert bench_tp.predicted_for("custom (not a BASELINE.json config)", 8, path=str(out)) is None
+    assert bench_tp.predicted_for("BASELINE configs[1] shapes sharded TP=4", 4, path=str(out)) is None        # no W = 4 shard line
+    per_rank = [{"rank": r, "stages": {"draft_step_us": 130.0 + r, "retrieval_verify_us": 1500.0 + 10 * r, "target_verify_us": 2900.0 - r},
+                 "exchange": {"gemm_with_exchange_us": 9.5, "gemm_alone_us": 5.0, "per_exchange_us": 4.5, "shape": "s"}} for r in range(8)]
+    rep = bench_tp.multi_rank_report(per_rank, None, types.SimpleNamespace(num_hidden_layers=32), 8,
+                                     {"inner_iterations_per_step": 3.9, "ms_per_step": 11.0}, "inside the GEMMs", pred)
+    assert set(rep) == {"stage_latency_us_per_rank", "stage_latency_us_slowest_rank", "exchange", "measured_step_terms_us", "predicted",
+                        "measured_minus_predicted_us"}
+    assert rep["stage_latency_us_slowest_rank"] == {"draft_step_us": 137.0, "retrieval_verify_us": 1570.0, "target_verify_us": 2900.0}
+    assert rep["exchange"]["per_forward"] == 64 and rep["exchange"]["per_step"] == round(64 * 4.9, 1)
+    assert rep["measured_minus_predicted_us"]["retrieval_verify_us"] == 130.0
+    t = rep["measured_step_terms_us"]
+    assert abs(t["target_verify"] + t["retrieval_verify"] + t["draft"] + t["host_and_broadcasts"] - 11000.0) < 1.0
+    # a rank without stage numbers (offloading tier: stages are not measured) leaves the slowest-rank fields empty
+    rep2 = bench_tp.multi_rank_report([{"rank": 0, "stages": None, "exchange": None}], None, types.SimpleNamespace(num_hidden_layers=2),
+                                      1, {"inner_iterations_per_step": 2.0, "ms_per_step": 1.0}, "none (one rank)")
+    assert rep2["stage_latency_us_slowest_rank"] is None and "predicted" not in rep2
 
 
 def test_tree_walk_limits_and_atomic_grow_map_cache(tmp_path):

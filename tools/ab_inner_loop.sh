@@ -8,7 +8,7 @@ python -m pytest tests/test_gpu_e2e.py -q -x > $O/pytest_e2e.log 2>&1; echo "e2e
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --random-steps 0"
 rm -f $O/bench_ab.jsonl
 for rep in $(seq $REPS); do
-  for v in "inner+lanes:" "lanes:TRIFORCE_INNER_GRAPH=0" "r04:TRIFORCE_INNER_GRAPH=0 TRIFORCE_LANES=0"; do
+  for v in "inner-graph:TRIFORCE_INNER_GRAPH=1" "four-launches:TRIFORCE_INNER_GRAPH=0"; do
     label=${v%%:*}; envs=${v#*:}
     env $envs $B 2>>$O/bench.err | grep '^{' | sed "s/^{/{\"variant\": \"$label\", /" >> $O/bench_ab.jsonl
   done

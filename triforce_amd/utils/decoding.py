@@ -133,50 +133,14 @@ class _Record:
         return view.tolist()
 
 
-# Two-lane launching (round 5).  The host learns that a chain of launches has EXECUTED by seeing its
-# decision record in pinned memory — 35-50 us before the record kernel's completion is visible to the runtime; a launch into
-# the same stream spends that time inside hipGraphLaunch (profiles/r04_hop_trace.txt).  So everything launched between two
-# record reads goes to ONE stream ("lane") and the lane is flipped at every read: the next chain enters a stream whose last
-# command completed long ago, ordered after the previous chain by the record itself.  What makes that sound: a record is the
-# LAST store of the last kernel of its chain, and what that kernel leaves for later chains on the device (token ids, the
-# uniform cursor) is written through and drained before the record (csrc/sampling.hip); everything earlier in the chain
-# completed at a kernel boundary.  TRIFORCE_LANES=0: one stream (rounds 1-4).
-LANES = __import__("os").environ.get("TRIFORCE_LANES", "1") != "0"
 # One hipGraph per inner iteration (draft step, draw, retrieval verify, accept test: utils/graph_infer._InnerGraphs) instead
 # of two replays + two eager kernels.  TRIFORCE_INNER_GRAPH=0: rounds 2-4's four launches.
+# (Round 5 also built the two-stream form the round-4 trace suggested — every chain of launches between two record reads on
+#  alternating streams, ordered by the record alone — and measured it on the same box against this form: +150..200 us per step
+#  (profiles/r05_inner_loop_ab.jsonl: a launch into the OTHER hardware queue starts later than one behind the still-completing
+#  accept kernel), and the runtime, which knows nothing of an ordering through host memory, elides the cache acquire at the
+#  head of such a chain — the token stream diverged at the first drafted token in tests/test_gpu_e2e.py.  Removed.)
 INNER_GRAPH = __import__("os").environ.get("TRIFORCE_INNER_GRAPH", "1") != "0"
-
-
-class _Lanes:
-    def __init__(self, device):
-        self.streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
-        self.i, self.home, self.flips = 0, None, 0
-
-    @property
-    def active(self):
-        return self.home is not None
-
-    def enter(self):
-        """Move launching from the caller's stream onto the current lane (ordered after everything the caller enqueued)."""
-        if self.home is None:
-            self.home = torch.cuda.current_stream()
-            lane = self.streams[self.i]
-            lane.wait_stream(self.home)
-            torch.cuda.set_stream(lane)
-
-    def flip(self):
-        """ONLY right after a record read: every launch so far has executed, the other lane has long been idle."""
-        if self.home is not None:
-            self.i ^= 1
-            self.flips += 1
-            torch.cuda.set_stream(self.streams[self.i])
-
-    def leave(self):
-        """Back to the caller's stream, ordered after the current lane's tail (all earlier chains were seen to finish)."""
-        if self.home is not None:
-            self.home.wait_stream(self.streams[self.i])
-            torch.cuda.set_stream(self.home)
-            self.home = None
 
 
 _MAILBOX_OK = {}
@@ -225,8 +189,6 @@ class _SpecBuffers:
         mailbox = bool(mailbox) and _mailbox_supported(device)
         self.mid_out = _Record(device, 4, mailbox)
         self.chain_out = _Record(device, 4, mailbox)
-        # two launch lanes, only with mailbox records (a record read is what licenses a flip) — see _Lanes
-        self.lanes = _Lanes(device) if (LANES and mailbox and torch.device(device).type == "cuda") else None
         self.pos_base = torch.arange(gamma + 1, dtype=torch.long, device=device).unsqueeze(0)
         # host -> device token lists go through one pinned staging row (a pageable source makes the copy synchronous)
         cuda = torch.device(device).type == "cuda"
@@ -272,7 +234,6 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
     rng = rng or UniformSource(device)
     if buffers is None:
         buffers = _buffers(graph_engine, gamma, eng.model.config.vocab_size, device, mailbox=sync_record is None)
-    lanes = buffers.lanes if (buffers.lanes is not None and buffers.lanes.active) else None
     inner = None
     if INNER_GRAPH and sync_record is None and buffers.mid_out.mailbox and buffers.shared_inputs \
             and hasattr(graph_engine, "inner_graphs"):
@@ -310,8 +271,6 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
         acc, b, d, at = rec.read(4)                                           # the one host read of this step
         if _HOP_TRACE is not None:
             _t_seen = time.perf_counter_ns()
-        if lanes is not None:
-            lanes.flip()
         rng.advanced_on_device(3, at)
         drafted += 1
         if acc:                                                               # decoding.py:193-209
@@ -350,8 +309,6 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
             if n + 1 < flat.numel():
                 flat[n + 1:n + 3].copy_(_mid_tokens(rec.tensor, n, gamma, flat))
         acc, b, d = rec.read(3)                                               # the one host read of this step
-        if lanes is not None and sync_record is None:
-            lanes.flip()
         if _HOP_TRACE is not None:
             _t_seen = time.perf_counter_ns()                # (the drain below counts as part of the hop)
         if _SYNC_AFTER_RECORD:
@@ -474,16 +431,6 @@ class TriForceRunner:
     def step(self):
         """One outer iteration: Middle_Spec drafting, target verify over the full KV, device-side
         accept/rollback, cache fix-ups.  Returns the number of tokens emitted."""
-        lanes = self.bufs.lanes
-        if lanes is None or self.sync_record is not None:
-            return self._step()
-        lanes.enter()                       # launches alternate between two streams, flipped at every record read
-        try:
-            return self._step()
-        finally:
-            lanes.leave()
-
-    def _step(self):
         eng, ge, gamma, device, bufs, rng = self.eng, self.ge, self.gamma, self.device, self.bufs, self.rng
         tokenizer, verbose = self.tokenizer, self.verbose
         next_token = self.next_token
@@ -536,8 +483,6 @@ class TriForceRunner:
         if self.sync_record is not None:
             self.sync_record(rec.tensor)
         count, pred, reason, consumed = rec.read(4)                      # the one host read of the outer step
-        if bufs.lanes is not None and self.sync_record is None:
-            bufs.lanes.flip()
         if self.health is not None:
             self.health()
         if self.inclusive_accept and reason == 1 and generated[g2 - 1] == self.eos:
