@@ -7,6 +7,7 @@ GPU box):   python -m oracle.gen_golden [sequoia | sequoia2 | cli | tp | tp2 | s
   sequoia     sequoia_tree512, sequoia_small            SpecTree + TP_llama_tree (test/offloading_seqouia.py)
   tp          tp_chain                                  TP_llama + TriForce_Dist at world size 1 (test/offloading_TP.py)
   tp2         tp_world2, tp_world4                      the same engine as 2 / 4 gloo processes: shards + all-reduces
+  tp8         tp_world8                                 ... as 8 gloo processes (8 heads, one per rank): BASELINE configs[4]'s world size
   shards      tp_shards                                 TP_layers' own weight slicing for every rank of a 4- / 8-way split
   sequoia2    sequoia_world2                            the Sequoia loop as TWO gloo processes
   offloading  offloading_small                          OffloadingFlashSimpleCache (test/offloading.py)
@@ -514,26 +515,31 @@ _TP2 = dict(tcfg=dict(hidden=256, inter=512, layers=3, heads=4), tseed=601, dsee
             prefill=1000, budget=128, chunk=8, gamma=6, gen_len=24, temperature=0.6, top_p=0.9, rng_seed=41)
 
 
-def _tp2_configs():
-    c = _TP2["tcfg"]
+# world size 8 needs 8 heads: hidden 512 = 8 x 64, 1024 MLP columns = 8 x 128 (one head and 8 column panels per rank)
+_TP8 = dict(_TP2, tcfg=dict(hidden=512, inter=1024, layers=3, heads=8), tseed=611, dseed=612, pseed=613, rng_seed=43)
+_TP_PARAMS = {"tp2": _TP2, "tp8": _TP8}
+
+
+def _tp2_configs(which="tp2"):
+    c = _TP_PARAMS[which]["tcfg"]
     tcfg = specs.llama_config(c["hidden"], c["inter"], c["layers"], c["heads"], vocab_size=1024,
                               max_position_embeddings=4096,
                               rope_scaling=dict(type="yarn", factor=8.0, original_max_position_embeddings=512),
-                              name="tiny-d64-tp2")
+                              name=f"tiny-d64-{which}")
     dcfg = specs.llama_config(128, 256, 2, 2, vocab_size=1024, max_position_embeddings=2048, name="tiny-draft-tp2")
     return tcfg, dcfg
 
 
-def _tp2_worker(rank, world, port, out_path):
+def _tp2_worker(rank, world, port, out_path, which="tp2"):
     """One rank of the reference's TP engine (TP_layers.py:126-147 sharding, tensor_op.py all-reduces) on CPU."""
     import tempfile
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.set_num_threads(4)
+    torch.set_num_threads(4 if world <= 4 else 1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ref = _refshim.load_reference_tp()
-    P = _TP2
-    tcfg, dcfg = _tp2_configs()
+    P = _TP_PARAMS[which]
+    tcfg, dcfg = _tp2_configs(which)
     tsd = specs.random_state_dict(tcfg, P["tseed"], head_std=P["head_std"])
     dsd = specs.random_state_dict(dcfg, P["dseed"], head_std=P["head_std"])
     prompt = specs.random_prompt(tcfg["vocab_size"], P["prefill"], P["pseed"])
@@ -553,7 +559,23 @@ def _tp2_worker(rank, world, port, out_path):
                                                                          "down_proj")}
     llm.reset()
     prefill_logits = llm.prefill(prompt[:, :-1])[:, -1].clone()
-    build_logits = llm.build_retrieval_cache(prompt[:, -1:]).clone()
+    # the chunks THIS rank's heads select (cache.py:531-536: torch.topk over the local heads' chunk scores), layer by layer:
+    # a near-tie at the k-th score may legitimately resolve differently on another implementation's scores, and one swapped
+    # chunk moves the retrieval-verify logits by more than any rounding tolerance — the product's tests compare their own
+    # selection tie-tolerantly and then run the verify stage over the reference's selection
+    topk_log, real_topk = [], torch.topk
+
+    def spy_topk(x, k, dim=-1, **kw):
+        out = real_topk(x, k=k, dim=dim, **kw)
+        if x.dim() == 3 and x.dtype == torch.float16:
+            topk_log.append(torch.cat([torch.zeros_like(out[1][0, :, :1]), out[1][0] + 1], dim=-1).clone())
+        return out
+    torch.topk = spy_topk
+    try:
+        build_logits = llm.build_retrieval_cache(prompt[:, -1:]).clone()
+    finally:
+        torch.topk = real_topk
+    assert len(topk_log) == tcfg["num_hidden_layers"], len(topk_log)
     S = int(llm.kv_cache.seq_len)
     vt = torch.tensor([[11, 12, 13] + [100] * (gamma - 2)])
     pos = torch.arange(S, S + gamma + 1).unsqueeze(0)
@@ -575,14 +597,14 @@ def _tp2_worker(rank, world, port, out_path):
         else:
             counts.append(cur + (1 if color == "blue" else 0))
             cur = 0
-    torch.save(dict(rank=rank, shard_shapes=shard_shapes, prefill_logits=prefill_logits, build_logits=build_logits,
+    torch.save(dict(rank=rank, shard_shapes=shard_shapes, topk_idx=topk_log, prefill_logits=prefill_logits, build_logits=build_logits,
                     spec_logits=spec_logits, verify_logits=verify_logits, S=S, tokens=tokens, counts=counts,
                     avg_tokens=avg, final_seq_len=int(llm.kv_cache.seq_len)), f"{out_path}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
 
 
-def tp_world2_case(name="tp_world2", world=2):
+def tp_world2_case(name="tp_world2", world=2, which="tp2"):
     """The reference's tensor-parallel engine at WORLD SIZE 2: two gloo processes on CPU run the unmodified
     TP_llama.DistributedLlama (head / MLP-column shards of TP_layers.py:126-147, fp16 all-reduce after wo and down_proj)
     and TriForce_Dist (rank 0 samples, tokens and uniforms broadcast).  Recorded: per-stage logits (identical on both
@@ -597,11 +619,11 @@ def tp_world2_case(name="tp_world2", world=2):
     s.close()
     out = os.path.join(tempfile.mkdtemp(), "tp2")
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_tp2_worker, args=(r, world, port, out)) for r in range(world)]
+    procs = [ctx.Process(target=_tp2_worker, args=(r, world, port, out, which)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=900)
+        p.join(timeout=1800)
         assert p.exitcode == 0, f"reference TP rank exited with {p.exitcode}"
     ranks = [torch.load(f"{out}.{r}", weights_only=False) for r in range(world)]
     r0 = ranks[0]
@@ -609,8 +631,8 @@ def tp_world2_case(name="tp_world2", world=2):
         for k in ("prefill_logits", "build_logits", "spec_logits", "verify_logits"):
             assert torch.equal(r0[k], r1[k]), f"[{name}] ranks disagree on {k}"
         assert r0["tokens"] == r1["tokens"] and r0["counts"] == r1["counts"] and r0["final_seq_len"] == r1["final_seq_len"]
-    P = _TP2
-    tcfg, dcfg = _tp2_configs()
+    P = _TP_PARAMS[which]
+    tcfg, dcfg = _tp2_configs(which)
     g = dict(name=name, world=world, tcfg=tcfg, dcfg=dcfg, **{k: v for k, v in P.items() if k != "tcfg"})
     from tests import helpers as Hh
     eng, _, _ = Hh.build_oracle_tp(g, P["temperature"], P["top_p"])
@@ -626,12 +648,14 @@ def tp_world2_case(name="tp_world2", world=2):
     gaps = {}
     for k, ours in (("prefill_logits", lp), ("build_logits", lb), ("spec_logits", ls), ("verify_logits", lv)):
         gaps[k] = float((ours - r0[k]).abs().max())
-        assert gaps[k] < 4e-3, f"[{name}] single-process restatement off by {gaps[k]:.2e} on {k}"
+        # (an 8-way fp16 all-reduce rounds seven partial sums where one process rounds none: twice the allowance of world <= 4)
+        assert gaps[k] < (4e-3 if world <= 4 else 8e-3), f"[{name}] single-process restatement off by {gaps[k]:.2e} on {k}"
     eng, _, _ = Hh.build_oracle_tp(g, P["temperature"], P["top_p"])
     torch.manual_seed(P["rng_seed"])
     res = M.triforce(eng, prompt, gamma, P["gen_len"], P["temperature"], P["top_p"], eos_token_id=-1, dist=True)
     same_stream = res["tokens"] == r0["tokens"]
-    g.update(shard_shapes=r0["shard_shapes"], prefill_logits=r0["prefill_logits"], build_logits=r0["build_logits"],
+    g.update(topk_idx=[r["topk_idx"] for r in ranks],           # [rank][layer] (H / world, select_sets), chunk 0 first
+             shard_shapes=r0["shard_shapes"], prefill_logits=r0["prefill_logits"], build_logits=r0["build_logits"],
              spec_logits=r0["spec_logits"], verify_logits=r0["verify_logits"], S=r0["S"], tokens=r0["tokens"],
              counts=r0["counts"], avg_tokens=r0["avg_tokens"], final_seq_len=r0["final_seq_len"],
              single_process_gaps=gaps, single_process_stream_identical=same_stream,
@@ -906,6 +930,9 @@ if __name__ == "__main__":
         os.makedirs(GOLDEN, exist_ok=True)
         tp_world2_case()
         tp_world2_case("tp_world4", world=4)              # one attention head per rank: the extreme shard
+    elif len(sys.argv) > 1 and sys.argv[1] == "tp8":
+        os.makedirs(GOLDEN, exist_ok=True)
+        tp_world2_case("tp_world8", world=8, which="tp8")  # BASELINE configs[4]'s world size (8 heads: one per rank)
     elif len(sys.argv) > 1 and sys.argv[1] == "sequoia2":
         os.makedirs(GOLDEN, exist_ok=True)
         sequoia_world2_case()
@@ -922,4 +949,5 @@ if __name__ == "__main__":
         offloading_case()
         tp_world2_case()
         tp_world2_case("tp_world4", world=4)
+        tp_world2_case("tp_world8", world=8, which="tp8")
         sequoia_world2_case()

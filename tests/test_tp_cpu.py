@@ -211,11 +211,15 @@ def _ref4_worker(rank, world, port, q):
     _ref_world_worker(rank, world, port, q, "tp_world4")
 
 
+def _ref8_worker(rank, world, port, q):
+    _ref_world_worker(rank, world, port, q, "tp_world8")
+
+
 def _ref_world_worker(rank, world, port, q, golden):
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-        torch.set_num_threads(2)
+        torch.set_num_threads(2 if world <= 4 else 1)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from tests import cpu_backend, helpers as Hh
         import triforce_amd.ops as ops
@@ -236,40 +240,52 @@ def _ref_world_worker(rank, world, port, q, golden):
         prompt = Hh.prompt_of(g)
         llm.reset()
         lp = llm.prefill(prompt[:, :-1])[:, -1]
+        swapped, log = 0, []
+        if "topk_idx" in g:                               # the reference's own chunk selection is recorded: teacher-force it
+            undo = Hh.force_reference_selection(ops, g["topk_idx"][rank], log)
         lb = llm.build_retrieval_cache(prompt[:, -1:])
+        if "topk_idx" in g:
+            undo()
+            swapped = Hh.check_selection(log)
         S = llm.kv_cache.seq_len
         vt = torch.tensor([[11, 12, 13] + [100] * (gamma - 2)])
         ls = llm.retrieval_inference(vt, torch.arange(S, S + gamma + 1).unsqueeze(0))
         lv = llm.inference(vt)
-        q.put((rank, "ok", S, lp, lb, ls, lv))
+        q.put((rank, "ok", S, lp, lb, ls, lv, swapped))
         dist.barrier()
         dist.destroy_process_group()
     except Exception:
         q.put((rank, "error", traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_tp_gloo_matches_the_reference_engine_at_the_same_world_size(world):
     """The product's sharded forward against logits the UNMODIFIED reference TP engine produced as `world` gloo
     processes on CPU (oracle/gen_golden.py tp2): same head / MLP-column shards (TP_layers.py:126-147; at world 4 one
     attention head per rank) and the same two fp16 all-reduces per layer.  In the build container the four stages are
     bit-identical at world 2; at world 4 the CPU GEMM picks another blocking for the product's fused q|k|v weight than
     for the reference's three separate shards, which moves ~70 % of the logits by one fp16 step of a hidden state
-    (max 2.4e-3 on logits of scale 0.65) — hence a tolerance, not equality."""
+    (max 2.4e-3 on logits of scale 0.65) — hence a tolerance, not equality.  World 8 (round 5; BASELINE configs[4]'s world
+    size; 8 heads of 64, one per rank, tests/golden/tp_world8.pt): the 8-way fp16 all-reduce rounds seven partial sums, the
+    pinned single-process restatement itself sits 4.4e-3 .. 5.6e-3 from the reference there — allowance 8e-3."""
     from tests import helpers as Hh
-    outs = _run_world(_ref2_worker if world == 2 else _ref4_worker, world)
+    outs = _run_world({2: _ref2_worker, 4: _ref4_worker, 8: _ref8_worker}[world], world)
     g = Hh.load_golden(f"tp_world{world}")
     assert g["world"] == world
     assert g["shard_shapes"]["wq"] == (g["tcfg"]["hidden_size"] // world, g["tcfg"]["hidden_size"])
     for r in range(world):
-        _, _, S, lp, lb, ls, lv = outs[r]
+        _, _, S, lp, lb, ls, lv = outs[r][:7]
         assert S == g["S"]
         for name, ours in (("prefill_logits", lp), ("build_logits", lb), ("spec_logits", ls), ("verify_logits", lv)):
             gap = (ours - g[name]).abs().max().item()
-            assert gap < 4e-3, f"rank {r} {name}: {gap:.2e} from the reference's world-{world} logits"
+            assert gap < (4e-3 if world <= 4 else 8e-3), f"rank {r} {name}: {gap:.2e} from the reference's world-{world} logits"
+    for r in range(1, world):                              # every rank holds the same bits after each all-reduce
+        for i in (3, 4, 5, 6):
+            assert torch.equal(outs[0][i], outs[r][i])
     exact = [name for name, i in (("prefill_logits", 3), ("build_logits", 4), ("spec_logits", 5), ("verify_logits", 6))
              if torch.equal(outs[0][i].reshape(g[name].shape), g[name])]
-    print("bit-identical stages:", exact)
+    print("bit-identical stages:", exact, "| chunks the product's own scores would have swapped at a tie:",
+          sum(outs[r][7] for r in range(world)))
 
 
 # ---- Sequoia against the REFERENCE's own world-2 run (tests/golden/sequoia_world2.pt) ------------------------------

@@ -243,6 +243,11 @@ class _InnerGraphs:
         self.key = _InnerGraphs.key_of(ge, gamma, rng, record)
         self.generation = 0
         self.graphs, self.p = [], []
+        # Their OWN memory pool: captured into the engine's pool — after every other graph — their static outputs would be
+        # carved from blocks the earlier captures had freed, i.e. from memory the target / draft graphs still use as scratch
+        # at replay time: the target verify that runs between Middle_Spec and the outer accept test would overwrite the
+        # probability rows the accept test is about to read (found by the stochastic stream test: divergence at token 1).
+        self.pool = torch.cuda.graphs.graph_pool_handle()
         flat = ge.tok_buf.view(-1)
         ge.tok_buf.fill_(0)                                    # valid token ids for the warm-up passes
         for n in range(gamma):
@@ -252,7 +257,7 @@ class _InnerGraphs:
                 p = eng.model_verify(input_ids=ge.tok_buf[:, :gamma + 1], position_ids=ge.pos_buf, **kw)
                 ops.middle_accept_cur(p, q_d, flat, rng.buf, rng.cursor, n, gamma, record)
                 return p
-            graph, p = _capture(run, (), ge.mempool, 2)
+            graph, p = _capture(run, (), self.pool, 2)
             self.graphs.append(graph)
             self.p.append(p)
         torch.cuda.synchronize()
