@@ -172,7 +172,8 @@ def exchange_cost_lockstep(llm, args, device, per_graph=64, replays=5):
         out["per_exchange_us"] = round(out["gemm_with_exchange_us"] - out["gemm_alone_us"], 2)
         out["shape"] = f"{rows} rows x K {W.wo[0].K} -> hidden {hid} (o_proj shard), {per_graph} calls per hipGraph x {replays} replays"
     except Exception as ex:                                    # a probe must never cost the bench line
-        ok, out = False, {"failed": f"{type(ex).__name__}: {ex}"[:300]}
+        import traceback
+        ok, out = False, {"failed": f"{type(ex).__name__}: {ex}"[:300], "where": traceback.format_exc()[-600:]}
     flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(flag, dist.ReduceOp.MIN)
     if not int(flag.item()) and ok:

@@ -325,7 +325,8 @@ int tf_skinny_qkv_rope_n8(const void* wqkv_n8, const void* x, int64_t xs_m, int6
  * gate|up shards of a tensor-parallel rank — split K across up to 4 workgroups per panel; their partial sums meet in
  * `ws` (zero-filled device memory, first 16 KiB = per-panel tickets, left zero by every launch; 8 MiB covers every shape
  * the rule splits), summed in split order by the last workgroup to arrive.  Without a registered workspace no GEMM is
- * split.  GEMMs running CONCURRENTLY on one device must not share a workspace.  ws = NULL removes it.  (tf_sg_tune key
+ * split.  The workspace is cut into 4 equal slots, one per LAUNCH STREAM (first come, first served): split GEMMs on different
+ * streams of one device may run concurrently; a fifth stream's GEMMs run unsplit.  ws = NULL removes it.  (tf_sg_tune key
  * 3: panel-group count below which the split applies, 0 = never.) */
 int tf_sg_workspace(void* ws, int64_t bytes);
 

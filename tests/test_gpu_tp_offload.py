@@ -792,6 +792,79 @@ def test_rccl_world2_and_exchange_litmus_across_two_devices():
     assert lines[0]["litmus_ok"] and lines[0]["failures"] == 0 and not lines[0]["share_device"]
 
 
+def test_fused_exchange_litmus_both_forms_two_processes_one_device():
+    """The litmus of the FUSED exchange itself (round 5; the staged exchange kernel has had one since round 4): two
+    processes on this box's GPU, `tools/xgmi_litmus.py --xchg` = utils.oneshot_ar.GemmExchange.litmus — fresh integer
+    pattern -> tf_skinny_gemm_xchg over an identity weight -> every element of the sum checked against the SAME iteration's
+    patterns, inside replayed hipGraphs, one rank delayed now and then — first the fence-free form, then (control blocks
+    reset collectively) the fenced one.  The engine runs exactly this on the real group at start-up and keeps the
+    fence-free form only if it is clean (models/TP_llama.py _xchg_litmus)."""
+    rc, lines, err = _run_litmus(2, ["--share-device", "--xchg", "--iters", "20000", "--per-graph", "100"])
+    assert rc == 0 and len(lines) == 1, err
+    j = lines[0]
+    assert j["litmus_ok"] and j["failures"] == 0 and j["kernel"] == "tf_skinny_gemm_xchg"
+    assert [f["fenced"] for f in j["forms"]] == [False, True]
+    for f in j["forms"]:
+        assert f["iterations"] >= 20000 and f["mismatched_elements"] == 0 and f["error_word"] == 0
+        assert all(e["error_word"] == 0 and e["mismatched_elements"] == 0 for e in f["per_rank"])
+
+
+def test_fused_exchange_litmus_across_two_devices():
+    """... across two devices (xGMI remote loads, remote flag stores).  Skipped on a one-GPU box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible devices")
+    rc, lines, err = _run_litmus(2, ["--xchg", "--iters", "200000"])
+    assert rc == 0 and len(lines) == 1, err
+    assert lines[0]["litmus_ok"] and not lines[0]["share_device"]
+
+
+def test_fused_exchange_timeout_is_wall_clock_and_reset_recovers():
+    """Advisor, round 4: a peer that never flags must be reported in SECONDS (wall clock, tf_xchg_tune key 1), not after
+    2^27 polls, and the group must be able to start over (tf_xchg_reset: per-panel counts, flags, error word).  Two virtual
+    ranks on this device; rank 1 simply does not launch: rank 0's exchange times out inside the limit, NaN-fills its panels
+    and sets the error word (+ host mirror); after a reset of both control blocks the pair exchanges correctly again."""
+    import time
+    from triforce_amd import ops
+    from triforce_amd.utils.oneshot_ar import GemmExchange
+    hidden, K, rows = 1024, 256, 7
+    dev = torch.device(DEV)
+    grp = GemmExchange.local_group(2, dev, 32 * hidden)
+    old = GemmExchange.set_timeout_ms(300)
+    try:
+        gen = torch.Generator(device=dev).manual_seed(5)
+        w = ops.PackedLinear((torch.randn(hidden, K, generator=gen, device=dev) * 0.05).to(torch.float16))
+        acts = [torch.randn(rows, K, generator=gen, device=dev).to(torch.float16) for _ in range(2)]
+        x0 = torch.zeros(rows, hidden, dtype=torch.float16, device=dev)
+        t0 = time.time()
+        grp[0].linear_reduce(acts[0], w, x0, ops.ss_buffer(hidden, dev))          # the peer never arrives
+        torch.cuda.synchronize()
+        waited = time.time() - t0
+        assert 0.2 < waited < 5.0, f"time-out after {waited:.2f} s (limit 0.3 s)"
+        assert grp[0].error() == 1 and grp[0].error_device() == 1 and bool(torch.isnan(x0.float()).any())
+        with pytest.raises(RuntimeError):
+            grp[0].check("test")
+        for g in grp:                                                              # collective by contract: nothing in flight
+            g.reset()
+        assert grp[0].error() == 0 and grp[0].error_device() == 0
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        outs = [torch.zeros(rows, hidden, dtype=torch.float16, device=dev) for _ in range(2)]
+        for it in range(3):                                                        # odd / even epochs: both staging halves
+            for o in outs:
+                o.zero_()
+            torch.cuda.synchronize()
+            for r in range(2):
+                with torch.cuda.stream(streams[r]):
+                    grp[r].linear_reduce(acts[r], w, outs[r], ops.ss_buffer(hidden, dev))
+            torch.cuda.synchronize()
+            want = (ops.linear(acts[0], w).float() + ops.linear(acts[1], w).float()).half()
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], want), it
+        assert grp[0].error() == 0 and grp[1].error() == 0
+    finally:
+        GemmExchange.set_timeout_ms(old)
+        for g in grp:
+            g.close()
+
+
 def test_oneshot_allreduce_error_path_poisons_output_and_raises():
     """A timed-out exchange must never pass for a result: with the sticky error word set (fault injection — what a
     READY / DONE timeout leaves behind) every later reduce returns at once with `out` NaN-filled, `check()` raises, and
@@ -861,6 +934,7 @@ def test_bench_tp_line_reports_allreduce_state_and_fails_loudly_on_a_timeout():
     ex = mr["exchange"]
     assert ex["per_forward"] == 4 and ex["per_step"] > 4 and "tf_skinny_gemm_xchg" in ex["form"] and "litmus" in ex["form"]
     for r in ex["per_rank"]:
+        assert "failed" not in r, r
         assert r["gemm_with_exchange_us"] > 0 and r["gemm_alone_us"] > 0 and "per_exchange_us" in r, r
     assert set(mr["measured_step_terms_us"]) >= {"target_verify", "retrieval_verify", "draft", "host_and_broadcasts"}
     assert j["stage_latency_us"] == {k: v for k, v in mr["stage_latency_us_per_rank"][0].items() if k != "rank"}

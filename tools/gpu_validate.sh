@@ -13,7 +13,9 @@ if [ "$1" = "tp" ]; then
   #     a failure COUNT, not a hang — run before anything that trusts the exchange (assumptions 1-3)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29541 tools/xgmi_litmus.py > $O/litmus_tp${N}.json 2> $O/litmus_tp${N}.err || rc=1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29542 tools/xgmi_litmus.py --alternate > $O/litmus_tp${N}_alt.json 2> $O/litmus_tp${N}_alt.err || rc=1
-  tail -c 600 $O/litmus_tp${N}.json $O/litmus_tp${N}_alt.json
+  # ... and of the FUSED exchange (the engine's default at world > 1), fence-free and fenced form
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29543 tools/xgmi_litmus.py --xchg --iters 200000 > $O/litmus_tp${N}_xchg.json 2> $O/litmus_tp${N}_xchg.err || rc=1
+  tail -c 600 $O/litmus_tp${N}.json $O/litmus_tp${N}_alt.json $O/litmus_tp${N}_xchg.json
   # (1) one-shot exchange REQUIRED (no silent RCCL fallback), whole-forward hipGraphs REQUIRED, world size checked
   python bench.py --gpus $N --steps 20 --warmup 5 --allreduce oneshot --require-graph-form whole > $O/bench_tp${N}_oneshot.json 2> $O/bench_tp${N}_oneshot.err || rc=1
   # (2) the same run over RCCL, for the A/B

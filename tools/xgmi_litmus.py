@@ -41,6 +41,10 @@ def main():
     ap.add_argument("--per-graph", type=int, default=200, help="iterations captured per hipGraph (even)")
     ap.add_argument("--alternate", action="store_true", help="the alternating-halves form (no DONE handshake)")
     ap.add_argument("--budget-s", type=float, default=50.0, help="stop the graph phase after this many seconds")
+    ap.add_argument("--xchg", action="store_true",
+                    help="litmus of the FUSED exchange instead (tf_skinny_gemm_xchg: GEMM + per-panel exchange in one launch, the "
+                         "engine's default at world > 1): both forms — fence-free, then fenced — through "
+                         "utils.oneshot_ar.GemmExchange.litmus, --iters iterations each; the engine runs the same at start-up")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", rank))
@@ -50,6 +54,32 @@ def main():
     from triforce_amd import hip
     from triforce_amd.utils.oneshot_ar import OneShotAllReduce
     L = hip.lib()
+    if args.xchg:
+        from triforce_amd.utils.oneshot_ar import GemmExchange
+        xc = GemmExchange(rank, world, dev, 32 * args.hidden)
+        res = {"world": world, "share_device": args.share_device, "kernel": "tf_skinny_gemm_xchg", "forms": []}
+        fails = 0
+        for fenced in (False, True):
+            dist.barrier()
+            xc.reset()
+            dist.barrier()
+            xc.set_fenced(fenced)
+            t0 = time.time()
+            r = xc.litmus(iters=min(args.iters, 200_000), rows=min(args.rows, 32), per_graph=args.per_graph)
+            r["seconds"] = round(time.time() - t0, 2)
+            everyone = [None] * world
+            dist.all_gather_object(everyone, {"rank": rank, "mismatched_elements": r["mismatched_elements"], "error_word": r["error_word"]})
+            r["per_rank"] = everyone
+            r["failures"] = sum(e["mismatched_elements"] + (1 if e["error_word"] else 0) for e in everyone)
+            fails += r["failures"]
+            res["forms"].append(r)
+        xc.set_fenced(False)
+        res["failures"], res["litmus_ok"] = fails, fails == 0
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        xc.close()
+        dist.destroy_process_group()
+        sys.exit(0 if fails == 0 else 1)
     n = args.rows * args.hidden
     ar = OneShotAllReduce(rank, world, dev, 32 * args.hidden, alternate=args.alternate)
     it_dev = torch.zeros(1, dtype=torch.int32, device=dev)

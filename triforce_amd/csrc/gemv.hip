@@ -120,6 +120,23 @@ struct SgKsplit {
 #endif
 static void* g_sg_ws[16] = {};
 static int64_t g_sg_ws_bytes[16] = {};
+// The workspace is cut into SG_WS_SLOTS equal slots (tickets + partials each), one per LAUNCH STREAM, first come first served:
+// split GEMMs issued on different streams of one device (virtual ranks of the tests, a side stream) can then run concurrently
+// without meeting in one ticket array (advisor, round 4).  A fifth stream gets no slot: its GEMMs run unsplit.  (A captured
+// launch keeps the slot of its capture stream; graphs of one engine replay one at a time.)
+#define SG_WS_SLOTS 4
+static hipStream_t g_sg_slot_stream[16][SG_WS_SLOTS] = {};
+static int g_sg_slots_used[16] = {};
+#include <mutex>
+static std::mutex g_sg_slot_mutex;
+static int sg_slot_of(int dev, hipStream_t st) {
+    std::lock_guard<std::mutex> lock(g_sg_slot_mutex);
+    for (int i = 0; i < g_sg_slots_used[dev]; ++i)
+        if (g_sg_slot_stream[dev][i] == st) return i;
+    if (g_sg_slots_used[dev] >= SG_WS_SLOTS) return -1;
+    g_sg_slot_stream[dev][g_sg_slots_used[dev]] = st;
+    return g_sg_slots_used[dev]++;
+}
 // Measured (profiles/r04_tp_shard_structural_ab.jsonl, r04_tp8_7b_kernel_timeline_after_splitk.json): NO gain in situ — the
 // 7B TP-8 gate|up GEMM stays at 13.2 us with 258 workgroups instead of 86, q|k|v goes 9.1 -> 10.9 us: at 12-22 MB these
 // launches are made of fixed costs (dispatch, the norm prologue's dependent loads, merge, epilogue, drain), not of the
@@ -1230,7 +1247,7 @@ struct SgArgs {                       // one GEMM call: operands with their layo
 // Workgroups per panel group along K: only few-panel grids (see SgKsplit), only with a registered workspace that holds the
 // partials, and only while every wave of every workgroup still gets >= 2 k-chunks.
 template <int MT, int NA, int WAVES, int P>
-static int sg_pick_ksplit(const SgArgs& a, SgKsplit& kx) {
+static int sg_pick_ksplit(const SgArgs& a, SgKsplit& kx, hipStream_t st = nullptr) {
     kx = SgKsplit{nullptr, nullptr, nullptr};
 #if SG_STAMPS
     {
@@ -1263,9 +1280,13 @@ static int sg_pick_ksplit(const SgArgs& a, SgKsplit& kx) {
     while (ks > 1 && nchunks / ks < 2 * WAVES) --ks;
     if (ks <= 1) return 1;
     const int64_t need = (int64_t)SG_TICKETS * 4 + (int64_t)panels * ks * NA * MT * 256 * 4;
-    if (need > g_sg_ws_bytes[dev]) return 1;
-    kx.tickets = reinterpret_cast<unsigned*>(g_sg_ws[dev]);
-    kx.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(g_sg_ws[dev]) + (int64_t)SG_TICKETS * 4);
+    const int64_t slot_bytes = (g_sg_ws_bytes[dev] / SG_WS_SLOTS) & ~(int64_t)255;
+    if (need > slot_bytes) return 1;
+    const int slot = sg_slot_of(dev, st);
+    if (slot < 0) return 1;                                   // more launch streams than slots: this one runs unsplit
+    char* base = reinterpret_cast<char*>(g_sg_ws[dev]) + slot * slot_bytes;
+    kx.tickets = reinterpret_cast<unsigned*>(base);
+    kx.ws = reinterpret_cast<float*>(base + (int64_t)SG_TICKETS * 4);
     return ks;
 }
 
@@ -1281,7 +1302,7 @@ static void launch_sg_w(const SgArgs& a, const SgRope& rp, hipStream_t st) {
         return;
     }
     if constexpr (P == 1 && MODE != SG_F32) {                     // few-panel grids only: never the P = 2 form, never lm_head
-        const int ks = sg_pick_ksplit<MT, (MODE == SG_GATEUP ? 2 : 1), WAVES, P>(a, kx);
+        const int ks = sg_pick_ksplit<MT, (MODE == SG_GATEUP ? 2 : 1), WAVES, P>(a, kx, st);
         if (ks > 1) {
             hipLaunchKernelGGL((skinny_gemm_kernel<MT, MODE, NORM, WAVES, P, true>), dim3(a.N / 16 / P, ks), dim3(WAVES * 64),
                                0, st, (const half8*)a.wp, (const half8*)a.wp_up, (const h16*)a.x, a.ss_in, (const h16*)a.ln_w, a.K, a.M,
@@ -1370,9 +1391,9 @@ extern "C" int tf_sg_tune(int key, int value) {
 }
 
 // Registers (ws != NULL) or removes the CURRENT device's split-K workspace: `bytes` of device memory, ZERO-filled, that
-// stays allocated while GEMMs may run; the first 16 KiB are the per-panel tickets (left zero by every launch), the rest
-// holds the partial sums of one launch at a time — GEMMs that may run CONCURRENTLY on one device (two streams) must not
-// share it (the engines issue their GEMMs on one stream).  8 MiB covers every shape the rule splits.
+// stays allocated while GEMMs may run, cut into SG_WS_SLOTS slots — one per launch stream (see sg_slot_of) — of 16 KiB of
+// per-panel tickets (left zero by every launch) + the partial sums of one launch at a time.  8 MiB (2 MiB per slot) covers
+// every shape the rule splits.
 extern "C" int tf_sg_workspace(void* ws, int64_t bytes) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -1380,6 +1401,10 @@ extern "C" int tf_sg_workspace(void* ws, int64_t bytes) {
     if (dev < 0 || dev >= 16 || (ws && bytes < (int64_t)SG_TICKETS * 4 + 4096) || (reinterpret_cast<uintptr_t>(ws) % 16)) return TF_EINVAL;
     g_sg_ws[dev] = ws;
     g_sg_ws_bytes[dev] = ws ? bytes : 0;
+    {
+        std::lock_guard<std::mutex> lock(g_sg_slot_mutex);    // a new workspace: the stream -> slot table starts over
+        g_sg_slots_used[dev] = 0;
+    }
     return TF_OK;
 }
 
