@@ -370,8 +370,9 @@ def run_tp(args, rank, world, local):
     # ---- what the scaling prediction is written in, measured on THIS group by every rank in lock-step ----
     my_stages = my_exchange = None
     if offload is None and on_gpu:
-        my_stages = stage_latencies_lockstep(llm, args, device, _timed)
-        my_exchange = exchange_cost_lockstep(llm, args, device)
+        with torch.inference_mode():                             # (the engine's buffers are inference tensors)
+            my_stages = stage_latencies_lockstep(llm, args, device, _timed)
+            my_exchange = exchange_cost_lockstep(llm, args, device)
     per_rank = [None] * world
     dist.all_gather_object(per_rank, {"rank": rank, "stages": my_stages, "exchange": my_exchange})
     if rank == 0:

@@ -577,9 +577,9 @@ def test_one_launch_inner_iterations_emit_the_identical_stream(temperature, top_
     about the arithmetic changes, so against rounds 2-4's form (two replays + two eager kernels per iteration) the emitted
     tokens, the per-step accept counts and the consumed uniforms must be IDENTICAL — over a run long enough (>= 150 outer
     steps at T = 0.8, ~600 inner iterations) that a token id, a probability row or a cursor value consumed before it was
-    visible, or a cursor out of step with the host's mirror, would show as a diverged stream (the two-stream form built
-    first did exactly that, at the first drafted token).  Also: a second runner with a fresh uniform stream on the same engine
-    (re-capture against the new buffers), and the cursor check itself (a host mirror pushed out of step must raise)."""
+    visible, or a cursor out of step with the host's mirror, would show as a diverged stream.  Also: a second runner with a
+    fresh uniform stream on the same engine (re-capture against the new buffers), and the cursor check itself (a host mirror
+    pushed out of step must raise)."""
     from triforce_amd.utils import decoding as Dm
     from triforce_amd.utils.decoding import TriForce, TriForceRunner
     from triforce_amd.utils.sampling import UniformSource

@@ -876,12 +876,14 @@ def test_narrow_panel_norm_gemms(M, packed, kind, N, K, HD, monkeypatch):
         wv = qkv[:, 2 * H * D:].view(M, H, D)
         # rotated q / k = a cos + b sin of two pre-RoPE values that may EACH sit on the neighbouring fp16 (another fp32 order of
         # the K sum than the CPU's): where the two terms cancel, the error is absolute — two spacings at the largest pre-RoPE
-        # magnitude of the block (the bare GEMM rows, v, keep 1 ulp)
+        # magnitude of the block
         spacing = 2.0 ** (math.floor(math.log2(float(qkv[:, :2 * H * D].float().abs().max()))) - 10)
         for res in (got, got_ss):
             ulp_report("n8 qkv_rope q", res[0], wq, max_ulp_frac=8e-2, ulps=2, atol=2 * spacing)
             ulp_report("n8 qkv_rope k", res[1], wk, max_ulp_frac=8e-2, ulps=2, atol=2 * spacing)
-            ulp_report("n8 qkv_rope v", res[2], wv, max_ulp_frac=5e-2, ulps=1, atol=1e-4)
+            # (v = the bare norm-prologue GEMM: the bound of test_skinny_gemm_norm_prologue_and_residual_epilogue — the 16-row
+            #  kernel, which serves the 25-row case here, needs it at K = 5120 just the same)
+            ulp_report("n8 qkv_rope v", res[2], wv, max_ulp_frac=5e-2, ulps=2, atol=2e-3)
         # vs the 16-row kernel: v is the bare GEMM (<= 1 ulp), rotated q / k add two such values (see the K-split test)
         # (two fp16 roundings of sums that differ in fp32 order: one ulp — of the LARGER binade when they straddle a power of two)
         #  + an ABSOLUTE part: the two kernels sum x^2 in different orders, a few normalised inputs land on the neighbouring

@@ -1525,11 +1525,15 @@ static int launch_sg_n8(const SgArgs& a, const SgRope& rp, hipStream_t st) {
     hipLaunchKernelGGL((skinny_gemm_n8_kernel<MT_, MODE, true, SG_N8_WAVES, U_>), dim3(a.N / 8), dim3(SG_N8_WAVES * 64), 0,  \
                        st, (const half8*)a.wp, (const half8*)a.wp_up, (const h16*)a.x, a.ss_in, (const h16*)a.ln_w, a.K,    \
                        a.M, (int)a.xa.sm, (int)a.xa.sk, a.eps, a.y, a.ya, rp)
-    // (the gate|up form holds two weight streams: from two row tiles up a batch of 4 keeps it inside 256 registers)
+    // (the gate|up form holds two weight streams: from two row tiles up a batch of 4 — or 13B's even 5 + 5 — keeps it inside 256 registers)
     if (a.M <= 8) {
         if (u5) N8_LAUNCH(1, 5); else N8_LAUNCH(1, 8);
     } else if constexpr (MODE == SG_GATEUP) {
-        if (a.M <= 16) N8_LAUNCH(2, 4); else N8_LAUNCH(3, 4);
+        if (a.M <= 16) {
+            if (u5) N8_LAUNCH(2, 5); else N8_LAUNCH(2, 4);
+        } else {
+            if (u5) N8_LAUNCH(3, 5); else N8_LAUNCH(3, 4);
+        }
     } else if (a.M <= 16) {
         if (u5) N8_LAUNCH(2, 5); else N8_LAUNCH(2, 8);
     } else {

@@ -138,8 +138,8 @@ class _Record:
 # (Round 5 also built the two-stream form the round-4 trace suggested — every chain of launches between two record reads on
 #  alternating streams, ordered by the record alone — and measured it on the same box against this form: +150..200 us per step
 #  (profiles/r05_inner_loop_ab.jsonl: a launch into the OTHER hardware queue starts later than one behind the still-completing
-#  accept kernel), and the runtime, which knows nothing of an ordering through host memory, elides the cache acquire at the
-#  head of such a chain — the token stream diverged at the first drafted token in tests/test_gpu_e2e.py.  Removed.)
+#  accept kernel); it is also unsound without an explicit acquire at the head of every chain — the runtime knows nothing of an
+#  ordering that goes through host memory.  Removed)
 INNER_GRAPH = __import__("os").environ.get("TRIFORCE_INNER_GRAPH", "1") != "0"
 
 

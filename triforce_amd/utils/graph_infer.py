@@ -245,8 +245,7 @@ class _InnerGraphs:
         self.graphs, self.p = [], []
         # Their OWN memory pool: captured into the engine's pool — after every other graph — their static outputs would be
         # carved from blocks the earlier captures had freed, i.e. from memory the target / draft graphs still use as scratch
-        # at replay time: the target verify that runs between Middle_Spec and the outer accept test would overwrite the
-        # probability rows the accept test is about to read (found by the stochastic stream test: divergence at token 1).
+        # at replay time, and the target verify runs between Middle_Spec and the outer accept test that reads these rows.
         self.pool = torch.cuda.graphs.graph_pool_handle()
         flat = ge.tok_buf.view(-1)
         ge.tok_buf.fill_(0)                                    # valid token ids for the warm-up passes
