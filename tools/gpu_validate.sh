@@ -68,10 +68,13 @@ find $O/prof $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/pmc_layer_fetch $O/pmc_lay
 if [ "$1" = "all" ]; then
   python bench.py --target lwm-128K --steps 20 --warmup 5 --no-cpu-baseline --random-steps 0 > $O/bench_lwm.json 2> $O/bench_lwm.err; echo "lwm rc=$?"; tail -c 300 $O/bench_lwm.json
   python bench.py --prefill 130048 --budget 12288 --gamma 16 --on-chip 9 --steps 8 --warmup 2 --no-cpu-baseline --random-steps 0 > $O/bench_offload.json 2> $O/bench_offload.err; echo "offload rc=$?"; tail -c 300 $O/bench_offload.json
-  python tools/acceptance_sweep.py $O/acceptance_sweep.json > $O/acceptance_sweep.log 2>&1; echo "sweep rc=$?"; tail -3 $O/acceptance_sweep.log
+  # (the 9-point acceptance sweep costs ~6 GPU-minutes: only with SWEEP=1; the tracked sweep is profiles/r04_acceptance_sweep.json)
+  if [ "$SWEEP" = "1" ]; then python tools/acceptance_sweep.py $O/acceptance_sweep.json > $O/acceptance_sweep.log 2>&1; echo "sweep rc=$?"; tail -3 $O/acceptance_sweep.log; fi
   python tools/verify_bench.py final > $O/verify_bench.json 2> $O/verify_bench.err; echo "verify_bench rc=$?"; tail -c 400 $O/verify_bench.json
   # BASELINE configs[4] parameters at world size 1 (13B, gamma 16): the single-GPU line of the gamma = 16 path
   python bench.py --target llama-13B-128K --prefill 130048 --budget 12288 --gamma 16 --steps 10 --warmup 2 --no-cpu-baseline --random-steps 0 > $O/bench_13b_cfg4.json 2> $O/bench_13b_cfg4.err; echo "13B rc=$?"; tail -c 300 $O/bench_13b_cfg4.json
+  # BASELINE configs[3] parameters with every layer resident (the loop statistics of the gamma = 16 7B line of the prediction)
+  python bench.py --prefill 130048 --budget 12288 --gamma 16 --steps 10 --warmup 2 --no-cpu-baseline --random-steps 0 > $O/bench_7b_cfg3_resident.json 2> $O/bench_7b_cfg3_resident.err; echo "7B cfg3 resident rc=$?"; tail -c 300 $O/bench_7b_cfg3_resident.json
   # per-rank stage latencies at W = 1 / 2 / 4 / 8 for configs[1] / [3] / [4] (rank 0's shard on this GPU, exchanges in their
   # shipped form against a one-rank group) -> the predicted scaling table the first multi-GPU run is judged against
   rm -f $O/tp_shard_by_world.jsonl
@@ -81,7 +84,9 @@ if [ "$1" = "all" ]; then
     python tools/tp_shard_bench.py llama-7B-128K $W --gamma 16 --prefill 130048 --budget 12288 $X 2>>$O/tp_shard.err | grep '^{' >> $O/tp_shard_by_world.jsonl
     python tools/tp_shard_bench.py llama-13B-128K $W --gamma 16 --prefill 130048 --budget 12288 $X 2>>$O/tp_shard.err | grep '^{' >> $O/tp_shard_by_world.jsonl
   done
-  python tools/predict_scaling.py --shards $O/tp_shard_by_world.jsonl --out $O/predicted_scaling.json > $O/predicted_scaling.md; echo "predict rc=$?"; head -8 $O/predicted_scaling.md
+  # loop statistics (tokens per step, inner iterations, host overhead) and the W = 1 row from THIS run's single-GPU lines
+  python tools/predict_scaling.py --shards $O/tp_shard_by_world.jsonl --out $O/predicted_scaling.json \
+      --bench "configs[1]=$O/bench.json" "configs[3]=$O/bench_7b_cfg3_resident.json" "configs[4]=$O/bench_13b_cfg4.json" > $O/predicted_scaling.md; echo "predict rc=$?"; head -8 $O/predicted_scaling.md
   (cd /tmp && export TMPDIR=/tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_tp8 -- python $R/tools/tp_shard_bench.py llama-7B-128K 8 --gamma 6 --prefill 124928 --budget 4096 --local-exchange --gemm-exchange > $R/$O/prof_tp8.log 2>&1)
   T8=$(ls -S $O/prof_tp8/*/*kernel_trace.csv | head -1)
   python tools/kernel_timeline.py $T8 $O/tp8_7b_kernel_timeline.json "rocprofv3 --kernel-trace of tools/tp_shard_bench.py llama-7B-128K 8 --gamma 6 --prefill 124928 --budget 4096 --local-exchange --gemm-exchange (rank 0 shard of an 8-way 7B engine on one MI355X), final build of the round (tools/gpu_validate.sh all)" > $O/tp8_7b_kernel_timeline.txt 2>&1

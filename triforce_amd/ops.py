@@ -293,6 +293,14 @@ def embed_rows(embed, ids, packed, out=None):
     tf_embed_rows straight in the k-octet-major form.  ``out``: write into this tensor / Act (static graph buffers)."""
     ids = ids.reshape(-1)
     if not packed:
+        if embed.is_cuda and embed.dtype == _HALF and embed.is_contiguous() and ids.numel() <= 32 and ids.dtype == torch.int64 \
+                and ids.is_contiguous() and embed.shape[1] % 8 == 0 and (out is None or (out.is_contiguous() and out.dtype == _HALF)):
+            # the same kernel with row-major strides (round 5: no torch gather kernel left inside the captured decode forwards)
+            n, (V, hid) = ids.numel(), embed.shape
+            x = torch.empty(n, hid, dtype=_HALF, device=embed.device) if out is None else out
+            assert tuple(x.shape) == (n, hid)
+            hip.check(hip.lib().tf_embed_rows(_ptr(embed), _ptr(ids), _ptr(x), hid, 8, n, hid, V, _stream()), "tf_embed_rows")
+            return x
         if out is None:
             return embed[ids]
         return out.copy_(embed[ids])

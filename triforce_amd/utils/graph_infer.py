@@ -249,15 +249,33 @@ class _InnerGraphs:
         self.pool = torch.cuda.graphs.graph_pool_handle()
         flat = ge.tok_buf.view(-1)
         ge.tok_buf.fill_(0)                                    # valid token ids for the warm-up passes
+        # TRIFORCE_INNER_SPLIT=1 (A/B): the iteration as TWO graphs launched back to back — [draft step, draw] (14 nodes: its
+        # packets reach the queue in a few us) and [retrieval verify, accept] (165 nodes, enqueued while the draft runs)
+        self.split = os.environ.get("TRIFORCE_INNER_SPLIT", "0") == "1"
         for n in range(gamma):
-            def run(n=n):
-                q_d = eng.draft_run(input_ids=ge.tok_buf[:, :n + 1], gamma_offset=n, **kw)
-                ops.sample_inverse_cdf_cur(q_d, rng.buf, rng.cursor, 0, flat[n + 1:n + 2])
+            cell = {}
+
+            def head(n=n, cell=cell):
+                cell["q"] = eng.draft_run(input_ids=ge.tok_buf[:, :n + 1], gamma_offset=n, **kw)
+                ops.sample_inverse_cdf_cur(cell["q"], rng.buf, rng.cursor, 0, flat[n + 1:n + 2])
+                return cell["q"]
+
+            def tail(n=n, cell=cell):
                 p = eng.model_verify(input_ids=ge.tok_buf[:, :gamma + 1], position_ids=ge.pos_buf, **kw)
-                ops.middle_accept_cur(p, q_d, flat, rng.buf, rng.cursor, n, gamma, record)
+                ops.middle_accept_cur(p, cell["q"], flat, rng.buf, rng.cursor, n, gamma, record)
                 return p
-            graph, p = _capture(run, (), self.pool, 2)
-            self.graphs.append(graph)
+
+            def run(head=head, tail=tail):
+                head()
+                return tail()
+            if self.split:
+                g_head, q_static = _capture(head, (), self.pool, 2)
+                cell["q"] = q_static
+                g_tail, p = _capture(tail, (), self.pool, 2)
+                self.graphs.append((g_head, g_tail))
+            else:
+                graph, p = _capture(run, (), self.pool, 2)
+                self.graphs.append(graph)
             self.p.append(p)
         torch.cuda.synchronize()
         rng.device_cursor = False                              # the warm-up passes advanced the device copy
@@ -268,7 +286,12 @@ class _InnerGraphs:
                 id(ge.engine.kv_cache), id(ge.engine.graph_cache), id(ge.engine.draft_cache))
 
     def replay(self, n):
-        self.graphs[n].replay()
+        g = self.graphs[n]
+        if self.split:
+            g[0].replay()
+            g[1].replay()
+        else:
+            g.replay()
         self.generation += 1
         return self.p[n]
 
