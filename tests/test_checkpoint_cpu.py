@@ -130,7 +130,7 @@ def _shard_worker(rank, world, port, q):
         assert isinstance(llm.config.model_config, LlamaConfig) and llm.config.model_config._name_or_path == path
         cli.shard_weights(llm, path, rank, world)                     # offloading_TP.py:97-102
         W = llm.weights
-        got = {k: v.clone() for k, v in _tensors(W).items()}
+        got = {k: v.contiguous().view(torch.int16).numpy().copy() for k, v in _tensors(W).items()}   # by value (bit patterns)
         q.put((rank, "ok", got, W.H_local, W.I_local))
         dist.barrier()
         dist.destroy_process_group()
@@ -148,6 +148,7 @@ def test_shard_weights_from_a_checkpoint_at_world_2(tmp_path, monkeypatch):
     H, D, I = tcfg["num_attention_heads"], tcfg["hidden_size"] // tcfg["num_attention_heads"], tcfg["intermediate_size"]
     for rank in range(world):
         _, _, got, Hl, Il = outs[rank]
+        got = {k: torch.from_numpy(v).view(torch.float16) for k, v in got.items()}
         assert (Hl, Il) == (H // world, I // world)
         _, want = specs.shard_of(tcfg, sd, rank, world)                # the reference's slicing (TP_layers.py:126-147)
         for i in range(tcfg["num_hidden_layers"]):

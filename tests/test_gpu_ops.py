@@ -955,6 +955,46 @@ def test_cursor_forms_of_the_sampling_kernels_equal_the_pointer_forms():
             assert int(cur) == base + int(rb[3])
 
 
+def test_launch_plans_equal_the_per_call_wrappers():
+    """Round 5: the decode loop's per-step launches over fixed buffers (retrieval-tail copy, draft-window shift, token /
+    position set-up) go through plans that validate their tensors once (ops.KvCopyPairPlan / KvShiftPairPlan / SetTokensPlan).
+    Same launches, same bytes as the per-call wrappers, and the same refusals of row ranges that leave the caches."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    src_k = torch.randn(3, 2, 40, 64, generator=g).half().to(DEV)
+    src_v = torch.randn(3, 2, 40, 64, generator=g).half().to(DEV)
+    for args in ((30, 4, 9), (0, 0, 16), (39, 15, 1)):
+        a_k, a_v = torch.zeros(3, 2, 16, 64, dtype=torch.float16, device=DEV), torch.zeros(3, 2, 16, 64, dtype=torch.float16, device=DEV)
+        b_k, b_v = a_k.clone(), a_v.clone()
+        ops.kv_copy_rows_pair(src_k, src_v, a_k, a_v, *args)
+        ops.KvCopyPairPlan(src_k, src_v, b_k, b_v)(*args)
+        assert torch.equal(a_k, b_k) and torch.equal(a_v, b_v) and a_k.abs().sum() > 0
+    plan = ops.KvCopyPairPlan(src_k, src_v, a_k, a_v)
+    for args in ((33, 0, 8), (0, 9, 8), (-1, 0, 2)):
+        with pytest.raises(IndexError):
+            plan(*args)
+    plan(0, 0, 0)                                                # nothing to copy: no launch, no error
+    for args in ((8, 0, 30), (10, 4, 30), (0, 6, 20)):
+        c_k, c_v = src_k.clone(), src_v.clone()
+        d_k, d_v = src_k.clone(), src_v.clone()
+        ops.kv_shift_rows_pair(c_k, c_v, *args)
+        ops.KvShiftPairPlan(d_k, d_v)(*args)
+        assert torch.equal(c_k, d_k) and torch.equal(c_v, d_v)
+    with pytest.raises(IndexError):
+        ops.KvShiftPairPlan(src_k, src_v)(20, 0, 30)
+    dst = torch.zeros(9, dtype=torch.int64, device=DEV)
+    pos = torch.zeros(7, dtype=torch.int64, device=DEV)
+    slot, sk = torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    d2, p2, s2, k2 = dst.clone(), pos.clone(), slot.clone(), sk.clone()
+    ops.set_tokens(dst, [5, 6, 7], 100, pos=pos, pos0=1234, slot=slot, sk=sk, sk_val=1241)
+    ops.SetTokensPlan(d2, p2, s2, k2)([5, 6, 7], 100, pos0=1234, sk_val=1241)
+    assert torch.equal(dst, d2) and torch.equal(pos, p2) and torch.equal(slot, s2) and torch.equal(sk, k2)
+    assert dst.tolist() == [5, 6, 7] + [100] * 6 and pos.tolist() == list(range(1234, 1241)) and int(slot) == 1234 and int(sk) == 1241
+    d3 = torch.full((9,), -1, dtype=torch.int64, device=DEV)
+    ops.SetTokensPlan(d3)([1, 2], 100, n_dst=5)                   # only the first n_dst entries are written
+    assert d3.tolist() == [1, 2, 100, 100, 100, -1, -1, -1, -1]
+
+
 def test_row_copy_wrappers_refuse_out_of_range_rows():
     """kv_copy_rows / kv_shift_rows / kv_gather_rows move whole token rows with no bounds check on the device: the
     wrappers refuse ranges that leave the tensors (a prompt longer than the declared prefill, a run past the

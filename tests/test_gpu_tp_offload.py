@@ -458,7 +458,7 @@ def _tp2_worker(rank, world, port, q, alternate=False, extra_env=None, loop_gamm
         ls = llm.retrieval_inference(vt, torch.arange(S, S + gamma + 1, device=DEV).unsqueeze(0))
         lv = llm.inference(vt)
         torch.cuda.synchronize()
-        out.update(S=S, stages=[t.float().cpu() for t in (lp, lb, ls, lv)],
+        out.update(S=S, stages=[t.float().cpu().numpy() for t in (lp, lb, ls, lv)],      # by value (see tests/test_tp_cpu.py)
                    ar_error_stage=llm._ar.error() if llm._ar is not None else -1,
                    xchg=llm._xchg is not None, xchg_form=getattr(llm, "xchg_form", None), note=getattr(llm, "allreduce_note", ""))
         if stages_only:
@@ -527,6 +527,7 @@ def test_tp_world2_on_one_device_real_kernels_and_oneshot_allreduce(alternate):
         assert o["oneshot_stage"] and o["oneshot_decode"], f"rank {r}: the engine fell back to the ring collective"
         assert o["ar_error_stage"] == 0 and o["ar_error_decode"] == 0, f"rank {r}: an all-reduce wait timed out"
         assert o["S"] == g["S"]
+        o["stages"] = [torch.from_numpy(x) for x in o["stages"]]
         for name, ours in zip(("prefill_logits", "build_logits", "spec_logits", "verify_logits"), o["stages"]):
             gap = (ours.reshape(g[name].shape) - g[name].float()).abs().max().item()
             assert gap < 4e-3, f"rank {r} {name}: {gap:.2e} from the reference's world-2 logits"
@@ -578,6 +579,7 @@ def test_tp_world8_on_one_device_matches_the_reference_world8_logits():
         assert o["oneshot_stage"], f"rank {r}: the engine fell back to the ring collective ({o['note']})"
         assert o["xchg"] and "litmus" in (o["xchg_form"] or ""), f"rank {r}: fused exchange not selected: {o['xchg_form']} / {o['note']}"
         assert o["ar_error_stage"] == 0 and o["S"] == g["S"]
+        o["stages"] = [torch.from_numpy(x) for x in o["stages"]]
         for name, ours in zip(("prefill_logits", "build_logits", "spec_logits", "verify_logits"), o["stages"]):
             gap = (ours.reshape(g[name].shape) - g[name].float()).abs().max().item()
             assert gap < 8e-3, f"rank {r} {name}: {gap:.2e} from the reference's world-8 logits"

@@ -81,6 +81,43 @@ def test_uniform_source_matches_injected_rng_across_wraparound():
         src.advance(k)
 
 
+def test_uniform_source_device_cursor_mirrors_the_host_position():
+    """Round 5: kernels captured inside a hipGraph read their uniforms as buf[cursor + k] (ops.*_cur) and advance the device
+    cursor themselves; the host mirrors it.  Pinned here (CPU tensors stand in for the device): the buffer keeps its ADDRESS
+    across refills and wrap-arounds (captured graphs hold it), cursor_tensor() brings a stale device copy up to date and makes
+    room first, advanced_on_device() checks the kernel's report against the mirror, and the numbers a cursor reader would see
+    are the numbers take() hands out."""
+    from triforce_amd.utils.sampling import UniformSource
+    src = UniformSource("cpu", seed=7, block=64)
+    ref = UniformSource("cpu", seed=7, block=64)
+    addr, caddr = src.buf.data_ptr(), src.cursor.data_ptr()
+    for k in [3, 5, 2, 40, 9, 3, 30, 3, 3, 50, 7]:
+        want = ref.take(k).clone()
+        ref.advance(k)
+        cur = src.cursor_tensor(k)                                # (may refill in place and reset the position)
+        assert cur.data_ptr() == caddr and src.buf.data_ptr() == addr and int(cur) == src.pos and src.device_cursor
+        got = src.buf[int(cur):int(cur) + k]
+        assert torch.equal(got, want)
+        at = int(cur)
+        src.cursor += k                                           # what the *_cur kernel that closes the decision does
+        src.advanced_on_device(k, at)
+        assert int(src.cursor) == src.pos
+    src.take(2)
+    src.advance(2)                                                # an eager kernel consumed two numbers through a pointer
+    assert not src.device_cursor and int(src.cursor) != src.pos
+    assert int(src.cursor_tensor(3)) == src.pos and src.device_cursor
+    with pytest.raises(RuntimeError, match="out of step"):
+        src.advanced_on_device(3, at=src.pos + 1)
+    fixed = UniformSource("cpu", values=[i / 13.0 for i in range(13)], block=32)
+    seen = []
+    for k in [5, 9, 11, 7, 12]:
+        c = int(fixed.cursor_tensor(k))
+        seen += fixed.buf[c:c + k].tolist()
+        fixed.cursor += k
+        fixed.advanced_on_device(k, c)
+    assert seen == pytest.approx([(i % 13) / 13.0 for i in range(len(seen))])
+
+
 def test_synthetic_dataset_and_null_tokenizer():
     from triforce_amd.data.dataset import NullTokenizer, get_dataset, load_tokenizer
     a = get_dataset("synthetic", datalen=100, vocab_size=500, num_prompts=2, seed=3)

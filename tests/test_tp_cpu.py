@@ -251,7 +251,9 @@ def _ref_world_worker(rank, world, port, q, golden):
         vt = torch.tensor([[11, 12, 13] + [100] * (gamma - 2)])
         ls = llm.retrieval_inference(vt, torch.arange(S, S + gamma + 1).unsqueeze(0))
         lv = llm.inference(vt)
-        q.put((rank, "ok", S, lp, lb, ls, lv, swapped))
+        # (by VALUE: a tensor travels through a multiprocessing queue as a shared-memory handle that dies with this process —
+        #  with 8 ranks the parent was seen unpickling after a rank had exited: FileNotFoundError / ConnectionResetError)
+        q.put((rank, "ok", S, *(t.float().numpy() for t in (lp, lb, ls, lv)), swapped))
         dist.barrier()
         dist.destroy_process_group()
     except Exception:
@@ -274,7 +276,9 @@ def test_tp_gloo_matches_the_reference_engine_at_the_same_world_size(world):
     assert g["world"] == world
     assert g["shard_shapes"]["wq"] == (g["tcfg"]["hidden_size"] // world, g["tcfg"]["hidden_size"])
     for r in range(world):
-        _, _, S, lp, lb, ls, lv = outs[r][:7]
+        S = outs[r][2]
+        lp, lb, ls, lv = (torch.from_numpy(a) for a in outs[r][3:7])
+        outs[r] = outs[r][:3] + (lp, lb, ls, lv) + outs[r][7:]
         assert S == g["S"]
         for name, ours in (("prefill_logits", lp), ("build_logits", lb), ("spec_logits", ls), ("verify_logits", lv)):
             gap = (ours - g[name]).abs().max().item()

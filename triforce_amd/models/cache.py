@@ -237,6 +237,16 @@ class RetrievalCache(Cache):
         g = kv_cache.seq_len - self.prefill
         if g > self.max_budget:
             raise IndexError(f"generated tail ({g}) exceeds the retrieval budget ({self.max_budget})")
+        whole = layers == slice(0, self.layers)
+        if whole and ops.HOST_PLANS and self.k.is_cuda and type(kv_cache) is FlashSimpleCache:
+            # the per-step refresh over all layers: the same tensors every step -> a launch plan (ops.KvCopyPairPlan); only for
+            # the resident cache, whose storage never moves (the offloading cache re-allocates its tail mirror)
+            plan = getattr(self, "_tail_plan", None)
+            if plan is None or plan[0] != (id(kv_cache), kv_cache.k.data_ptr()):
+                src_k, src_v, t0 = kv_cache.tail_source(layers, self.prefill)
+                plan = self._tail_plan = ((id(kv_cache), kv_cache.k.data_ptr()), ops.KvCopyPairPlan(src_k, src_v, self.k, self.v), t0)
+            plan[1](plan[2], self.max_budget - g, g)
+            return
         src_k, src_v, t0 = kv_cache.tail_source(layers, self.prefill)
         ops.kv_copy_rows_pair(src_k, src_v, self.k[layers], self.v[layers], t0, self.max_budget - g, g)
 
@@ -325,6 +335,12 @@ class StreamingLLMEvictionCache(Cache):
         self.seq_len = self.start_size + self.recent_size - incoming
 
     def evict_for_spec(self, current_seq_len):
+        if ops.HOST_PLANS and self.k.is_cuda:
+            plan = getattr(self, "_shift_plan", None)
+            if plan is None:
+                plan = self._shift_plan = ops.KvShiftPairPlan(self.k, self.v)
+            plan(current_seq_len - self.recent_size, self.start_size, self.recent_size)
+            return
         ops.kv_shift_rows_pair(self.k, self.v, current_seq_len - self.recent_size, self.start_size, self.recent_size)
 
 

@@ -809,6 +809,83 @@ def kv_shift_rows_pair(k_cache, v_cache, src_t0, dst_t0, n):
                                               L, H, D, _stream()), "tf_kv_shift_rows_pair")
 
 
+# ---- launch plans (round 5) ---------------------------------------------------------------------------------------------
+# The decode loop issues the same few launches over the same buffers every step — the tail copy of the retrieval cache, the
+# draft window shift, the token / position set-up — and the host time between a decision record and the next launch is GPU idle
+# time (profiles/r05a_gap_analysis_decode_steps_inner_graph.txt: 36-108 us in front of each of them under the profiler).  A plan
+# validates its tensors ONCE (what the wrappers above do on every call: device, dtype, shapes, strides, slicing views) and keeps
+# the ctypes arguments; a call then checks its row range with integer arithmetic and goes straight into the library.
+# TRIFORCE_HOST_PLANS=0: the per-call wrappers.
+HOST_PLANS = _os.environ.get("TRIFORCE_HOST_PLANS", "1") != "0"
+
+
+class KvCopyPairPlan:
+    """kv_copy_rows_pair(src_k, src_v, dst_k, dst_v, ...) over fixed tensors."""
+
+    def __init__(self, src_k, src_v, dst_k, dst_v):
+        assert src_k.shape == src_v.shape and dst_k.shape == dst_v.shape and _lhtd(src_k) == _lhtd(src_v) \
+            and _lhtd(dst_k) == _lhtd(dst_v), "K and V must share shapes and strides"
+        _dev(src_k, src_v, dst_k, dst_v)
+        L, H, _, D = src_k.shape
+        assert dst_k.shape[0] == L and dst_k.shape[1] == H and dst_k.shape[3] == D
+        self.keep = (src_k, src_v, dst_k, dst_v)
+        self.src_rows, self.dst_rows = src_k.shape[2], dst_k.shape[2]
+        self.head = (_ptr(src_k), _ptr(src_v)) + _lhtd(src_k) + (_ptr(dst_k), _ptr(dst_v)) + _lhtd(dst_k)
+        self.dims = (L, H, D)
+        self.fn = hip.lib().tf_kv_copy_rows_pair
+
+    def __call__(self, src_t0, dst_t0, n):
+        if n <= 0:
+            return
+        if src_t0 < 0 or dst_t0 < 0 or src_t0 + n > self.src_rows or dst_t0 + n > self.dst_rows:
+            raise IndexError(f"kv_copy_rows: rows [{src_t0}, {src_t0 + n}) of {self.src_rows} -> [{dst_t0}, {dst_t0 + n}) of "
+                             f"{self.dst_rows} leave the cache (the kernel does not bounds-check)")
+        hip.check(self.fn(*self.head, int(src_t0), int(dst_t0), int(n), *self.dims, _stream()), "tf_kv_copy_rows_pair")
+
+
+class KvShiftPairPlan:
+    """kv_shift_rows_pair(k_cache, v_cache, ...) over fixed tensors."""
+
+    def __init__(self, k_cache, v_cache):
+        assert k_cache.shape == v_cache.shape and _lhtd(k_cache) == _lhtd(v_cache), "K and V must share shapes and strides"
+        _dev(k_cache, v_cache)
+        L, H, T, D = k_cache.shape
+        self.keep, self.rows = (k_cache, v_cache), T
+        self.head = (_ptr(k_cache), _ptr(v_cache)) + _lhtd(k_cache)
+        self.dims = (L, H, D)
+        self.fn = hip.lib().tf_kv_shift_rows_pair
+
+    def __call__(self, src_t0, dst_t0, n):
+        if n <= 0 or src_t0 == dst_t0:
+            return
+        if src_t0 < 0 or dst_t0 < 0 or src_t0 + n > self.rows or dst_t0 + n > self.rows:
+            raise IndexError(f"kv_shift_rows: rows [{src_t0}, {src_t0 + n}) -> [{dst_t0}, {dst_t0 + n}) leave the {self.rows}-row cache")
+        hip.check(self.fn(*self.head, int(src_t0), int(dst_t0), int(n), *self.dims, _stream()), "tf_kv_shift_rows_pair")
+
+
+class SetTokensPlan:
+    """set_tokens over fixed buffers: dst (its first n_dst entries are written, n_dst <= dst.numel()), pos, slot, sk."""
+
+    def __init__(self, dst, pos=None, slot=None, sk=None):
+        assert dst is None or (dst.dtype == torch.int64 and dst.is_contiguous() and dst.numel() <= 32)
+        assert pos is None or (pos.dtype == torch.int64 and pos.is_contiguous() and pos.numel() <= 64)
+        assert (slot is None or slot.dtype == torch.int32) and (sk is None or sk.dtype == torch.int32)
+        _dev(dst, pos, slot, sk)
+        self.keep = (dst, pos, slot, sk)
+        self.n_dst = 0 if dst is None else dst.numel()
+        self.p_dst, self.p_pos, self.n_pos = _ptr(dst), _ptr(pos), 0 if pos is None else pos.numel()
+        self.p_slot, self.p_sk = _ptr(slot), _ptr(sk)
+        self.fn = hip.lib().tf_set_tokens
+        self.arr = ctypes.c_int64 * 32
+
+    def __call__(self, vals, pad, pos0=0, sk_val=0, n_dst=None):
+        n_vals = len(vals)
+        n_dst = self.n_dst if n_dst is None else n_dst
+        assert n_vals <= 32 and n_dst <= self.n_dst
+        hip.check(self.fn(self.p_dst, n_dst, self.arr(*vals), n_vals, int(pad), self.p_pos, self.n_pos, int(pos0), self.p_slot,
+                          self.p_sk, int(sk_val), _stream()), "tf_set_tokens")
+
+
 def kv_gather_rows(k_cache, v_cache, offset, idx, max_index=None):
     """Rows offset+idx[j] -> offset+j of every layer/head of the (L,H,T,D) K and V views (idx: device int32,
     strictly increasing) — gather_kv_incremental (reference cache.py:333-343).  max_index: the largest entry of idx as

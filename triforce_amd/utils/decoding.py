@@ -184,6 +184,8 @@ class _SpecBuffers:
         else:
             self.verify_tokens = torch.full((1, gamma + 1), PAD_TOKEN, dtype=torch.long, device=device)
             self.positions = torch.zeros((1, gamma + 1), dtype=torch.long, device=device)
+        self.start_plan = self.pass_plan = None      # ops.SetTokensPlan of Middle_Spec's first launch / of the pass tokens
+        self.inner_for = None                        # (inner-iteration graphs, the uniform stream they were captured for)
         self.spec_rows = torch.empty(gamma + 2, vocab, dtype=torch.float32, device=device)
         self.rows_generation = None                # lifetime token of static (un-copied) retrieval-verify rows
         mailbox = bool(mailbox) and _mailbox_supported(device)
@@ -235,9 +237,12 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
     if buffers is None:
         buffers = _buffers(graph_engine, gamma, eng.model.config.vocab_size, device, mailbox=sync_record is None)
     inner = None
-    if INNER_GRAPH and sync_record is None and buffers.mid_out.mailbox and buffers.shared_inputs \
-            and hasattr(graph_engine, "inner_graphs"):
-        inner = graph_engine.inner_graphs(gamma, rng, buffers.mid_out.tensor, capture=False)   # (the runner captured them)
+    if INNER_GRAPH and sync_record is None and buffers.mid_out.mailbox and buffers.shared_inputs:
+        cached = getattr(buffers, "inner_for", None)           # (graphs, rng) the runner captured for exactly this stream
+        if cached is not None and cached[1] is rng and cached[0].key[0] == gamma:
+            inner = cached[0]
+        elif hasattr(graph_engine, "inner_graphs"):
+            inner = graph_engine.inner_graphs(gamma, rng, buffers.mid_out.tensor, capture=False)
     S = eng.kv_cache.seq_len
     n = accepted = drafted = 0
     ids = [int(next_token)]
@@ -245,7 +250,12 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
     # [next, PAD...] and the gamma + 1 positions S, S + 1, ... in one launch (the token id travels as a kernel argument)
     if (HOST_FAST_MASK & 1) and vt.numel() <= 32 and buffers.positions.numel() <= 64:      # (tf_set_tokens' limits)
         position_ids = buffers.positions
-        ops.set_tokens(vt, ids, PAD_TOKEN, pos=position_ids, pos0=S)
+        if ops.HOST_PLANS and vt.is_cuda:
+            if buffers.start_plan is None:
+                buffers.start_plan = ops.SetTokensPlan(vt.view(-1), position_ids)
+            buffers.start_plan(ids, PAD_TOKEN, pos0=S)
+        else:
+            ops.set_tokens(vt, ids, PAD_TOKEN, pos=position_ids, pos0=S)
     else:
         vt.fill_(PAD_TOKEN)
         vt[0, 0] = ids[0]
@@ -388,6 +398,7 @@ class TriForceRunner:
         if INNER_GRAPH and sync_record is None and self.bufs.mid_out.mailbox and self.bufs.shared_inputs \
                 and hasattr(graph_engine, "inner_graphs"):
             self.inner = graph_engine.inner_graphs(gamma, self.rng, self.bufs.mid_out.tensor)   # captured here, not in a step
+            self.bufs.inner_for = (self.inner, self.rng) if self.inner is not None else None
         self.resample_count = self.accepted_count = self.target_sample_count = self.draft_count = 0
         self.n = 0
         self.inner_iters = 0          # Middle_Spec iterations = 68M draft calls = retrieval-verify replays
@@ -507,9 +518,16 @@ class TriForceRunner:
         if (HOST_FAST_MASK & 8) and tok_buf is not None and tok_buf.shape[0] == 1 and tok_buf.shape[1] >= len(pass_tokens) \
                 and tok_buf.is_cuda and len(pass_tokens) <= 32:
             # straight into the draft graphs' static input (the next Middle_Spec re-initialises it): one launch, no copies
-            row = tok_buf[:, :len(pass_tokens)]
-            ops.set_tokens(row, pass_tokens, PAD_TOKEN)
-            ge.graph_draft_inference(input_ids=row, gamma_offset=g2 + 1)
+            replay = getattr(ge, "replay_draft", None)
+            if ops.HOST_PLANS and replay is not None and getattr(ge, "static_outputs", False) and tok_buf.numel() <= 32:
+                if bufs.pass_plan is None:
+                    bufs.pass_plan = ops.SetTokensPlan(tok_buf.view(-1))
+                bufs.pass_plan(pass_tokens, PAD_TOKEN, n_dst=len(pass_tokens))
+                replay(g2 + 1)                                            # (the graph reads tok_buf itself: no input checks)
+            else:
+                row = tok_buf[:, :len(pass_tokens)]
+                ops.set_tokens(row, pass_tokens, PAD_TOKEN)
+                ge.graph_draft_inference(input_ids=row, gamma_offset=g2 + 1)
         else:
             ge.graph_draft_inference(input_ids=bufs.to_device(pass_tokens), gamma_offset=g2 + 1)
 

@@ -347,6 +347,7 @@ class _TargetGraph:
             return logits, None
 
         self.graph, (self.logits, self.out_probs) = _capture(run, (), mempool, n_warmups)
+        self._plan = None
 
     def __call__(self, input_ids):
         """input_ids: a (1, q_len) device tensor, or a python list of q_len ids (then they travel as kernel arguments)."""
@@ -356,7 +357,12 @@ class _TargetGraph:
             raise IndexError(f"FlashSimpleCache overflow: {S}+{self.q_len} > {kvc.max_budget}")
         if isinstance(input_ids, (list, tuple)):
             assert len(input_ids) == self.q_len <= 32
-            ops.set_tokens(self.ids, input_ids, 0, pos=self.pos, pos0=S, slot=self.slot, sk=self.sk, sk_val=S + self.q_len)
+            if ops.HOST_PLANS and self.ids.is_cuda:
+                if self._plan is None:                         # (validated once: ops.SetTokensPlan)
+                    self._plan = ops.SetTokensPlan(self.ids.view(-1), self.pos, self.slot, self.sk)
+                self._plan(input_ids, 0, pos0=S, sk_val=S + self.q_len)
+            else:
+                ops.set_tokens(self.ids, input_ids, 0, pos=self.pos, pos0=S, slot=self.slot, sk=self.sk, sk_val=S + self.q_len)
         elif self.ids.is_cuda and self.q_len <= 64 and os.environ.get("TRIFORCE_HOST_FAST", "1") != "0":   # (tf_set_tokens: <= 64 positions)
             self.ids.copy_(input_ids)
             ops.set_tokens(None, (), 0, pos=self.pos, pos0=S, slot=self.slot, sk=self.sk, sk_val=S + self.q_len)
