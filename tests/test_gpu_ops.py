@@ -974,7 +974,7 @@ def test_launch_plans_equal_the_per_call_wrappers():
         with pytest.raises(IndexError):
             plan(*args)
     plan(0, 0, 0)                                                # nothing to copy: no launch, no error
-    for args in ((8, 0, 30), (10, 4, 30), (0, 6, 20)):
+    for args in ((8, 0, 30), (10, 4, 30), (12, 0, 28)):           # (the window only ever moves DOWN: evict_for_spec)
         c_k, c_v = src_k.clone(), src_v.clone()
         d_k, d_v = src_k.clone(), src_v.clone()
         ops.kv_shift_rows_pair(c_k, c_v, *args)
