@@ -68,3 +68,14 @@ _Zk: ; @_Zk
         assert v.get("preload") == 14, (k, v)
         assert v["scalar_wait_before_first_load"] is False, (k, v)
         assert v["loads_before_first_wait"] >= 24 and v["first_vmcnt"] > 0, (k, v)
+    # round 5: the narrow-panel forms (skinny_gemm_n8_kernel) keep the same prologue shape, and none of them may spill — at
+    # <= 1 workgroup per CU they are allowed every register, but the epilogue's fully unrolled wave merge once cost 171 spills
+    n8 = {k: v for k, v in shapes.items() if k.startswith("_Z21skinny_gemm_n8_kernel") and v.get("loads_before_first_wait") is not None}
+    assert len(n8) >= 10, sorted(shapes)[:4]
+    for k, v in n8.items():
+        assert v.get("preload") == 14 and v["scalar_wait_before_first_load"] is False, (k, v)
+        assert v["loads_before_first_wait"] >= 24 and v["first_vmcnt"] > 0, (k, v)
+    text = isa_lint.compile_to_asm(os.path.join(CSRC, "gemv.hip"), extra=extra)
+    import re
+    spills = re.findall(r"\.name:\s+(_Z21skinny_gemm_n8_kernel\S+)[\s\S]*?\.vgpr_spill_count:\s+(\d+)", text)
+    assert len(spills) >= 10 and all(int(n) == 0 for _, n in spills), [(k[:48], n) for k, n in spills if int(n)]
