@@ -368,10 +368,22 @@ int tf_middle_accept(const float* p, const float* q_d, int64_t* tokens, const fl
  * polls `out` in pinned memory may launch the next chain on ANOTHER stream the moment it sees the record. */
 int tf_sample_inverse_cdf_cur(const float* probs, const float* ubuf, const int64_t* cursor, int off, int64_t* token_out,
                               int V, void* stream);
-int tf_middle_accept_cur(const float* p, const float* q_d, int64_t* tokens, const float* ubuf, int64_t* cursor, int n,
-                         int gamma, int V, int64_t* out, void* stream);
+int tf_middle_accept_cur(const float* p, const float* q_d, int64_t* tokens, int tokens_len, const float* ubuf,
+                         int64_t* cursor, int n, int gamma, int V, int64_t* out, void* stream);
 int tf_accept_chain_cur(const float* p, const float* q, const int64_t* tokens, const float* ubuf, int64_t* cursor, int g2,
                         int V, int inclusive, int64_t eos_token_id, int64_t* out, void* stream);
+/* tf_middle_accept_cur: a `tokens` buffer of >= gamma + 2 entries (the engine's shared token buffer) also receives the
+ *   follow-up token of the LAST position (index gamma + 1), so that after the inner loop it holds all of [next, t_1 .. t_g2].
+ * tf_accept_chain_step: tf_accept_chain_cur over tok_buf[1 ..] that also leaves on the device what follows its record
+ *   (utils/decoding.py:124,137): tok_buf[0 .. g2 + 1] = the PASS TOKENS of the catch-up draft forward ([next, accepted ...,
+ *   resampled | bonus token, pad ...]; pad in its place after an accepted eos), and for nsets <= 2 captured target-verify lengths
+ *   the positions (n_pos entries from S'), append slot (S') and key count (S' + qlen) of the NEXT verify, S' = *s_src + count + 1
+ *   = the cache length after the roll-back (s_src: the append slot of the verify just run).  Neither the catch-up draft nor the
+ *   next target verify then needs a set-up launch behind a record read.  tok_len >= g2 + 2; g2 <= 62. */
+int tf_accept_chain_step(const float* p, const float* q, int64_t* tok_buf, int tok_len, const float* ubuf, int64_t* cursor,
+                         int g2, int V, int inclusive, int64_t eos_token_id, int64_t pad, const int32_t* s_src, int nsets,
+                         int64_t* pos_a, int n_pos_a, int32_t* slot_a, int32_t* sk_a, int qlen_a, int64_t* pos_b, int n_pos_b,
+                         int32_t* slot_b, int32_t* sk_b, int qlen_b, int64_t* out, void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Sequoia tree verification (utils/SpecTree_TP.py:147-199: accept_step + the walk in verify()).

@@ -953,6 +953,28 @@ def test_cursor_forms_of_the_sampling_kernels_equal_the_pointer_forms():
             ops.accept_chain_cur(p, q, toks, ubuf, cur, g2, False, 2, rb)
             assert torch.equal(ra, rb), (trial, g2, ra.tolist(), rb.tolist())
             assert int(cur) == base + int(rb[3])
+            # ... and the form that also prepares what follows its record (tf_accept_chain_step): same record, the pass tokens
+            # of reference decoding.py:137 in the token buffer, the next verify's positions / slot / key count for both lengths
+            for eos in (2, int(toks[min(1, g2 - 1)])):            # an eos inside the chain: pad instead of a correction token
+                S = 1000 + 13 * trial
+                tok_buf = torch.cat([torch.tensor([777], device=DEV), toks, torch.full((gamma + 3 - 1 - g2,), -5, device=DEV)])
+                want_rec = torch.zeros(4, dtype=torch.int64, device=DEV)
+                cur.fill_(base)
+                ops.accept_chain_cur(p, q, toks, ubuf, cur, g2, False, eos, want_rec)
+                count, nxt, reason, _ = want_rec.tolist()
+                sets = [(torch.zeros(ql, dtype=torch.int64, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV),
+                         torch.zeros(1, dtype=torch.int32, device=DEV), ql) for ql in (gamma + 1, gamma + 2)]
+                s_src = torch.tensor([S], dtype=torch.int32, device=DEV)
+                rc = torch.zeros(4, dtype=torch.int64, device=DEV)
+                cur.fill_(base)
+                ops.accept_chain_step(p, q, tok_buf, ubuf, cur, g2, False, eos, 100, s_src, sets, rc)
+                assert torch.equal(rc, want_rec) and int(cur) == base + int(rc[3])
+                want_tok = [777] + toks[:count].tolist() + ([nxt] if reason != 2 else [100]) + [100] * (g2 - count)
+                assert tok_buf[:g2 + 2].tolist() == want_tok, (tok_buf.tolist(), want_tok, count, reason)
+                assert tok_buf[g2 + 2:].tolist() == [-5] * (gamma + 3 - g2 - 2)
+                for pos, slot, sk, ql in sets:
+                    assert pos.tolist() == list(range(S + count + 1, S + count + 1 + ql))
+                    assert int(slot) == S + count + 1 and int(sk) == S + count + 1 + ql
 
 
 def test_launch_plans_equal_the_per_call_wrappers():

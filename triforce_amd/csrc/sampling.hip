@@ -138,10 +138,26 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(const float* __res
     if (threadIdx.x == 0) *token_out = (int64_t)t;
 }
 
+// What the outer accept can leave on the DEVICE for the launches that follow its record (round 5, tf_accept_chain_step), so that
+// neither of them needs an eager set-up launch behind a record read (the two largest idle sources left in
+// profiles/r05_gap_analysis_decode_steps.txt): the PASS TOKENS of the catch-up draft forward, written into the shared token
+// buffer (reference decoding.py:137: [next, accepted..., resampled | bonus, PAD...]), and the positions / append slot / key
+// count of the NEXT target verify for both captured lengths (the cache length after the roll-back, S + count + 1, :124).
+struct ChainStep {
+    int64_t* tok;                    // token buffer base (tok[0] = next, tok[1 + i] = drafted token i); NULL = not used
+    int64_t pad;
+    const int32_t* s_src;            // cache length BEFORE this verify (the replayed graph's append slot)
+    int64_t* pos[2];
+    int32_t* slot[2];
+    int32_t* sk[2];
+    int n_pos[2], qlen[2];
+    int nsets;
+};
+
 __global__ __launch_bounds__(SAMP_THREADS) void accept_chain_kernel(
     const float* __restrict__ p, const float* __restrict__ q, const int64_t* __restrict__ tokens,
     const float* __restrict__ uniforms_base, int64_t* cursor, int g2, int V, int inclusive, int64_t eos,
-    int64_t* __restrict__ out) {
+    int64_t* __restrict__ out, ChainStep cs) {
     __shared__ SampleShared sh;
     __shared__ int s_count, s_reason;
     const int tid = threadIdx.x;
@@ -181,6 +197,22 @@ __global__ __launch_bounds__(SAMP_THREADS) void accept_chain_kernel(
     } else {
         next = block_sample<false>(p + (int64_t)g2 * V, nullptr, V, uniforms[examined], &sh);
     }
+    if (cs.tok && tid < 64) {
+        // pass tokens: tok[0 .. count] stay; tok[count + 1] = the resampled / bonus token (PAD after an accepted eos); PAD up to
+        // g2 + 1 — and the next verify's scalars; all write-through, drained (below) before the record
+        const int i = tid;
+        if (i >= count + 1 && i <= g2 + 1) st_agent_i64(&cs.tok[i], (i == count + 1 && reason != 2) ? next : cs.pad);
+        const int32_t s_new = *cs.s_src + count + 1;
+        for (int k = 0; k < cs.nsets; ++k) {
+            if (i < cs.n_pos[k]) st_agent_i64(&cs.pos[k][i], (int64_t)s_new + i);
+            if (i == 0) {
+                __hip_atomic_store(cs.slot[k], s_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(cs.sk[k], s_new + cs.qlen[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        drain_stores();
+    }
+    __syncthreads();
     if (tid == 0) {
         const int consumed = examined + (reason != 2 ? 1 : 0);
         if (cursor) {
@@ -196,7 +228,8 @@ __global__ __launch_bounds__(SAMP_THREADS) void accept_chain_kernel(
 
 __global__ __launch_bounds__(SAMP_THREADS) void middle_accept_kernel(
     const float* __restrict__ p, const float* __restrict__ q_d, int64_t* __restrict__ tokens,
-    const float* __restrict__ uniforms_base, int64_t* cursor, int uoff, int n, int gamma, int V, int64_t* __restrict__ out) {
+    const float* __restrict__ uniforms_base, int64_t* cursor, int uoff, int n, int gamma, int V, int64_t* __restrict__ out,
+    int write_limit) {
     __shared__ SampleShared sh;
     int64_t at;
     const float* uniforms = cur_uniforms(uniforms_base, cursor, &at) + uoff;
@@ -207,7 +240,9 @@ __global__ __launch_bounds__(SAMP_THREADS) void middle_accept_kernel(
     const int b = block_sample<false>(p + (int64_t)(n + acc) * V, nullptr, V, uniforms[1], &sh);
     if (threadIdx.x == 0) {
         // first what the next chain reads on the device (write-through, drained), then the record the host waits for
-        if (n + 1 + acc <= gamma) st_agent_i64(&tokens[n + 1 + acc], (int64_t)b);
+        // (write_limit = gamma: the verify block's gamma + 1 entries; gamma + 1 when `tokens` is the engine's longer token buffer,
+        //  so that after the last iteration it holds ALL of [next, t_1 .. t_g2] for the target verify to read in place)
+        if (n + 1 + acc <= write_limit) st_agent_i64(&tokens[n + 1 + acc], (int64_t)b);
         if (cursor) st_agent_i64(cursor, at + uoff + 2);
         drain_stores();
         out[0] = acc;
@@ -510,7 +545,7 @@ extern "C" int tf_accept_chain(const float* p, const float* q, const int64_t* to
                                int V, int inclusive, int64_t eos_token_id, int64_t* out, void* stream) {
     if (!p || !q || !tokens || !uniforms || !out || g2 < 1 || g2 > 63 || V < 1) return TF_EINVAL;
     hipLaunchKernelGGL(accept_chain_kernel, dim3(1), dim3(SAMP_THREADS), 0, (hipStream_t)stream, p, q, tokens,
-                       uniforms, (int64_t*)nullptr, g2, V, inclusive, eos_token_id, out);
+                       uniforms, (int64_t*)nullptr, g2, V, inclusive, eos_token_id, out, ChainStep{});
     TF_LAUNCH_CHECK();
     return TF_OK;
 }
@@ -519,7 +554,7 @@ extern "C" int tf_middle_accept(const float* p, const float* q_d, int64_t* token
                                 int gamma, int V, int64_t* out, void* stream) {
     if (!p || !q_d || !tokens || !uniforms || !out || n < 0 || n >= gamma || V < 1) return TF_EINVAL;
     hipLaunchKernelGGL(middle_accept_kernel, dim3(1), dim3(SAMP_THREADS), 0, (hipStream_t)stream, p, q_d, tokens,
-                       uniforms, (int64_t*)nullptr, 0, n, gamma, V, out);
+                       uniforms, (int64_t*)nullptr, 0, n, gamma, V, out, gamma);
     TF_LAUNCH_CHECK();
     return TF_OK;
 }
@@ -538,11 +573,13 @@ extern "C" int tf_sample_inverse_cdf_cur(const float* probs, const float* ubuf, 
     return TF_OK;
 }
 
-extern "C" int tf_middle_accept_cur(const float* p, const float* q_d, int64_t* tokens, const float* ubuf, int64_t* cursor,
-                                    int n, int gamma, int V, int64_t* out, void* stream) {
-    if (!p || !q_d || !tokens || !ubuf || !cursor || !out || n < 0 || n >= gamma || V < 1) return TF_EINVAL;
+extern "C" int tf_middle_accept_cur(const float* p, const float* q_d, int64_t* tokens, int tokens_len, const float* ubuf,
+                                    int64_t* cursor, int n, int gamma, int V, int64_t* out, void* stream) {
+    if (!p || !q_d || !tokens || !ubuf || !cursor || !out || n < 0 || n >= gamma || V < 1 || tokens_len < gamma + 1) return TF_EINVAL;
+    // a token buffer with room for it also receives the follow-up token of the LAST position (index gamma + 1)
+    const int limit = tokens_len >= gamma + 2 ? gamma + 1 : gamma;
     hipLaunchKernelGGL(middle_accept_kernel, dim3(1), dim3(SAMP_THREADS), 0, (hipStream_t)stream, p, q_d, tokens, ubuf, cursor,
-                       1, n, gamma, V, out);
+                       1, n, gamma, V, out, limit);
     TF_LAUNCH_CHECK();
     return TF_OK;
 }
@@ -551,7 +588,30 @@ extern "C" int tf_accept_chain_cur(const float* p, const float* q, const int64_t
                                    int g2, int V, int inclusive, int64_t eos_token_id, int64_t* out, void* stream) {
     if (!p || !q || !tokens || !ubuf || !cursor || !out || g2 < 1 || g2 > 63 || V < 1) return TF_EINVAL;
     hipLaunchKernelGGL(accept_chain_kernel, dim3(1), dim3(SAMP_THREADS), 0, (hipStream_t)stream, p, q, tokens, ubuf, cursor,
-                       g2, V, inclusive, eos_token_id, out);
+                       g2, V, inclusive, eos_token_id, out, ChainStep{});
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}
+
+// tf_accept_chain_cur that also prepares, on the device, what follows its record (see ChainStep): tok_buf[0 .. g2] must hold
+// [next, t_1 .. t_g2] (the chain tests tok_buf[1 ..]); afterwards tok_buf[0 .. g2 + 1] are the pass tokens of the catch-up draft
+// forward, and for each of the nsets (<= 2) captured verify lengths pos / slot / sk describe a verify at the rolled-back cache
+// length *s_src + count + 1.  tok_buf needs g2 + 2 entries.
+extern "C" int tf_accept_chain_step(const float* p, const float* q, int64_t* tok_buf, int tok_len, const float* ubuf,
+                                    int64_t* cursor, int g2, int V, int inclusive, int64_t eos_token_id, int64_t pad,
+                                    const int32_t* s_src, int nsets, int64_t* pos_a, int n_pos_a, int32_t* slot_a, int32_t* sk_a,
+                                    int qlen_a, int64_t* pos_b, int n_pos_b, int32_t* slot_b, int32_t* sk_b, int qlen_b,
+                                    int64_t* out, void* stream) {
+    if (!p || !q || !tok_buf || !ubuf || !cursor || !out || !s_src || g2 < 1 || g2 > 62 || V < 1 || tok_len < g2 + 2) return TF_EINVAL;
+    if (nsets < 0 || nsets > 2 || (nsets >= 1 && (!pos_a || !slot_a || !sk_a || n_pos_a < 0 || n_pos_a > 64)) ||
+        (nsets == 2 && (!pos_b || !slot_b || !sk_b || n_pos_b < 0 || n_pos_b > 64)))
+        return TF_EINVAL;
+    ChainStep cs = {};
+    cs.tok = tok_buf, cs.pad = pad, cs.s_src = s_src, cs.nsets = nsets;
+    cs.pos[0] = pos_a, cs.slot[0] = slot_a, cs.sk[0] = sk_a, cs.n_pos[0] = n_pos_a, cs.qlen[0] = qlen_a;
+    cs.pos[1] = pos_b, cs.slot[1] = slot_b, cs.sk[1] = sk_b, cs.n_pos[1] = n_pos_b, cs.qlen[1] = qlen_b;
+    hipLaunchKernelGGL(accept_chain_kernel, dim3(1), dim3(SAMP_THREADS), 0, (hipStream_t)stream, p, q, tok_buf + 1, ubuf, cursor,
+                       g2, V, inclusive, eos_token_id, out, cs);
     TF_LAUNCH_CHECK();
     return TF_OK;
 }

@@ -1001,8 +1001,8 @@ def middle_accept_cur(p, q_d, tokens, ubuf, cursor, n, gamma, out):
     assert p.dtype == torch.float32 and p.is_contiguous() and q_d.dtype == torch.float32 and q_d.numel() == V
     assert tokens.dtype == torch.int64 and tokens.numel() >= gamma + 1 and out.numel() >= 4
     assert ubuf.dtype == torch.float32 and cursor.dtype == torch.int64
-    hip.check(hip.lib().tf_middle_accept_cur(_ptr(p), _ptr(q_d), _ptr(tokens), _ptr(ubuf), _ptr(cursor), int(n), int(gamma), V,
-                                             _ptr(out), _stream()), "tf_middle_accept_cur")
+    hip.check(hip.lib().tf_middle_accept_cur(_ptr(p), _ptr(q_d), _ptr(tokens), tokens.numel(), _ptr(ubuf), _ptr(cursor), int(n),
+                                             int(gamma), V, _ptr(out), _stream()), "tf_middle_accept_cur")
 
 
 def accept_chain_cur(p, q, tokens, ubuf, cursor, g2, inclusive, eos_token_id, out):
@@ -1017,6 +1017,25 @@ def accept_chain_cur(p, q, tokens, ubuf, cursor, g2, inclusive, eos_token_id, ou
     hip.check(hip.lib().tf_accept_chain_cur(_ptr(p), _ptr(q), _ptr(tokens), _ptr(ubuf), _ptr(cursor), int(g2), V,
                                             1 if inclusive else 0, int(eos_token_id), _ptr(out), _stream()),
               "tf_accept_chain_cur")
+
+
+def accept_chain_step(p, q, tok_buf, ubuf, cursor, g2, inclusive, eos_token_id, pad, s_src, sets, out):
+    """accept_chain_cur over tok_buf[1:] that also writes the pass tokens into tok_buf and, for each (pos, slot, sk, qlen) in
+    ``sets`` (<= 2), the next target verify's positions / append slot / key count (include/triforce_hip.h)."""
+    _dev(p, q, tok_buf, ubuf, cursor, s_src)
+    _dev_or_pinned(out)
+    V = p.shape[-1]
+    assert p.dtype == torch.float32 and p.is_contiguous() and p.shape[0] >= g2 + 1
+    assert q.dtype == torch.float32 and q.is_contiguous() and q.shape[0] >= g2 and q.shape[-1] == V
+    assert tok_buf.dtype == torch.int64 and tok_buf.is_contiguous() and tok_buf.numel() >= g2 + 2
+    assert out.dtype == torch.int64 and out.numel() >= 4 and s_src.dtype == torch.int32 and len(sets) <= 2
+    flat = []
+    for pos, slot, sk, qlen in list(sets) + [(None, None, None, 0)] * (2 - len(sets)):
+        assert pos is None or (pos.dtype == torch.int64 and pos.is_contiguous() and slot.dtype == torch.int32 and sk.dtype == torch.int32)
+        flat += [_ptr(pos), 0 if pos is None else pos.numel(), _ptr(slot), _ptr(sk), int(qlen)]
+    hip.check(hip.lib().tf_accept_chain_step(_ptr(p), _ptr(q), _ptr(tok_buf), tok_buf.numel(), _ptr(ubuf), _ptr(cursor), int(g2), V,
+                                             1 if inclusive else 0, int(eos_token_id), int(pad), _ptr(s_src), len(sets), *flat,
+                                             _ptr(out), _stream()), "tf_accept_chain_step")
 
 
 def kv_h2d_async(dst_dev, src_host, n_tokens, stream):

@@ -141,6 +141,10 @@ class _Record:
 #  accept kernel); it is also unsound without an explicit acquire at the head of every chain — the runtime knows nothing of an
 #  ordering that goes through host memory.  Removed)
 INNER_GRAPH = __import__("os").environ.get("TRIFORCE_INNER_GRAPH", "1") != "0"
+# With the inner graphs: the outer accept kernel also writes the catch-up draft's pass tokens and the next target verify's
+# positions / slot / key count on the device (tf_accept_chain_step), and the target verify reads its tokens from the shared token
+# buffer — no set-up launch behind either record.  TRIFORCE_STEP_ON_DEVICE=0: the host sets them up (tf_set_tokens).
+STEP_ON_DEVICE = __import__("os").environ.get("TRIFORCE_STEP_ON_DEVICE", "1") != "0"
 
 
 _MAILBOX_OK = {}
@@ -462,11 +466,25 @@ class TriForceRunner:
         self.rebuilds += int(rebuild)
         eager = self.eager_every > 0 and (len(self.counts) + 1) % self.eager_every == 0
         fast = None
-        if (HOST_FAST_MASK & 4) and self.top_k <= 0 and not rebuild and not eager and hasattr(ge, "verify_probs_ids") \
+        # STEP_ON_DEVICE (round 5): the verify reads its tokens from the shared token buffer (the inner graphs left all of
+        # [next, t_1 .. t_g2] there) and its positions / slot / key count from device scalars the PREVIOUS step's accept kernel
+        # wrote — the chain behind the last inner record is one graph replay, no set-up launch (tf_accept_chain_step)
+        on_device = None
+        if STEP_ON_DEVICE and self.inner is not None and self.sync_record is None and not self.inclusive_accept and self.top_k <= 0 \
+                and not rebuild and not eager and (self.temperature, self.top_p) == (ge.sampling["temperature"], ge.sampling["top_p"]):
+            on_device = ge.verify_sets(gamma)
+        if on_device is not None:
+            if not ge.verify_lengths_current(gamma):
+                ge.sync_verify_lengths(gamma)                          # stale (first step, after an eager / rebuild step): one launch each
+            tg = ge.target_graphs[len(ids)]
+            probs, verify_tokens = tg.replay_in_place(), tg.ids
+        elif (HOST_FAST_MASK & 4) and self.top_k <= 0 and not rebuild and not eager and hasattr(ge, "verify_probs_ids") \
                 and len(ids) <= 32:
             # captured forward + temperature / top-p: ids, positions and lengths set by ONE launch (ids as kernel arguments)
             fast = ge.verify_probs_ids(ids, self.temperature, self.top_p)
-        if fast is not None:
+        if on_device is not None:
+            pass
+        elif fast is not None:
             probs, verify_tokens = fast
         else:
             verify_tokens = bufs.to_device(ids)
@@ -483,7 +501,11 @@ class TriForceRunner:
         rec = bufs.chain_out
         rec.arm(4)
         on_cursor = self.inner is not None and self.sync_record is None and not self.inclusive_accept
-        if on_cursor:
+        if on_device is not None:
+            # ... and leaves the pass tokens in the token buffer and the NEXT verify's scalars (rolled-back length) on the device
+            ops.accept_chain_step(probs, spec_rows, ge.tok_buf.view(-1), rng.buf, rng.cursor_tensor(g2 + 1), g2, False, self.eos,
+                                  PAD_TOKEN, ge.target_graphs[len(ids)].slot, on_device, rec.tensor)
+        elif on_cursor:
             # the uniform stream's device cursor is live (the inner-iteration graphs advance it): the chain reads its numbers
             # behind it and advances it by what it consumed, so no step ever has to re-synchronise the device copy
             ops.accept_chain_cur(probs, spec_rows, verify_tokens.view(-1)[1:], rng.buf, rng.cursor_tensor(g2 + 1), g2,
@@ -515,7 +537,10 @@ class TriForceRunner:
         # shift and the next iteration's first launches; issued last, each of those short launches was a host-bound gap
         # (profiles/r04_gap_analysis_decode_steps.txt).
         tok_buf = getattr(ge, "tok_buf", None)
-        if (HOST_FAST_MASK & 8) and tok_buf is not None and tok_buf.shape[0] == 1 and tok_buf.shape[1] >= len(pass_tokens) \
+        if on_device is not None:
+            ge.dev_len = eng.kv_cache.seq_len - (g2 - count)            # what the accept kernel wrote: the rolled-back length
+            ge.replay_draft(g2 + 1)                                      # the pass tokens are in the token buffer already
+        elif (HOST_FAST_MASK & 8) and tok_buf is not None and tok_buf.shape[0] == 1 and tok_buf.shape[1] >= len(pass_tokens) \
                 and tok_buf.is_cuda and len(pass_tokens) <= 32:
             # straight into the draft graphs' static input (the next Middle_Spec re-initialises it): one launch, no copies
             replay = getattr(ge, "replay_draft", None)
@@ -532,6 +557,11 @@ class TriForceRunner:
             ge.graph_draft_inference(input_ids=bufs.to_device(pass_tokens), gamma_offset=g2 + 1)
 
         eng.kv_cache.seq_len -= (g2 - count)                              # rollback (:124)
+        if on_device is None and STEP_ON_DEVICE and self.inner is not None and self.sync_record is None and self.top_k <= 0 \
+                and hasattr(ge, "verify_sets") and ge.verify_sets(gamma) is not None:
+            # this step set its verify up from the host (eager / rebuild step, first step): bring the device scalars to the
+            # rolled-back length HERE, behind the catch-up draft forward, not at the head of the next step's verify chain
+            ge.sync_verify_lengths(gamma)
         ge.update_graph_cache()                                           # refresh the retrieval tail (:125)
 
         self.accepted_count += count

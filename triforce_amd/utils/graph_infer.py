@@ -329,11 +329,14 @@ class _TargetGraph:
     (tf_skinny_qkv_rope slot0_dev, tf_attn_decode sk_dev) and the launch is sized by the cache capacity, so one
     capture serves every cache length.  With ``probs`` the temperature / top-p normalisation is part of the graph."""
 
-    def __init__(self, engine, q_len, mempool, n_warmups, probs, temperature, top_p):
+    def __init__(self, engine, q_len, mempool, n_warmups, probs, temperature, top_p, ids=None):
         dev = engine.model.device
         self.engine, self.q_len, self.probs = engine, q_len, probs
         self.cache = engine.kv_cache               # the graph reads and appends THIS cache's storage
-        self.ids = torch.zeros((1, q_len), dtype=torch.long, device=dev)
+        # ``ids``: capture over this (1, q_len) view instead of an own buffer — the engine passes the head of its shared token
+        # buffer, which after the inner loop already holds [next, t_1 .. t_g2]: the verify then needs no token set-up at all
+        self.ids = torch.zeros((1, q_len), dtype=torch.long, device=dev) if ids is None else ids
+        assert tuple(self.ids.shape) == (1, q_len) and self.ids.is_contiguous()
         self.base = torch.arange(q_len, dtype=torch.long, device=dev)
         self.pos = torch.arange(q_len, dtype=torch.long, device=dev)
         self.slot = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -348,6 +351,7 @@ class _TargetGraph:
 
         self.graph, (self.logits, self.out_probs) = _capture(run, (), mempool, n_warmups)
         self._plan = None
+        self.stale = True
 
     def __call__(self, input_ids):
         """input_ids: a (1, q_len) device tensor, or a python list of q_len ids (then they travel as kernel arguments)."""
@@ -355,6 +359,7 @@ class _TargetGraph:
         S = kvc.seq_len
         if S + self.q_len > kvc.max_budget:
             raise IndexError(f"FlashSimpleCache overflow: {S}+{self.q_len} > {kvc.max_budget}")
+        self.stale = True                          # (scalars now encode THIS call's length: the owner's dev_len is void)
         if isinstance(input_ids, (list, tuple)):
             assert len(input_ids) == self.q_len <= 32
             if ops.HOST_PLANS and self.ids.is_cuda:
@@ -375,6 +380,17 @@ class _TargetGraph:
         kvc.seq_len = S + self.q_len
         return self.logits, self.out_probs
 
+    def replay_in_place(self):
+        """The verify over the tokens ALREADY in ``ids`` with positions / slot / key count ALREADY on the device (left there by
+        tf_accept_chain_step for the cache length the host also holds): the replay and the host-side length, nothing else."""
+        kvc = self.engine.kv_cache
+        S = kvc.seq_len
+        if S + self.q_len > kvc.max_budget:
+            raise IndexError(f"FlashSimpleCache overflow: {S}+{self.q_len} > {kvc.max_budget}")
+        self.graph.replay()
+        kvc.seq_len = S + self.q_len
+        return self.out_probs
+
 
 class GraphInferenceEngine:
     """The object the decode loops drive (reference graph_infer.py:129-194): ``inference`` /
@@ -388,6 +404,7 @@ class GraphInferenceEngine:
         self.static_outputs = True                 # graph_draft_inference / graph_verify accept clone=False
         self.tok_buf = self.pos_buf = None         # shared static inputs of the draft / verify graphs (graphs only)
         self._inner = {}                           # inner-iteration graphs per (rng, record): see inner_graphs()
+        self.dev_len = None
         self.mempool = None
         self.sampling = dict(probs=False, temperature=0.6, top_p=0.9)
 
@@ -415,8 +432,10 @@ class GraphInferenceEngine:
                 and isinstance(self.engine.kv_cache, _graphable_cache()):
             # target verify (gamma+1 / gamma+2 tokens: Middle_Spec ends at n = gamma or gamma + 1) and the AR step
             for q_len in sorted({1, gamma + 1, gamma + 2}):
+                # the two verify lengths read their tokens from the head of the shared token buffer (see _TargetGraph)
                 self.target_graphs[q_len] = _TargetGraph(self.engine, q_len, self.mempool, 3, probs and q_len > 1,
-                                                         temperature, top_p)
+                                                         temperature, top_p, ids=self.tok_buf[:, :q_len] if q_len > 1 else None)
+        self.dev_len = None                        # cache length the verify graphs' device scalars encode (None: unknown)
         self.engine.clear_kv()
 
     def initialize_eager(self, gamma=6, probs=True, temperature=0.6, top_p=0.9):
@@ -467,6 +486,31 @@ class GraphInferenceEngine:
                 or (temperature, top_p) != (self.sampling["temperature"], self.sampling["top_p"]):
             return None
         return tg(list(ids))[1], tg.ids
+
+    def verify_sets(self, gamma):
+        """(pos, slot, sk, q_len) of the captured verify lengths gamma + 1 / gamma + 2 — what tf_accept_chain_step keeps current —
+        or None when one of them is missing, bound to another cache, or not fed from the shared token buffer."""
+        out = []
+        for q_len in (gamma + 1, gamma + 2):
+            tg = self.target_graphs.get(q_len)
+            if tg is None or tg.cache is not self.engine.kv_cache or not tg.probs or self.tok_buf is None \
+                    or tg.ids.data_ptr() != self.tok_buf.data_ptr():
+                return None
+            out.append((tg.pos, tg.slot, tg.sk, q_len))
+        return out
+
+    def sync_verify_lengths(self, gamma):
+        """Bring the verify graphs' device scalars to the cache's current length (one launch per graph; only when they are stale:
+        first step of a prompt, after an eager / rebuild / autoregressive forward)."""
+        S = self.engine.kv_cache.seq_len
+        for q_len in (gamma + 1, gamma + 2):
+            tg = self.target_graphs[q_len]
+            ops.set_tokens(None, (), 0, pos=tg.pos, pos0=S, slot=tg.slot, sk=tg.sk, sk_val=S + q_len)
+            tg.stale = False
+        self.dev_len = S
+
+    def verify_lengths_current(self, gamma):
+        return self.dev_len == self.engine.kv_cache.seq_len and not any(self.target_graphs[q].stale for q in (gamma + 1, gamma + 2))
 
     @torch.inference_mode()
     def decode_step(self, input_ids):
