@@ -149,8 +149,10 @@ def test_predict_scaling_composes_stage_latencies_and_exchange_prices(tmp_path):
               "budget": 4096, "gamma": 6, "draft_step_us": 130.0, "retrieval_verify_us": 1900.0, "target_verify_us": 3300.0}]
     shards, out = tmp_path / "shards.jsonl", tmp_path / "pred.json"
     shards.write_text("\n".join(json.dumps(l) for l in lines))
+    # (no bench line of the round for this configuration: the embedded fall-back statistics and the shard file's own W = 1 row;
+    #  with one, the W = 1 row is the single-GPU graph engine — tests/test_host_edges_cpu.py covers that)
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "predict_scaling.py"), "--shards", str(shards), "--out",
-                    str(out)], check=True, capture_output=True)
+                    str(out), "--bench", f"configs[1]={tmp_path / 'no_such_bench.json'}"], check=True, capture_output=True)
     res = json.load(open(out))
     cfg = res["configs"]["configs[1]"]
     k, tps, host = cfg["loop"]["inner_iterations"], cfg["loop"]["tokens_per_step"], cfg["loop"]["host_overhead_us"]
