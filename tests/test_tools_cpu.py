@@ -152,7 +152,8 @@ def test_predict_scaling_composes_stage_latencies_and_exchange_prices(tmp_path):
     # (no bench line of the round for this configuration: the embedded fall-back statistics and the shard file's own W = 1 row;
     #  with one, the W = 1 row is the single-GPU graph engine — tests/test_host_edges_cpu.py covers that)
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "predict_scaling.py"), "--shards", str(shards), "--out",
-                    str(out), "--bench", f"configs[1]={tmp_path / 'no_such_bench.json'}"], check=True, capture_output=True)
+                    str(out), "--bench", f"configs[1]={tmp_path / 'no_such_bench.json'}", "--tp-host",
+                    f"configs[1]={tmp_path / 'no_such_tp_bench.json'}"], check=True, capture_output=True)
     res = json.load(open(out))
     cfg = res["configs"]["configs[1]"]
     k, tps, host = cfg["loop"]["inner_iterations"], cfg["loop"]["tokens_per_step"], cfg["loop"]["host_overhead_us"]
@@ -163,7 +164,9 @@ def test_predict_scaling_composes_stage_latencies_and_exchange_prices(tmp_path):
     w8 = cfg["predictions"]["gemm_exchange"][1]
     x = 2 * 32 * (1 + k)
     lo, hi = res["scenarios_us_per_exchange"]["gemm_exchange"]
-    step8 = 3300.0 + k * 1900.0 + (k + 1) * 130.0 + host + 2 * (k + 1) * res["broadcast_us"][0] + x * lo
+    tp_extra = cfg["loop"]["tp_host_extra_us"]                 # what the TP engine's loop adds on the host at W > 1
+    assert tp_extra >= 0
+    step8 = 3300.0 + k * 1900.0 + (k + 1) * 130.0 + host + tp_extra + 2 * (k + 1) * res["broadcast_us"][0] + x * lo
     assert abs(w8["low"]["ms_per_step"] - step8 / 1e3) < 1e-3 and w8["low"]["exchanges_per_step"] == round(x)
     assert w8["high"]["tokens_per_s"] < w8["low"]["tokens_per_s"]
     assert abs(w8["low"]["efficiency"] - w8["low"]["speedup_vs_w1"] / 8) < 2e-3

@@ -12,7 +12,7 @@ cp $V/pmc_mfma_attn_target_verify.json $P/${R}_pmc_mfma_attn_target_verify.json
 cp $V/pmc_retrieval_verify_layer.json $P/${R}_pmc_retrieval_verify_layer.json
 cp $V/parity_notes.txt $P/${R}_parity_notes.txt
 tail -12 $V/pytest.log | grep -a "passed\|failed" > $P/${R}_gpu_pytest_summary.txt; tail -1 $V/smoke.log >> $P/${R}_gpu_pytest_summary.txt
-for f in bench_lwm:bench_lwm_128k_full_n1 bench_offload:bench_offload_cfg3_world1 bench_13b_cfg4:bench_13b_cfg4_world1 bench_7b_cfg3_resident:bench_7b_cfg3_resident_world1 verify_bench:verify_bench_final; do
+for f in bench_lwm:bench_lwm_128k_full_n1 bench_offload:bench_offload_cfg3_world1 bench_13b_cfg4:bench_13b_cfg4_world1 bench_7b_cfg3_resident:bench_7b_cfg3_resident_world1 bench_tp_world1:bench_tp_engine_world1 verify_bench:verify_bench_final; do
   [ -s $V/${f%%:*}.json ] && cp $V/${f%%:*}.json $P/${R}_${f#*:}.json
 done
 [ -s $V/tp_shard_by_world.jsonl ] && cp $V/tp_shard_by_world.jsonl $P/${R}_tp_shard_by_world.jsonl

@@ -84,9 +84,11 @@ if [ "$1" = "all" ]; then
     python tools/tp_shard_bench.py llama-7B-128K $W --gamma 16 --prefill 130048 --budget 12288 $X 2>>$O/tp_shard.err | grep '^{' >> $O/tp_shard_by_world.jsonl
     python tools/tp_shard_bench.py llama-13B-128K $W --gamma 16 --prefill 130048 --budget 12288 $X 2>>$O/tp_shard.err | grep '^{' >> $O/tp_shard_by_world.jsonl
   done
+  # the TP engine's own loop at world 1 on the headline workload: what its host path costs on top of the graph engine's
+  python bench.py --engine tp --steps 20 --warmup 5 --no-cpu-baseline --random-steps 0 > $O/bench_tp_world1.json 2> $O/bench_tp_world1.err; echo "tp world1 rc=$?"
   # loop statistics (tokens per step, inner iterations, host overhead) and the W = 1 row from THIS run's single-GPU lines
   python tools/predict_scaling.py --shards $O/tp_shard_by_world.jsonl --out $O/predicted_scaling.json \
-      --bench "configs[1]=$O/bench.json" "configs[3]=$O/bench_7b_cfg3_resident.json" "configs[4]=$O/bench_13b_cfg4.json" > $O/predicted_scaling.md; echo "predict rc=$?"; head -8 $O/predicted_scaling.md
+      --bench "configs[1]=$O/bench.json" "configs[3]=$O/bench_7b_cfg3_resident.json" "configs[4]=$O/bench_13b_cfg4.json" --tp-host "configs[1]=$O/bench_tp_world1.json" > $O/predicted_scaling.md; echo "predict rc=$?"; head -8 $O/predicted_scaling.md
   (cd /tmp && export TMPDIR=/tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_tp8 -- python $R/tools/tp_shard_bench.py llama-7B-128K 8 --gamma 6 --prefill 124928 --budget 4096 --local-exchange --gemm-exchange > $R/$O/prof_tp8.log 2>&1)
   T8=$(ls -S $O/prof_tp8/*/*kernel_trace.csv | head -1)
   python tools/kernel_timeline.py $T8 $O/tp8_7b_kernel_timeline.json "rocprofv3 --kernel-trace of tools/tp_shard_bench.py llama-7B-128K 8 --gamma 6 --prefill 124928 --budget 4096 --local-exchange --gemm-exchange (rank 0 shard of an 8-way 7B engine on one MI355X), final build of the round (tools/gpu_validate.sh all)" > $O/tp8_7b_kernel_timeline.txt 2>&1

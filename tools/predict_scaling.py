@@ -15,7 +15,8 @@ Inputs
 Model (one outer step):
   step(W) = target_verify(W) + k * retrieval_verify(W) + (k + 1) * draft_step + host(W) + X(W) * extra_per_exchange
   X(W)    = exchanges per outer step = 2 L (1 + k)           (two per layer and forward; none at W = 1)
-  host(W) = step overhead measured at W = 1 + (k + 1) * 2 small broadcasts (drafted token, decision record) at W > 1
+  host(W) = step overhead measured at W = 1 (single-GPU graph engine); at W > 1 + what the TP engine's loop adds on the host
+            (TP_HOST_EXTRA_US, measured at world 1) + (k + 1) * 2 small broadcasts (drafted token, decision record)
   extra_per_exchange: what a multi-GPU node adds per exchange to the measured one-GPU figure — one scenario per
   exchange form, low / high:
       gemm_exchange         (shipped) per-panel flag hop + one remote-read round trip over xGMI      +2.5 .. +6 us
@@ -79,6 +80,11 @@ def apply_bench(loop, path):
             "measured_tokens_per_s": j["value"]}
 
 
+# What the TENSOR-PARALLEL engine's decode loop costs the host per step on top of the single-GPU graph engine's, before any
+# broadcast: its records are device tensors read with a blocking copy (they are broadcast first at W > 1: no pinned mailbox, no
+# one-graph inner iteration, no device-side step set-up).  Measured at world 1 on the same workload (`bench.py --engine tp`,
+# --tp-host name=path; default: profiles/r05_bench_tp_engine_world1.json against r05_bench_default_n1.json: 602 - 252 us).
+TP_HOST_EXTRA_US = 350.0
 SCENARIOS = {"gemm_exchange": (2.5, 6.0), "exchange_kernel_done": (5.5, 14.6), "rccl": (10.0, 20.0)}
 BCAST_US = (8.0, 20.0)            # one small RCCL broadcast, low / high; two per inner iteration and outer step at W > 1
 
@@ -88,7 +94,7 @@ def predict(line, loop, extra, bcast):
     k = loop["inner_iterations"]
     tv, rv, dr = line["target_verify_us"], line["retrieval_verify_us"], line["draft_step_us"]
     x = 0 if W == 1 else 2 * L * (1 + k)
-    host = loop["host_overhead_us"] + (0 if W == 1 else 2 * (k + 1) * bcast)
+    host = loop["host_overhead_us"] + (0 if W == 1 else loop.get("tp_host_extra_us", TP_HOST_EXTRA_US) + 2 * (k + 1) * bcast)
     terms = {"target_verify": tv, "retrieval_verify": k * rv, "draft": (k + 1) * dr, "host": host, "exchange_xgmi": x * extra}
     step = sum(terms.values())
     return step, terms, x
@@ -98,12 +104,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shards", required=True)
     ap.add_argument("--out", required=True)
+    ap.add_argument("--tp-host", nargs="*", default=[], help="name=path of `bench.py --engine tp` lines at world 1: the TP loop's own host cost")
     ap.add_argument("--bench", nargs="*", default=[], help="name=path of this round's single-GPU bench.py lines, e.g. "
                                                            "'configs[1]=gpurun_out/validate/bench.json'")
     args = ap.parse_args()
     for item in args.bench:
         name, path = item.split("=", 1)
         LOOP[name]["bench"] = path
+    for item in args.tp_host:                                    # a `bench.py --engine tp` line at world 1 of the same workload
+        name, path = item.split("=", 1)
+        LOOP[name]["tp_bench"] = path
     lines = [json.loads(l) for l in open(args.shards) if l.startswith("{") and "emulated_world" in l]
     out = {"model": __doc__.split("Model (one outer step")[1].split("python tools")[0].strip(), "scenarios_us_per_exchange": SCENARIOS,
            "broadcast_us": BCAST_US, "configs": {}}
@@ -114,6 +124,12 @@ def main():
         if not rows:
             continue
         w1 = apply_bench(loop, loop["bench"])
+        tpj = load_bench_line(loop.get("tp_bench", "profiles/r05_bench_tp_engine_world1.json" if name == "configs[1]" else ""))
+        if tpj and (tpj.get("multi_rank") or {}).get("measured_step_terms_us"):
+            loop["tp_host_extra_us"] = round(max(0.0, tpj["multi_rank"]["measured_step_terms_us"]["host_and_broadcasts"]
+                                                 - loop["host_overhead_us"]), 1)
+        else:
+            loop["tp_host_extra_us"] = TP_HOST_EXTRA_US
         if w1 is not None:                                    # the product at one GPU is the graph engine, not TP at world 1
             w1["layers"] = rows[0]["layers"]
             w1.update({k: rows[0][k] for k in ("target", "prefill", "budget", "gamma") if k in rows[0]})
