@@ -356,6 +356,9 @@ int tf_accept_chain(const float* p, const float* q, const int64_t* tokens, const
                     int g2, int V, int inclusive, int64_t eos_token_id, int64_t* out, void* stream);
 int tf_middle_accept(const float* p, const float* q_d, int64_t* tokens, const float* uniforms,
                      int n, int gamma, int V, int64_t* out, void* stream);
+/* tf_mid_record_tokens: tokens[n + 1] (, tokens[n + 2]) as a tf_middle_accept record (accepted, follow-up, drafted) implies —
+ * the tensor-parallel loop applies RANK 0's broadcast record (utils/decoding.py:452-470) with it in one launch. */
+int tf_mid_record_tokens(const int64_t* rec, int64_t* tokens, int tokens_len, int n, void* stream);
 /* The same three kernels with their uniforms behind a DEVICE CURSOR (round 5): u_k = ubuf[*cursor + k] — the form that
  * can sit INSIDE a captured hipGraph (frozen arguments, fresh numbers at every replay), which is how the inner loop of
  * utils/decoding.py:163-223 becomes ONE graph launch per iteration (draft forward, draw, retrieval verify, accept test).

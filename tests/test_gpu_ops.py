@@ -977,6 +977,24 @@ def test_cursor_forms_of_the_sampling_kernels_equal_the_pointer_forms():
                     assert int(slot) == S + count + 1 and int(sk) == S + count + 1 + ql
 
 
+def test_mid_record_tokens_equals_the_torch_form():
+    """The tensor-parallel loop applies RANK 0's broadcast middle_accept record to the token buffer (reference
+    utils/decoding.py:452-470: the accepted drafted token stays, the follow-up goes behind it; rejected: the follow-up replaces
+    it) — tf_mid_record_tokens in one launch against the torch statement it replaces, every position, both outcomes, the end of
+    the buffer."""
+    ops = _ops()
+    from triforce_amd.utils.decoding import _mid_tokens
+    gamma = 6
+    for n in range(gamma):
+        for acc in (0, 1):
+            rec = torch.tensor([acc, 4242, 1717, 0], dtype=torch.int64, device=DEV)
+            a = torch.arange(100, 100 + gamma + 1, dtype=torch.int64, device=DEV)
+            b = a.clone()
+            a[n + 1:n + 3].copy_(_mid_tokens(rec, n, gamma, a))
+            ops.mid_record_tokens(rec, b, n)
+            assert torch.equal(a, b), (n, acc, a.tolist(), b.tolist())
+
+
 def test_launch_plans_equal_the_per_call_wrappers():
     """Round 5: the decode loop's per-step launches over fixed buffers (retrieval-tail copy, draft-window shift, token /
     position set-up) go through plans that validate their tensors once (ops.KvCopyPairPlan / KvShiftPairPlan / SetTokensPlan).

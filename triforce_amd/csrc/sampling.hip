@@ -559,6 +559,21 @@ extern "C" int tf_middle_accept(const float* p, const float* q_d, int64_t* token
     return TF_OK;
 }
 
+// Tensor-parallel loop: the record every rank goes on with is RANK 0's (broadcast; the reference's sample_dist / r broadcast,
+// utils/decoding.py:230-239,452-470).  tokens[n + 1], tokens[n + 2] as that record implies — accepted: the drafted token d stays
+// at n + 1 and the follow-up b goes to n + 2 (when it fits), rejected: b at n + 1 — in one launch (torch: six tiny kernels).
+__global__ void mid_record_tokens_kernel(const int64_t* __restrict__ rec, int64_t* __restrict__ tokens, int n, int limit) {
+    const int64_t acc = rec[0], b = rec[1], d = rec[2];
+    if (n + 1 <= limit) tokens[n + 1] = acc > 0 ? d : b;
+    if (acc > 0 && n + 2 <= limit) tokens[n + 2] = b;
+}
+extern "C" int tf_mid_record_tokens(const int64_t* rec, int64_t* tokens, int tokens_len, int n, void* stream) {
+    if (!rec || !tokens || n < 0 || tokens_len < n + 2) return TF_EINVAL;
+    hipLaunchKernelGGL(mid_record_tokens_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rec, tokens, n, tokens_len - 1);
+    TF_LAUNCH_CHECK();
+    return TF_OK;
+}
+
 // The same three kernels with their uniforms behind a device cursor (see cur_uniforms): u_k = ubuf[*cursor + k].
 //   tf_sample_inverse_cdf_cur : token = sample(probs) with u = ubuf[*cursor + off]; the cursor is left alone
 //   tf_middle_accept_cur      : accept test with ubuf[*cursor + 1], follow-up sample with ubuf[*cursor + 2] (the draw of the

@@ -66,6 +66,7 @@ SIGNATURES = {
     "tf_sample_inverse_cdf": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "tf_accept_chain": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
     "tf_middle_accept": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "tf_mid_record_tokens": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "tf_sample_inverse_cdf_cur": (_i32, [_vp, _vp, _vp, _i32, _vp, _i32, _vp]),
     "tf_middle_accept_cur": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "tf_accept_chain_step": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _vp, _i32,

@@ -722,7 +722,7 @@ class DistributedLlama:
         return dict(form="segments", graphs=graphs, out=out, st=st, T=self.temperature, P=self.top_p,
                     parity=(base & 1) if (ar is not None and ar.alternate) else None)
 
-    def _replay(self, cap):
+    def _replay(self, cap, clone=True):
         if cap["form"] == "whole":
             cap["graph"].replay()
         else:
@@ -733,7 +733,7 @@ class DistributedLlama:
                 g.replay()
                 if exchange is not None:
                     exchange()
-        return cap["out"].clone()
+        return cap["out"].clone() if clone else cap["out"]
 
     def _agree(self, ok):
         """Same verdict on every rank (a capture that failed on one rank must be dropped by all)."""
@@ -857,7 +857,7 @@ class DistributedLlama:
         return out
 
     @torch.inference_mode()
-    def draft_run(self, input_ids, gamma_offset: int = 0, probs=True, temperature=0.6, top_p=0.9):
+    def draft_run(self, input_ids, gamma_offset: int = 0, probs=True, temperature=0.6, top_p=0.9, clone=True):
         """Replicated 68M draft (TP_llama.py:117-132).  NB the reference's call sites never pass temperature /
         top_p, so the draft always samples at 0.6 / 0.9 — kept."""
         g = getattr(self, "_draft_graphs", None)
@@ -866,7 +866,7 @@ class DistributedLlama:
             graph, ids, out = g[gamma_offset]
             ids.copy_(input_ids)
             graph.replay()
-            return out.clone()
+            return out.clone() if clone else out           # (clone=False: valid until THIS graph replays again)
         return self._draft_run_eager(input_ids, gamma_offset, probs, temperature, top_p)
 
     def _draft_run_eager(self, input_ids, gamma_offset, probs, temperature, top_p):
@@ -905,11 +905,12 @@ class DistributedLlama:
         return self._finish(x, d)
 
     @torch.inference_mode()
-    def retrieval_verify(self, input_ids, position_ids, temperature=0.6, top_p=0.9):
+    def retrieval_verify(self, input_ids, position_ids, temperature=0.6, top_p=0.9, clone=True):
         cap = getattr(self, "_verify_cap", None)
         if cap is not None and (temperature, top_p) == (cap["T"], cap["P"]):
             cap["st"]["ids"].copy_(input_ids)
             cap["st"]["pos"].copy_(position_ids.reshape(-1))
-            return self._replay(cap)
+            self._verify_gen = getattr(self, "_verify_gen", 0) + 1      # lifetime token of a static output handed out
+            return self._replay(cap, clone=clone)
         logits = self.retrieval_inference(input_ids, position_ids)
         return norm_logits(logits[0], temperature=temperature, top_k=-1, top_p=top_p)

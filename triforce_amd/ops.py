@@ -981,6 +981,13 @@ def middle_accept(p, q_d, tokens, uniforms, n, gamma, out):
                                          _ptr(out), _stream()), "tf_middle_accept")
 
 
+def mid_record_tokens(rec, tokens, n):
+    """tokens[n + 1] (, tokens[n + 2]) <- what the middle_accept record ``rec`` (accepted, follow-up, drafted) implies."""
+    _dev(rec, tokens)
+    assert rec.dtype == torch.int64 and tokens.dtype == torch.int64 and tokens.is_contiguous() and rec.numel() >= 3
+    hip.check(hip.lib().tf_mid_record_tokens(_ptr(rec), _ptr(tokens), tokens.numel(), int(n), _stream()), "tf_mid_record_tokens")
+
+
 # ---- the same three kernels with their uniforms behind a device cursor: u_k = ubuf[cursor[0] + k] (capturable) -------------
 def sample_inverse_cdf_cur(probs, ubuf, cursor, off, token_out):
     """token_out[0] <- sample(probs) with u = ubuf[cursor[0] + off]; the cursor is left alone."""

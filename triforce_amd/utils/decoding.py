@@ -320,8 +320,11 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
         ops.middle_accept(p, q_d, flat, u[1:3], n, gamma, rec.tensor)         # accept test + follow-up sample
         if sync_record is not None:                                           # TP: rank 0's decision wins
             sync_record(rec.tensor)
-            if n + 1 < flat.numel():
-                flat[n + 1:n + 3].copy_(_mid_tokens(rec.tensor, n, gamma, flat))
+            if n + 1 < flat.numel() and not _single_rank():                   # (one rank: the record IS the kernel's own)
+                if flat.is_cuda:
+                    ops.mid_record_tokens(rec.tensor, flat, n)               # one launch (the torch form below: six)
+                else:
+                    flat[n + 1:n + 3].copy_(_mid_tokens(rec.tensor, n, gamma, flat))
         acc, b, d = rec.read(3)                                               # the one host read of this step
         if _HOP_TRACE is not None:
             _t_seen = time.perf_counter_ns()                # (the drain below counts as part of the hop)
@@ -358,6 +361,11 @@ def Middle_Spec(next_token, graph_engine, gamma, verbose, tokenizer, rng=None, b
         return ids, p[:len(ids) - 1], accepted / drafted
     buffers.rows_generation = None
     return ids, buffers.spec_rows[:len(ids) - 1], accepted / drafted
+
+
+def _single_rank():
+    import torch.distributed as _d
+    return not (_d.is_available() and _d.is_initialized() and _d.get_world_size() > 1)
 
 
 def _mid_tokens(rec, n, gamma, flat):
@@ -661,12 +669,22 @@ class _DistEngine:
             model=types.SimpleNamespace(device=llm.device, config=llm.config.model_config),
             kv_cache=llm.kv_cache, graph_cache=llm.retrieval_cache, draft_cache=llm.draft_cache)
 
-    def graph_draft_inference(self, input_ids, gamma_offset=0):
-        return self.llm.draft_run(input_ids=input_ids, gamma_offset=gamma_offset)       # 0.6/0.9 hard-wired
+    @property
+    def static_outputs(self):
+        """The captured draft / retrieval-verify forwards can hand out their static output buffers (valid until the same graph
+        replays again — what the decode loops need: no 0.9 MB clone and no per-position row copies per inner iteration)."""
+        return getattr(self.llm, "_verify_cap", None) is not None and bool(getattr(self.llm, "_draft_graphs", None)) \
+            and __import__("os").environ.get("TRIFORCE_TP_STATIC_OUTPUTS", "1") != "0"
 
-    def graph_verify(self, input_ids, position_ids):
+    def graph_draft_inference(self, input_ids, gamma_offset=0, clone=True):
+        return self.llm.draft_run(input_ids=input_ids, gamma_offset=gamma_offset, clone=clone)   # 0.6/0.9 hard-wired (SURVEY §7)
+
+    def graph_verify(self, input_ids, position_ids, clone=True):
         return self.llm.retrieval_verify(input_ids=input_ids, position_ids=position_ids,
-                                         temperature=self.llm.temperature, top_p=self.llm.top_p)
+                                         temperature=self.llm.temperature, top_p=self.llm.top_p, clone=clone)
+
+    def verify_generation(self):
+        return getattr(self.llm, "_verify_gen", None) if getattr(self.llm, "_verify_cap", None) is not None else None
 
     def inference(self, input_ids, eager=False):
         return self.llm.inference(input_ids=input_ids, eager=eager)
