@@ -234,7 +234,7 @@ def run_tp(args, rank, world, local):
     from triforce_amd.models.cache import StreamingLLMEvictionCache
     from triforce_amd.models.modeling_llama_68m import LlamaForCausalLM as Draft68M
     from triforce_amd.models.TP_llama import DistributedLlama, distributed_init
-    from triforce_amd.utils.decoding import TriForceRunner, _DistEngine, _bcast_record
+    from triforce_amd.utils.decoding import ReplicaCheck, TriForceRunner, _DistEngine, tp_sync_record
     from triforce_amd.utils.sampling import UniformSource
 
     on_gpu = torch.cuda.is_available()
@@ -294,8 +294,10 @@ def run_tp(args, rank, world, local):
 
     ge = _DistEngine(llm)
     run = TriForceRunner(_Tok(), ge, args.gamma, top_k=-1, top_p=args.top_p, temperature=args.temp,
-                         rng=UniformSource(device, seed=args.seed), inclusive_accept=True, sync_record=_bcast_record)
+                         rng=UniformSource(device, seed=args.seed), inclusive_accept=True, sync_record=tp_sync_record())
     run.health = ge.health                                      # a timed-out exchange raises instead of emitting tokens
+    # TRIFORCE_TP_REPLICATED_DECISIONS=1: no record broadcasts, the ranks' streams compared by digest (utils/decoding.ReplicaCheck)
+    replicas = ReplicaCheck(device) if run.sync_record is None else None
     t0 = time.time()
     llm.reset()
     if args.prefill_mode == "real":
@@ -337,7 +339,11 @@ def run_tp(args, rank, world, local):
     try:
         for _ in range(args.steps):
             run.step()
-    except RuntimeError as ex:                                  # one-shot all-reduce timeout surfaced by run.health
+            if replicas is not None:
+                replicas(run)                                   # (inside the timed region: it is part of that loop's cost)
+        if replicas is not None:
+            replicas(run, force=True)
+    except RuntimeError as ex:                                  # exchange timeout (run.health) / ranks off the common stream
         failure = f"{type(ex).__name__}: {ex}"
     torch.cuda.synchronize()
     if failure is None:
@@ -428,6 +434,9 @@ def run_tp(args, rank, world, local):
                                   if getattr(getattr(llm, "_ar", None), "alternate", False) else
                                   "one-shot peer reads (tf_allreduce_oneshot)")) if getattr(llm, "_ar", None) is not None
             else ("rccl" if world > 1 else "none (one rank)"),
+            "decisions": ("replicated on every rank (same uniform stream, bit-identical exchanges): no record broadcasts, "
+                          f"{replicas.checks} stream-digest checks across the ranks in the timed region" if replicas is not None else
+                          "rank 0's records broadcast (2 per inner iteration + 1 per outer step), blocking reads"),
             "ranks_share_one_device": bool(share), "allreduce_error": int(ar_err),
             "allreduce_requested": getattr(args, "allreduce", "auto"),
             "allreduce_note": getattr(llm, "allreduce_note", "") or None,

@@ -410,7 +410,8 @@ def test_oneshot_allreduce_across_two_processes_through_hipipc(alternate):
         assert ok, f"rank {rank}: result differs from the collective by up to {worst}"
 
 
-def _tp2_worker(rank, world, port, q, alternate=False, extra_env=None, loop_gamma=None, golden="tp_world2", stages_only=False):
+def _tp2_worker(rank, world, port, q, alternate=False, extra_env=None, loop_gamma=None, golden="tp_world2", stages_only=False,
+                loop_only=False):
     """One rank of the tensor-parallel engine at world size 2 with BOTH ranks on this box's single GPU: real kernels on
     each rank's head / MLP-column shard, the decode-sized all-reduces through the one-shot kernel over hipIpc mappings
     (the production path), prefill-sized ones and the token broadcast through gloo."""
@@ -432,6 +433,8 @@ def _tp2_worker(rank, world, port, q, alternate=False, extra_env=None, loop_gamm
         from triforce_amd.models.TP_llama import DistributedLlama
         from triforce_amd.utils.decoding import TriForce_Dist
         out = {}
+        if loop_only:
+            return _tp2_decode_loop(rank, world, q, out, loop_gamma)
         # 1) the four forward stages against the REFERENCE engine's own world-2 logits (tests/golden/tp_world2.pt)
         g = Hh.load_golden(golden)
         tcfg = LlamaConfig.from_dict(g["tcfg"])
@@ -467,29 +470,44 @@ def _tp2_worker(rank, world, port, q, alternate=False, extra_env=None, loop_gamm
             dist.destroy_process_group()
             return
         del llm
-        # 2) the whole decode loop (draft + retrieval verify + target verify, hipGraphs) on the small_gamma6 fixture
-        g = Hh.load_golden("small_gamma6")
-        gamma = loop_gamma or g["gamma"]
-        draft = Draft.from_state_dict(LlamaConfig.from_dict(g["dcfg"]),
-                                      specs.random_state_dict(g["dcfg"], g["dseed"], head_std=g["head_std"]), DEV)
-        dcache = StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - gamma, gamma=gamma)
-        tcfg = LlamaConfig.from_dict(g["tcfg"])
-        llm = DistributedLlama("unused", config=tcfg, device=DEV, local_rank=rank, world_size=world,
-                               prefill=g["prefill"], gen_len=g["gen_len"], temperature=g["temperature"], top_p=g["top_p"],
-                               retrieval_budget=g["budget"], kv_offload=True, on_chip_layers=tcfg.num_hidden_layers,
-                               draft=draft, draft_cache=dcache, gamma=gamma)
-        llm.init_parameters(specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g["head_std"]))
-        llm.initialize_graphs()
-        res = TriForce_Dist(Hh.FakeTokenizer(), llm, Hh.prompt_of(g).to(DEV), gamma=gamma, max_len=24, top_k=-1,
-                            top_p=g["top_p"], temperature=g["temperature"], return_details=True)
-        torch.cuda.synchronize()
-        out.update(tokens=res["tokens"], counts=res["counts"], seq_len=llm.kv_cache.seq_len, graph_form=llm.graph_form,
-                   oneshot_decode=llm._ar is not None, ar_error_decode=llm._ar.error() if llm._ar is not None else -1)
-        dist.barrier()
-        q.put((rank, "ok", out))
-        dist.destroy_process_group()
+        _tp2_decode_loop(rank, world, q, out, loop_gamma)
     except Exception:
         q.put((rank, "error", traceback.format_exc()))
+
+
+def _tp2_decode_loop(rank, world, q, out, loop_gamma=None):
+    """2) the whole decode loop (draft + retrieval verify + target verify, hipGraphs) on the small_gamma6 fixture;
+    $TF_TEST_TP_SAMPLING = "T,top_p" replaces the fixture's greedy target by a stochastic one."""
+    import os
+    import torch.distributed as dist
+    from triforce_amd.models.cache import StreamingLLMEvictionCache
+    from triforce_amd.models.config_yarn import LlamaConfig
+    from triforce_amd.models.modeling_llama_68m import LlamaForCausalLM as Draft
+    from triforce_amd.models.TP_llama import DistributedLlama
+    from triforce_amd.utils.decoding import TriForce_Dist
+    g = Hh.load_golden("small_gamma6")
+    if os.environ.get("TF_TEST_TP_SAMPLING"):
+        g["temperature"], g["top_p"] = (float(x) for x in os.environ["TF_TEST_TP_SAMPLING"].split(","))
+    gamma = loop_gamma or g["gamma"]
+    draft = Draft.from_state_dict(LlamaConfig.from_dict(g["dcfg"]),
+                                  specs.random_state_dict(g["dcfg"], g["dseed"], head_std=g["head_std"]), DEV)
+    dcache = StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - gamma, gamma=gamma)
+    tcfg = LlamaConfig.from_dict(g["tcfg"])
+    llm = DistributedLlama("unused", config=tcfg, device=DEV, local_rank=rank, world_size=world,
+                           prefill=g["prefill"], gen_len=g["gen_len"], temperature=g["temperature"], top_p=g["top_p"],
+                           retrieval_budget=g["budget"], kv_offload=True, on_chip_layers=tcfg.num_hidden_layers,
+                           draft=draft, draft_cache=dcache, gamma=gamma)
+    llm.init_parameters(specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g["head_std"]))
+    llm.initialize_graphs()
+    res = TriForce_Dist(Hh.FakeTokenizer(), llm, Hh.prompt_of(g).to(DEV), gamma=gamma, max_len=24, top_k=-1,
+                        top_p=g["top_p"], temperature=g["temperature"], return_details=True)
+    torch.cuda.synchronize()
+    out.update(tokens=res["tokens"], counts=res["counts"], seq_len=llm.kv_cache.seq_len, graph_form=llm.graph_form,
+               decisions=res["decisions"], replica_checks=res["replica_checks"],
+               oneshot_decode=llm._ar is not None, ar_error_decode=llm._ar.error() if llm._ar is not None else -1)
+    dist.barrier()
+    q.put((rank, "ok", out))
+    dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("alternate", [False, True], ids=["done-handshake", "alternating-halves"])
@@ -539,6 +557,49 @@ def test_tp_world2_on_one_device_real_kernels_and_oneshot_allreduce(alternate):
     gaps = Hh.teacher_forced_gaps(g6, a["tokens"])
     assert max(gaps) < 8e-3, f"TP stream leaves the oracle's greedy path: gap {max(gaps):.4f}"
     assert Hh.common_prefix(a["tokens"], g6["ar_tokens"]) >= 12
+
+
+def _run_tp2(**kw):
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_tp2_worker, args=(r, 2, port, q), kwargs=kw) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = {}
+    try:
+        for _ in range(2):
+            o = q.get(timeout=600)
+            outs[o[0]] = o
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    for o in outs.values():
+        assert o[1] == "ok", o[2]
+    return outs[0][2], outs[1][2]
+
+
+def test_tp_world2_replicated_decisions_emit_the_broadcast_stream_on_the_device():
+    """TRIFORCE_TP_REPLICATED_DECISIONS=1 with the real kernels (two processes on this GPU, the exchange across the process
+    boundary, whole-forward hipGraphs): no record broadcast, the records through each rank's pinned mailbox — both ranks emit
+    the broadcast form's stream, accept counts and cache length under a stochastic target (T = 0.8, top-p 0.9), the stream
+    digest agreed across the ranks at every check, no exchange error."""
+    env = {"TF_TEST_TP_SAMPLING": "0.8,0.9"}
+    base, _ = _run_tp2(extra_env=env, loop_only=True)
+    a, b = _run_tp2(extra_env=dict(env, TRIFORCE_TP_REPLICATED_DECISIONS="1", TRIFORCE_TP_REPLICA_CHECK_EVERY="2"), loop_only=True)
+    assert base["decisions"] == "broadcast" and a["decisions"] == b["decisions"] == "replicated"
+    for r, o in ((0, a), (1, b)):
+        assert o["tokens"] == base["tokens"] and o["counts"] == base["counts"] and o["seq_len"] == base["seq_len"], \
+            f"rank {r} left the broadcast form's stream"
+        assert o["replica_checks"] >= len(o["counts"]) // 2 and o["ar_error_decode"] == 0 and o["oneshot_decode"]
+    assert len(set(base["tokens"])) > 4
+    print(f"[tp2 replicated decisions] {len(a['tokens'])} tokens, accept counts {a['counts']}, {a['replica_checks']} digest checks")
 
 
 def test_tp_world8_on_one_device_matches_the_reference_world8_logits():

@@ -6,6 +6,7 @@ import socket
 import sys
 import traceback
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -77,6 +78,8 @@ def _worker(rank, world, port, q):
         draft = Draft.from_state_dict(LlamaConfig.from_dict(g["dcfg"]), dsd, "cpu")
         dcache = StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - gamma, gamma=gamma)
         tcfg = LlamaConfig.from_dict(g["tcfg"])
+        if os.environ.get("TF_TEST_TP_SAMPLING"):                      # "T,top_p": a stochastic target instead of the golden's greedy one
+            g["temperature"], g["top_p"] = (float(x) for x in os.environ["TF_TEST_TP_SAMPLING"].split(","))
         llm = DistributedLlama("unused", config=tcfg, device="cpu", local_rank=rank, world_size=world,
                                prefill=g["prefill"], gen_len=g["gen_len"], temperature=g["temperature"], top_p=g["top_p"],
                                retrieval_budget=g["budget"], kv_offload=True, on_chip_layers=tcfg.num_hidden_layers,
@@ -94,7 +97,8 @@ def _worker(rank, world, port, q):
         # 2) decode
         res = TriForce_Dist(Hh.FakeTokenizer(), llm, prompt, gamma=gamma, max_len=24, top_k=-1, top_p=g["top_p"],
                             temperature=g["temperature"], return_details=True)
-        q.put((rank, "ok", logits, spec_logits, res["tokens"], res["counts"], llm.kv_cache.seq_len))
+        q.put((rank, "ok", logits.numpy(), spec_logits.numpy(), res["tokens"], res["counts"], llm.kv_cache.seq_len,
+               {"decisions": res["decisions"], "replica_checks": res["replica_checks"]}))
         dist.barrier()
         dist.destroy_process_group()
     except Exception:
@@ -116,16 +120,71 @@ def test_tp2_gloo_matches_oracle():
     so = oeng.model.forward(torch.tensor([[11, 12, 13] + [100] * (gamma - 2)]), oeng.kv_cache, oeng.graph_cache,
                             position_ids=torch.arange(S, S + gamma + 1).unsqueeze(0), spec=True)
     for r in range(world):
-        _, _, logits, spec_logits, tokens, counts, seq_len = outs[r]
+        _, _, logits, spec_logits, tokens, counts, seq_len = outs[r][:7]
+        logits, spec_logits = torch.from_numpy(logits), torch.from_numpy(spec_logits)
+        assert outs[r][7] == {"decisions": "broadcast", "replica_checks": 0}
         assert (logits - lo).abs().max() < 4e-3, f"rank {r} prefill logits off by {(logits - lo).abs().max():.2e}"
         assert (spec_logits - so).abs().max() < 4e-3, f"rank {r} spec logits off by {(spec_logits - so).abs().max():.2e}"
     # ranks are in lock-step: identical logits (all-reduce gives every rank the same bits), tokens, rollbacks
-    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+    assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3])
     assert outs[0][4] == outs[1][4] and outs[0][5] == outs[1][5] and outs[0][6] == outs[1][6]
     # lossless: the TP stream is the target's greedy stream (teacher-forced against the oracle)
     gaps = Hh.teacher_forced_gaps(g, outs[0][4])
     assert max(gaps) < 8e-3, f"TP stream leaves the oracle's greedy path: gap {max(gaps):.4f}"
     assert Hh.common_prefix(outs[0][4], g["ar_tokens"]) >= 12
+
+
+def test_tp2_replicated_decisions_emit_the_broadcast_stream(monkeypatch):
+    """TRIFORCE_TP_REPLICATED_DECISIONS=1 (utils/decoding.py): no record is broadcast — every rank reaches rank 0's decisions
+    from its own copy of the uniform stream and the bit-identical all-reduced probabilities.  A stochastic target (T = 0.8,
+    top-p 0.9) so that every kind of decision draws numbers: both ranks emit the stream, accept counts and cache length of the
+    broadcast form, and the digest check ran across the ranks (every 2 outer steps here + once at the end)."""
+    monkeypatch.setenv("TF_TEST_TP_SAMPLING", "0.8,0.9")
+    base = _run_world(_worker, 2)
+    monkeypatch.setenv("TRIFORCE_TP_REPLICATED_DECISIONS", "1")
+    monkeypatch.setenv("TRIFORCE_TP_REPLICA_CHECK_EVERY", "2")
+    repl = _run_world(_worker, 2)
+    assert base[0][7]["decisions"] == "broadcast" and repl[0][7]["decisions"] == "replicated"
+    steps = len(repl[0][5])
+    for r in range(2):
+        assert repl[r][4] == base[0][4] and repl[r][5] == base[0][5] and repl[r][6] == base[0][6], f"rank {r} left the broadcast stream"
+        assert repl[r][7]["replica_checks"] >= steps // 2
+    assert len(set(base[0][4])) > 4 and len(base[0][4]) >= 24
+
+
+def _diverged_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import types
+        from triforce_amd.utils.decoding import ReplicaCheck
+        check = ReplicaCheck("cpu", every=4)
+        run = types.SimpleNamespace(emitted=[5, 6, 7], counts=[2], n=3)
+        check(run)                                              # 1 step < every: no collective
+        none_yet = check.checks
+        run.counts, run.emitted, run.n = [2, 1, 3, 1], [5, 6, 7, 8, 9, 10, 11], 7
+        check(run)                                              # same stream everywhere: passes
+        run.emitted = run.emitted + ([12] if rank == 0 else [13])     # same length, another token on rank 1
+        run.n = 8
+        try:
+            check(run, force=True)
+            verdict = "passed"
+        except RuntimeError as ex:
+            verdict = str(ex)
+        q.put((rank, "ok", none_yet, check.checks, verdict))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_replica_check_raises_on_every_rank_when_one_rank_leaves_the_stream():
+    outs = _run_world(_diverged_worker, 2)
+    for r in range(2):
+        _, _, none_yet, checks, verdict = outs[r]
+        assert none_yet == 0 and checks == 2
+        assert "left the common token stream" in verdict, verdict
 
 
 # ---- Sequoia tree path at world_size 2 -----------------------------------------------------------------------

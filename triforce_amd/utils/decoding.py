@@ -653,6 +653,60 @@ def _bcast_record(t):
         dist.broadcast(t, src=0)
 
 
+# Who decides.  The reference broadcasts rank 0's samples and its accept draws (decoding.py:230-239, 345-346) because every
+# rank draws from its own generator.  Here every rank holds the SAME uniform stream (same seed, explicit numbers) and, behind
+# each exchange, bit-identical activations (every rank adds the same partials in the same order: csrc/allreduce.hip, the
+# replicated lm_head and draft model do the rest), so every rank reaches rank 0's decision on its own — the path has no
+# exchange step for decisions.  TRIFORCE_TP_REPLICATED_DECISIONS=1 runs the loops that way: no broadcast (two per inner
+# iteration + one per outer step otherwise), and with the broadcasts the blocking device-to-host reads go — the records travel
+# through the pinned mailbox like the single-GPU loop's.  A digest of the emitted stream is compared across the ranks every
+# TRIFORCE_TP_REPLICA_CHECK_EVERY outer steps and when a loop ends (ReplicaCheck): a rank that left the common stream raises
+# on every rank.  Default off: the broadcast form is the reference's, and neither form has met a second device yet.
+TP_REPLICATED_DECISIONS = __import__("os").environ.get("TRIFORCE_TP_REPLICATED_DECISIONS", "0") == "1"
+TP_REPLICA_CHECK_EVERY = max(1, int(__import__("os").environ.get("TRIFORCE_TP_REPLICA_CHECK_EVERY", "32")))
+
+
+def tp_sync_record():
+    """The `sync_record` of the tensor-parallel loops: rank 0's record broadcast, or None when the ranks replicate decisions."""
+    return None if TP_REPLICATED_DECISIONS else _bcast_record
+
+
+class ReplicaCheck:
+    """Replicated decisions only: every rank folds the tokens it emitted into a 61-bit digest; every `every` outer steps
+    (and on `force`) ONE 4-word MAX all-reduce of (digest, -digest, n, -n) tells every rank whether all ranks hold the same
+    stream.  The call sites are functions of the outer step count alone, so ranks that agree meet in the collective; ranks whose
+    forwards fell out of step never get here — their exchanges time out first (RuntimeError from `health`)."""
+
+    MOD = (1 << 61) - 1
+
+    def __init__(self, device, every=None):
+        self.device, self.every = device, int(every or TP_REPLICA_CHECK_EVERY)
+        self.seen = self.digest = self.checks = self.last_step = 0
+
+    def fold(self, tokens):
+        d = self.digest
+        for t in tokens[self.seen:]:
+            d = (d * 1_000_003 + int(t) + 1) % self.MOD
+        self.digest, self.seen = d, len(tokens)
+
+    def __call__(self, run, force=False):
+        steps = len(run.counts)
+        if not (force or steps - self.last_step >= self.every):
+            return
+        self.last_step = steps
+        self.fold(run.emitted)
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        t = torch.tensor([self.digest, -self.digest, run.n, -run.n], dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        hi, lo, n_hi, n_lo = t.tolist()
+        self.checks += 1
+        if hi != -lo or n_hi != -n_lo:
+            raise RuntimeError(f"tensor-parallel ranks left the common token stream (rank {dist.get_rank()}: {run.n} tokens, digest "
+                               f"{self.digest:#x}; across ranks n in [{-n_lo}, {n_hi}]): replicated decisions need identical "
+                               "uniform streams and bit-identical exchanges — unset TRIFORCE_TP_REPLICATED_DECISIONS to broadcast rank 0's")
+
+
 def sample_dist(probs, rng=None):
     """Rank 0 samples, everyone gets the token (reference decoding.py:230-239) — one 8-byte broadcast, no barrier."""
     tok = sample(probs, rng=rng)
@@ -730,7 +784,7 @@ def Baseline_Dist(tokenizer, graph_engine, input_ids, max_len=256, top_k=-1, top
 def Middle_Spec_Dist(next_token, llm, gamma, verbose, tokenizer, rng=None):
     """Reference decoding.py:432-495."""
     ge = llm if isinstance(llm, _DistEngine) else _DistEngine(llm)
-    return Middle_Spec(next_token, ge, gamma, verbose, tokenizer, rng=rng, sync_record=_bcast_record)
+    return Middle_Spec(next_token, ge, gamma, verbose, tokenizer, rng=rng, sync_record=tp_sync_record())
 
 
 @torch.inference_mode()
@@ -740,8 +794,9 @@ def TriForce_Dist(tokenizer, llm, input_ids, gamma=4, max_len=256, top_k=-1, top
     ge = _DistEngine(llm)
     rng = rng or UniformSource(llm.device, seed=1)          # same seed on every rank: identical uniform streams
     run = TriForceRunner(tokenizer, ge, gamma, top_k, top_p, temperature, verbose, rng, inclusive_accept=True,
-                         sync_record=_bcast_record)
+                         sync_record=tp_sync_record())
     run.health = ge.health
+    replicas = ReplicaCheck(llm.device) if run.sync_record is None else None
     llm.reset()
     if input_ids.shape[1] != llm.prefill_len:
         # the retrieval cache's chunk grid and the device mirror of the generated rows are laid out for exactly this
@@ -760,13 +815,19 @@ def TriForce_Dist(tokenizer, llm, input_ids, gamma=4, max_len=256, top_k=-1, top
     time1 = time.time()
     while run.n < max_len:
         run.step()
+        if replicas is not None:
+            replicas(run)
         # the TP loop stops when the token that closed the accept scan — accepted or resampled — is eos
         # (decoding.py:382-383); a bonus token is sampled after that check and never ends the loop
         if run.next_token == eos and run.last_reason != 1:
             break
+    if replicas is not None:
+        replicas(run, force=True)
     _sync(llm.device)
     time2 = time.time()
     st = run.stats(time2 - time1)
+    st["decisions"] = "broadcast" if replicas is None else "replicated"
+    st["replica_checks"] = 0 if replicas is None else replicas.checks
     if return_details:
         return st
     return st["avg_tokens"], (time2 - time1) / max(run.n, 1)
