@@ -617,6 +617,42 @@ def test_one_launch_inner_iterations_emit_the_identical_stream(temperature, top_
         run.step()
 
 
+def test_uniform_stream_refill_in_place_under_the_inner_graphs(monkeypatch):
+    """The captured inner iterations and the on-device step read their uniforms as buf[cursor + k] behind FIXED addresses, so
+    `UniformSource` refills its one buffer in place and resets the device cursor when a block is used up (every 65 536 numbers
+    in production — ~3 600 outer steps — which no other device test reaches).  A seeded stream with a 48-number block refills every
+    few outer steps: tokens, accept counts and the final stream position must equal the four-launch form's, which draws the
+    same blocks through plain pointers."""
+    from triforce_amd.utils import decoding as Dm
+    from triforce_amd.utils.decoding import TriForce
+    from triforce_amd.utils.sampling import UniformSource
+    g = dict(Hh.load_golden("small_gamma6"), gen_len=120, budget=320)
+    prompt, tok = Hh.prompt_of(g).to(DEV), Hh.FakeTokenizer()
+    out, refills = {}, {}
+    for mode, inner in {"four launches": False, "one graph": True}.items():
+        monkeypatch.setattr(Dm, "INNER_GRAPH", inner)
+        ge = Hh.build_product(g, DEV, temperature=0.8, top_p=0.9, graphs=True)
+        rng = UniformSource(DEV, seed=5, block=48)
+        count = [0]
+        room = rng._room
+
+        def counting(n, room=room, rng=rng, count=count):
+            before = rng.pos
+            room(n)
+            count[0] += int(rng.pos < before)
+        rng._room = counting
+        res = TriForce(tok, ge, prompt, gamma=g["gamma"], max_len=96, top_k=-1, top_p=0.9, temperature=0.8, rng=rng,
+                       return_details=True)
+        out[mode], refills[mode] = (res["tokens"], res["counts"], rng.pos), count[0]
+        assert bool(ge._inner) == inner
+    assert refills["one graph"] >= 3 and refills["one graph"] == refills["four launches"], refills
+    ref, got = out["four launches"], out["one graph"]
+    assert got[0] == ref[0], f"tokens diverge at {Hh.common_prefix(got[0], ref[0])} of {len(ref[0])} ({refills} refills)"
+    assert got[1] == ref[1] and got[2] == ref[2]
+    Hh.note(f"uniform stream refilled in place {refills['one graph']} times under the inner graphs: {len(ref[0])} tokens identical "
+            "to the four-launch form")
+
+
 def test_draft_prefill_graph_equals_eager(monkeypatch):
     """The 68M draft's prompt pass replays ONE captured steady-state step (shift the StreamingLLM window by 64 rows, run 64
     rows) per full chunk once the window is full; the result must equal the all-eager pass bit for bit: returned logits,
