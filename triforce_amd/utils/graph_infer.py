@@ -235,7 +235,7 @@ class _InnerGraphs:
     issues these as two graph replays with host-side sampling and three blocking reads in between; rounds 2-4 as two
     replays + two eager kernels + one record read.  Here an inner iteration is one launch and one record read: the draw /
     accept kernels sit inside the graph with their uniforms behind the stream's device cursor (ops.*_cur), the record is
-    the LAST store of the graph's last kernel, so a host that sees it may launch the next iteration on another stream."""
+    the LAST store of the graph's last kernel, behind write-through stores of the token id and the cursor."""
 
     def __init__(self, ge, gamma, rng, record):
         eng, kw = ge.engine, ge.sampling
