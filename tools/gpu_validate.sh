@@ -22,10 +22,13 @@ if [ "$1" = "tp" ]; then
   python bench.py --gpus $N --steps 20 --warmup 5 --allreduce rccl > $O/bench_tp${N}_rccl.json 2> $O/bench_tp${N}_rccl.err || rc=1
   # (3) the one-shot exchange with alternating staging halves (no DONE handshake) — opt-in until it has a multi-GPU number
   TRIFORCE_AR_ALTERNATE=1 python bench.py --gpus $N --steps 20 --warmup 5 --allreduce oneshot --require-graph-form whole > $O/bench_tp${N}_oneshot_alt.json 2> $O/bench_tp${N}_oneshot_alt.err || rc=1
-  python - "$N" $O/bench_tp${N}_oneshot.json $O/bench_tp${N}_rccl.json $O/bench_tp${N}_oneshot_alt.json <<'PY' || rc=1
+  # (4) replicated decisions (no record broadcasts) — opt-in; same tokens per step as (1) expected, and
+  #     `decisions` in the line says how many stream-digest checks passed across the ranks
+  TRIFORCE_TP_REPLICATED_DECISIONS=1 TRIFORCE_TP_REPLICA_CHECK_EVERY=4 python bench.py --gpus $N --steps 20 --warmup 5 --allreduce oneshot --require-graph-form whole > $O/bench_tp${N}_replicated.json 2> $O/bench_tp${N}_replicated.err || rc=1
+  python - "$N" $O/bench_tp${N}_oneshot.json $O/bench_tp${N}_rccl.json $O/bench_tp${N}_oneshot_alt.json $O/bench_tp${N}_replicated.json <<'PY' || rc=1
 import json, sys
 n, bad = int(sys.argv[1]), []
-for path, want in ((sys.argv[2], "one-shot"), (sys.argv[3], "rccl"), (sys.argv[4], "one-shot")):
+for path, want in ((sys.argv[2], "one-shot"), (sys.argv[3], "rccl"), (sys.argv[4], "one-shot"), (sys.argv[5], "one-shot")):
     try:
         j = json.loads([l for l in open(path) if l.startswith("{")][-1])
     except Exception as e:
@@ -35,7 +38,7 @@ for path, want in ((sys.argv[2], "one-shot"), (sys.argv[3], "rccl"), (sys.argv[4
     if not str(j.get("decode_allreduce", "")).startswith(want): bad.append(f"{path}: decode_allreduce = {j.get('decode_allreduce')!r}, wanted {want}")
     if j.get("allreduce_error"): bad.append(f"{path}: allreduce_error {j['allreduce_error']}")
     if want == "one-shot" and j.get("graph_form") != "whole": bad.append(f"{path}: graph_form {j.get('graph_form')}")
-    print(path, {k: j.get(k) for k in ("value", "ms_per_step", "graph_form", "decode_allreduce", "allreduce_error", "acceptance_rate")})
+    print(path, {k: j.get(k) for k in ("value", "ms_per_step", "tokens", "graph_form", "decode_allreduce", "allreduce_error", "acceptance_rate", "decisions")})
 print(json.dumps({"tp_validate_ok": not bad, "problems": bad}))
 sys.exit(1 if bad else 0)
 PY
