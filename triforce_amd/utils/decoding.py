@@ -657,7 +657,8 @@ def _bcast_record(t):
 # rank draws from its own generator.  Here every rank holds the SAME uniform stream (same seed, explicit numbers) and, behind
 # each exchange, bit-identical activations (every rank adds the same partials in the same order: csrc/allreduce.hip, the
 # replicated lm_head and draft model do the rest), so every rank reaches rank 0's decision on its own — the path has no
-# exchange step for decisions.  TRIFORCE_TP_REPLICATED_DECISIONS=1 runs the loops that way: no broadcast (two per inner
+# exchange step for decisions.  TRIFORCE_TP_REPLICATED_DECISIONS=1 runs TriForce_Dist / Middle_Spec_Dist that way (the autoregressive
+# baseline and the tree loop keep their one broadcast per token / per level): no broadcast (two per inner
 # iteration + one per outer step otherwise), and with the broadcasts the blocking device-to-host reads go — the records travel
 # through the pinned mailbox like the single-GPU loop's.  A digest of the emitted stream is compared across the ranks every
 # TRIFORCE_TP_REPLICA_CHECK_EVERY outer steps and when a loop ends (ReplicaCheck): a rank that left the common stream raises
