@@ -164,6 +164,33 @@ int tf_draft_forward_68m(const TfDraftModel* model, const TfDraftCache* cache, c
                          int kv_len, float* logits_out, float* probs_out, float temperature, float top_p,
                          void* ws, int64_t ws_bytes, void* stream);
 
+/* The same forward as ONE LAUNCH (csrc/draft_persist.hip; replaces the ~40 kernels of models/modeling_llama_68m.py:129-190
+ * + utils/sampling.py:5-27,43-60 per draft step, and the 13 launches of tf_draft_forward_68m): 256 co-resident workgroups,
+ * the stages meet through per-edge arrival counters in `ctl` (write-through stores, agent-scope loads, no fences, no
+ * cooperative launch).  Outputs — logits, the probability row, the K / V rows written — are BIT-IDENTICAL to
+ * tf_draft_forward_68m.  Shapes: hidden 768, 12 heads of 64, inter 3072, 1-2 layers, vocab % 16 == 0 and <= 32768,
+ * 1 <= n <= 16, kv_len <= 384, a device with >= 256 compute units (tf_draft_persist_supported: 0 = taken, TF_EINVAL /
+ * TF_ERANGE otherwise — the caller keeps tf_draft_forward_68m).
+ *   ws    >= tf_draft_persist_ws_bytes(model) bytes of device scratch, 256-byte aligned, owned by this control block's launches
+ *   ctl   tf_draft_persist_ctl_bytes() bytes of device memory, 64-byte aligned, ZERO-filled once (tf_draft_persist_reset);
+ *         launches on one ctl must be stream-ordered (graph replays of one engine are).
+ * Every wait is bounded by wall-clock time (tf_draft_persist_tune key 0, ms, default 2000; frozen into captured graphs).
+ * A time-out sets the sticky error word of ctl (+ the optional pinned host mirror): the outputs of that and of every later
+ * launch are NaN until tf_draft_persist_reset.  tf_draft_persist_error: 0 or 1 + index of the edge whose wait timed out
+ * (blocking read).  tf_draft_persist_tune key 1 = fault injection for tests (edge index + 1 whose first producer loses its
+ * arrival; 0 off).  tf_draft_persist_stamps: device buffer of 256 x (return value) u64 100-MHz wall-clock stamps per
+ * workgroup written by the following launches (NULL: off) — tools/draft_persist_stamps.py. */
+int64_t tf_draft_persist_ctl_bytes(void);
+int64_t tf_draft_persist_ws_bytes(const TfDraftModel* model);
+int tf_draft_persist_supported(const TfDraftModel* model, int n, int kv_len);
+int tf_draft_forward_68m_persist(const TfDraftModel* model, const TfDraftCache* cache, const int64_t* ids, int n, int slot0,
+                                 int kv_len, float* logits_out, float* probs_out, float temperature, float top_p,
+                                 void* ws, int64_t ws_bytes, void* ctl, void* stream);
+int tf_draft_persist_tune(int key, int value);
+int tf_draft_persist_stamps(void* buf);
+int tf_draft_persist_error(const void* ctl);
+int tf_draft_persist_reset(void* ctl, void* host_mirror, int set_mirror);
+
 /* -------------------------------------------------------------------------------------------
  * Retrieval-cache build (models/cache.py:146-178 == :517-556): chunk-mean scoring, per-head
  * top-k, chunk gather.

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtriforce_hip.so")
-SOURCES = ["attn.hip", "retrieval.hip", "elementwise.hip", "sampling.hip", "offload.hip", "gemv.hip", "allreduce.hip", "draft.hip", "abi.hip"]
+SOURCES = ["attn.hip", "retrieval.hip", "elementwise.hip", "sampling.hip", "offload.hip", "gemv.hip", "allreduce.hip", "draft.hip", "draft_persist.hip", "abi.hip"]
 # -amdgpu-kernarg-preload-count: the leading pointer / scalar kernel arguments (up to 14 dwords) arrive in SGPRs with the
 # dispatch instead of through s_load + s_waitcnt at the top of every kernel (gfx950 hardware feature; the compiler keeps a
 # backward-compatible entry for firmware without it).  The decode kernels order their arguments for it (csrc/gemv.hip).

@@ -120,6 +120,15 @@ class TfDraftCache(_c.Structure):
 SIGNATURES["tf_draft_forward_ws_bytes"] = (_i64, [_c.POINTER(TfDraftModel), _i32])
 SIGNATURES["tf_draft_forward_68m"] = (_i32, [_c.POINTER(TfDraftModel), _c.POINTER(TfDraftCache), _vp, _i32, _i32, _i32, _vp,
                                              _vp, _f32, _f32, _vp, _i64, _vp])
+SIGNATURES["tf_draft_persist_ctl_bytes"] = (_i64, [])
+SIGNATURES["tf_draft_persist_ws_bytes"] = (_i64, [_c.POINTER(TfDraftModel)])
+SIGNATURES["tf_draft_persist_supported"] = (_i32, [_c.POINTER(TfDraftModel), _i32, _i32])
+SIGNATURES["tf_draft_forward_68m_persist"] = (_i32, [_c.POINTER(TfDraftModel), _c.POINTER(TfDraftCache), _vp, _i32, _i32, _i32,
+                                                     _vp, _vp, _f32, _f32, _vp, _i64, _vp, _vp])
+SIGNATURES["tf_draft_persist_tune"] = (_i32, [_i32, _i32])
+SIGNATURES["tf_draft_persist_stamps"] = (_i32, [_vp])
+SIGNATURES["tf_draft_persist_error"] = (_i32, [_vp])
+SIGNATURES["tf_draft_persist_reset"] = (_i32, [_vp, _vp, _i32])
 
 ABI_VERSION = 1
 _lib = None

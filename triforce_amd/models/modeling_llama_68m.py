@@ -76,6 +76,10 @@ class LlamaForCausalLM:
                   and isinstance(W.lm_head, ops.PackedLinear))
             self._native = ops.draft_model_struct(W.embed, W.ln1, W.wqkv, W.wo, W.ln2, W.wgu, W.wd, W.norm, W.lm_head,
                                                   self.cos, self.sin, W.H, W.D, W.eps, self.scale) if ok else None
+            # the one-launch form's control block + workspace (ops.DraftPersist) when the shape is the 68M draft's
+            self._persist = None
+            if self._native is not None and ops.DRAFT_PERSIST and ops.draft_persist_supported(self._native, 1, 1):
+                self._persist = ops.DraftPersist(self._native, self.device)
             self._native_key = key
         return self._native
 
@@ -104,7 +108,8 @@ class LlamaForCausalLM:
                 kv_len = slot0 + q_len
                 for i in range(W.L):
                     c.append_slot(i, q_len)
-            logits, p = ops.draft_forward(native, self._native_cache(c), input_ids.reshape(-1), slot0, kv_len, probs)
+            logits, p = ops.draft_forward(native, self._native_cache(c), input_ids.reshape(-1), slot0, kv_len, probs,
+                                          persist=self._persist)
             out = CausalLMOutput(logits.unsqueeze(0))
             out.probs = p
             return out

@@ -670,18 +670,63 @@ def draft_cache_struct(cache, L):
     return c
 
 
-def draft_forward(model, cache, ids, slot0, kv_len, probs=None):
+class DraftPersist:
+    """Device state of the one-launch draft forward (tf_draft_forward_68m_persist): the control block (arrival counters,
+    launch epoch, sticky error word, top-p scratch) and the activation workspace, both owned by ONE draft model — its
+    launches are stream-ordered (eager calls and graph replays of one engine).  ``mirror``: a pinned host word that
+    receives the error code without a device read (None until ``enable_mirror``)."""
+
+    def __init__(self, model, device):
+        L = hip.lib()
+        self.device = torch.device(device)
+        self.ctl = torch.zeros(int(L.tf_draft_persist_ctl_bytes()), dtype=torch.uint8, device=self.device)
+        self.ws = torch.empty(int(L.tf_draft_persist_ws_bytes(ctypes.byref(model))), dtype=torch.uint8, device=self.device)
+        self.mirror = None
+        assert self.ctl.data_ptr() % 64 == 0 and self.ws.data_ptr() % 256 == 0
+
+    def enable_mirror(self):
+        if self.mirror is None:
+            self.mirror = torch.zeros(1, dtype=torch.int32).pin_memory()
+            hip.check(hip.lib().tf_draft_persist_reset(_ptr(self.ctl), self.mirror.data_ptr(), 1), "tf_draft_persist_reset")
+        return self.mirror
+
+    def error(self):
+        """0, or 1 + the index of the edge whose wait timed out (sticky).  Reads the pinned mirror when there is one (no device
+        synchronisation), else the control block (blocking)."""
+        if self.mirror is not None:
+            return int(self.mirror[0])
+        return int(hip.lib().tf_draft_persist_error(_ptr(self.ctl)))
+
+    def reset(self):
+        hip.check(hip.lib().tf_draft_persist_reset(_ptr(self.ctl), None, 0), "tf_draft_persist_reset")
+
+
+DRAFT_PERSIST = _os.environ.get("TRIFORCE_DRAFT_PERSIST", "1") != "0"
+
+
+def draft_persist_supported(model, n, kv_len):
+    return hip.lib().tf_draft_persist_supported(ctypes.byref(model), int(n), int(kv_len)) == 0
+
+
+def draft_forward(model, cache, ids, slot0, kv_len, probs=None, persist=None):
     """tf_draft_forward_68m: ids (n,) int64 -> fp32 logits (n, vocab) [and the top-p probability row of the last token
-    when ``probs`` = (temperature, top_p)] in one native call."""
+    when ``probs`` = (temperature, top_p)] in one native call — ONE launch (tf_draft_forward_68m_persist) when ``persist``
+    (a DraftPersist) is given and the shape is one it takes, else the 13-launch chain; the two are bit-identical."""
     _dev(ids)
     n = ids.numel()
     assert ids.dtype == torch.int64 and ids.is_contiguous() and 1 <= n <= SKINNY_MAX_ROWS
     L = hip.lib()
-    nbytes = L.tf_draft_forward_ws_bytes(ctypes.byref(model), n)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=ids.device)
     logits = torch.empty(n, model.vocab, dtype=torch.float32, device=ids.device)
     p = torch.empty(model.vocab, dtype=torch.float32, device=ids.device) if probs is not None else None
     T, top_p = probs if probs is not None else (1.0, 1.0)
+    if persist is not None and DRAFT_PERSIST and draft_persist_supported(model, n, kv_len):
+        hip.check(L.tf_draft_forward_68m_persist(ctypes.byref(model), ctypes.byref(cache), _ptr(ids), n, int(slot0),
+                                                 int(kv_len), _ptr(logits), _ptr(p), float(T), float(top_p),
+                                                 _ptr(persist.ws), persist.ws.numel(), _ptr(persist.ctl), _stream()),
+                  "tf_draft_forward_68m_persist")
+        return logits, p
+    nbytes = L.tf_draft_forward_ws_bytes(ctypes.byref(model), n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=ids.device)
     hip.check(L.tf_draft_forward_68m(ctypes.byref(model), ctypes.byref(cache), _ptr(ids), n, int(slot0), int(kv_len),
                                      _ptr(logits), _ptr(p), float(T), float(top_p), _ptr(ws), nbytes, _stream()),
               "tf_draft_forward_68m")
