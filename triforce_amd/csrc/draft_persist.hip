@@ -301,9 +301,10 @@ __device__ __forceinline__ bool dp_role_qkv(DpCtx& c, int l, float* sm, float* r
         if (!dp_wait(c, 5 * (l - 1) + E_DOWN, OD_LO, OD_HI)) return false;
         const h16* xr = P.x + (int64_t)(rowv ? li : 0) * HID + 8 * g;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const half8 v = ld_act8(xr + 32 * (c0 + u));
-            b[u] = rowv ? v : zero8;
+        for (int u = 0; u < 3; ++u) b[u] = zero8;
+        if (rowv) {                                                      // (rows past n: no request at all)
+#pragma unroll
+            for (int u = 0; u < 3; ++u) b[u] = ld_act8(xr + 32 * (c0 + u));
         }
         const float tot = dp_fold_ss<32>(P.ss, red, c.tid, li);
         inv = 1.0f / sqrtf(tot / (float)HID + P.eps);
@@ -379,9 +380,10 @@ __device__ __forceinline__ bool dp_role_plain(DpCtx& c, const half8* wp, const h
     const h16* xr = xin + (int64_t)(rowv ? li : 0) * ldx + 8 * g;
     half8 b[CPW];
 #pragma unroll
-    for (int u = 0; u < CPW; ++u) {
-        const half8 v = ld_act8(xr + 32 * (c0 + u));
-        b[u] = rowv ? v : zero8;
+    for (int u = 0; u < CPW; ++u) b[u] = zero8;
+    if (rowv) {                                                          // (rows past n: no request at all)
+#pragma unroll
+        for (int u = 0; u < CPW; ++u) b[u] = ld_act8(xr + 32 * (c0 + u));
     }
     const int y_off = 16 * panel + 4 * g;
     half4 res = {0, 0, 0, 0};
@@ -440,9 +442,10 @@ __device__ __forceinline__ bool dp_role_gateup(DpCtx& c, int l, float* sm, float
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const h16* xr = P.x + (int64_t)(rowv ? li : 0) * HID + 8 * g;
 #pragma unroll
-    for (int u = 0; u < 6; ++u) {
-        const half8 v = ld_act8(xr + 32 * (c0 + u));
-        b[u] = rowv ? v : zero8;
+    for (int u = 0; u < 6; ++u) b[u] = zero8;
+    if (rowv) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) b[u] = ld_act8(xr + 32 * (c0 + u));
     }
     const float tot = dp_fold_ss<16>(P.ss, red, c.tid, li);
     const float inv = 1.0f / sqrtf(tot / (float)HID + P.eps);
@@ -586,11 +589,13 @@ __device__ __forceinline__ bool dp_role_attn(DpCtx& c, int l, unsigned char* sme
     }
     __syncthreads();
     dp_stamp(c);
-    // softmax: wave owns rows 2w, 2w + 1
+    // softmax: wave owns rows w, w + 8; rows past sq are skipped (their P rows stay whatever LDS held: an MFMA output row
+    // depends on its own A row only, and rows past sq are never stored)
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-        const int row = wave * 2 + rr;
-        const int kmax = (row < sq) ? (kv_len - sq + row) : -1;          // bottom-right causal
+        const int row = wave + DP_WAVES * rr;
+        if (row >= sq) continue;
+        const int kmax = kv_len - sq + row;                              // bottom-right causal
         float mloc = -1.0e30f;
         for (int j = lane; j <= kmax; j += 64) mloc = fmaxf(mloc, sS[(size_t)row * kvp + j]);
         const float mx = wave_max(mloc);
@@ -664,8 +669,8 @@ struct DpTopp {                                                          // LDS
     u64 zpart[DP_WAVES];
     float wmax[DP_WAVES];
     int red_i[DP_WAVES];
-    u64 S, tau, nkeep, zk, Z;
-    unsigned ties;
+    u64 S, tau, nkeep, zk, Z, hsel;
+    unsigned ties, nlist;
     int digit;                                                           // >= 0 boundary bin, -1 keep everything, -2 below the candidate cut
     long long istar;                                                     // index of the last kept tie (tie ranking)
 };
@@ -687,38 +692,49 @@ __device__ __forceinline__ void dp_hist_add(DpTopp* sh, bool active, int digit, 
         if (count) atomicAdd(&sh->cnt[DP_HB(digit)], 1u);
     }
 }
-// One wavefront scans 1024 bins from the top: lane l holds the masses of bins [16l, 16l+16).  Names the bin d with
-// S(d) <= tau < S(d) + mass(d), S(d) = base + mass of the bins above d.  found (wave-uniform), digit, S(d), mass(d).
-__device__ __forceinline__ bool dp_scan(const u64 (&h)[16], u64 base, u64 tau, int lane, int& digit, u64& Sd, u64& hd) {
-    u64 tot = 0ull;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) tot += h[k];
-    u64 inc = tot;                                                       // inclusive suffix sum over the lanes
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned lo = (unsigned)__shfl_down((int)(unsigned)inc, o, 64);
-        const unsigned hi = (unsigned)__shfl_down((int)(unsigned)(inc >> 32), o, 64);
-        if (lane + o < 64) inc += ((u64)hi << 32) | lo;
-    }
+// Inclusive prefix sum of a 64-bit value over the 64 lanes of a wave on the DPP path (row shifts inside the rows of 16, then
+// the two row broadcasts): 6 steps of two v_mov_dpp + a 64-bit add.  (__shfl_* is ds_bpermute — an LDS round trip per step
+// and per 32-bit half: the one-wave scan of the first build spent more than a microsecond per round in them.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u64 dp_dpp_add(u64 v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    return v + (((u64)hi << 32) | lo);
+}
+__device__ __forceinline__ u64 dp_wave_prefix_u64(u64 v) {
+    v = dp_dpp_add<0x111, 0xf>(v);                                       // row_shr:1
+    v = dp_dpp_add<0x112, 0xf>(v);                                       // row_shr:2
+    v = dp_dpp_add<0x114, 0xf>(v);                                       // row_shr:4
+    v = dp_dpp_add<0x118, 0xf>(v);                                       // row_shr:8
+    v = dp_dpp_add<0x142, 0xa>(v);                                       // row_bcast:15 -> rows 1, 3
+    v = dp_dpp_add<0x143, 0xc>(v);                                       // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// All 512 threads scan 1024 bins from the top: thread t holds the masses of bins 1023 - 2t (hA) and 1022 - 2t (hB).  Names the
+// bin d with S(d) <= tau < S(d) + mass(d), S(d) = base + mass of the bins above d: the one thread that owns it writes
+// tp->digit / tp->S / tp->hsel (tp->digit must be -1 on entry).  Two barriers; the caller reads the result behind them.
+__device__ __forceinline__ void dp_scan512(DpTopp* tp, u64 hA, u64 hB, u64 base, u64 tau, int tid, int lane, int wave) {
+    const u64 tot = hA + hB;
+    const u64 inc = dp_wave_prefix_u64(tot);
+    if (lane == 63) tp->zpart[wave] = inc;
+    __syncthreads();
     u64 S = base + (inc - tot);
-    int found = -1;
-    u64 Sf = 0ull, hf = 0ull;
 #pragma unroll
-    for (int k = 15; k >= 0; --k) {
-        if (found < 0 && h[k] != 0ull && S <= tau && tau - S < h[k]) {
-            found = k;
-            Sf = S;
-            hf = h[k];
+    for (int k = 0; k < DP_WAVES; ++k)
+        if (k < wave) S += tp->zpart[k];
+    if (hA != 0ull && S <= tau && tau - S < hA) {
+        tp->digit = 1023 - 2 * tid;
+        tp->S = S;
+        tp->hsel = hA;
+    } else {
+        S += hA;
+        if (hB != 0ull && S <= tau && tau - S < hB) {
+            tp->digit = 1022 - 2 * tid;
+            tp->S = S;
+            tp->hsel = hB;
         }
-        S += h[k];
     }
-    const u64 hit = __ballot(found >= 0);
-    if (!hit) return false;
-    const int src = __ffsll((long long)hit) - 1;
-    digit = 16 * src + __shfl(found, src, 64);
-    Sd = dp_shfl_u64(Sf, src);
-    hd = dp_shfl_u64(hf, src);
-    return true;
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -961,13 +977,22 @@ __global__ __launch_bounds__(DP_THREADS) void draft_persist_kernel(DpParams P) {
     if (w == 0 && tid == 0) st4u(&P.ctl->epoch, c.epoch + 1u);           // every workgroup has passed its last wait's arrival
 
     // ---------------- top-p, part (b): every workgroup finds the boundary of the WHOLE row ----------------
-    // The row's e values are staged in LDS, float4 f = tid + 512 it owned by thread tid (nobody else reads them: no barrier);
-    // ascending index = (it, tid, j) lexicographic — only the tie ranking at the boundary needs it.
+    // Round 1 (bits 29..20) comes from the global histogram.  The row's e values are read once: every thread keeps its 64
+    // (float4 f = tid + 512 it; ascending index = (it, tid, j)) in registers, parks them in LDS (nobody else reads them: no
+    // barrier) and files the entries of the boundary bin in a LIST.  A real row leaves a few hundred entries there, so rounds 2
+    // and 3 walk the list (<= 2 entries per thread) instead of the row; a list that overflows (flat rows: thousands of entries
+    // in one bin) falls back to walking the parked row.  All loads — histogram, total, row — are requested before anything waits.
     constexpr int NIT = 16;                                              // 16 x 512 x 4 = 32768 entries
+    constexpr int LIST_CAP = 1024;
     f32x4* mine = reinterpret_cast<f32x4*>(role_smem + 16384) + tid;     // entry block it at mine[512 * it]
+    u64* list = reinterpret_cast<u64*>(role_smem + 16384 + 32768 * 4);   // [LIST_CAP] (pattern << 32) | index
+    const int nf4 = V / 4;
+    f32x4 ev[NIT];
     {
-        const int nf4 = V / 4;
-        f32x4 ev[NIT];
+        const u64 gA = ld8(&P.ctl->ghist[par][1023 - 2 * tid]), gB = ld8(&P.ctl->ghist[par][1022 - 2 * tid]);
+        u64 Z = 0ull;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Z += ld8(&P.ctl->gz[par][k][0]);     // (wave-uniform addresses: one request each)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int f = tid + DP_THREADS * it;
@@ -977,114 +1002,121 @@ __global__ __launch_bounds__(DP_THREADS) void draft_persist_kernel(DpParams P) {
                 ev[it] = __builtin_bit_cast(f32x4, v);
             }
         }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) mine[DP_THREADS * it] = ev[it];
-    }
-    dp_stamp(c);
-    // round 1 from the global histogram
-    if (wave == 0) {
-        u64 h[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) h[k] = ld8(&P.ctl->ghist[par][16 * lane + k]);
-        u64 zs = lane < 8 ? ld8(&P.ctl->gz[par][lane][0]) : 0ull;
-        const u64 Z = dp_wave_sum_u64(zs);
         const double t = (double)top_p * (double)Z;
         const u64 tau = (t >= 18446744073709549568.0) ? ~0ull : __double2ull_rd(t);
-        int d = -1;
-        u64 Sd = 0ull, hd = 0ull;
-        const bool hit = dp_scan(h, 0ull, tau, lane, d, Sd, hd);
-        if (lane == 0) {
+        if (tid == 0) {
             tp->tau = tau;
             tp->Z = Z;
             tp->zk = Z;
-            tp->S = Sd;
-            tp->digit = hit ? d : (tau < Z ? -2 : -1);
+            tp->S = 0ull;
+            tp->digit = -1;
             tp->ties = 0u;
             tp->nkeep = 0ull;
+            tp->nlist = 0u;
         }
+        dp_scan512(tp, gA, gB, 0ull, tau, tid, lane, wave);              // (its first barrier orders the initialisation above)
+        if (tid == 0 && tp->digit < 0 && tau < Z) tp->digit = -2;        // crossing below the candidate cut
     }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) mine[DP_THREADS * it] = ev[it];
     __syncthreads();
-    // one local round: bins dig(b) over the entries with sel(b), scanned from base tp->S.  A float4 none of whose entries is
-    // selected costs a few instructions (the usual case: a language model's row is peaked and the boundary bin holds a few entries)
-    auto local_round = [&](auto sel, auto dig, bool last) {
-#pragma unroll 1
-        for (int it = 0; it < NIT; ++it) {
-            const f32x4 x = mine[DP_THREADS * it];
-            bool in[4];
-            bool any = false;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                in[j] = sel(__float_as_uint(x[j]));
-                any |= in[j];
-            }
-            if (__ballot(any)) {
-                // (plain per-lane LDS atomics under the execution mask: a float4 without a selected entry costs a compare and
-                //  a skipped branch per entry.  The pre-summed form of dp_hist_add — ballots and shuffles per entry, for every
-                //  lane of the wave — made a row with a few hundred boundary-bin entries cost 13 us here.)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (in[j]) {
-                        const u64 m = dp_fix(x[j]);
-                        if (m != 0ull) {
-                            const int d = dig(__float_as_uint(x[j]));
-                            atomicAdd(&tp->hist[DP_HB(d)], m);
-                            if (last) atomicAdd(&tp->cnt[DP_HB(d)], 1u);
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (wave == 0) {
-            u64 h[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                h[k] = tp->hist[DP_HB(16 * lane + k)];
-                tp->hist[DP_HB(16 * lane + k)] = 0ull;
-            }
-            int d = -1;
-            u64 Sd = 0ull, hd = 0ull;
-            const bool hit = dp_scan(h, tp->S, tp->tau, lane, d, Sd, hd);
-            unsigned T = 0u;
-            if (hit && last) T = tp->cnt[DP_HB(d)];
-            if (last) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) tp->cnt[DP_HB(16 * lane + k)] = 0u;
-            }
-            if (lane == 0) {
-                tp->digit = hit ? d : -1;
-                if (hit) {
-                    tp->S = Sd;
-                    if (last) {
-                        const u64 m = hd / (u64)T;                        // all ties share one pattern, hence one mass
-                        u64 nk = (tp->tau - Sd) / m + 1ull;
-                        if (nk > (u64)T) nk = T;
-                        tp->ties = T;
-                        tp->nkeep = nk;
-                        tp->zk = Sd + nk * m;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    };
     dp_stamp(c);
     int d1 = tp->digit;
-    if (d1 == -2) {                                                      // boundary below the candidate cut (kept exact): all entries
+    const u64 tau = tp->tau;
+    // one round over the parked row: bins dig(b) over the entries with sel(b) (hist / cnt are zero on entry)
+    auto row_round = [&](auto sel, auto dig, bool last) {
+#pragma unroll 2
+        for (int it = 0; it < NIT; ++it) {
+            const f32x4 x = mine[DP_THREADS * it];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (sel(__float_as_uint(x[j]))) {
+                    const u64 m = dp_fix(x[j]);
+                    if (m != 0ull) {
+                        const int d = dig(__float_as_uint(x[j]));
+                        atomicAdd(&tp->hist[DP_HB(d)], m);
+                        if (last) atomicAdd(&tp->cnt[DP_HB(d)], 1u);
+                    }
+                }
+            }
+        }
+    };
+    // scan the bins a round filled (and clear them), from base tp->S; the last round also resolves the ties at the boundary
+    auto finish_round = [&](bool last) {
         __syncthreads();
-        if (tid == 0) tp->S = 0ull;
-        __syncthreads();
-        local_round([](unsigned) { return true; }, [](unsigned b) { return (int)(b >> 20); }, false);
+        const int bA = DP_HB(1023 - 2 * tid), bB = DP_HB(1022 - 2 * tid);
+        const u64 hA = tp->hist[bA], hB = tp->hist[bB];
+        tp->hist[bA] = 0ull;
+        tp->hist[bB] = 0ull;
+        const u64 base = tp->S;
+        if (tid == 0) tp->digit = -1;
+        dp_scan512(tp, hA, hB, base, tau, tid, lane, wave);
+        if (last) {
+            const int d = tp->digit;
+            if (d >= 0 && (d == 1023 - 2 * tid || d == 1022 - 2 * tid)) {
+                const unsigned T = tp->cnt[DP_HB(d)];
+                const u64 m = tp->hsel / (u64)T;                          // all ties share one pattern, hence one mass
+                u64 nk = (tau - tp->S) / m + 1ull;
+                if (nk > (u64)T) nk = T;
+                tp->ties = T;
+                tp->nkeep = nk;
+                tp->zk = tp->S + nk * m;
+            }
+            __syncthreads();
+            tp->cnt[bA] = 0u;
+            tp->cnt[bB] = 0u;
+        }
+    };
+    if (d1 == -2) {                                                      // (kept exact; unreachable for the cut of part (a)): all entries
+        row_round([](unsigned) { return true; }, [](unsigned b) { return (int)(b >> 20); }, false);
+        finish_round(false);
         d1 = tp->digit;
     }
     unsigned ustar = 0u, ties = 0u;
     u64 nkeep = 0ull;
     if (d1 >= 0) {
-        local_round([d1](unsigned b) { return (int)(b >> 20) == d1; }, [](unsigned b) { return (int)((b >> 10) & 1023u); }, false);
+        // file the boundary bin's entries (pattern, index) from the registers
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned b = __float_as_uint(ev[it][j]);
+                if ((int)(b >> 20) == d1 && dp_fix(ev[it][j]) != 0ull) {
+                    const unsigned at = atomicAdd(&tp->nlist, 1u);
+                    if (at < (unsigned)LIST_CAP) list[at] = ((u64)b << 32) | (unsigned)(4 * (tid + DP_THREADS * it) + j);
+                }
+            }
+        __syncthreads();
+        const unsigned nlist = tp->nlist;
+        const bool use_list = nlist <= (unsigned)LIST_CAP;
         dp_stamp(c);
+        // ---- round 2: bits 19..10 inside the boundary bin ----
+        if (use_list) {
+            for (unsigned i = tid; i < nlist; i += DP_THREADS) {
+                const unsigned b = (unsigned)(list[i] >> 32);
+                atomicAdd(&tp->hist[DP_HB((int)((b >> 10) & 1023u))], dp_fix(__uint_as_float(b)));
+            }
+        } else {
+            row_round([d1](unsigned b) { return (int)(b >> 20) == d1; }, [](unsigned b) { return (int)((b >> 10) & 1023u); }, false);
+        }
+        finish_round(false);
         const unsigned pre = ((unsigned)d1 << 10) | (unsigned)tp->digit;
-        local_round([pre](unsigned b) { return (b >> 10) == pre; }, [](unsigned b) { return (int)(b & 1023u); }, true);
+        dp_stamp(c);
+        // ---- round 3: bits 9..0, with tie counts ----
+        if (use_list) {
+            for (unsigned i = tid; i < nlist; i += DP_THREADS) {
+                const unsigned b = (unsigned)(list[i] >> 32);
+                if ((b >> 10) == pre) {
+                    atomicAdd(&tp->hist[DP_HB((int)(b & 1023u))], dp_fix(__uint_as_float(b)));
+                    atomicAdd(&tp->cnt[DP_HB((int)(b & 1023u))], 1u);
+                }
+            }
+        } else {
+            row_round([pre](unsigned b) { return (b >> 10) == pre; }, [](unsigned b) { return (int)(b & 1023u); }, true);
+        }
+        finish_round(true);
         ustar = (pre << 10) | (unsigned)tp->digit;
+        __syncthreads();
         ties = tp->ties;
         nkeep = tp->nkeep;
     }
@@ -1093,7 +1125,7 @@ __global__ __launch_bounds__(DP_THREADS) void draft_persist_kernel(DpParams P) {
     const bool rank_ties = d1 >= 0 && nkeep < (u64)ties;
     long long istar = -1;
     if (rank_ties) {
-        // index of the nkeep-th tie in index order: block-wide exclusive scan per entry block
+        // index of the nkeep-th tie in index order: block-wide exclusive scan per entry block of the parked row
         int basecnt = 0;
         if (tid == 0) tp->istar = -1;
         __syncthreads();
@@ -1153,7 +1185,7 @@ size_t dp_lds_bytes(int kv_len) {
     const size_t kvp = (size_t)((kv_len + 31) & ~31), PS = kvp + DP_KPAD;
     const size_t attn = kvp * (HD + DP_KPAD) * 2 + HD * PS * 2 + 2 * 16 * PS * 2 + 16 * kvp * 4 + 64;
     const size_t gemm = 16384 + 16 * (HID + 8) * 2;                       // merge scratch + normalised rows of lm_head
-    const size_t topp = 16384 + (size_t)32768 * 4;                        // select scratch + the staged row
+    const size_t topp = 16384 + (size_t)32768 * 4 + 1024 * 8;             // select scratch + the parked row + the boundary-bin list
     size_t m = attn > gemm ? attn : gemm;
     if (topp > m) m = topp;
     return 64 + ((m + 15) & ~(size_t)15);

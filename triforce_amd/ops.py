@@ -683,6 +683,14 @@ class DraftPersist:
         self.ws = torch.empty(int(L.tf_draft_persist_ws_bytes(ctypes.byref(model))), dtype=torch.uint8, device=self.device)
         self.mirror = None
         assert self.ctl.data_ptr() % 64 == 0 and self.ws.data_ptr() % 256 == 0
+        self.enable_mirror()
+
+    def check(self):
+        """Raise if a launch on this control block has timed out (its outputs are NaN from then on): one plain host load."""
+        if self.mirror is not None and int(self.mirror[0]) != 0:
+            raise hip.TriforceHipError(f"one-launch draft forward: wait on edge {int(self.mirror[0]) - 1} timed out "
+                                       "(a workgroup never became resident, or an arrival was lost); outputs are NaN until "
+                                       "DraftPersist.reset()")
 
     def enable_mirror(self):
         if self.mirror is None:

@@ -526,6 +526,9 @@ class TriForceRunner:
         count, pred, reason, consumed = rec.read(4)                      # the one host read of the outer step
         if self.health is not None:
             self.health()
+        dp = getattr(getattr(eng, "draft", None), "_persist", None)                        # one-launch draft forward: pinned mirror of its error word
+        if dp is not None:
+            dp.check()
         if self.inclusive_accept and reason == 1 and generated[g2 - 1] == self.eos:
             # TP loop only: an eos accepted as the LAST drafted token ends the loop before the bonus sample
             # (decoding.py:357-360,382-383); the on-chip loop — and tf_accept_chain — go on to the bonus token (:127)
