@@ -121,16 +121,19 @@ def test_one_launch_draft_graph_replay_and_soak(sd68, monkeypatch):
     assert m1._persist.error() == 0
 
 
-@pytest.mark.parametrize("kind", ["ties", "flat", "peaked"])
+@pytest.mark.parametrize("kind", ["ties", "ties8", "flat", "peaked"])
 def test_one_launch_top_p_on_degenerate_rows(kind, monkeypatch):
     """Rows the exact select must get right bit for bit: `ties` — lm_head with 16 distinct rows repeated (2 000 entries share
-    every logit: the boundary falls inside a tie group and the ties are ranked by index), `flat` — lm_head = 0 (32 000 equal
+    every logit: the boundary falls inside a tie group and the ties are ranked by index — through the parked row, the list
+    overflows; `ties8`: tie groups of 8, ranked through the boundary-bin list), `flat` — lm_head = 0 (32 000 equal
     entries), `peaked` — one dominant logit (a trained draft's usual row)."""
     cfg = _cfg()
     sd = dict(specs.random_state_dict(cfg, 23, head_std=0.05))
     head = sd["lm_head.weight"].clone()
     if kind == "ties":
         head = head[:16].repeat(2000, 1)
+    elif kind == "ties8":                                              # 4 000 tie groups of 8, sharper logits: the boundary cuts a
+        head = (head[:4000] * 4.0).repeat_interleave(8, dim=0)         # group that fits the boundary-bin list (ranked through it)
     elif kind == "flat":
         head.zero_()
     else:

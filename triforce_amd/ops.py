@@ -487,8 +487,13 @@ ATTN_TIMER_EVERY = max(1, int(_os.environ.get("TRIFORCE_ATTN_TIMER_EVERY", "8"))
 _attn_calls = 0
 
 
+_NSPLIT_FORCE = int(_os.environ.get("TRIFORCE_ATTN_NSPLIT", "0"))      # A/B only (tools/tp_shard_bench.py): > 0 overrides the rule
+
+
 @functools.lru_cache(maxsize=4096)
 def _pick_nsplit(H, sk):
+    if _NSPLIT_FORCE > 0:
+        return max(1, min(_NSPLIT_FORCE, (int(sk) + 15) // 16))
     return hip.lib().tf_attn_decode_pick_nsplit(H, sk)
 
 
