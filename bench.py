@@ -517,7 +517,8 @@ def pmc_traffic(alg_bytes, H, D):
         return {"traffic": None}
     f, j = best
     return {"traffic": j["traffic_bytes_per_launch"], "traffic_unit": "bytes/launch",
-            "traffic_source": os.path.relpath(f, ROOT), "traffic_over_algorithmic": j["traffic_over_algorithmic"]}
+            "traffic_source": os.path.relpath(f, ROOT), "traffic_measured_on": j.get("measured_on"),
+            "traffic_over_algorithmic": j["traffic_over_algorithmic"]}
 
 
 def attn_roofline(timer, retrieval_rows, H, D):
@@ -540,6 +541,42 @@ def attn_roofline(timer, retrieval_rows, H, D):
     return roof
 
 
+def block_stats(stamps, blocks=10):
+    """mean / stdev of ms per step over `blocks` equal blocks of the timed steps (host stamps behind each step's record read):
+    what a sub-1 % claim has to be read against.  None below 2 steps per block."""
+    n = len(stamps) - 1
+    if n < 2 * blocks:
+        return None
+    per = n // blocks
+    ms = [(stamps[(b + 1) * per] - stamps[b * per]) / per * 1e3 for b in range(blocks)]
+    mean = sum(ms) / blocks
+    sd = (sum((x - mean) ** 2 for x in ms) / (blocks - 1)) ** 0.5
+    return {"blocks": blocks, "steps_per_block": per, "mean": round(mean, 3), "stdev": round(sd, 3), "min": round(min(ms), 3),
+            "max": round(max(ms), 3), "rel_stdev": round(sd / mean, 5)}
+
+
+def operating_points(label_cfg):
+    """Other points of the acceptance dial, from the newest committed sweep of this workload (tools/acceptance_sweep.py: one
+    prefill, nine (draft, retrieval) acceptance settings): three of them ride in the line beside the configured one."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*acceptance_sweep*.json")))
+    for f in reversed(files):
+        try:
+            j = json.load(open(f))
+            pts = j["points"]
+        except Exception:
+            continue
+        want = [(0.5, 0.8), (0.7, 0.9), (0.9, 0.95), (0.9, 0.96)]
+        pick = [p for p in pts if (p.get("requested_draft_acc"), p.get("requested_retrieval_acc")) in want]
+        if not pick:
+            continue
+        keys = ("requested_draft_acc", "requested_retrieval_acc", "tokens_per_s", "tokens_per_step", "ms_per_step", "avg_accepted_len",
+                "per_token_acceptance_target", "per_token_acceptance_middle", "inner_iterations_per_step")
+        return {"source": os.path.relpath(f, ROOT), "measured_on": j.get("measured_on"), "workload": j.get("workload", label_cfg),
+                "points": [{k: p[k] for k in keys if k in p} for p in pick]}
+    return None
+
+
 def timed_steps(run, steps, eager_every=0, sample_attn=False):
     """Exactly ``steps`` outer iterations bracketed by device syncs -> dict of counters over the timed region.
     eager_every = N > 0: every N-th target verify runs eagerly (instead of its hipGraph) so that its attention launches
@@ -551,17 +588,20 @@ def timed_steps(run, steps, eager_every=0, sample_attn=False):
     ops.ATTN_TIMER = [] if sample_attn else None
     torch.cuda.synchronize()
     t1 = time.time()
+    stamps = [t1]
     for _ in range(steps):
         run.step()
+        stamps.append(time.time())       # (host clock behind the step's record read: no extra device sync)
     torch.cuda.synchronize()
     t2 = time.time()
+    stamps[-1] = t2
     timer, ops.ATTN_TIMER = ops.ATTN_TIMER, None
     run.eager_every = 0
     accepted, drafted = run.accepted_count - acc0, run.draft_count - dr0
     tests = accepted + (run.resample_count - rs0)           # accept tests the target ran (one per examined token)
     mids = run.acc_rate_middle_list[mid0:]
     inner = run.inner_iters - in0
-    return dict(seconds=t2 - t1, tokens=run.n - n0, accepted=accepted, drafted=drafted, inner=inner, timer=timer,
+    return dict(seconds=t2 - t1, tokens=run.n - n0, accepted=accepted, drafted=drafted, inner=inner, timer=timer, stamps=stamps,
                 per_token_acceptance=accepted / max(tests, 1),
                 middle_acceptance=sum(mids) / max(len(mids), 1))
 
@@ -679,6 +719,13 @@ def main():
         "kv_seq_len": ge.engine.kv_cache.seq_len,
         "roofline": roof, "roofline_stages": roofline_stages,
     }
+    bs = block_stats(m["stamps"])
+    if bs is not None:
+        result["ms_per_step_blocks"] = bs
+    if kind == "aligned":
+        op = operating_points(label)
+        if op is not None:
+            result["operating_points"] = op
     dp = getattr(draft, "_persist", None)
     result["draft_forward"] = {
         "form": "one launch: tf_draft_forward_68m_persist, 256 co-resident workgroups, arrival counters + READY flags"
@@ -691,7 +738,7 @@ def main():
         result["value_note"] = (f"configured-acceptance scenario: synthetic weights {wlabel} SET the draft->retrieval and "
                                 "retrieval->target acceptance rates (models/aligned.py); tokens/s and avg_accepted_len follow "
                                 "from that dial — stage_latency_us, roofline* and random_weights do not depend on it; other "
-                                "operating points: profiles/r04_acceptance_sweep.json; not comparable to the reference's "
+                                "operating points: `operating_points` (newest profiles/*acceptance_sweep*.json); not comparable to the reference's "
                                 "trained-weights 2.2x")
     elif kind == "random":
         result["value_note"] = "random-init weights: acceptance ~0, the loop's worst case (gamma inner iterations per token)"

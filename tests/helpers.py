@@ -24,6 +24,42 @@ def note(msg):
         pass
 
 
+def record(check, used, **info):
+    """One row of the tolerance table (profiles/r06_parity_table.md): which test, which kind of check, how
+    much of its bound the measured deviation used (1.0 = at the bound), and the raw figures.  Appended to
+    gpurun_out/parity_table.jsonl; tools/parity_table.py folds the file into the table."""
+    import json
+    row = {"test": os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], "check": check, "used": round(float(used), 5)}
+    row.update({k: (round(float(v), 9) if isinstance(v, float) else v) for k, v in info.items()})
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_table.jsonl"), "a") as f:
+            f.write(json.dumps(row) + "\n")
+    except OSError:
+        pass
+
+
+def bound(what, value, limit):
+    """`value < limit`, with the pair put on record (a bare `assert x < 2e-2` leaves no trace of how close x came)."""
+    record("bound", float(value) / float(limit), what=what, value=float(value), limit=float(limit))
+    return float(value) < float(limit)
+
+
+def close(got, want, what="", **kw):
+    """torch.testing.assert_close with the measured deviation put on record: `used` = max |d| / (atol + rtol |want|)."""
+    atol, rtol = kw.get("atol"), kw.get("rtol")
+    if atol is not None and rtol is not None and got.shape == want.shape and got.numel():
+        g, w = got.detach().float().cpu(), want.detach().float().cpu()
+        d = (g - w).abs()
+        lim = atol + rtol * w.abs()
+        ok = lim > 0
+        used = float((d[ok] / lim[ok]).max()) if bool(ok.any()) else (0.0 if float(d.max()) == 0.0 else float("inf"))
+        record("assert_close", used, what=what, max_abs=float(d.max()), mean_abs=float(d.mean()), atol=float(atol), rtol=float(rtol),
+               max_ref=float(w.abs().max()))
+    torch.testing.assert_close(got, want, **kw)
+
+
 def load_golden(name):
     return torch.load(os.path.join(GOLDEN, f"{name}.pt"), weights_only=False)
 

@@ -7,6 +7,8 @@ tests (tests/test_gpu_ops.py) these results are compared with.  Reference call s
 import pytest
 import torch
 
+from tests import helpers as Hh
+
 from oracle import ref_ops as R
 
 pytestmark = pytest.mark.gpu
@@ -178,7 +180,7 @@ def test_exchange_with_packed_residual_stream(rows, hidden, world, alternate):
                 assert g.error() == 0 and g.error_device() == 0
             for x, ss in zip(outs, sss):
                 assert torch.equal(x.rows(), want)
-                torch.testing.assert_close(ss[:, :rows], (want.float() ** 2).view(rows, hidden // 16, 16).sum(-1).t(),
+                Hh.close(ss[:, :rows], (want.float() ** 2).view(rows, hidden // 16, 16).sum(-1).t(),
                                            rtol=1e-5, atol=1e-6)
     finally:
         for g in group:

@@ -9,6 +9,8 @@ import math
 import pytest
 import torch
 
+from tests import helpers as Hh
+
 from oracle import ref_ops as R
 
 pytestmark = pytest.mark.gpu
@@ -34,6 +36,9 @@ def ulp_report(name, got, want, max_ulp_frac=2e-3, atol=0.0, ulps=1):
     ulp = torch.maximum(want.abs(), torch.tensor(6.1e-5)) * 2 ** -10
     bad = diff > (ulp * (ulps + 0.01) + atol)
     frac = (diff > 0).float().mean().item()
+    Hh.record("ulp_report", float((diff / (ulp * (ulps + 0.01) + atol)).max()), what=name, max_abs=float(diff.max()),
+              mean_abs=float(diff.mean()), ulps=ulps, atol=float(atol), frac_differing=frac, frac_allowed=max_ulp_frac,
+              frac_used=frac / max_ulp_frac, max_ref=float(want.abs().max()))
     assert not bad.any(), f"{name}: {int(bad.sum())} elements off by >{ulps} ulp, max diff {diff.max().item():.3e}"
     assert frac <= max_ulp_frac, f"{name}: {frac:.4%} elements differ (allowed {max_ulp_frac:.2%})"
 
@@ -148,7 +153,7 @@ def test_attn_decode_matches_oracle(sq, sk, H, D, nsplit):
     q, k, v, kd, vd = _attn_inputs(sq, sk, H, D, seed=10 + sq + sk)
     want = R.attn_kvcache(q, k, v, scale).reshape(sq, H * D)
     got = ops.attn_decode(q.to(DEV), kd, vd, sk, scale, nsplit=nsplit)
-    torch.testing.assert_close(got.float().cpu(), want.float(), atol=DECODE_ATOL, rtol=DECODE_RTOL)
+    Hh.close(got.float().cpu(), want.float(), atol=DECODE_ATOL, rtol=DECODE_RTOL)
 
 
 @pytest.mark.parametrize("sq,sk,H,D,nsplit", ATTN_CASES + [(7, 4103, 32, 128, 8), (17, 12305, 16, 128, 48),
@@ -208,11 +213,11 @@ def test_attn_decode_token_major_and_device_seqlen():
     q, k, v, kd, vd = _attn_inputs(sq, sk, H, D, seed=99, head_major=False, cap=cap)
     want = R.attn_kvcache(q, k[:sk], v[:sk], scale).reshape(sq, H * D)
     got = ops.attn_decode(q.to(DEV), kd, vd, sk, scale)
-    torch.testing.assert_close(got.float().cpu(), want.float(), atol=DECODE_ATOL, rtol=DECODE_RTOL)
+    Hh.close(got.float().cpu(), want.float(), atol=DECODE_ATOL, rtol=DECODE_RTOL)
     # key count read from device memory, launch sized by the capacity
     skd = torch.tensor([sk], dtype=torch.int32, device=DEV)
     got2 = ops.attn_decode(q.to(DEV), kd, vd, cap, scale, sk_dev=skd, nsplit=4)
-    torch.testing.assert_close(got2.float().cpu(), want.float(), atol=DECODE_ATOL, rtol=DECODE_RTOL)
+    Hh.close(got2.float().cpu(), want.float(), atol=DECODE_ATOL, rtol=DECODE_RTOL)
 
 
 def test_attn_decode_online_softmax_rescale_is_exercised():
@@ -228,7 +233,7 @@ def test_attn_decode_online_softmax_rescale_is_exercised():
     want = R.attn_kvcache(q, k, v, scale).reshape(sq, H * D)
     for ns in (1, 2, 5):
         got = ops.attn_decode(q.to(DEV), kd, vd, sk, scale, nsplit=ns)
-        torch.testing.assert_close(got.float().cpu(), want.float(), atol=DECODE_ATOL, rtol=DECODE_RTOL)
+        Hh.close(got.float().cpu(), want.float(), atol=DECODE_ATOL, rtol=DECODE_RTOL)
 
 
 @pytest.mark.parametrize("sq,sk,H,D", [(128, 640, 2, 128), (128, 128, 2, 128), (64, 64, 3, 64), (100, 1000, 2, 128),
@@ -240,7 +245,7 @@ def test_attn_prefill_block_equals_oracle(sq, sk, H, D):
     q, k, v, kd, vd = _attn_inputs(sq, sk, H, D, seed=3 + sq)
     want = R.attn_kvcache(q, k, v, scale).reshape(sq, H * D)
     got = ops.attn_prefill(q.to(DEV), kd, vd, sk, scale)
-    torch.testing.assert_close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+    Hh.close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
 
 
 @pytest.mark.parametrize("sq,sk,H,D", [(300, 700, 2, 128), (1024, 1024, 4, 128), (1024, 5000, 8, 128), (1000, 3333, 4, 64),
@@ -258,10 +263,10 @@ def test_attn_prefill_one_launch_equals_oracle_and_block_by_block(sq, sk, H, D, 
     got = ops.attn_prefill(qd, kd, vd, sk, scale)
     monkeypatch.setattr(ops, "ATTN_PREFILL_ONE_LAUNCH", False)
     blocks = ops.attn_prefill(qd, kd, vd, sk, scale)
-    torch.testing.assert_close(got.float(), blocks.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+    Hh.close(got.float(), blocks.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
     if sq * sk <= 1024 * 5000:                       # the CPU oracle materialises sq x sk scores per head
         want = R.attn_kvcache(q, k, v, scale).reshape(sq, H * D)
-        torch.testing.assert_close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+        Hh.close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
     monkeypatch.setattr(ops, "ATTN_PREFILL_ONE_LAUNCH", True)
     kd2 = kd.clone()
     kd2[:, sk - 1] += 1.0
@@ -279,7 +284,7 @@ def test_attn_block_splits_agree_and_match_decode_kernel():
     ref = torch.cat([ops.attn_decode(qd[r:r + 32].contiguous(), kd, vd, sk - (sq - r - 32), scale) for r in (0, 32, 64)])
     for ns in (1, 3, 16):
         got = ops.attn_block(qd, kd, vd, sk, scale, nsplit=ns)
-        torch.testing.assert_close(got.float(), ref.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+        Hh.close(got.float(), ref.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
 
 
 def test_attn_block_full_size_prefill_chunk():
@@ -295,7 +300,7 @@ def test_attn_block_full_size_prefill_chunk():
     qd = torch.randn(sq, H, D, generator=g, device=DEV, dtype=torch.float16)
     got = ops.attn_block(qd, kd, vd, sk, scale)
     ref = torch.cat([ops.attn_decode(qd[r:r + 32].contiguous(), kd, vd, sk - (sq - r - 32), scale) for r in range(0, sq, 32)])
-    torch.testing.assert_close(got.float(), ref.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+    Hh.close(got.float(), ref.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
     kd[:, sk - 1] += 4.0
     got2 = ops.attn_block(qd, kd, vd, sk, scale)
     assert torch.equal(got2[:sq - 1], got[:sq - 1]) and not torch.equal(got2[sq - 1], got[sq - 1])
@@ -312,10 +317,10 @@ def test_attn_decode_full_size_cfg2_layer():
     q = torch.randn(sq, H, D, generator=g, device=DEV, dtype=torch.float16)
     got = ops.attn_decode(q, kd, vd, sk, scale)
     want = R.attn_kvcache(q.cpu(), kd.permute(1, 0, 2).cpu(), vd.permute(1, 0, 2).cpu(), scale).reshape(sq, H * D)
-    torch.testing.assert_close(got.float().cpu(), want.float(), atol=DECODE_ATOL, rtol=DECODE_RTOL)
+    Hh.close(got.float().cpu(), want.float(), atol=DECODE_ATOL, rtol=DECODE_RTOL)
     # size-independent property: attention is linear in V (doubling V is exact in fp16: the same bits, one exponent up)
     got2 = ops.attn_decode(q, kd, vd * 2, sk, scale)
-    torch.testing.assert_close(got2.float(), got.float() * 2, atol=2 * DECODE_ATOL, rtol=DECODE_RTOL)
+    Hh.close(got2.float(), got.float() * 2, atol=2 * DECODE_ATOL, rtol=DECODE_RTOL)
 
 
 @pytest.mark.parametrize("sq,kv_len,H", [(1, 5, 2), (3, 64, 12), (9, 259, 12), (64, 200, 12), (7, 130, 3), (64, 314, 12), (128, 378, 12), (17, 384, 4),
@@ -329,7 +334,7 @@ def test_attn_rope_on_read(sq, kv_len, H):
     kr = R.apply_rope(k[:kv_len], cos, sin, torch.arange(kv_len))
     want = R.attn_kvcache(q, kr, v[:kv_len], scale).reshape(sq, H * D)
     got = ops.attn_rope_on_read(q.to(DEV), kd, vd, cos.to(DEV), sin.to(DEV), kv_len, scale)
-    torch.testing.assert_close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+    Hh.close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
 
 
 # ------------------------------------------------------------------------------------------
@@ -515,7 +520,7 @@ def test_topp_probs_matches_oracle(V, T, P):
     for r in range(lg.shape[0]):
         sg, sw = got[r] > 0, want[r] > 0
         if torch.equal(sg, sw):
-            torch.testing.assert_close(got[r], want[r], rtol=2e-4, atol=1e-8)
+            Hh.close(got[r], want[r], rtol=2e-4, atol=1e-8)
         else:
             # the kept set may differ only at the top-p boundary, where the cumulative mass (summed in a
             # different fp32 order) is within rounding of top_p; ties must still resolve to the lower token id
@@ -691,7 +696,7 @@ def test_skinny_gemm_norm_prologue_and_residual_epilogue(M, N, K):
     ops.linear(xd, pl, ln=lnd, eps=eps, resid=buf, out=buf, ss_out=ss)
     assert torch.equal(buf, resd + yn)
     rows_ss = ss[:, :M].sum(dim=0)
-    torch.testing.assert_close(rows_ss, (buf.float() ** 2).sum(dim=1), rtol=1e-5, atol=1e-3)
+    Hh.close(rows_ss, (buf.float() ** 2).sum(dim=1), rtol=1e-5, atol=1e-3)
     if N % 32 == 0 and N <= 11008:
         w2 = rnd(256, N, seed=214, scale=0.05)
         ln2 = (1 + 0.1 * rnd(N, seed=215).float()).half().to(DEV)

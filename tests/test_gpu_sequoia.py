@@ -50,11 +50,11 @@ def test_tree_attention_matches_sdpa_oracle(sq, prefix, T, H, D, row0):
     add = torch.cat([torch.zeros(sq, prefix), RT.additive_tree_mask(gm["mask"])[row0:row0 + sq].float()], dim=-1)
     want = RT.attn_sdpa(q, k, v, add).reshape(sq, H * D)
     got = ops.attn_tree(q.to(DEV), kd, vd, sk, 1.0 / math.sqrt(D), bits, prefix, mask_row0=row0)
-    torch.testing.assert_close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+    Hh.close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
     for ns in (1, 3):                                     # split count must not matter
         got2 = ops.attn_block(q.to(DEV), kd, vd, sk, 1.0 / math.sqrt(D), nsplit=ns, tree_mask=bits, mask_row0=row0,
                               tree_start=prefix)
-        torch.testing.assert_close(got2.float(), got.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+        Hh.close(got2.float(), got.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
 
 
 def test_tree_attention_verify_shape_512_rows():
@@ -68,7 +68,7 @@ def test_tree_attention_verify_shape_512_rows():
     add = torch.cat([torch.zeros(sq, prefix), RT.additive_tree_mask(gm["mask"]).float()], dim=-1)
     want = RT.attn_sdpa(q, k, v, add).reshape(sq, H * D)
     got = ops.attn_tree(q.to(DEV), kd, vd, prefix + 512, 1.0 / math.sqrt(D), bits, prefix)
-    torch.testing.assert_close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+    Hh.close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
     # a node must not see anything but its ancestors: perturbing a non-ancestor key/value leaves its row unchanged
     node = 300
     stranger = next(j for j in range(1, 512) if gm["mask"][node, j] == 0)
@@ -168,7 +168,7 @@ def test_sample_without_replacement_matches_oracle(rows, V, k, T):
         assert len(set(got[r].tolist())) == k and int(got[r].min()) >= 0 and int(got[r].max()) < V
         q = torch.softmax(logits[r] / T, -1)
         keys = rand[r].log().float() / q
-        torch.testing.assert_close(keys[got[r]], keys[want[r]], rtol=1e-4, atol=0.0)
+        Hh.close(keys[got[r]], keys[want[r]], rtol=1e-4, atol=0.0)
         distinct = keys[want[r]].unique().numel() == k and (keys == keys[want[r]][-1]).sum() == 1
         if distinct:
             differ = (got[r] != want[r]).nonzero().flatten().tolist()

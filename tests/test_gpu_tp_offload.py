@@ -284,7 +284,7 @@ def test_oneshot_allreduce_protocol_on_one_device(world, alternate):
             for r in range(world):
                 assert torch.equal(ys[r], want_y[r])
                 want_ss = want_y[r].float().square().view(rows, hidden // 16, 16).sum(-1).t()       # (panels, rows)
-                torch.testing.assert_close(sss[r][:, :rows], want_ss, rtol=1e-5, atol=1e-6)
+                Hh.close(sss[r][:, :rows], want_ss, rtol=1e-5, atol=1e-6)
                 assert (sss[r][:, rows:] == -1.0).all()             # rows beyond the block are not touched
         assert [g.error() for g in group] == [0] * world
         with pytest.raises(AssertionError):
@@ -548,7 +548,7 @@ def test_tp_world2_on_one_device_real_kernels_and_oneshot_allreduce(alternate):
         o["stages"] = [torch.from_numpy(x) for x in o["stages"]]
         for name, ours in zip(("prefill_logits", "build_logits", "spec_logits", "verify_logits"), o["stages"]):
             gap = (ours.reshape(g[name].shape) - g[name].float()).abs().max().item()
-            assert gap < 4e-3, f"rank {r} {name}: {gap:.2e} from the reference's world-2 logits"
+            assert Hh.bound("rank logits vs the reference's world-2 golden logits", gap, 4e-3), f"rank {r} {name}: {gap:.2e} from the reference's world-2 logits"
     for x, y in zip(a["stages"], b["stages"]):
         assert torch.equal(x, y)                                  # every rank holds the same bits after each all-reduce
     assert a["tokens"] == b["tokens"] and a["counts"] == b["counts"] and a["seq_len"] == b["seq_len"]
@@ -643,7 +643,7 @@ def test_tp_world8_on_one_device_matches_the_reference_world8_logits():
         o["stages"] = [torch.from_numpy(x) for x in o["stages"]]
         for name, ours in zip(("prefill_logits", "build_logits", "spec_logits", "verify_logits"), o["stages"]):
             gap = (ours.reshape(g[name].shape) - g[name].float()).abs().max().item()
-            assert gap < 8e-3, f"rank {r} {name}: {gap:.2e} from the reference's world-8 logits"
+            assert Hh.bound("rank logits vs the reference's world-8 golden logits", gap, 8e-3), f"rank {r} {name}: {gap:.2e} from the reference's world-8 logits"
     for o in res[1:]:
         for x, y in zip(res[0]["stages"], o["stages"]):
             assert torch.equal(x, y)                              # every rank holds the same bits after each all-reduce
@@ -730,7 +730,7 @@ def test_gemm_exchange_protocol_on_one_device(world, hidden):
                 got = xs[r].rows() if packed else xs[r]
                 assert torch.equal(got, want2), (f"trip {it}, rank {r}, {rows} rows, packed={packed}: max err "
                                                  f"{(got.float() - want2.float()).abs().max()}, errors {[g.error() for g in group]}")
-                torch.testing.assert_close(sss[r][:, :rows], want2.float().square().view(rows, hidden // 16, 16).sum(-1).t(),
+                Hh.close(sss[r][:, :rows], want2.float().square().view(rows, hidden // 16, 16).sum(-1).t(),
                                            rtol=1e-5, atol=1e-6)
         assert [g.error() for g in group] == [0] * world and [g.error_device() for g in group] == [0] * world
         # error path: a poisoned control block NaN-fills the output and check() raises

@@ -250,6 +250,18 @@ def test_bench_helpers_on_cpu():
     kind, tspec, dspec, _ = bench.resolve_weights(bench.parse(["--weights", "random:3"]))
     assert (kind, tspec, dspec) == ("random", "random:4", "random:5")
     kind, tspec, _, _ = bench.resolve_weights(bench.parse(["--weights", "aligned:0.5:0.95:7"]))
+    # round 6: ms per step as mean +- stdev over 10 blocks of the timed steps (host stamps behind every step)
+    stamps = [0.0]
+    for i in range(200):
+        stamps.append(stamps[-1] + (0.027 if i < 100 else 0.028))
+    bs = bench.block_stats(stamps)
+    assert bs["blocks"] == 10 and bs["steps_per_block"] == 20 and abs(bs["mean"] - 27.5) < 1e-6
+    assert abs(bs["min"] - 27.0) < 1e-6 and abs(bs["max"] - 28.0) < 1e-6 and 0.52 < bs["stdev"] < 0.53
+    assert bench.block_stats(stamps[:20]) is None                                   # fewer than 2 steps per block
+    # ... and three other points of the acceptance dial from the newest committed sweep, with their provenance
+    op = bench.operating_points("cfg")
+    assert op is not None and op["source"].startswith("profiles/") and 1 <= len(op["points"]) <= 4
+    assert all("tokens_per_s" in p and "requested_draft_acc" in p for p in op["points"])
     assert kind == "aligned" and tspec == "aligned:0.5:0.95:7"
 
 

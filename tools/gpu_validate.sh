@@ -44,11 +44,17 @@ sys.exit(1 if bad else 0)
 PY
   echo "tp validate rc=$rc"; exit $rc
 fi
-rm -f gpurun_out/parity_notes.txt
+rm -f gpurun_out/parity_notes.txt gpurun_out/parity_table.jsonl
 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest.log
 cp gpurun_out/parity_notes.txt $O/parity_notes.txt 2>/dev/null; grep -c "" $O/parity_notes.txt
+# the tolerance table: every recorded check -> measured max / mean |d|, bound, slack
+cp gpurun_out/parity_table.jsonl $O/parity_table.jsonl 2>/dev/null; python tools/parity_table.py $O/parity_table.jsonl $O/parity_table.md --json $O/parity_table.json
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 800 $O/bench.json
+# 200 timed steps: ms_per_step as mean +- stdev over 10 blocks of 20 (what a sub-1 % claim is read against)
+python bench.py --steps 200 --warmup 5 --no-cpu-baseline --random-steps 0 --roofline-every 0 > $O/bench_200.json 2> $O/bench_200.err; echo "bench200 rc=$?"; python -c "import json;j=json.loads([l for l in open('$O/bench_200.json') if l.startswith('{')][-1]);print(j['value'],j['ms_per_step'],j.get('ms_per_step_blocks'))"
+# the draft step: 13-launch chain against the one-launch form (hipGraph replays), with the per-role timeline
+python tools/draft_persist_bench.py --rows 1 3 7 --stamps --tag validate --out $O/draft_persist.jsonl > $O/draft_persist.log 2>&1; echo "draft persist rc=$?"; grep -c "" $O/draft_persist.jsonl
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --random-steps 0 > $R/$O/bench_prof.json 2> $R/$O/bench_prof.err; echo "rocprof rc=$?"
 # target-verify / retrieval-verify launches of the split-KV kernel separated by duration cluster + priced (tracked copy -> profiles/)
@@ -69,6 +75,7 @@ python tools/pmc_mfma.py $O/pmc_mfma $O/pmc_mfma_attn_target_verify.json "tools/
 find $O/prof $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/pmc_layer_fetch $O/pmc_layer_write -name "*kernel_trace.csv" -size +20M -delete
 # the other full-size configs (BASELINE configs[2], and configs[3] at world size 1: offloading tier), only with "all"
 if [ "$1" = "all" ]; then
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --random-steps 0 --eager-comparator > $O/bench_eager_comparator.json 2> $O/bench_eager_comparator.err; echo "eager comparator rc=$?"
   python bench.py --target lwm-128K --steps 20 --warmup 5 --no-cpu-baseline --random-steps 0 > $O/bench_lwm.json 2> $O/bench_lwm.err; echo "lwm rc=$?"; tail -c 300 $O/bench_lwm.json
   python bench.py --prefill 130048 --budget 12288 --gamma 16 --on-chip 9 --steps 8 --warmup 2 --no-cpu-baseline --random-steps 0 > $O/bench_offload.json 2> $O/bench_offload.err; echo "offload rc=$?"; tail -c 300 $O/bench_offload.json
   # (the 9-point acceptance sweep costs ~6 GPU-minutes: only with SWEEP=1; the tracked sweep is profiles/r04_acceptance_sweep.json)
