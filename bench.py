@@ -224,7 +224,8 @@ def stage_latencies(ge, args, device):
     # launches: the figure quoted as draft_step_us up to round 5)
     with_io = _timed(lambda: ge.graph_draft_inference(ids[:, :3], gamma_offset=2), 20)
     if getattr(ge, "tok_buf", None) is not None and hasattr(ge, "replay_draft"):
-        ge.tok_buf[:, :3].copy_(ids[:, :3])
+        with torch.inference_mode():                           # (the engine's static buffers are inference tensors)
+            ge.tok_buf[:, :3].copy_(ids[:, :3])
         replay_only = _timed(lambda: ge.replay_draft(2), 20)
     else:
         replay_only = with_io

@@ -124,6 +124,20 @@ def exchange_cost_lockstep(llm, args, device, per_graph=64, replays=5):
         return None
     rows, hid, W = args.gamma + 1, llm.hidden_size, llm.weights
     out, ok = {}, True
+    cpu_flags = dist.get_backend() != "nccl"
+
+    class _PeerFailed(Exception):
+        pass
+
+    def _agree(mine):
+        """MIN over the ranks of `mine`, in front of every collective phase: a rank that failed its set-up or a capture says so
+        HERE, where every rank meets, instead of leaving its peers inside a barrier or an exchange it will never join (the
+        collectives then no longer pair up: the probe hung, or waited out the exchange time-out and poisoned the group —
+        advisor, round 5).  Raises on every rank when any rank reports a failure."""
+        f = torch.tensor([1 if mine else 0], dtype=torch.int64, device="cpu" if cpu_flags else device)
+        dist.all_reduce(f, dist.ReduceOp.MIN)
+        if not int(f.item()):
+            raise _PeerFailed("a rank failed the exchange probe")
     try:
         packed = ops.act_packed(rows)
         a0 = torch.randn(rows, W.wo[0].K, device=device).to(torch.float16) * 0.05
@@ -165,19 +179,26 @@ def exchange_cost_lockstep(llm, args, device, per_graph=64, replays=5):
             e.record()
             torch.cuda.synchronize(device)
             return s.elapsed_time(e) / (replays * per_graph) * 1e3
-        dist.barrier()
+        _agree(True)                                             # set-up done on every rank (else: nobody enters an exchange)
         out["gemm_with_exchange_us"] = round(graph_us(with_exchange), 2)
-        dist.barrier()
+        _agree(True)
         out["gemm_alone_us"] = round(graph_us(without), 2)
         out["per_exchange_us"] = round(out["gemm_with_exchange_us"] - out["gemm_alone_us"], 2)
         out["shape"] = f"{rows} rows x K {W.wo[0].K} -> hidden {hid} (o_proj shard), {per_graph} calls per hipGraph x {replays} replays"
+    except _PeerFailed as ex:                                  # (every rank raised at the same agreement point)
+        return {"failed": str(ex)}
     except Exception as ex:                                    # a probe must never cost the bench line
         import traceback
-        ok, out = False, {"failed": f"{type(ex).__name__}: {ex}"[:300], "where": traceback.format_exc()[-600:]}
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device if dist.get_backend() == "nccl" else "cpu")
-    dist.all_reduce(flag, dist.ReduceOp.MIN)
-    if not int(flag.item()) and ok:
-        out = {"failed": "a peer rank failed the probe"}
+        out = {"failed": f"{type(ex).__name__}: {ex}"[:300], "where": traceback.format_exc()[-600:]}
+        try:
+            _agree(False)                                      # tell the peers at THEIR next agreement point
+        except _PeerFailed:
+            pass
+        return out
+    try:
+        _agree(True)                                           # the closing agreement every successful rank reaches
+    except _PeerFailed as ex:
+        return {"failed": str(ex)}
     return out
 
 
@@ -294,7 +315,7 @@ def run_tp(args, rank, world, local):
 
     ge = _DistEngine(llm)
     run = TriForceRunner(_Tok(), ge, args.gamma, top_k=-1, top_p=args.top_p, temperature=args.temp,
-                         rng=UniformSource(device, seed=args.seed), inclusive_accept=True, sync_record=tp_sync_record())
+                         rng=UniformSource(device, seed=args.seed), inclusive_accept=True, sync_record=tp_sync_record(llm))
     run.health = ge.health                                      # a timed-out exchange raises instead of emitting tokens
     # TRIFORCE_TP_REPLICATED_DECISIONS=1: no record broadcasts, the ranks' streams compared by digest (utils/decoding.ReplicaCheck)
     replicas = ReplicaCheck(device) if run.sync_record is None else None
@@ -441,6 +462,15 @@ def run_tp(args, rank, world, local):
             "allreduce_requested": getattr(args, "allreduce", "auto"),
             "allreduce_note": getattr(llm, "allreduce_note", "") or None,
             "inner_iterations_per_step": round(inner_per_step, 3), "stage_latency_us": stages,
+            # what a step costs beyond its model calls (bench.py's definition: step - [target verify + k x retrieval verify +
+            # (k + 1) x draft step]), and which launch structure the loop ran
+            "step_overhead_us": (round(max(0.0, seconds / args.steps * 1e6 - (stages["target_verify_us"] + inner_per_step *
+                                 (stages["retrieval_verify_us"] + stages["draft_step_us"]) + stages["draft_step_us"])), 1)
+                                 if stages else None),
+            "loop_structure": ("one hipGraph per inner iteration (draft step, draw, retrieval verify with its exchanges, accept "
+                               "test), records through the pinned mailbox, uniforms behind the device cursor"
+                               if run.inner is not None else
+                               "draft replay + draw + retrieval-verify replay + accept per inner iteration, device records"),
             "multi_rank": multi_rank_report(
                 per_rank, args, tcfg, world,
                 {"inner_iterations_per_step": inner_per_step, "ms_per_step": seconds / args.steps * 1e3},

@@ -394,8 +394,11 @@ int tf_mid_record_tokens(const int64_t* rec, int64_t* tokens, int tokens_len, in
  *                              out[3] = the cursor value the decision started from (the host checks its mirror).
  *   tf_accept_chain_cur      : the chain over ubuf[*cursor ...]; *cursor += out[3].
  * In ALL forms (cursor or not) what the kernel leaves for the next chain of launches on the device — the token id in
- * `tokens`, the cursor — is stored write-through (agent scope) and drained BEFORE the record `out` is stored: a host that
- * polls `out` in pinned memory may launch the next chain on ANOTHER stream the moment it sees the record. */
+ * `tokens`, the cursor — is stored write-through (agent scope) and drained BEFORE the record `out` is stored.  CONTRACT: a
+ * host that polls `out` in pinned memory may enqueue the next chain the moment it sees the record ONLY ON THE SAME STREAM
+ * (stream order then also orders the chain behind this kernel's completion).  A chain on another stream is ordered by the
+ * record alone, which the runtime knows nothing about: its first kernel would need an explicit agent-scope acquire of what it
+ * reads, and none of the entry points does that (the two-stream loop of round 5 was removed for this reason). */
 int tf_sample_inverse_cdf_cur(const float* probs, const float* ubuf, const int64_t* cursor, int off, int64_t* token_out,
                               int V, void* stream);
 int tf_middle_accept_cur(const float* p, const float* q_d, int64_t* tokens, int tokens_len, const float* ubuf,

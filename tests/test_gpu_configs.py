@@ -77,7 +77,7 @@ def test_lwm_plain_rope_theta1e7_layer_logits_match_oracle():
     _logit_check("LWM-width layer, retrieval-cache forward", got, want)
     s = pg.spec_slot                                       # rows appended by the fused RoPE epilogue: rotated K, bit for bit
     dk = (pg.k[0, :, s:].permute(1, 0, 2).cpu().float() - ogc.key_cache[0, s:].float()).abs()
-    assert Hh.bound("appended K rows, max", dk.max(), 2e-2) and Hh.bound("appended K rows, mean", dk.mean(), 2e-4)
+    assert Hh.bound("appended K rows, max", dk.max(), 8e-3) and Hh.bound("appended K rows, mean", dk.mean(), 2e-6)
     trail = want.max(-1).values - want.gather(-1, got.argmax(-1, keepdim=True))[..., 0]
     assert float(trail.max()) < GAP_TOL
     # full-cache branch (target verify): 8 rows appended behind 2 000 cached keys whose positions end at 110 000
@@ -128,7 +128,7 @@ def test_full_size_cfg2_single_layer_target_verify_matches_oracle():
     _deviation(f"configs[1] full-size single layer: {rows} rows over {S + rows} keys x 32 heads", got, want)
     _logit_check("full-size cfg2 layer, target verify", got, want)
     dk = (pkv.k[0, :, S:S + rows].permute(1, 0, 2).cpu().float() - okv.key_cache[0, S:S + rows].float()).abs()
-    assert Hh.bound("appended K rows at positions >= 124 928, max", dk.max(), 2e-2) and Hh.bound("appended K rows at positions >= 124 928, mean", dk.mean(), 2e-4), "appended K rows (RoPE at positions >= 124 928) differ"
+    assert Hh.bound("appended K rows at positions >= 124 928, max", dk.max(), 8e-3) and Hh.bound("appended K rows at positions >= 124 928, mean", dk.mean(), 2e-6), "appended K rows (RoPE at positions >= 124 928) differ"
     trail = want.max(-1).values - want.gather(-1, got.argmax(-1, keepdim=True))[..., 0]
     assert float(trail.max()) < GAP_TOL
 

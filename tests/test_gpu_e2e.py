@@ -89,12 +89,12 @@ def test_logits_and_retrieval_stages_match_oracle(name):
     _logit_check("prefill logits", lp, lo)
     pk = ge.engine.kv_cache.k.permute(0, 2, 1, 3).cpu()[:, :g["prefill"]]
     dk = (pk.float() - oeng.kv_cache.key_cache[:, :g["prefill"]].float()).abs()
-    assert Hh.bound("prefill: cached keys, max", dk.max(), 2e-2) and Hh.bound("prefill: cached keys, mean", dk.mean(), 2e-4), f"cached keys: max {dk.max():.2e} mean {dk.mean():.2e}"
+    assert Hh.bound("prefill: cached keys, max", dk.max(), 8e-3) and Hh.bound("prefill: cached keys, mean", dk.mean(), 2e-4), f"cached keys: max {dk.max():.2e} mean {dk.mean():.2e}"
     pg, og = ge.engine.graph_cache, oeng.graph_cache
     for l in range(og.layers):
         dev_scores = pg.last_scores[l].cpu()
         ds = (dev_scores.float() - og.last_scores[l].float()).abs()
-        assert Hh.bound("retrieval scores (fp16 dot of a chunk mean)", ds.max(), 3e-2), f"layer {l} retrieval scores differ by {ds.max():.3e}"
+        assert Hh.bound("retrieval scores (fp16 dot of a chunk mean)", ds.max(), 8e-3), f"layer {l} retrieval scores differ by {ds.max():.3e}"
         # top-k: exact w.r.t. the scores the device itself produced
         assert torch.equal(pg.last_idx[l].cpu().long(), R.retrieval_topk(dev_scores, og.select_sets))
         # gather: exact w.r.t. the device's indices and the device's own full cache
@@ -117,7 +117,7 @@ def test_logits_and_retrieval_stages_match_oracle(name):
     ge.graph_draft_prefill(prompt.to(DEV))
     qo = oeng.graph_draft_inference(vt[:, :3], gamma_offset=2)
     qp = ge.graph_draft_inference(vt[:, :3].to(DEV), gamma_offset=2).cpu()
-    assert Hh.bound("draft probability row (top-p)", (qo - qp).abs().max(), 5e-3), f"draft probs differ by {(qo - qp).abs().max():.3e}"
+    assert Hh.bound("draft probability row (top-p)", (qo - qp).abs().max(), 5e-4), f"draft probs differ by {(qo - qp).abs().max():.3e}"
 
 
 def test_native_draft_forward_is_bit_identical_to_the_op_by_op_chain(monkeypatch):
@@ -384,7 +384,7 @@ def test_7b_dimension_layer_logits_match_oracle():
     _logit_check("7B-width layer, retrieval-cache forward", got, want)
     s = pg.spec_slot                                                     # the gamma+1 rows written by the fused epilogue
     dk = (pg.k[0, :, s:].permute(1, 0, 2).cpu().float() - ogc.key_cache[0, s:].float()).abs()
-    assert Hh.bound("7B-width layer: appended K rows, max", dk.max(), 2e-2) and Hh.bound("7B-width layer: appended K rows, mean", dk.mean(), 2e-4)
+    assert Hh.bound("7B-width layer: appended K rows, max", dk.max(), 8e-3) and Hh.bound("7B-width layer: appended K rows, mean", dk.mean(), 2e-6)
     trail = want.max(-1).values - want.gather(-1, got.argmax(-1, keepdim=True))[..., 0]   # device argmax vs oracle's best
     assert float(trail.max()) < GAP_TOL
 
@@ -463,7 +463,7 @@ def test_captured_target_verify_equals_eager(name):
         p_graph = ge.verify_probs(ids, g["temperature"], g["top_p"]).clone()
         kvc.seq_len = S
         p_eager = norm_logits(want[0], temperature=g["temperature"], top_k=-1, top_p=g["top_p"])
-        assert Hh.bound("captured vs eager target verify: probability rows", (p_graph - p_eager).abs().max(), 2e-2)
+        assert Hh.bound("captured vs eager target verify: probability rows", (p_graph - p_eager).abs().max(), 1e-3)
         kvc.seq_len = S
     tok = prompt[:, -1:]
     a = ge.decode_step(tok).clone()

@@ -181,7 +181,7 @@ def test_exchange_with_packed_residual_stream(rows, hidden, world, alternate):
             for x, ss in zip(outs, sss):
                 assert torch.equal(x.rows(), want)
                 Hh.close(ss[:, :rows], (want.float() ** 2).view(rows, hidden // 16, 16).sum(-1).t(),
-                                           rtol=1e-5, atol=1e-6)
+                                           rtol=2e-6, atol=1e-6)
     finally:
         for g in group:
             g.close()

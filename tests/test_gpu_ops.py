@@ -263,7 +263,7 @@ def test_attn_prefill_one_launch_equals_oracle_and_block_by_block(sq, sk, H, D, 
     got = ops.attn_prefill(qd, kd, vd, sk, scale)
     monkeypatch.setattr(ops, "ATTN_PREFILL_ONE_LAUNCH", False)
     blocks = ops.attn_prefill(qd, kd, vd, sk, scale)
-    Hh.close(got.float(), blocks.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+    Hh.close(got.float(), blocks.float(), atol=1e-3, rtol=ATTN_RTOL)
     if sq * sk <= 1024 * 5000:                       # the CPU oracle materialises sq x sk scores per head
         want = R.attn_kvcache(q, k, v, scale).reshape(sq, H * D)
         Hh.close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
@@ -284,7 +284,7 @@ def test_attn_block_splits_agree_and_match_decode_kernel():
     ref = torch.cat([ops.attn_decode(qd[r:r + 32].contiguous(), kd, vd, sk - (sq - r - 32), scale) for r in (0, 32, 64)])
     for ns in (1, 3, 16):
         got = ops.attn_block(qd, kd, vd, sk, scale, nsplit=ns)
-        Hh.close(got.float(), ref.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+        Hh.close(got.float(), ref.float(), atol=5e-4, rtol=ATTN_RTOL)
 
 
 def test_attn_block_full_size_prefill_chunk():
@@ -300,7 +300,7 @@ def test_attn_block_full_size_prefill_chunk():
     qd = torch.randn(sq, H, D, generator=g, device=DEV, dtype=torch.float16)
     got = ops.attn_block(qd, kd, vd, sk, scale)
     ref = torch.cat([ops.attn_decode(qd[r:r + 32].contiguous(), kd, vd, sk - (sq - r - 32), scale) for r in range(0, sq, 32)])
-    Hh.close(got.float(), ref.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+    Hh.close(got.float(), ref.float(), atol=6e-5, rtol=ATTN_RTOL)
     kd[:, sk - 1] += 4.0
     got2 = ops.attn_block(qd, kd, vd, sk, scale)
     assert torch.equal(got2[:sq - 1], got[:sq - 1]) and not torch.equal(got2[sq - 1], got[sq - 1])
@@ -317,7 +317,7 @@ def test_attn_decode_full_size_cfg2_layer():
     q = torch.randn(sq, H, D, generator=g, device=DEV, dtype=torch.float16)
     got = ops.attn_decode(q, kd, vd, sk, scale)
     want = R.attn_kvcache(q.cpu(), kd.permute(1, 0, 2).cpu(), vd.permute(1, 0, 2).cpu(), scale).reshape(sq, H * D)
-    Hh.close(got.float().cpu(), want.float(), atol=DECODE_ATOL, rtol=DECODE_RTOL)
+    Hh.close(got.float().cpu(), want.float(), atol=1e-5, rtol=DECODE_RTOL)
     # size-independent property: attention is linear in V (doubling V is exact in fp16: the same bits, one exponent up)
     got2 = ops.attn_decode(q, kd, vd * 2, sk, scale)
     Hh.close(got2.float(), got.float() * 2, atol=2 * DECODE_ATOL, rtol=DECODE_RTOL)
@@ -334,7 +334,7 @@ def test_attn_rope_on_read(sq, kv_len, H):
     kr = R.apply_rope(k[:kv_len], cos, sin, torch.arange(kv_len))
     want = R.attn_kvcache(q, kr, v[:kv_len], scale).reshape(sq, H * D)
     got = ops.attn_rope_on_read(q.to(DEV), kd, vd, cos.to(DEV), sin.to(DEV), kv_len, scale)
-    Hh.close(got.float().cpu(), want.float(), atol=ATTN_ATOL, rtol=ATTN_RTOL)
+    Hh.close(got.float().cpu(), want.float(), atol=6e-4, rtol=ATTN_RTOL)
 
 
 # ------------------------------------------------------------------------------------------
@@ -520,7 +520,7 @@ def test_topp_probs_matches_oracle(V, T, P):
     for r in range(lg.shape[0]):
         sg, sw = got[r] > 0, want[r] > 0
         if torch.equal(sg, sw):
-            Hh.close(got[r], want[r], rtol=2e-4, atol=1e-8)
+            Hh.close(got[r], want[r], rtol=2e-6, atol=1e-9)                        # measured: 6e-8 on p ~ 0.5 (an fp32 ulp)
         else:
             # the kept set may differ only at the top-p boundary, where the cumulative mass (summed in a
             # different fp32 order) is within rounding of top_p; ties must still resolve to the lower token id
@@ -696,7 +696,7 @@ def test_skinny_gemm_norm_prologue_and_residual_epilogue(M, N, K):
     ops.linear(xd, pl, ln=lnd, eps=eps, resid=buf, out=buf, ss_out=ss)
     assert torch.equal(buf, resd + yn)
     rows_ss = ss[:, :M].sum(dim=0)
-    Hh.close(rows_ss, (buf.float() ** 2).sum(dim=1), rtol=1e-5, atol=1e-3)
+    Hh.close(rows_ss, (buf.float() ** 2).sum(dim=1), rtol=2e-6, atol=1e-3)    # measured: 1.6e-7 relative (fp32 sums of 4 096 squares)
     if N % 32 == 0 and N <= 11008:
         w2 = rnd(256, N, seed=214, scale=0.05)
         ln2 = (1 + 0.1 * rnd(N, seed=215).float()).half().to(DEV)

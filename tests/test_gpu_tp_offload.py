@@ -284,7 +284,7 @@ def test_oneshot_allreduce_protocol_on_one_device(world, alternate):
             for r in range(world):
                 assert torch.equal(ys[r], want_y[r])
                 want_ss = want_y[r].float().square().view(rows, hidden // 16, 16).sum(-1).t()       # (panels, rows)
-                Hh.close(sss[r][:, :rows], want_ss, rtol=1e-5, atol=1e-6)
+                Hh.close(sss[r][:, :rows], want_ss, rtol=2e-6, atol=1e-6)
                 assert (sss[r][:, rows:] == -1.0).all()             # rows beyond the block are not touched
         assert [g.error() for g in group] == [0] * world
         with pytest.raises(AssertionError):
@@ -489,6 +489,13 @@ def _tp2_decode_loop(rank, world, q, out, loop_gamma=None):
     if os.environ.get("TF_TEST_TP_SAMPLING"):
         g["temperature"], g["top_p"] = (float(x) for x in os.environ["TF_TEST_TP_SAMPLING"].split(","))
     gamma = loop_gamma or g["gamma"]
+    max_len = int(os.environ.get("TF_TEST_TP_MAXLEN", "24"))
+    if max_len > 24:
+        # a long run: the retrieval cache's tail holds every generated token (reference cache.py:180-182), so the budget — and
+        # with it the prompt — must be longer than the run: 4 096-token prompt, budget = run length + slack (multiple of the chunk)
+        g["prefill"], g["gen_len"] = 4096, max_len + 64
+        g["budget"] = min(4096 - 512, ((max_len + 128 + 7) // 8) * 8)
+        g["tcfg"] = dict(g["tcfg"], max_position_embeddings=8192)        # RoPE tables must cover prompt + generated positions
     draft = Draft.from_state_dict(LlamaConfig.from_dict(g["dcfg"]),
                                   specs.random_state_dict(g["dcfg"], g["dseed"], head_std=g["head_std"]), DEV)
     dcache = StreamingLLMEvictionCache(draft, start_size=16, recent_size=256 - 16 - gamma, gamma=gamma)
@@ -499,11 +506,23 @@ def _tp2_decode_loop(rank, world, q, out, loop_gamma=None):
                            draft=draft, draft_cache=dcache, gamma=gamma)
     llm.init_parameters(specs.random_state_dict(g["tcfg"], g["tseed"], head_std=g["head_std"]))
     llm.initialize_graphs()
-    res = TriForce_Dist(Hh.FakeTokenizer(), llm, Hh.prompt_of(g).to(DEV), gamma=gamma, max_len=24, top_k=-1,
-                        top_p=g["top_p"], temperature=g["temperature"], return_details=True)
+    tok = Hh.FakeTokenizer()
+    if max_len > 24:
+        tok.eos_token_id = 1 << 30                         # a long run: no id ends it (a random model samples id 2 within ~200 tokens)
+    try:
+        res = TriForce_Dist(tok, llm, Hh.prompt_of(g).to(DEV), gamma=gamma, max_len=max_len, top_k=-1,
+                            top_p=g["top_p"], temperature=g["temperature"], return_details=True)
+    except RuntimeError as ex:                             # a loop that failed LOUDLY (stream digest / exchange time-out)
+        if not os.environ.get("TF_TEST_TP_EXPECT_FAILURE"):
+            raise
+        out.update(failed=f"{type(ex).__name__}: {ex}"[:400])
+        q.put((rank, "ok", out))
+        q.close()
+        q.join_thread()                                    # (flush before the hard exit)
+        os._exit(0)                                        # (the group is out of step: no barrier, no orderly shutdown)
     torch.cuda.synchronize()
     out.update(tokens=res["tokens"], counts=res["counts"], seq_len=llm.kv_cache.seq_len, graph_form=llm.graph_form,
-               decisions=res["decisions"], replica_checks=res["replica_checks"],
+               decisions=res["decisions"], replica_checks=res["replica_checks"], inner_graphs=res.get("inner_graphs"),
                oneshot_decode=llm._ar is not None, ar_error_decode=llm._ar.error() if llm._ar is not None else -1)
     dist.barrier()
     q.put((rank, "ok", out))
@@ -573,7 +592,7 @@ def _run_tp2(**kw):
     outs = {}
     try:
         for _ in range(2):
-            o = q.get(timeout=600)
+            o = q.get(timeout=300)
             outs[o[0]] = o
     finally:
         for p in procs:
@@ -591,15 +610,58 @@ def test_tp_world2_replicated_decisions_emit_the_broadcast_stream_on_the_device(
     the broadcast form's stream, accept counts and cache length under a stochastic target (T = 0.8, top-p 0.9), the stream
     digest agreed across the ranks at every check, no exchange error."""
     env = {"TF_TEST_TP_SAMPLING": "0.8,0.9"}
-    base, _ = _run_tp2(extra_env=env, loop_only=True)
+    base, _ = _run_tp2(extra_env=dict(env, TRIFORCE_TP_REPLICATED_DECISIONS="0"), loop_only=True)
     a, b = _run_tp2(extra_env=dict(env, TRIFORCE_TP_REPLICATED_DECISIONS="1", TRIFORCE_TP_REPLICA_CHECK_EVERY="2"), loop_only=True)
     assert base["decisions"] == "broadcast" and a["decisions"] == b["decisions"] == "replicated"
     for r, o in ((0, a), (1, b)):
         assert o["tokens"] == base["tokens"] and o["counts"] == base["counts"] and o["seq_len"] == base["seq_len"], \
             f"rank {r} left the broadcast form's stream"
         assert o["replica_checks"] >= len(o["counts"]) // 2 and o["ar_error_decode"] == 0 and o["oneshot_decode"]
+        # round 6: with whole-forward graphs the replicated loop runs the single-GPU loop's structure — one hipGraph per inner
+        # iteration (draft step, draw, retrieval verify WITH its exchanges, accept test), records through the pinned mailbox
+        assert o["inner_graphs"] == (o["graph_form"] == "whole"), (o["inner_graphs"], o["graph_form"])
+    assert not base["inner_graphs"]                                  # a broadcast cannot sit inside an iteration's graph
     assert len(set(base["tokens"])) > 4
     print(f"[tp2 replicated decisions] {len(a['tokens'])} tokens, accept counts {a['counts']}, {a['replica_checks']} digest checks")
+
+
+@pytest.mark.parametrize("xchg", ["1", "0"], ids=["exchange-in-gemm", "staged-exchange"])
+def test_tp_world2_replicated_decisions_soak_2000_tokens(xchg):
+    """The evidence behind the "auto" default (utils/decoding.tp_sync_record): two processes on this GPU, T = 1.0 / top-p 0.95 (every
+    decision draws numbers), 2 000+ tokens, in both exchange forms (inside the o_proj / down_proj GEMMs; GEMM -> staging ->
+    exchange kernel).  With NO setting the start-up litmus must find the ranks' forwards bit-identical and select replicated
+    decisions; both ranks then emit, token for token, the stream of the forced broadcast form, with the same accept counts and
+    cache length, every digest check agreeing and no exchange error."""
+    env = {"TF_TEST_TP_SAMPLING": "1.0,0.95", "TF_TEST_TP_MAXLEN": "2000", "TRIFORCE_TP_GEMM_XCHG": xchg,
+           "TRIFORCE_TP_REPLICA_CHECK_EVERY": "16"}
+    base, base1 = _run_tp2(extra_env=dict(env, TRIFORCE_TP_REPLICATED_DECISIONS="0"), loop_only=True)
+    a, b = _run_tp2(extra_env=env, loop_only=True)                               # default: auto
+    assert base["decisions"] == "broadcast" and a["decisions"] == b["decisions"] == "replicated", (base["decisions"], a["decisions"])
+    assert len(base["tokens"]) >= 2000 and base["tokens"] == base1["tokens"]
+    for r, o in ((0, a), (1, b)):
+        assert o["tokens"] == base["tokens"] and o["counts"] == base["counts"] and o["seq_len"] == base["seq_len"], \
+            f"rank {r} left the broadcast form's stream after {Hh.common_prefix(o['tokens'], base['tokens'])} tokens"
+        assert o["replica_checks"] >= len(o["counts"]) // 16 and o["ar_error_decode"] == 0 and o["oneshot_decode"]
+        assert o["inner_graphs"] == (o["graph_form"] == "whole")
+    assert len(set(base["tokens"])) > 100
+    Hh.note(f"tp2 replicated-decision soak ({'exchange in the GEMMs' if xchg == '1' else 'staged exchange'}): {len(a['tokens'])} tokens / "
+            f"{len(a['counts'])} outer steps identical to the broadcast form, {a['replica_checks']} digest checks, graph form {a['graph_form']}")
+
+
+def test_tp_world2_replicated_decisions_fail_loudly_when_a_rank_leaves_the_stream():
+    """Rank 1's uniform stream is knocked one number out of step at outer step 6 (TF_TEST_TP_KNOCK_RANK_AT): its decisions now
+    differ from rank 0's.  Replicated decisions have no broadcast to paper over that — the job must STOP, on every rank, within
+    the digest interval: either the stream digests disagree (ReplicaCheck) or the ranks' forwards fall out of step and an
+    exchange times out.  What must not happen is two ranks finishing with two streams."""
+    env = {"TF_TEST_TP_SAMPLING": "1.0,0.95", "TF_TEST_TP_MAXLEN": "400", "TRIFORCE_TP_REPLICATED_DECISIONS": "1",
+           "TRIFORCE_TP_REPLICA_CHECK_EVERY": "8", "TF_TEST_TP_KNOCK_RANK_AT": "1,6", "TF_TEST_TP_EXPECT_FAILURE": "1",
+           "TRIFORCE_XCHG_TIMEOUT_MS": "1500"}
+    a, b = _run_tp2(extra_env=env, loop_only=True)
+    for r, o in ((0, a), (1, b)):
+        assert "failed" in o, f"rank {r} finished {len(o.get('tokens', []))} tokens as if nothing had happened"
+    why = a["failed"] + " | " + b["failed"]                # (the second rank to notice may only see its peer gone)
+    assert "left the common token stream" in why or "timed out" in why or "time-out" in why or "exchange" in why, why
+    Hh.note(f"tp2 knocked rank: rank 0 stopped with [{a['failed'][:90]}], rank 1 with [{b['failed'][:90]}]")
 
 
 def test_tp_world8_on_one_device_matches_the_reference_world8_logits():
@@ -731,7 +793,7 @@ def test_gemm_exchange_protocol_on_one_device(world, hidden):
                 assert torch.equal(got, want2), (f"trip {it}, rank {r}, {rows} rows, packed={packed}: max err "
                                                  f"{(got.float() - want2.float()).abs().max()}, errors {[g.error() for g in group]}")
                 Hh.close(sss[r][:, :rows], want2.float().square().view(rows, hidden // 16, 16).sum(-1).t(),
-                                           rtol=1e-5, atol=1e-6)
+                                           rtol=2e-6, atol=1e-6)
         assert [g.error() for g in group] == [0] * world and [g.error_device() for g in group] == [0] * world
         # error path: a poisoned control block NaN-fills the output and check() raises
         group[0].inject_error(1)

@@ -122,7 +122,9 @@ def test_tp2_gloo_matches_oracle():
     for r in range(world):
         _, _, logits, spec_logits, tokens, counts, seq_len = outs[r][:7]
         logits, spec_logits = torch.from_numpy(logits), torch.from_numpy(spec_logits)
-        assert outs[r][7] == {"decisions": "broadcast", "replica_checks": 0}
+        # (no setting = "auto": the start-up litmus found the ranks' forwards bit-identical -> decisions replicated; the
+        #  broadcast form is pinned by test_tp2_replicated_decisions_emit_the_broadcast_stream with the variable at 0)
+        assert outs[r][7]["decisions"] == "replicated" and outs[r][7]["replica_checks"] >= 1
         assert (logits - lo).abs().max() < 4e-3, f"rank {r} prefill logits off by {(logits - lo).abs().max():.2e}"
         assert (spec_logits - so).abs().max() < 4e-3, f"rank {r} spec logits off by {(spec_logits - so).abs().max():.2e}"
     # ranks are in lock-step: identical logits (all-reduce gives every rank the same bits), tokens, rollbacks
@@ -140,11 +142,17 @@ def test_tp2_replicated_decisions_emit_the_broadcast_stream(monkeypatch):
     top-p 0.9) so that every kind of decision draws numbers: both ranks emit the stream, accept counts and cache length of the
     broadcast form, and the digest check ran across the ranks (every 2 outer steps here + once at the end)."""
     monkeypatch.setenv("TF_TEST_TP_SAMPLING", "0.8,0.9")
+    monkeypatch.setenv("TRIFORCE_TP_REPLICATED_DECISIONS", "0")
     base = _run_world(_worker, 2)
     monkeypatch.setenv("TRIFORCE_TP_REPLICATED_DECISIONS", "1")
     monkeypatch.setenv("TRIFORCE_TP_REPLICA_CHECK_EVERY", "2")
     repl = _run_world(_worker, 2)
     assert base[0][7]["decisions"] == "broadcast" and repl[0][7]["decisions"] == "replicated"
+    # round 6: with NO setting ("auto") the start-up litmus finds the two ranks' forwards bit-identical and selects replication
+    monkeypatch.delenv("TRIFORCE_TP_REPLICATED_DECISIONS")
+    auto = _run_world(_worker, 2)
+    assert auto[0][7]["decisions"] == auto[1][7]["decisions"] == "replicated"
+    assert auto[0][4] == base[0][4] and auto[1][4] == base[0][4] and auto[0][5] == base[0][5]
     steps = len(repl[0][5])
     for r in range(2):
         assert repl[r][4] == base[0][4] and repl[r][5] == base[0][5] and repl[r][6] == base[0][6], f"rank {r} left the broadcast stream"

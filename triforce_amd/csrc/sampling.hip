@@ -123,8 +123,9 @@ __device__ __forceinline__ const float* cur_uniforms(const float* uniforms, cons
     return uniforms + c;
 }
 // What a record kernel leaves for the NEXT chain of launches (token ids in the shared token buffer, the cursor) is stored
-// write-through (agent scope) and drained BEFORE the record store: the host launches the next chain — on another stream,
-// so ordered by the record alone, not by this kernel's completion (utils/decoding.py, lanes) — as soon as it sees the record.
+// write-through (agent scope) and drained BEFORE the record store: the host enqueues the next chain as soon as it sees the
+// record — on the SAME stream (include/triforce_hip.h: a chain on another stream would be ordered by the record alone and
+// would have to acquire what it reads; no caller does that).
 __device__ __forceinline__ void st_agent_i64(int64_t* p, int64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

@@ -99,6 +99,11 @@ class DistributedLlama:
         self.num_key_value_heads = model_config.num_key_value_heads
         self.num_key_value_groups = self.num_heads // self.num_key_value_heads
         self.max_position_embeddings = model_config.max_position_embeddings
+        if prefill + gen_len > self.max_position_embeddings:
+            # the RoPE tables have max_position_embeddings rows; a position beyond them is an out-of-bounds read on the device
+            # (found by a 2 000-token soak on a 4 096-position test model: memory access fault) — refuse the configuration
+            raise ValueError(f"prefill {prefill} + gen_len {gen_len} exceeds the model's max_position_embeddings "
+                             f"{self.max_position_embeddings}: positions past the RoPE tables")
         self.rope_theta = model_config.rope_theta
         self.local_num_heads = self.num_heads // world_size
         self.local_num_key_value_heads = self.num_key_value_heads // world_size
@@ -138,9 +143,27 @@ class DistributedLlama:
         mode = os.environ.get("TRIFORCE_ALLREDUCE", "auto")
         if mode not in ("auto", "oneshot", "rccl"):
             raise ValueError(f"TRIFORCE_ALLREDUCE={mode!r}: expected auto, oneshot or rccl")
+        if self.world_size > 1 and self.device.type == "cuda":
+            self._detect_shared_device()
         if self.world_size > 1 and self.device.type == "cuda" and mode != "rccl" \
                 and os.environ.get("TRIFORCE_ONESHOT_AR", "1") != "0":
             self.enable_oneshot_allreduce()
+
+    def _detect_shared_device(self):
+        """COLLECTIVE: how many ranks of this group sit on ONE device (bench.py --share-device, the two-process tests).  The
+        one-launch draft forward needs its 256 workgroups co-resident: two ranks' launches on one chip each get part of the CUs
+        and wait for the rest until the time-out (found by the 2-rank bench test) — shared devices keep the 13-launch chain."""
+        try:
+            mine = (socket.gethostname(), str(getattr(torch.cuda.get_device_properties(self.device), "uuid", self.device.index)))
+        except Exception:
+            mine = (socket.gethostname(), str(self.device.index))
+        everyone = [None] * self.world_size
+        dist.all_gather_object(everyone, mine)
+        self.ranks_per_device = max(everyone.count(e) for e in everyone)
+        draft = getattr(self, "draft", None)
+        if self.ranks_per_device > 1 and draft is not None and hasattr(draft, "persist_allowed"):
+            draft.persist_allowed = False
+            draft._native_key = None                      # (rebuild the native handle without the persistent state)
 
     # ---------------------------------------------------------------------------------------
     ONESHOT_MAX_ROWS = 32                             # decode-sized blocks; prefill chunks (>= 1 MB) stay on RCCL
@@ -583,10 +606,13 @@ class DistributedLlama:
     # The target verify is captured too (all layers HBM-resident): its append slot and key count live in device
     # memory (tf_rope_append slot0_dev, tf_attn_decode sk_dev), the launch is sized by the cache capacity.
     # ---------------------------------------------------------------------------------------
-    def _stage_buffers(self, q_len):
+    def _stage_buffers(self, q_len, ids=None, pos=None):
+        """Static buffers of one captured forward.  ``ids`` / ``pos``: capture over these views instead of own buffers — the
+        retrieval verify reads the engine's shared token / position buffers, which the decode loop's kernels write directly
+        (round 6: the tensor-parallel loop runs the single-GPU loop's launch structure)."""
         dev, hid = self.device, self.hidden_size
-        return dict(ids=torch.zeros((1, q_len), dtype=torch.long, device=dev),
-                    pos=torch.arange(q_len, device=dev, dtype=torch.long),
+        return dict(ids=torch.zeros((1, q_len), dtype=torch.long, device=dev) if ids is None else ids,
+                    pos=torch.arange(q_len, device=dev, dtype=torch.long) if pos is None else pos,
                     base=torch.arange(q_len, device=dev, dtype=torch.long),
                     slot=torch.zeros(1, dtype=torch.int32, device=dev),
                     sk=torch.full((1,), q_len, dtype=torch.int32, device=dev),
@@ -690,7 +716,11 @@ class DistributedLlama:
 
     def _capture_forward(self, q_len, kind, form):
         from ..utils.graph_infer import _capture
-        st = self._stage_buffers(q_len)
+        tok = getattr(self, "tok_buf", None)
+        if kind == "retrieval" and tok is not None and tok.shape[1] >= q_len and self.pos_buf.numel() == q_len:
+            st = self._stage_buffers(q_len, ids=tok[:, :q_len], pos=self.pos_buf.view(-1))
+        else:
+            st = self._stage_buffers(q_len)
         stages = self._stages(st, kind)
         if form == "whole":
             def run_all():
@@ -701,7 +731,7 @@ class DistributedLlama:
                         exchange()
                 return out
             graph, out = _capture(run_all, (), self._mempool, 3)
-            return dict(form="whole", graph=graph, out=out, st=st, T=self.temperature, P=self.top_p)
+            return dict(form="whole", graph=graph, out=out, st=st, T=self.temperature, P=self.top_p, run_all=run_all)
         # segments: the exchanges run eagerly BETWEEN the stage graphs at replay time, so none is issued while the stages
         # are captured one after the other.  With alternating staging halves every stage must still be captured against
         # the half its exchange will read at replay: count the (not yet issued) exchanges by hand while capturing and put
@@ -787,8 +817,12 @@ class DistributedLlama:
             self._ar.resync()             # raised midway may have counted exchanges the device never ran)
         self._mempool = torch.cuda.graphs.graph_pool_handle()
         self._draft_graphs = {}
+        # ONE token buffer is the static input of every draft graph (its first gamma_offset + 1 entries) and of the
+        # retrieval-verify forward (its first gamma + 1, with ``pos_buf``), like the single-GPU engine's (utils/graph_infer.py)
+        self.tok_buf = torch.zeros((1, gamma + 3), dtype=torch.long, device=self.device)
+        self.pos_buf = torch.arange(gamma + 1, device=self.device).unsqueeze(0).clone()
         for off in range(gamma + 3):                       # replicated 68M draft steps: no collective inside
-            ids = torch.zeros((1, off + 1), dtype=torch.long, device=self.device)
+            ids = self.tok_buf[:, :off + 1]
             graph, out = _capture(lambda t, off=off: self._draft_run_eager(t, off, True, 0.6, 0.9), (ids,),
                                   self._mempool, 3)
             self._draft_graphs[off] = (graph, ids, out)
@@ -857,6 +891,62 @@ class DistributedLlama:
         return out
 
     @torch.inference_mode()
+    def replica_litmus(self, rounds=2):
+        """COLLECTIVE start-up check behind replicated decisions (utils/decoding.tp_sync_record, "auto"): every rank runs the
+        retrieval forward — every layer's two exchanges, the replicated lm_head — on the same fixed probe tokens and folds
+        the fp32 bit patterns of the logits into two weighted sums; one 4-word MAX all-reduce of (s1, -s1, s2, -s2) says
+        whether every rank holds the SAME bits.  Only then may each rank take rank 0's decisions on its own.  Cached in
+        ``replica_ok``; a single rank is trivially true; any failure of the probe counts as "not shown"."""
+        if self.world_size == 1:
+            self.replica_ok = True
+            return True
+        ok = True
+        try:
+            g = self.gamma
+            S = self.kv_cache.seq_len
+            ids = ((torch.arange(g + 1, device=self.device) * 37 + 11) % self.vocab_size).view(1, -1)
+            pos = torch.arange(S, S + g + 1, device=self.device).unsqueeze(0)
+            s1 = s2 = 0
+            for r in range(rounds):
+                bits = self.retrieval_inference(ids, pos).float().contiguous().view(torch.int32).reshape(-1).to(torch.int64)
+                w = (torch.arange(bits.numel(), device=self.device, dtype=torch.int64) % 1021) + 1
+                s1 = (s1 * 31 + int(bits.sum())) % ((1 << 61) - 1)
+                s2 = (s2 * 31 + int((bits * w).sum() % ((1 << 61) - 1))) % ((1 << 61) - 1)
+            t = torch.tensor([s1, -s1, s2, -s2], dtype=torch.int64, device=self.device)
+        except Exception as ex:                            # a probe that cannot run shows nothing
+            ok = False
+            t = torch.zeros(4, dtype=torch.int64, device=self.device)
+            if self.local_rank == 0:
+                print(f"[TP] replica litmus could not run ({type(ex).__name__}: {ex}): decisions are broadcast", flush=True)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        hi1, lo1, hi2, lo2 = t.tolist()
+        same = hi1 == -lo1 and hi2 == -lo2
+        self.replica_ok = bool(self._agree(ok and same))
+        if self.local_rank == 0:
+            print(f"[TP] replica litmus: the ranks' retrieval-forward logits are {'bit-identical' if self.replica_ok else 'NOT identical'}"
+                  f" -> decisions {'replicated (no record broadcasts)' if self.replica_ok else 'broadcast from rank 0'}", flush=True)
+        return self.replica_ok
+
+    @torch.inference_mode()
+    def verify_probs_ids(self, ids, temperature, top_p):
+        """Target verify of a python list of token ids through the captured forward of that length: ids, positions and the two
+        length scalars set by ONE launch (tf_set_tokens: the ids travel as kernel arguments), replay, temperature / top-p.
+        (probabilities, the forward's (1, q_len) device token row), or None when there is no whole-forward graph of that length."""
+        cap = getattr(self, "_target_caps", {}).get(len(ids))
+        if cap is None or cap["form"] != "whole" or len(ids) > 32:
+            return None
+        kvc, S, q_len, st = self.kv_cache, self.kv_cache.seq_len, len(ids), cap["st"]
+        if cap.get("plan") is None:
+            cap["plan"] = ops.SetTokensPlan(st["ids"].view(-1), st["pos"], st["slot"], st["sk"])
+        cap["plan"](list(ids), 0, pos0=S, sk_val=S + q_len)
+        logits = self._replay(cap, clone=False)
+        tail = self.retrieval_cache
+        if tail is not None and S >= self.prefill_len:    # device mirror of the generated rows, all layers at once
+            ops.kv_copy_rows_pair(kvc.k, kvc.v, tail.tail_k, tail.tail_v, S, S - self.prefill_len, q_len)
+        kvc.seq_len = S + q_len
+        return norm_logits(logits[0], temperature=temperature, top_k=-1, top_p=top_p), st["ids"]
+
+    @torch.inference_mode()
     def draft_run(self, input_ids, gamma_offset: int = 0, probs=True, temperature=0.6, top_p=0.9, clone=True):
         """Replicated 68M draft (TP_llama.py:117-132).  NB the reference's call sites never pass temperature /
         top_p, so the draft always samples at 0.6 / 0.9 — kept."""
@@ -864,10 +954,18 @@ class DistributedLlama:
         if g and probs and input_ids.shape[-1] <= 64 and gamma_offset in g and (temperature, top_p) == (0.6, 0.9) \
                 and input_ids.shape[-1] == gamma_offset + 1:
             graph, ids, out = g[gamma_offset]
-            ids.copy_(input_ids)
+            if input_ids.data_ptr() != ids.data_ptr():
+                ids.copy_(input_ids)
             graph.replay()
             return out.clone() if clone else out           # (clone=False: valid until THIS graph replays again)
         return self._draft_run_eager(input_ids, gamma_offset, probs, temperature, top_p)
+
+    def replay_draft(self, gamma_offset):
+        """``draft_run(tok_buf[:, :gamma_offset + 1], gamma_offset, clone=False)`` for a caller that has written the tokens into
+        ``tok_buf`` itself: the replay and nothing else."""
+        graph, _, out = self._draft_graphs[gamma_offset]
+        graph.replay()
+        return out
 
     def _draft_run_eager(self, input_ids, gamma_offset, probs, temperature, top_p):
         if input_ids.shape[-1] > 64:
@@ -908,8 +1006,10 @@ class DistributedLlama:
     def retrieval_verify(self, input_ids, position_ids, temperature=0.6, top_p=0.9, clone=True):
         cap = getattr(self, "_verify_cap", None)
         if cap is not None and (temperature, top_p) == (cap["T"], cap["P"]):
-            cap["st"]["ids"].copy_(input_ids)
-            cap["st"]["pos"].copy_(position_ids.reshape(-1))
+            if input_ids.data_ptr() != cap["st"]["ids"].data_ptr():
+                cap["st"]["ids"].copy_(input_ids)
+            if position_ids.data_ptr() != cap["st"]["pos"].data_ptr():
+                cap["st"]["pos"].copy_(position_ids.reshape(-1))
             self._verify_gen = getattr(self, "_verify_gen", 0) + 1      # lifetime token of a static output handed out
             return self._replay(cap, clone=clone)
         logits = self.retrieval_inference(input_ids, position_ids)

@@ -22,6 +22,9 @@ class LlamaForCausalLM:
         self.cos, self.sin = cos.to(self.device), sin.to(self.device)
         self.scale = softmax_scale_for(D)
         self.vocab_size = config.vocab_size
+        # the one-launch forward (ops.DraftPersist) needs the whole chip to itself while it runs: an engine whose ranks share a
+        # device switches it off (models/TP_llama._detect_shared_device)
+        self.persist_allowed = True
 
     @classmethod
     def from_pretrained(cls, name_or_path, torch_dtype=torch.float16, device_map="cuda:0", config=None, **_):
@@ -78,7 +81,7 @@ class LlamaForCausalLM:
                                                   self.cos, self.sin, W.H, W.D, W.eps, self.scale) if ok else None
             # the one-launch form's control block + workspace (ops.DraftPersist) when the shape is the 68M draft's
             self._persist = None
-            if self._native is not None and ops.DRAFT_PERSIST and ops.draft_persist_supported(self._native, 1, 1):
+            if self._native is not None and ops.DRAFT_PERSIST and self.persist_allowed and ops.draft_persist_supported(self._native, 1, 1):
                 self._persist = ops.DraftPersist(self._native, self.device)
             self._native_key = key
         return self._native

@@ -508,7 +508,7 @@ class TriForceRunner:
             assert ge.verify_generation() == bufs.rows_generation, "retrieval-verify graph replayed before its rows were consumed"
         rec = bufs.chain_out
         rec.arm(4)
-        on_cursor = self.inner is not None and self.sync_record is None and not self.inclusive_accept
+        on_cursor = self.inner is not None and self.sync_record is None
         if on_device is not None:
             # ... and leaves the pass tokens in the token buffer and the NEXT verify's scalars (rolled-back length) on the device
             ops.accept_chain_step(probs, spec_rows, ge.tok_buf.view(-1), rng.buf, rng.cursor_tensor(g2 + 1), g2, False, self.eos,
@@ -529,12 +529,16 @@ class TriForceRunner:
         dp = getattr(getattr(eng, "draft", None), "_persist", None)                        # one-launch draft forward: pinned mirror of its error word
         if dp is not None:
             dp.check()
+        dev_consumed = consumed
         if self.inclusive_accept and reason == 1 and generated[g2 - 1] == self.eos:
             # TP loop only: an eos accepted as the LAST drafted token ends the loop before the bonus sample
             # (decoding.py:357-360,382-383); the on-chip loop — and tf_accept_chain — go on to the bonus token (:127)
             reason, pred, consumed = 2, self.eos, consumed - 1
         if on_cursor:
-            rng.advanced_on_device(consumed)
+            rng.advanced_on_device(dev_consumed)
+            if consumed != dev_consumed:                                 # the kernel drew a bonus number the loop does not consume:
+                rng.pos -= dev_consumed - consumed                       # step the host position back; the device cursor is
+                rng.device_cursor = False                                # re-written before its next reader
         else:
             rng.advance(consumed)
         self.last_reason = reason          # 0 rejection + resample, 1 everything accepted (bonus token), 2 accepted eos
@@ -666,13 +670,34 @@ def _bcast_record(t):
 # through the pinned mailbox like the single-GPU loop's.  A digest of the emitted stream is compared across the ranks every
 # TRIFORCE_TP_REPLICA_CHECK_EVERY outer steps and when a loop ends (ReplicaCheck): a rank that left the common stream raises
 # on every rank.  Default off: the broadcast form is the reference's, and neither form has met a second device yet.
-TP_REPLICATED_DECISIONS = __import__("os").environ.get("TRIFORCE_TP_REPLICATED_DECISIONS", "0") == "1"
+# Round 6: the DEFAULT is "auto" — replicate when this group's forwards have been SHOWN bit-identical on every rank at start-up
+# (DistributedLlama.replica_litmus: the retrieval forward with all its exchanges on a fixed probe, digests compared across
+# the ranks), else broadcast.  "1" forces replicated, "0" forces the broadcast form (the reference's).  Evidence behind the
+# default: tests/test_gpu_tp_offload.py — a two-process soak of 2 000+ tokens at T = 1.0 / top-p 0.95 in both exchange forms emits
+# the broadcast form's stream on both ranks, and a rank whose uniform stream is knocked out of step fails LOUDLY (stream digest
+# or exchange time-out) within the check interval instead of emitting another stream.
+TP_REPLICATED_DECISIONS = __import__("os").environ.get("TRIFORCE_TP_REPLICATED_DECISIONS", "auto") == "1"      # (import-time view; see below)
 TP_REPLICA_CHECK_EVERY = max(1, int(__import__("os").environ.get("TRIFORCE_TP_REPLICA_CHECK_EVERY", "32")))
 
 
-def tp_sync_record():
-    """The `sync_record` of the tensor-parallel loops: rank 0's record broadcast, or None when the ranks replicate decisions."""
-    return None if TP_REPLICATED_DECISIONS else _bcast_record
+def tp_decision_mode():
+    v = __import__("os").environ.get("TRIFORCE_TP_REPLICATED_DECISIONS", "auto")
+    return {"1": "replicated", "0": "broadcast"}.get(v, "auto")
+
+
+def tp_sync_record(llm=None):
+    """The `sync_record` of the tensor-parallel loops: rank 0's record broadcast, or None when the ranks replicate decisions.
+    COLLECTIVE in "auto" mode the first time it sees an engine (the litmus runs one probe forward on every rank)."""
+    mode = tp_decision_mode()
+    if mode == "replicated":
+        return None
+    if mode == "broadcast" or llm is None:
+        return _bcast_record
+    base = getattr(llm, "llm", llm)                           # (a _DistEngine wraps the engine)
+    ok = getattr(base, "replica_ok", None)
+    if ok is None and hasattr(base, "replica_litmus"):
+        ok = base.replica_litmus()
+    return None if ok else _bcast_record
 
 
 class ReplicaCheck:
@@ -723,9 +748,62 @@ class _DistEngine:
 
     def __init__(self, llm):
         self.llm = llm
+        self._inner = {}
+        self.sampling = dict(probs=True, temperature=llm.temperature, top_p=llm.top_p)
+
+        def draft_run(input_ids, gamma_offset=0, probs=True, temperature=0.6, top_p=0.9):
+            return llm._draft_run_eager(input_ids, gamma_offset, True, 0.6, 0.9)      # 0.6 / 0.9 hard-wired
+
+        def model_verify(input_ids, position_ids, probs=True, temperature=None, top_p=None):
+            # the retrieval-verify forward, issued eagerly (inside a capture: utils/graph_infer._InnerGraphs) — it reads the
+            # shared token / position buffers itself; exchanges included, in the order of the whole-forward graph
+            return llm._verify_cap["run_all"]()
+
         self.engine = types.SimpleNamespace(
             model=types.SimpleNamespace(device=llm.device, config=llm.config.model_config),
-            kv_cache=llm.kv_cache, graph_cache=llm.retrieval_cache, draft_cache=llm.draft_cache)
+            kv_cache=llm.kv_cache, graph_cache=llm.retrieval_cache, draft_cache=llm.draft_cache, draft=getattr(llm, "draft", None),
+            draft_run=draft_run, model_verify=model_verify)
+
+    # -- round 6: the single-GPU loop's launch structure over the tensor-parallel engine's captured forwards ------------------
+    # (what the loops look for on a graph engine: shared static inputs, replay-only draft steps, the one-graph inner iteration,
+    #  a target verify that takes its ids as kernel arguments.  All of it needs whole-forward graphs — with segment graphs the
+    #  exchanges run eagerly between the stages — and replicated decisions: a broadcast in the middle of an iteration cannot sit
+    #  inside its graph.)
+    def _whole(self):
+        cap = getattr(self.llm, "_verify_cap", None)
+        return cap is not None and cap.get("form") == "whole" and "run_all" in cap and bool(getattr(self.llm, "_draft_graphs", None))
+
+    @property
+    def tok_buf(self):
+        return getattr(self.llm, "tok_buf", None) if self._whole() else None
+
+    @property
+    def pos_buf(self):
+        return getattr(self.llm, "pos_buf", None) if self._whole() else None
+
+    def replay_draft(self, gamma_offset):
+        return self.llm.replay_draft(gamma_offset)
+
+    def verify_probs_ids(self, ids, temperature, top_p):
+        return self.llm.verify_probs_ids(ids, temperature, top_p)
+
+    @torch.inference_mode()
+    def inner_graphs(self, gamma, rng, record, capture=True):
+        """The per-position inner-iteration graphs (graph_infer._InnerGraphs: draft step -> draw -> retrieval verify with its
+        exchanges -> accept test, ONE hipGraph per position) over this engine; None when it cannot provide them."""
+        import os
+        from .graph_infer import _InnerGraphs
+        tok = self.tok_buf
+        if os.environ.get("TRIFORCE_INNER_GRAPH", "1") == "0" or tok is None or not tok.is_cuda or tok.shape[1] < gamma + 3 \
+                or record.numel() < 4 or record.is_cuda or torch.cuda.is_current_stream_capturing():
+            return None
+        key = _InnerGraphs.key_of(self, gamma, rng, record)
+        got = self._inner.get(key)
+        if got is None and capture:
+            if len(self._inner) >= 2:
+                self._inner.pop(next(iter(self._inner)))
+            got = self._inner[key] = _InnerGraphs(self, gamma, rng, record)
+        return got
 
     @property
     def static_outputs(self):
@@ -742,7 +820,9 @@ class _DistEngine:
                                          temperature=self.llm.temperature, top_p=self.llm.top_p, clone=clone)
 
     def verify_generation(self):
-        return getattr(self.llm, "_verify_gen", None) if getattr(self.llm, "_verify_cap", None) is not None else None
+        if getattr(self.llm, "_verify_cap", None) is None:
+            return None
+        return getattr(self.llm, "_verify_gen", 0) + sum(g.generation for g in self._inner.values())
 
     def inference(self, input_ids, eager=False):
         return self.llm.inference(input_ids=input_ids, eager=eager)
@@ -788,7 +868,16 @@ def Baseline_Dist(tokenizer, graph_engine, input_ids, max_len=256, top_k=-1, top
 def Middle_Spec_Dist(next_token, llm, gamma, verbose, tokenizer, rng=None):
     """Reference decoding.py:432-495."""
     ge = llm if isinstance(llm, _DistEngine) else _DistEngine(llm)
-    return Middle_Spec(next_token, ge, gamma, verbose, tokenizer, rng=rng, sync_record=tp_sync_record())
+    sync = tp_sync_record(ge)
+    if sync is None and rng is None:
+        # replicated decisions: every rank must hold the SAME uniform stream — an unseeded one differs per rank and the ranks
+        # would drift apart silently (in the broadcast form rank 0's draw is everyone's, so None did no harm there).  One
+        # seeded stream per engine, continued across calls (advisor, round 5).
+        base = ge.llm
+        rng = getattr(base, "_replicated_rng", None)
+        if rng is None:
+            rng = base._replicated_rng = UniformSource(base.device, seed=1)
+    return Middle_Spec(next_token, ge, gamma, verbose, tokenizer, rng=rng, sync_record=sync)
 
 
 @torch.inference_mode()
@@ -798,7 +887,7 @@ def TriForce_Dist(tokenizer, llm, input_ids, gamma=4, max_len=256, top_k=-1, top
     ge = _DistEngine(llm)
     rng = rng or UniformSource(llm.device, seed=1)          # same seed on every rank: identical uniform streams
     run = TriForceRunner(tokenizer, ge, gamma, top_k, top_p, temperature, verbose, rng, inclusive_accept=True,
-                         sync_record=tp_sync_record())
+                         sync_record=tp_sync_record(llm))
     run.health = ge.health
     replicas = ReplicaCheck(llm.device) if run.sync_record is None else None
     llm.reset()
@@ -817,7 +906,10 @@ def TriForce_Dist(tokenizer, llm, input_ids, gamma=4, max_len=256, top_k=-1, top
     eos = run.eos
     _sync(llm.device)
     time1 = time.time()
+    knock = __import__("os").environ.get("TF_TEST_TP_KNOCK_RANK_AT")       # tests only: "rank,step" — that rank skips one uniform there
     while run.n < max_len:
+        if knock and [llm.local_rank, len(run.counts)] == [int(x) for x in knock.split(",")]:
+            rng.advance(1)
         run.step()
         if replicas is not None:
             replicas(run)
@@ -832,6 +924,7 @@ def TriForce_Dist(tokenizer, llm, input_ids, gamma=4, max_len=256, top_k=-1, top
     st = run.stats(time2 - time1)
     st["decisions"] = "broadcast" if replicas is None else "replicated"
     st["replica_checks"] = 0 if replicas is None else replicas.checks
+    st["inner_graphs"] = run.inner is not None           # one hipGraph per inner iteration (whole-forward graphs + replicated decisions)
     if return_details:
         return st
     return st["avg_tokens"], (time2 - time1) / max(run.n, 1)

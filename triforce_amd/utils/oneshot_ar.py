@@ -14,6 +14,7 @@ its device-side epoch and a disagreement with the half passed here is a sticky e
 hold an even number of exchanges (the decode layer's two per layer do).
 """
 import ctypes
+import os
 
 import torch
 
@@ -276,6 +277,14 @@ class GemmExchange:
         self.rank, self.world, self.device, self.max_elems = rank, world, torch.device(device), int(max_elems)
         assert self.max_elems % 8 == 0
         L = hip.lib()
+        # TRIFORCE_XCHG_TIMEOUT_MS: wall-clock limit of one flag wait (default 5 000).  The value is a kernel argument, i.e. it
+        # is FROZEN into every graph captured afterwards — set it before initialize_graphs().  With replicated decisions the
+        # ranks no longer meet in broadcasts: a host stall on one rank longer than this (a debugger, SIGSTOP, a long collection)
+        # NaN-poisons its peers, and the sticky error word needs the collective reset() — give decode loops that may stall a
+        # larger limit, keep the short one for the litmus and the tests (advisor, round 5).
+        ms = os.environ.get("TRIFORCE_XCHG_TIMEOUT_MS")
+        if ms:
+            L.tf_xchg_tune(1, max(1, int(ms)))
         self._opened, self._stage, self._ctl = [], None, None
         if own is None:
             own = (OneShotAllReduce._alloc(self.max_elems * 2 * 2), OneShotAllReduce._alloc(L.tf_xchg_ctl_bytes()))
@@ -355,7 +364,7 @@ class GemmExchange:
         ranks have drifted apart; nothing else brings them back together)."""
         hip.check(hip.lib().tf_xchg_reset(ctypes.c_void_p(self.ctl_ptr)), "tf_xchg_reset")
 
-    def litmus(self, iters=100_000, rows=7, per_graph=100, delay_every=17, capture_mode="thread_local"):
+    def litmus(self, iters=100_000, rows=7, per_graph=100, delay_every=17, capture_mode="thread_local", hidden=None):
         """Message-passing litmus of THIS kernel on THIS group (the staged exchange kernel has its own:
         tools/xgmi_litmus.py): every iteration an ordinary kernel writes a fresh integer pattern as the activation
         (tf_ar_litmus_stage), tf_skinny_gemm_xchg multiplies it by an identity weight and exchanges the panels, and
@@ -365,8 +374,12 @@ class GemmExchange:
         ahead as far as the protocol lets them).  Collective: every rank passes the same arguments.  Returns a dict."""
         from .. import ops
         L, dev = hip.lib(), self.device
-        hidden = self.max_elems // 32
+        # ``hidden``: width of the identity exchange (default: what 32 rows leave of the staging half — the engine sizes it
+        # as ONESHOT_MAX_ROWS x hidden_size with 32 rows; pass it explicitly when that is not how max_elems was chosen)
+        hidden = self.max_elems // 32 if hidden is None else int(hidden)
         rows = min(rows, 32)
+        assert hidden % 16 == 0 and hidden // 16 <= 512 and rows * hidden <= self.max_elems, \
+            f"litmus shape {rows} x {hidden} does not fit a staging half of {self.max_elems} elements"
         eye = ops.PackedLinear(torch.eye(hidden, dtype=torch.float16, device=dev))
         a = torch.zeros(rows, hidden, dtype=torch.float16, device=dev)
         out = torch.zeros(rows, hidden, dtype=torch.float16, device=dev)
