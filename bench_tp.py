@@ -78,7 +78,10 @@ def offload_report(llm, args, tcfg, world, device):
 def predicted_for(label, world, path=None):
     """This configuration's row of the tracked scaling prediction (tools/predict_scaling.py -> profiles/r05_predicted_scaling.json):
     per-rank stage latencies measured on ONE GPU + the low / high step the model composes from them; None when absent."""
-    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_predicted_scaling.json")
+    if path is None:                                            # the newest tracked prediction (profiles/rNN_predicted_scaling.json)
+        import glob
+        found = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9][0-9]_predicted_scaling.json")))
+        path = found[-1] if found else os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_predicted_scaling.json")
     try:
         cfgs = json.load(open(path))["configs"]
     except Exception:

@@ -93,8 +93,13 @@ def predict(line, loop, extra, bcast):
     W, L = line["emulated_world"], line["layers"]
     k = loop["inner_iterations"]
     tv, rv, dr = line["target_verify_us"], line["retrieval_verify_us"], line["draft_step_us"]
+    if loop.get("draft_step_us_in_loop"):
+        # the 68M draft is replicated: inside the one-graph inner iteration it is the SAME launch at every world size (the shard
+        # tool's figure adds an input copy and an output clone, and its random weights give flat rows: the slow case of the top-p select)
+        dr = loop["draft_step_us_in_loop"]
     x = 0 if W == 1 else 2 * L * (1 + k)
-    host = loop["host_overhead_us"] + (0 if W == 1 else loop.get("tp_host_extra_us", TP_HOST_EXTRA_US) + 2 * (k + 1) * bcast)
+    host = loop["host_overhead_us"] + (0 if W == 1 else loop.get("tp_host_extra_us", TP_HOST_EXTRA_US)
+                                       + loop.get("broadcasts_per_iteration", 2) * (k + 1) * bcast)
     terms = {"target_verify": tv, "retrieval_verify": k * rv, "draft": (k + 1) * dr, "host": host, "exchange_xgmi": x * extra}
     step = sum(terms.values())
     return step, terms, x
@@ -125,11 +130,22 @@ def main():
             continue
         w1 = apply_bench(loop, loop["bench"])
         tpj = load_bench_line(loop.get("tp_bench", "profiles/r05_bench_tp_engine_world1.json" if name == "configs[1]" else ""))
-        if tpj and (tpj.get("multi_rank") or {}).get("measured_step_terms_us"):
+        sj = load_bench_line(loop["bench"])
+        if tpj and sj and tpj.get("ms_per_step") and sj.get("ms_per_step") and tpj.get("tokens_per_step") == sj.get("tokens_per_step", tpj.get("tokens_per_step")):
+            # round 6: both engines ran the SAME loop statistics on the same workload — the TP loop's own host cost is the
+            # difference of their steps (the difference of the two `step_overhead_us` also carries the difference of how each line
+            # times its target verify: 165 us of the 178 the old formula gave on the round-6 box)
+            loop["tp_host_extra_us"] = round(max(0.0, (tpj["ms_per_step"] - sj["ms_per_step"]) * 1e3), 1)
+            loop["tp_host_extra_from"] = "ms_per_step of the TP engine at world 1 minus the graph engine's, same workload and loop statistics"
+        elif tpj and (tpj.get("multi_rank") or {}).get("measured_step_terms_us"):
             loop["tp_host_extra_us"] = round(max(0.0, tpj["multi_rank"]["measured_step_terms_us"]["host_and_broadcasts"]
                                                  - loop["host_overhead_us"]), 1)
         else:
             loop["tp_host_extra_us"] = TP_HOST_EXTRA_US
+        if tpj and sj and str(tpj.get("loop_structure", "")).startswith("one hipGraph") and (sj.get("stage_latency_us") or {}).get("draft_step_us"):
+            loop["draft_step_us_in_loop"] = sj["stage_latency_us"]["draft_step_us"]
+        # decisions: replicated by default since round 6 (no record broadcasts at W > 1) unless the TP line says otherwise
+        loop["broadcasts_per_iteration"] = 0 if (tpj and str(tpj.get("decisions", "")).startswith("replicated")) else 2
         if w1 is not None:                                    # the product at one GPU is the graph engine, not TP at world 1
             w1["layers"] = rows[0]["layers"]
             w1.update({k: rows[0][k] for k in ("target", "prefill", "budget", "gamma") if k in rows[0]})
