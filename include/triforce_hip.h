@@ -386,6 +386,25 @@ int tf_middle_accept(const float* p, const float* q_d, int64_t* tokens, const fl
 /* tf_mid_record_tokens: tokens[n + 1] (, tokens[n + 2]) as a tf_middle_accept record (accepted, follow-up, drafted) implies —
  * the tensor-parallel loop applies RANK 0's broadcast record (utils/decoding.py:452-470) with it in one launch. */
 int tf_mid_record_tokens(const int64_t* rec, int64_t* tokens, int tokens_len, int n, void* stream);
+/* tf_topp_probs_multi (csrc/topp_multi.hip; round 6): tf_topp_probs with every row spread over 16 (8 from 17 rows up) workgroups of
+ * ONE launch — the slices of a row meet through two in-launch edges (row maximum; mass sums + compacted candidates), then every
+ * workgroup of the row runs the exact-integer select over the row's candidates and writes its own entries.  Probabilities are
+ * BIT-IDENTICAL to tf_topp_probs (utils/sampling.py:5-27,43-60).  rows <= 32, V % 4 == 0, 64 <= V <= 32768, rows x slices <= the
+ * device's CU count (TF_ERANGE otherwise: the caller keeps tf_topp_probs).
+ *   panel_max  NULL, or [V / 16][32] fp32: per-16-column-panel row maxima of the logits as the lm_head GEMM's epilogue leaves them
+ *              (tf_skinny_gemm_act with out_f32 = 1 and ss_out != NULL): the first edge is skipped
+ *   ctl        tf_topp_multi_ctl_bytes() bytes, 64-byte aligned, ZERO-filled once; launches on one ctl must not overlap
+ *   ws         >= tf_topp_multi_ws_bytes(rows, V) bytes of device scratch, 256-byte aligned
+ * Bounded waits (tf_topp_multi_tune key 0 = ms, default 2000; key 1 = fault injection for tests): a time-out sets the sticky
+ * error word (tf_topp_multi_error) and NaN-fills the rows until tf_topp_multi_reset. */
+int64_t tf_topp_multi_ctl_bytes(void);
+int64_t tf_topp_multi_ws_bytes(int rows, int V);
+int tf_topp_probs_multi(const float* logits, const float* panel_max, float* probs, int rows, int V, float temperature,
+                        float top_p, void* ctl, void* ws, int64_t ws_bytes, void* stream);
+int tf_topp_multi_tune(int key, int value);
+int tf_topp_multi_error(const void* ctl);
+int tf_topp_multi_reset(void* ctl);
+
 /* The same three kernels with their uniforms behind a DEVICE CURSOR (round 5): u_k = ubuf[*cursor + k] — the form that
  * can sit INSIDE a captured hipGraph (frozen arguments, fresh numbers at every replay), which is how the inner loop of
  * utils/decoding.py:163-223 becomes ONE graph launch per iteration (draft forward, draw, retrieval verify, accept test).

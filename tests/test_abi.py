@@ -69,7 +69,7 @@ def test_bad_arguments_are_rejected_without_launching():
     assert lib.tf_draft_forward_ws_bytes(None, 7) == 0
     assert lib.tf_draft_forward_68m(ctypes.byref(m), None, null, 7, 0, 7, null, null, 0.6, 0.9, null, 0, null) == -22
     # the one-launch form: control block / workspace sizes, shape gate (the device query is not reached for a refused shape)
-    assert lib.tf_draft_persist_ctl_bytes() == 64 + 12 * 8 * 64 + 2 * 64 + 2 * 1024 * 8
+    assert lib.tf_draft_persist_ctl_bytes() == 64 + 12 * 9 * 64 + 12 * 8 * 64 + 2 * 8 * 64 + 2 * 1024 * 8      # head, counters, READY flags, Z shards, histograms
     assert lib.tf_draft_persist_ws_bytes(ctypes.byref(m)) == 3 * 24576 + 98304 + 6144 + 1024 + 131072
     assert lib.tf_draft_persist_ws_bytes(None) == 0
     assert lib.tf_draft_persist_supported(ctypes.byref(m), 17, 100) == -22 and lib.tf_draft_persist_supported(None, 1, 1) == -22
@@ -79,6 +79,12 @@ def test_bad_arguments_are_rejected_without_launching():
     assert lib.tf_draft_forward_68m_persist(ctypes.byref(m), None, null, 7, 0, 7, null, null, 0.6, 0.9, null, 0, null, null) == -22
     assert lib.tf_draft_persist_error(null) == -22 and lib.tf_draft_persist_reset(null, null, 0) == -22
     assert lib.tf_draft_persist_tune(9, 1) == -1
+    # the multi-workgroup top-p: sizes, shape gate
+    assert lib.tf_topp_multi_ctl_bytes() == 64 + 2 * 2 * 32 * 64
+    assert lib.tf_topp_multi_ws_bytes(7, 32000) == 512 + 1024 + 512 + 7 * 16 * 500 * 4 * 8
+    assert lib.tf_topp_multi_ws_bytes(33, 32000) == 0 and lib.tf_topp_multi_ws_bytes(4, 32002) == 0
+    assert lib.tf_topp_probs_multi(null, null, null, 7, 32000, 0.6, 0.9, null, null, 0, null) == -22
+    assert lib.tf_topp_multi_error(null) == -22 and lib.tf_topp_multi_reset(null) == -22 and lib.tf_topp_multi_tune(5, 1) == -1
     assert lib.tf_attn_prefill_pick_nsplit(32, 1024, 124928) == 4          # 1024 / (32 heads x 8 row blocks)
     assert lib.tf_attn_prefill_pick_nsplit(32, 1024, 1024) == 1            # 16 slabs: no split
     assert (12 * lib.tf_attn_prefill_pick_nsplit(12, 256, 4096)) % 8 == 0  # pairs are dealt to the 8 XCDs
@@ -106,7 +112,8 @@ _QUERIES = {"tf_abi_version", "tf_attn_block_pick_nsplit", "tf_attn_block_ws_flo
             "tf_attn_prefill_pick_nsplit", "tf_attn_prefill_ws_floats", "tf_draft_forward_ws_bytes",
             "tf_attn_decode_ws_floats", "tf_ar_flags_bytes", "tf_ar_ipc_handle_bytes",
             "tf_sg_tune", "tf_sg_workspace", "tf_xchg_ctl_bytes", "tf_attn_tune", "tf_xchg_tune",
-            "tf_draft_persist_ctl_bytes", "tf_draft_persist_ws_bytes", "tf_draft_persist_tune", "tf_draft_persist_stamps"}   # launch-rule knob / workspace registration: nothing launched (NULL = remove)
+            "tf_draft_persist_ctl_bytes", "tf_draft_persist_ws_bytes", "tf_draft_persist_tune", "tf_draft_persist_stamps",
+            "tf_topp_multi_ctl_bytes", "tf_topp_multi_ws_bytes", "tf_topp_multi_tune"}   # launch-rule knob / workspace registration: nothing launched (NULL = remove)
 
 
 @pytest.mark.parametrize("fill", [1, 8, -1])

@@ -538,6 +538,79 @@ def test_topp_probs_matches_oracle(V, T, P):
         assert torch.equal(got, want)
 
 
+def _topp_rows(rows, V, kind, seed):
+    lg = rnd(rows, V, seed=seed, dtype=torch.float32) * 2.5
+    if kind == "fp16":                                 # what an lm_head produces: fp16-valued logits, exact ties everywhere
+        lg = lg.half().float()
+    elif kind == "peaked":
+        lg = (lg * 4).half().float()
+    elif kind == "ties":
+        lg = lg[:, :16].repeat(1, V // 16 + 1)[:, :V].contiguous()
+    elif kind == "flat":
+        lg = (lg * 0.01).half().float()
+    elif kind == "equal":
+        lg = torch.zeros_like(lg)
+    return lg
+
+
+@pytest.mark.parametrize("rows,V", [(1, 32000), (7, 32000), (8, 32768), (18, 32000), (3, 1024), (32, 4096)])
+@pytest.mark.parametrize("kind", ["fp16", "peaked", "ties", "flat", "equal"])
+def test_topp_multi_workgroup_form_is_bit_identical_to_the_one_workgroup_kernel(rows, V, kind, monkeypatch):
+    """tf_topp_probs_multi (every row over 16 / 8 workgroups of one launch, two in-launch hand-offs, candidates compacted per
+    slice) against tf_topp_probs (one workgroup per row, itself pinned to the oracle above): torch.equal for fp16-valued rows,
+    sharp rows, rows of 16 distinct values (2 000-entry tie groups cut at the boundary), near-flat rows (every entry a candidate:
+    the rounds walk global memory) and all-equal rows, at four (T, top_p) settings incl. top_p = 1 and the greedy emulation; with and
+    without the per-panel maxima an lm_head epilogue hands over; twice in a row on the same control block."""
+    ops = _ops()
+    lg = _topp_rows(rows, V, kind, 300 + rows).to(DEV)
+    pm = None
+    if V % 16 == 0:
+        pm = torch.full((V // 16, 32), float("-inf"), dtype=torch.float32, device=DEV)
+        pm[:, :rows] = lg.view(rows, V // 16, 16).max(-1).values.t()
+    for T, P in ((0.6, 0.9), (1.0, 0.95), (0.8, 1.0), (1.0, 1e-9)):
+        monkeypatch.setattr(ops, "TOPP_MULTI", False)
+        want = ops.topp_probs(lg, T, P)
+        monkeypatch.setattr(ops, "TOPP_MULTI", True)
+        for panel in (None, pm):
+            for _ in range(2):
+                got = ops.topp_probs(lg, T, P, panel_max=panel)
+                assert torch.equal(got, want), (kind, T, P, panel is not None, int((got != want).sum()),
+                                                float((got - want).abs().max()))
+    st = ops._topp_multi(torch.device(DEV))
+    assert _ops_lib().tf_topp_multi_error(ops._ptr(st[0])) == 0
+
+
+def _ops_lib():
+    from triforce_amd import hip
+    return hip.lib()
+
+
+def test_topp_multi_lost_arrival_times_out_poisons_and_recovers(monkeypatch):
+    ops, L = _ops(), _ops_lib()
+    lg = _topp_rows(7, 32000, "fp16", 5).to(DEV)
+    monkeypatch.setattr(ops, "TOPP_MULTI", True)
+    want = ops.topp_probs(lg, 0.6, 0.9)
+    st = ops._topp_multi(torch.device(DEV))
+    old = L.tf_topp_multi_tune(0, 50)
+    try:
+        for edge in (0, 1):
+            L.tf_topp_multi_tune(1, edge + 1)
+            bad = ops.topp_probs(lg, 0.6, 0.9)
+            torch.cuda.synchronize()
+            L.tf_topp_multi_tune(1, 0)
+            assert L.tf_topp_multi_error(ops._ptr(st[0])) == edge + 1
+            assert bool(torch.isnan(bad[0]).all())                   # the row whose arrival was lost; sticky from here on
+            again = ops.topp_probs(lg, 0.6, 0.9)
+            torch.cuda.synchronize()
+            assert bool(torch.isnan(again).all())
+            assert L.tf_topp_multi_reset(ops._ptr(st[0])) == 0
+            good = ops.topp_probs(lg, 0.6, 0.9)
+            assert torch.equal(good, want)
+    finally:
+        L.tf_topp_multi_tune(1, 0)
+        L.tf_topp_multi_tune(0, old)
+
+
 def test_norm_logits_routes_to_fused_kernel_and_draft_row_shortcut():
     from triforce_amd.utils.sampling import norm_logits
     lg = rnd(7, 32000, seed=5, dtype=torch.float32).to(DEV) * 3

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtriforce_hip.so")
-SOURCES = ["attn.hip", "retrieval.hip", "elementwise.hip", "sampling.hip", "offload.hip", "gemv.hip", "allreduce.hip", "draft.hip", "draft_persist.hip", "abi.hip"]
+SOURCES = ["attn.hip", "retrieval.hip", "elementwise.hip", "sampling.hip", "offload.hip", "gemv.hip", "allreduce.hip", "draft.hip", "draft_persist.hip", "topp_multi.hip", "abi.hip"]
 # -amdgpu-kernarg-preload-count: the leading pointer / scalar kernel arguments (up to 14 dwords) arrive in SGPRs with the
 # dispatch instead of through s_load + s_waitcnt at the top of every kernel (gfx950 hardware feature; the compiler keeps a
 # backward-compatible entry for firmware without it).  The decode kernels order their arguments for it (csrc/gemv.hip).
@@ -30,7 +30,7 @@ def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "tree_mask.h"),
+    deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "tree_mask.h"), os.path.join(CSRC, "select_common.h"),
                         os.path.join(HERE, "..", "include", "triforce_hip.h"), os.path.abspath(__file__)]   # (flags live here)
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 

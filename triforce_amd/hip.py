@@ -120,6 +120,12 @@ class TfDraftCache(_c.Structure):
 SIGNATURES["tf_draft_forward_ws_bytes"] = (_i64, [_c.POINTER(TfDraftModel), _i32])
 SIGNATURES["tf_draft_forward_68m"] = (_i32, [_c.POINTER(TfDraftModel), _c.POINTER(TfDraftCache), _vp, _i32, _i32, _i32, _vp,
                                              _vp, _f32, _f32, _vp, _i64, _vp])
+SIGNATURES["tf_topp_multi_ctl_bytes"] = (_i64, [])
+SIGNATURES["tf_topp_multi_ws_bytes"] = (_i64, [_i32, _i32])
+SIGNATURES["tf_topp_probs_multi"] = (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _i64, _vp])
+SIGNATURES["tf_topp_multi_tune"] = (_i32, [_i32, _i32])
+SIGNATURES["tf_topp_multi_error"] = (_i32, [_vp])
+SIGNATURES["tf_topp_multi_reset"] = (_i32, [_vp])
 SIGNATURES["tf_draft_persist_ctl_bytes"] = (_i64, [])
 SIGNATURES["tf_draft_persist_ws_bytes"] = (_i64, [_c.POINTER(TfDraftModel)])
 SIGNATURES["tf_draft_persist_supported"] = (_i32, [_c.POINTER(TfDraftModel), _i32, _i32])

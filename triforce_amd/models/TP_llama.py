@@ -160,6 +160,10 @@ class DistributedLlama:
         everyone = [None] * self.world_size
         dist.all_gather_object(everyone, mine)
         self.ranks_per_device = max(everyone.count(e) for e in everyone)
+        if self.ranks_per_device > 1:
+            # same for the multi-workgroup top-p (rows x 16 resident workgroups per launch): 18-row verifies of two ranks do not
+            # fit one chip together
+            ops.TOPP_MULTI = False
         draft = getattr(self, "draft", None)
         if self.ranks_per_device > 1 and draft is not None and hasattr(draft, "persist_allowed"):
             draft.persist_allowed = False

@@ -994,11 +994,45 @@ def tree_accept(p_rows, draft_logits, tokens, succ_off, succ, uniforms, temperat
 TOPP_MAX_VOCAB = 32768
 
 
-def topp_probs(logits, temperature, top_p):
-    """softmax(top_p_filter(logits / temperature)) for (rows, V) fp32 logits, V <= 32768 — one fused kernel."""
+TOPP_MULTI = _os.environ.get("TRIFORCE_TOPP_MULTI", "1") != "0"
+_topp_multi_state = {}
+
+
+def _topp_multi(device):
+    """(control block, workspace) of tf_topp_probs_multi for this device, allocated at the first call OUTSIDE a capture (a
+    graph's warm-up passes always come first); None while capturing without one.  One per device: the launches of a process are
+    stream-ordered or synchronised against each other (warm-up stream -> capture -> replays); a caller that runs top-p on two
+    streams at once sets TRIFORCE_TOPP_MULTI=0."""
+    key = torch.device(device).index or 0
+    st = _topp_multi_state.get(key)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        L = hip.lib()
+        st = (torch.zeros(int(L.tf_topp_multi_ctl_bytes()), dtype=torch.uint8, device=device),
+              torch.empty(int(L.tf_topp_multi_ws_bytes(32, 32768)), dtype=torch.uint8, device=device))
+        _topp_multi_state[key] = st
+    return st
+
+
+def topp_probs(logits, temperature, top_p, panel_max=None):
+    """softmax(top_p_filter(logits / temperature)) for (rows, V) fp32 logits, V <= 32768 — one fused kernel: every row over 16
+    workgroups with in-launch hand-offs (tf_topp_probs_multi) where the shape allows, else one workgroup per row
+    (tf_topp_probs); bit-identical.  ``panel_max``: the per-panel row maxima the lm_head GEMM left (ops.linear(...,
+    out_f32=True, ss_out=...)): the multi-workgroup form then skips its first hand-off."""
     _dev(logits)
     assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.is_contiguous()
     probs = torch.empty_like(logits)
+    rows, V = logits.shape
+    if TOPP_MULTI and rows <= 32 and V % 4 == 0 and 64 <= V <= 32768 and logits.data_ptr() % 16 == 0:
+        st = _topp_multi(logits.device)
+        if st is not None:
+            rc = hip.lib().tf_topp_probs_multi(_ptr(logits), _ptr(panel_max), _ptr(probs), rows, V, float(temperature),
+                                               float(top_p), _ptr(st[0]), _ptr(st[1]), st[1].numel(), _stream())
+            if rc == 0:
+                return probs
+            if rc != -34:                                        # TF_ERANGE: more workgroups than CUs — the one-per-row kernel
+                hip.check(rc, "tf_topp_probs_multi")
     hip.check(hip.lib().tf_topp_probs(_ptr(logits), _ptr(probs), logits.shape[0], logits.shape[1], float(temperature),
                                       float(top_p), _stream()), "tf_topp_probs")
     return probs
