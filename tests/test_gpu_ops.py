@@ -567,16 +567,24 @@ def test_topp_multi_workgroup_form_is_bit_identical_to_the_one_workgroup_kernel(
     if V % 16 == 0:
         pm = torch.full((V // 16, 32), float("-inf"), dtype=torch.float32, device=DEV)
         pm[:, :rows] = lg.view(rows, V // 16, 16).max(-1).values.t()
+    from triforce_amd import hip
+    L = hip.lib()
+    st = ops._topp_multi(torch.device(DEV))
+
+    def multi(T, P, panel):                            # the entry point itself (ops.topp_probs routes > 16 rows to the one-workgroup kernel)
+        out = torch.empty_like(lg)
+        hip.check(L.tf_topp_probs_multi(ops._ptr(lg), ops._ptr(panel), ops._ptr(out), rows, V, T, P, ops._ptr(st[0]), ops._ptr(st[1]),
+                                        st[1].numel(), ops._stream()), "tf_topp_probs_multi")
+        return out
     for T, P in ((0.6, 0.9), (1.0, 0.95), (0.8, 1.0), (1.0, 1e-9)):
         monkeypatch.setattr(ops, "TOPP_MULTI", False)
         want = ops.topp_probs(lg, T, P)
         monkeypatch.setattr(ops, "TOPP_MULTI", True)
         for panel in (None, pm):
             for _ in range(2):
-                got = ops.topp_probs(lg, T, P, panel_max=panel)
+                got = multi(T, P, panel) if rows > 16 else ops.topp_probs(lg, T, P, panel_max=panel)
                 assert torch.equal(got, want), (kind, T, P, panel is not None, int((got != want).sum()),
                                                 float((got - want).abs().max()))
-    st = ops._topp_multi(torch.device(DEV))
     assert _ops_lib().tf_topp_multi_error(ops._ptr(st[0])) == 0
 
 

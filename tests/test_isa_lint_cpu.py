@@ -79,3 +79,40 @@ _Zk: ; @_Zk
     import re
     spills = re.findall(r"\.name:\s+(_Z21skinny_gemm_n8_kernel\S+)[\s\S]*?\.vgpr_spill_count:\s+(\d+)", text)
     assert len(spills) >= 10 and all(int(n) == 0 for _, n in spills), [(k[:48], n) for k, n in spills if int(n)]
+
+
+def test_handoff_kernels_store_write_through_drain_before_every_arrival_and_use_no_fences():
+    """Round 6: the one-launch draft forward and the multi-workgroup top-p hand data between workgroups INSIDE a
+    launch.  What makes that correct on gfx950 is visible only in the ISA: the payload goes out with `sc1` (write-through) stores
+    and comes in with `sc1` loads (past this CU's L1), every arrival — a returning atomic add on an edge counter — sits behind an
+    `s_waitcnt vmcnt(0)` with no store in between, and no agent-scope fence (`buffer_wbl2` / `buffer_inv`) exists at all (one that
+    crept in would cost ~1.7 us per edge and could hide a missing drain).  Also pinned: no register spills where none are expected."""
+    synthetic = """
+_Zk: ; @_Zk
+\tglobal_store_dwordx2 v[0:1], v[2:3], off sc1
+\tglobal_atomic_add_u32 v4, v[5:6], v7, off sc0 sc1
+\ts_waitcnt vmcnt(0)
+\tglobal_atomic_add_u32 v4, v[5:6], v7, off sc0 sc1
+\tglobal_load_dwordx2 v[8:9], v[10:11], off sc1
+\tbuffer_inv sc1
+\ts_endpgm
+.Lfunc_end0:
+"""
+    sh = isa_lint.handoff_shape(synthetic)["_Zk"]
+    assert sh == dict(sc1_loads=1, sc1_stores=1, fences=1, arrivals=2, arrivals_without_drain=1)
+    from triforce_amd.build import FLAGS
+    extra = [f for f in FLAGS if f == "-mllvm" or f.startswith("-amdgpu-")]
+    draft = isa_lint.handoff_shape(isa_lint.compile_to_asm(os.path.join(CSRC, "draft_persist.hip"), extra=extra))
+    d1 = next(v for k, v in draft.items() if "draft_persist_kernelILi1E" in k)
+    d2 = next(v for k, v in draft.items() if "draft_persist_kernelILi2E" in k)
+    # 5 layer edges per layer + lm + the top-p edge, some arrived at from two code paths (with / without the probability row)
+    assert d1["arrivals"] >= 8 and d2["arrivals"] >= 13
+    for v in (d1, d2):
+        assert v["arrivals_without_drain"] == 0 and v["fences"] == 0, v
+        assert v["sc1_loads"] >= 60 and v["sc1_stores"] >= 40, v
+    assert d1["vgpr_spills"] == 0 and d2["vgpr_spills"] <= 48, (d1, d2)      # (two layers sit at the 256-register limit: DESIGN 15.1)
+    topp = isa_lint.handoff_shape(isa_lint.compile_to_asm(os.path.join(CSRC, "topp_multi.hip"), extra=extra))
+    assert len(topp) == 2
+    for k, v in topp.items():
+        assert v["arrivals"] == 2 and v["arrivals_without_drain"] == 0 and v["fences"] == 0, (k, v)
+        assert v["sc1_loads"] >= 20 and v["sc1_stores"] >= 8 and v["vgpr_spills"] == 0 and v["vgprs"] <= 128, (k, v)

@@ -210,3 +210,23 @@ def test_build_variant_command_line(monkeypatch):
     cmd = seen[-1]
     assert "-mllvm" not in cmd and not any(c.startswith("-amdgpu-kernarg-preload") for c in cmd)
     assert "--offload-arch=gfx950" in cmd and not any(c.startswith("-D!") or c.startswith("!") for c in cmd)
+
+
+def test_parity_table_folds_recorded_checks_into_the_tolerance_table(tmp_path):
+    """tools/parity_table.py: the worst use of a bound over a test's parametrisations, slack = 1 / used, and the
+    list of checks with >= 4x slack."""
+    import json
+    import subprocess
+    import sys
+    rows = [{"test": "tests/test_x.py::test_a[1]", "check": "assert_close", "used": 0.2, "what": "", "max_abs": 2e-4, "mean_abs": 1e-6, "atol": 1e-3, "rtol": 1e-3, "max_ref": 1.0},
+            {"test": "tests/test_x.py::test_a[2]", "check": "assert_close", "used": 0.6, "what": "", "max_abs": 6e-4, "mean_abs": 2e-6, "atol": 1e-3, "rtol": 1e-3, "max_ref": 1.0},
+            {"test": "tests/test_x.py::test_b", "check": "bound", "used": 0.1, "what": "rows", "value": 1e-3, "limit": 1e-2},
+            {"test": "tests/test_x.py::test_c", "check": "logit_check", "used": 0.75, "what": "logits", "max_abs": 5.9e-3, "mean_abs": 6e-4, "bound": 7.8e-3,
+             "mean_bound": 1e-3, "mean_used": 0.6, "max_ref": 7.0, "spacings": 2.0}]
+    src, dst, js = tmp_path / "t.jsonl", tmp_path / "t.md", tmp_path / "t.json"
+    src.write_text("\n".join(json.dumps(r) for r in rows) + "\n")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_table.py"), str(src), str(dst), "--json", str(js)], check=True)
+    table = {t["test"]: t for t in json.load(open(js))}
+    assert table["test_x.py::test_a"]["cases"] == 2 and abs(table["test_x.py::test_a"]["used"] - 0.6) < 1e-9
+    assert table["test_x.py::test_b — rows"]["slack"] == 10.0 and table["test_x.py::test_c — logits"]["slack"] == 1.33
+    assert "1 with >= 4x slack: test_x.py::test_b — rows (10.0x)" in dst.read_text()

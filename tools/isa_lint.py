@@ -174,3 +174,36 @@ def main():
 
 if __name__ == "__main__":
     sys.exit(main())
+
+
+# ---- third check (round 6): the in-launch hand-off kernels (csrc/draft_persist.hip, csrc/topp_multi.hip) ----------------------
+# Their correctness rests on instruction-level facts the source only implies (MI355X_MICROARCH.md, inter-workgroup visibility):
+#   * data handed to another workgroup is stored write-through and read past the L1: `global_store* ... sc1` / `global_load* ... sc1`;
+#   * every arrival (a returning `global_atomic_add ... sc1` on a counter) is preceded by `s_waitcnt vmcnt(0)` — the drain of the
+#     stores it publishes — with no store in between;
+#   * there is no agent-scope FENCE in the kernels (`buffer_wbl2` / `buffer_inv`): a fence that crept in (e.g. a seq_cst atomic)
+#     would cost ~1.7 us per edge and hide a missing drain.
+# handoff_shape() reports, per kernel: sc1 loads / stores, fences, arrivals and how many of them lack the drain, registers, spills.
+def handoff_shape(text):
+    out = {}
+    for m in re.finditer(r"^(_Z\w+):\s*;\s*@\1\n([\s\S]*?)\n\.Lfunc_end\d+:", text, re.M):
+        name, body = m.group(1), m.group(2)
+        lines = [l.strip() for l in body.split("\n")]
+        arrivals = undrained = 0
+        drained = False                                   # a vmcnt(0) wait with no store issued since
+        for l in lines:
+            if l.startswith("s_waitcnt") and re.search(r"vmcnt\(0\)", l):
+                drained = True
+            elif re.match(r"(global|flat|buffer)_store", l):
+                drained = False
+            elif re.match(r"global_atomic_add(_u32)?\s+v\d+", l) and "sc0" in l:      # returning add = an arrival
+                arrivals += 1
+                undrained += 0 if drained else 1
+        out[name] = {"sc1_loads": sum(1 for l in lines if l.startswith("global_load") and " sc1" in l),
+                     "sc1_stores": sum(1 for l in lines if l.startswith("global_store") and " sc1" in l),
+                     "fences": sum(1 for l in lines if l.startswith("buffer_wbl2") or l.startswith("buffer_inv")),
+                     "arrivals": arrivals, "arrivals_without_drain": undrained}
+    for m in re.finditer(r"\.name:\s+(_Z\w+)[\s\S]*?\.vgpr_count:\s+(\d+)[\s\S]*?\.vgpr_spill_count:\s+(\d+)", text):
+        if m.group(1) in out:
+            out[m.group(1)].update(vgprs=int(m.group(2)), vgpr_spills=int(m.group(3)))
+    return out

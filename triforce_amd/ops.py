@@ -1024,7 +1024,9 @@ def topp_probs(logits, temperature, top_p, panel_max=None):
     assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.is_contiguous()
     probs = torch.empty_like(logits)
     rows, V = logits.shape
-    if TOPP_MULTI and rows <= 32 and V % 4 == 0 and 64 <= V <= 32768 and logits.data_ptr() % 16 == 0:
+    # (<= 16 rows: from 17 rows the launch has 8 slices of 4 000 entries per row — 36.8 -> 30.2 us on model-like rows, but
+    #  52.6 -> 81.5 on near-flat ones: profiles/r06_topp_one_workgroup_vs_multi.jsonl; those calls keep one workgroup per row)
+    if TOPP_MULTI and rows <= 16 and V % 4 == 0 and 64 <= V <= 32768 and logits.data_ptr() % 16 == 0:
         st = _topp_multi(logits.device)
         if st is not None:
             rc = hip.lib().tf_topp_probs_multi(_ptr(logits), _ptr(panel_max), _ptr(probs), rows, V, float(temperature),
