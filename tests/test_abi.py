@@ -69,8 +69,8 @@ def test_bad_arguments_are_rejected_without_launching():
     assert lib.tf_draft_forward_ws_bytes(None, 7) == 0
     assert lib.tf_draft_forward_68m(ctypes.byref(m), None, null, 7, 0, 7, null, null, 0.6, 0.9, null, 0, null) == -22
     # the one-launch form: control block / workspace sizes, shape gate (the device query is not reached for a refused shape)
-    assert lib.tf_draft_persist_ctl_bytes() == 64 + 12 * 9 * 64 + 12 * 8 * 64 + 2 * 8 * 64 + 2 * 1024 * 8      # head, counters, READY flags, Z shards, histograms
-    assert lib.tf_draft_persist_ws_bytes(ctypes.byref(m)) == 3 * 24576 + 98304 + 6144 + 1024 + 131072
+    assert lib.tf_draft_persist_ctl_bytes() == 64 + 12 * 9 * 64 + 12 * 8 * 64      # head, counters, READY flags
+    assert lib.tf_draft_persist_ws_bytes(ctypes.byref(m)) == 3 * 24576 + 98304 + 6144 + 1024 + 256 * 128 * 8 + 2048 + 1024    # ..., candidates, sums, counts
     assert lib.tf_draft_persist_ws_bytes(None) == 0
     assert lib.tf_draft_persist_supported(ctypes.byref(m), 17, 100) == -22 and lib.tf_draft_persist_supported(None, 1, 1) == -22
     m.inter = 2048

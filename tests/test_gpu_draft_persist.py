@@ -121,12 +121,14 @@ def test_one_launch_draft_graph_replay_and_soak(sd68, monkeypatch):
     assert m1._persist.error() == 0
 
 
-@pytest.mark.parametrize("kind", ["ties", "ties8", "flat", "peaked"])
+@pytest.mark.parametrize("kind", ["ties", "ties8", "ties20", "mid", "flat", "peaked"])
 def test_one_launch_top_p_on_degenerate_rows(kind, monkeypatch):
     """Rows the exact select must get right bit for bit: `ties` — lm_head with 16 distinct rows repeated (2 000 entries share
-    every logit: the boundary falls inside a tie group and the ties are ranked by index — through the parked row, the list
-    overflows; `ties8`: tie groups of 8, ranked through the boundary-bin list), `flat` — lm_head = 0 (32 000 equal
-    entries), `peaked` — one dominant logit (a trained draft's usual row)."""
+    every logit: the boundary falls inside a tie group and the ties are ranked by index — by the radix select on the index,
+    streamed when the candidates overflow the list; `ties8`: tie groups of 8; `ties20`: 20 equal dominant logits, top_p cuts
+    the group — the in-wave finish ranks them), `mid` — logits of a few units' spread (hundreds of candidates, a boundary bin
+    of more or fewer than 64 entries depending on the setting), `flat` — lm_head = 0 (32 000 equal entries), `peaked` — one
+    dominant logit (a trained draft's usual row)."""
     cfg = _cfg()
     sd = dict(specs.random_state_dict(cfg, 23, head_std=0.05))
     head = sd["lm_head.weight"].clone()
@@ -134,6 +136,10 @@ def test_one_launch_top_p_on_degenerate_rows(kind, monkeypatch):
         head = head[:16].repeat(2000, 1)
     elif kind == "ties8":                                              # 4 000 tie groups of 8, sharper logits: the boundary cuts a
         head = (head[:4000] * 4.0).repeat_interleave(8, dim=0)         # group that fits the boundary-bin list (ranked through it)
+    elif kind == "ties20":
+        head[100:120] = head[777] * 40.0
+    elif kind == "mid":
+        head *= 12.0
     elif kind == "flat":
         head.zero_()
     else:

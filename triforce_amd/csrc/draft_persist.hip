@@ -65,8 +65,6 @@ struct DpCtl {                               // device memory, zero-filled once 
     unsigned pad1[10];
     unsigned cnt[DP_EDGES][9][16];           // arrival counters: edge, 8 shards + the shards' top counter, one 64-byte line each
     unsigned flag[DP_EDGES][8][16];          // READY flags: 8 copies per edge (workgroup w polls copy w & 7), = epoch + 1
-    u64 gz[2][8][8];                         // top-p: sum of all masses, 8 shards on their own lines, per launch parity
-    u64 ghist[2][1024];                      // top-p: round-1 mass histogram, per launch parity
 };
 
 struct DpParams {
@@ -94,7 +92,9 @@ struct DpParams {
     h16* act;                                // [16][INTER] SwiGLU output
     float* ss;                               // [48][32]    per-panel sums of squares (norm hand-off)
     float* wgmax;                            // [256]       top-p: per-workgroup row maximum
-    float* ebuf;                             // [V]         top-p: exp(x - max)
+    u64* cand;                               // [256][128]  top-p: every workgroup's candidates (pattern << 32) | index
+    u64* zslice;                             // [256]       top-p: every workgroup's exact mass sum
+    unsigned* ccount;                        // [256]       top-p: every workgroup's candidate count
     DpCtl* ctl;
     u64* stamps;                             // 0 or [DP_GRID][DP_STAMPS]
     u64 timeout_ticks;
@@ -668,13 +668,6 @@ __global__ __launch_bounds__(DP_THREADS) void draft_persist_kernel(DpParams P) {
         poison();
         return;
     }
-    // top-p scratch of the NEXT launch's parity: nobody uses it in this launch
-    {
-        const int nb = (int)((c.epoch + 1u) & 1u);
-        if (tid < 4) st8(&P.ctl->ghist[nb][4 * w + tid], 0ull);
-        if (w == 0 && tid >= 8 && tid < 16) st8(&P.ctl->gz[nb][tid - 8][0], 0ull);
-    }
-
     const bool r_qkv = w >= QKV_LO && w < QKV_HI, r_gu = w >= GU_LO && w < GU_HI;
     const bool r_att = w >= ATT_LO && w < ATT_HI, r_od = w >= OD_LO && w < OD_HI;
     // lm_head weights: this wave's panel, 24 KiB in registers, requested as early as the workgroup's own first role allows —
@@ -799,13 +792,17 @@ __global__ __launch_bounds__(DP_THREADS) void draft_persist_kernel(DpParams P) {
         return;
     }
 
-    // ---------------- top-p, part (a): e = exp(x - max), masses, round-1 bins of the candidates ----------------
+    // ---------------- top-p, part (a): e = exp(x - max), masses, this workgroup's CANDIDATES ----------------
+    // Candidates = entries at or above the cut (1 - top_p) / (2 V): they provably contain the top-p crossing
+    // (tests/test_host_edges_cpu.py::test_topp_candidate_cut_always_contains_the_crossing).  Every workgroup leaves its <= 128 as
+    // (pattern, index) pairs + a count + its exact mass sum; part (b) then reads a few KB of candidates instead of the 128 KB row
+    // (round 6's first build read the row — 4.9 us through the fabric, write-through lines sit in no L2 — and added masses to a
+    // global histogram with atomics that 256 workgroups of a flat row all aimed at the same three bins).
     if (!dp_wait(c, E_LM, 0, DP_GRID)) {
         poison();
         return;
     }
     dp_stamp(c);
-    const int par = (int)(c.epoch & 1u);
     const float top_p = P.top_p;
     unsigned cutpat = 0u;
     if (top_p < 1.0f) cutpat = __float_as_uint((1.0f - top_p) / (2.0f * (float)V)) & ~((1u << 20) - 1u);
@@ -817,40 +814,35 @@ __global__ __launch_bounds__(DP_THREADS) void draft_persist_kernel(DpParams P) {
             const U64x2 v = {ld8(P.wgmax + 4 * lane), ld8(P.wgmax + 4 * lane + 2)};
             const f32x4 f = __builtin_bit_cast(f32x4, v);
             mx = wave_max(fmaxf(fmaxf(f[0], f[1]), fmaxf(f[2], f[3])));
-            if (lane == 0) tp->wmax[0] = mx;
+            if (lane == 0) {
+                tp->wmax[0] = mx;
+                tp->nlist = 0u;
+            }
         }
         __syncthreads();
         mx = tp->wmax[0];
         u64 zacc = 0ull;
+        u64* mycand = P.cand + (int64_t)w * 128;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float e = own ? expf(xrow[r] - mx) : 0.f;
             erow[r] = e;
             const u64 m = own ? dp_fix(e) : 0ull;
             zacc += m;
-            const bool cand = m != 0ull && __float_as_uint(e) >= cutpat;
-            dp_hist_add(tp, cand, (int)(__float_as_uint(e) >> 20), m, false, lane);
-        }
-        if (own) {
-            const U64x2 ev = __builtin_bit_cast(U64x2, (f32x4){erow[0], erow[1], erow[2], erow[3]});
-            float* dst = P.ebuf + lm_panel * 16 + 4 * g;
-            st8(dst, ev.lo);
-            st8(dst + 2, ev.hi);
+            if (m != 0ull && __float_as_uint(e) >= cutpat) {             // (order within the segment is irrelevant: sums are exact)
+                const unsigned at = atomicAdd(&tp->nlist, 1u);
+                st8(mycand + at, ((u64)__float_as_uint(e) << 32) | (unsigned)(lm_panel * 16 + 4 * g + r));
+            }
         }
         const u64 zw = dp_wave_sum_u64(zacc);
         if (lane == 0) tp->zpart[wave] = zw;
         __syncthreads();
-        // flush this workgroup's bins and mass: exact integers, so the order in which the atomics land does not matter
-        for (int b = tid; b < 1024; b += DP_THREADS) {
-            const u64 hv = tp->hist[DP_HB(b)];
-            if (hv != 0ull) __hip_atomic_fetch_add(&P.ctl->ghist[par][b], hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tp->hist[DP_HB(b)] = 0ull;
-        }
         if (tid == 0) {
             u64 z = 0ull;
 #pragma unroll
             for (int k = 0; k < DP_WAVES; ++k) z += tp->zpart[k];
-            if (z != 0ull) __hip_atomic_fetch_add(&P.ctl->gz[par][w & 7][0], z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st8(P.zslice + w, z);
+            st4u(P.ccount + w, tp->nlist);
         }
     }
     dp_stamp(c);
@@ -863,35 +855,44 @@ __global__ __launch_bounds__(DP_THREADS) void draft_persist_kernel(DpParams P) {
     if (w == 0 && tid == 0) st4u(&P.ctl->epoch, c.epoch + 1u);           // every workgroup has passed its last wait's arrival
 
     // ---------------- top-p, part (b): every workgroup finds the boundary of the WHOLE row ----------------
-    // Round 1 (bits 29..20) comes from the global histogram.  The row's e values are read once: every thread keeps its 64
-    // (float4 f = tid + 512 it; ascending index = (it, tid, j)) in registers, parks them in LDS (nobody else reads them: no
-    // barrier) and files the entries of the boundary bin in a LIST.  A real row leaves a few hundred entries there, so rounds 2
-    // and 3 walk the list (<= 2 entries per thread) instead of the row; a list that overflows (flat rows: thousands of entries
-    // in one bin) falls back to walking the parked row.  All loads — histogram, total, row — are requested before anything waits.
-    constexpr int NIT = 16;                                              // 16 x 512 x 4 = 32768 entries
-    constexpr int LIST_CAP = 1024;
-    f32x4* mine = reinterpret_cast<f32x4*>(role_smem + 16384) + tid;     // entry block it at mine[512 * it]
-    u64* list = reinterpret_cast<u64*>(role_smem + 16384 + 32768 * 4);   // [LIST_CAP] (pattern << 32) | index
-    const int nf4 = V / 4;
-    f32x4 ev[NIT];
+    // Z, tau and the candidate offsets from the 256 per-workgroup sums / counts; the candidates gathered into an LDS list (each wave
+    // its 32 segments, one entry per lane and segment in flight together: a model's row leaves a few dozen per segment); the three
+    // radix rounds on the list with 512-thread DPP scans; a cut tie group ranked by a two-round radix select on the index.  More
+    // candidates than the list holds (near-flat rows): round 1 streams them and only the boundary bin is filed; a boundary bin
+    // that still does not fit is streamed by every round.
+    constexpr int LIST_CAP = 16384;
+    u64* list = reinterpret_cast<u64*>(role_smem + 16384);               // [LIST_CAP]
+    unsigned* offs = reinterpret_cast<unsigned*>(role_smem + 16384 + LIST_CAP * 8);    // [DP_GRID + 1] candidate offsets
+    u64* fin = reinterpret_cast<u64*>(role_smem + 16384 + LIST_CAP * 8 + 1088);        // [64] the boundary bin's entries
+    // (the first 16 entries — one 128-byte line — of this wave's 32 segments are requested WITH the counts, a quarter wave per segment:
+    //  lanes past a segment's count read stale workspace and drop it.  One round trip and 32 KB per workgroup for the usual row; a
+    //  segment with more than 16 candidates costs a second trip for the rest.)
+    constexpr int SPEC = 16;
+    u64 spec[8];
     {
-        const u64 gA = ld8(&P.ctl->ghist[par][1023 - 2 * tid]), gB = ld8(&P.ctl->ghist[par][1022 - 2 * tid]);
+        const unsigned cmine = tid < DP_GRID ? ld4u(P.ccount + tid) : 0u;
+        const u64 zmine = tid < DP_GRID ? ld8(P.zslice + tid) : 0ull;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) spec[j] = ld8(P.cand + (int64_t)(32 * wave + 4 * j + (lane >> 4)) * 128 + (lane & 15));
+        const unsigned incl = dp_wave_prefix_u32(cmine);
+        const u64 zincl = dp_wave_prefix_u64(zmine);
+        if (lane == 63) {
+            tp->red_i[wave] = (int)incl;
+            tp->zpart[wave] = zincl;
+        }
+        __syncthreads();
+        unsigned before = 0u;
         u64 Z = 0ull;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) Z += ld8(&P.ctl->gz[par][k][0]);     // (wave-uniform addresses: one request each)
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int f = tid + DP_THREADS * it;
-            ev[it] = f32x4{0.f, 0.f, 0.f, 0.f};                          // past V: zero mass, pattern 0
-            if (f < nf4) {
-                const U64x2 v = {ld8(P.ebuf + 4 * f), ld8(P.ebuf + 4 * f + 2)};
-                ev[it] = __builtin_bit_cast(f32x4, v);
-            }
+        for (int k = 0; k < DP_WAVES; ++k) {
+            if (k < wave) before += (unsigned)tp->red_i[k];
+            Z += tp->zpart[k];
         }
-        const double t = (double)top_p * (double)Z;
-        const u64 tau = (t >= 18446744073709549568.0) ? ~0ull : __double2ull_rd(t);
+        if (tid < DP_GRID) offs[tid + 1] = before + incl;
         if (tid == 0) {
-            tp->tau = tau;
+            offs[0] = 0u;
+            const double t = (double)top_p * (double)Z;
+            tp->tau = (t >= 18446744073709549568.0) ? ~0ull : __double2ull_rd(t);
             tp->Z = Z;
             tp->zk = Z;
             tp->S = 0ull;
@@ -899,36 +900,77 @@ __global__ __launch_bounds__(DP_THREADS) void draft_persist_kernel(DpParams P) {
             tp->ties = 0u;
             tp->nkeep = 0ull;
             tp->nlist = 0u;
+            tp->nfin = 0u;
         }
-        dp_scan512(tp, gA, gB, 0ull, tau, tid, lane, wave);              // (its first barrier orders the initialisation above)
-        if (tid == 0 && tp->digit < 0 && tau < Z) tp->digit = -2;        // crossing below the candidate cut
+        __syncthreads();
     }
+    const unsigned C = offs[DP_GRID];
+    const u64 tau = tp->tau, Zall = tp->Z;
+    unsigned maxc = 0u;                                                  // largest segment of THIS wave's 32
+    for (int q = 0; q < 32; ++q) maxc = max(maxc, offs[32 * wave + q + 1] - offs[32 * wave + q]);
+    // walk the row's candidates where they lie: wave w owns the segments of workgroups 32 w .. 32 w + 31
+    auto stream = [&](auto fn) {                                         // (every lane calls fn: it may use wave collectives)
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) mine[DP_THREADS * it] = ev[it];
-    __syncthreads();
-    dp_stamp(c);
-    int d1 = tp->digit;
-    const u64 tau = tp->tau;
-    // one round over the parked row: bins dig(b) over the entries with sel(b) (hist / cnt are zero on entry)
-    auto row_round = [&](auto sel, auto dig, bool last) {
-#pragma unroll 2
-        for (int it = 0; it < NIT; ++it) {
-            const f32x4 x = mine[DP_THREADS * it];
+        for (int j = 0; j < 8; ++j) {
+            const int sg = 32 * wave + 4 * j + (lane >> 4);
+            const unsigned cn = offs[sg + 1] - offs[sg], en = (unsigned)(lane & 15);
+            fn(spec[j], offs[sg] + en, en < cn);
+        }
+        if (maxc <= (unsigned)SPEC) return;
+        for (int q0 = 0; q0 < 32; q0 += 16) {                            // entries 16 .. 127: 16 segments' loads in flight together
+            u64 v[16][2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (sel(__float_as_uint(x[j]))) {
-                    const u64 m = dp_fix(x[j]);
-                    if (m != 0ull) {
-                        const int d = dig(__float_as_uint(x[j]));
-                        atomicAdd(&tp->hist[DP_HB(d)], m);
-                        if (last) atomicAdd(&tp->cnt[DP_HB(d)], 1u);
-                    }
+            for (int q = 0; q < 16; ++q) {
+                const int sg = 32 * wave + q0 + q;
+                const unsigned cn = offs[sg + 1] - offs[sg];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const unsigned en = SPEC + lane + 64 * k;
+                    v[q][k] = (en < cn && en < 128u) ? ld8(P.cand + (int64_t)sg * 128 + en) : 0ull;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int sg = 32 * wave + q0 + q;
+                const unsigned cn = offs[sg + 1] - offs[sg];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const unsigned en = SPEC + lane + 64 * k;
+                    fn(v[q][k], offs[sg] + en, en < cn && en < 128u);
                 }
             }
         }
     };
-    // scan the bins a round filled (and clear them), from base tp->S; the last round also resolves the ties at the boundary
-    auto finish_round = [&](bool last) {
+    unsigned nlist = 0u;
+    bool use_list = C <= (unsigned)LIST_CAP;
+    if (use_list) {
+        stream([&](u64 e, unsigned at, bool ok) {
+            if (ok) list[at] = e;
+        });
+        nlist = C;
+        __syncthreads();
+    }
+    dp_stamp(c);
+    auto for_each = [&](auto fn) {
+        if (use_list) {
+            for (unsigned i = tid; i < nlist; i += DP_THREADS) fn(list[i]);
+        } else {
+            stream([&](u64 e, unsigned, bool ok) {
+                if (ok) fn(e);
+            });
+        }
+    };
+    // one round: bins dig(pattern) of the candidates with sel(pattern) (+ how many fell in each when `count`); then the 512-thread
+    // scan from base tp->S; tp->ties = the entries of the bin the scan names (count rounds only)
+    auto round = [&](auto sel, auto dig, bool count) {
+        for_each([&](u64 e) {
+            const unsigned bb = (unsigned)(e >> 32);
+            if (sel(bb)) {
+                const int d = dig(bb);
+                atomicAdd(&tp->hist[DP_HB(d)], dp_fix(__uint_as_float(bb)));
+                if (count) atomicAdd(&tp->cnt[DP_HB(d)], 1u);
+            }
+        });
         __syncthreads();
         const int bA = DP_HB(1023 - 2 * tid), bB = DP_HB(1022 - 2 * tid);
         const u64 hA = tp->hist[bA], hB = tp->hist[bB];
@@ -937,179 +979,121 @@ __global__ __launch_bounds__(DP_THREADS) void draft_persist_kernel(DpParams P) {
         const u64 base = tp->S;
         if (tid == 0) tp->digit = -1;
         dp_scan512(tp, hA, hB, base, tau, tid, lane, wave);
-        if (last) {
+        if (count) {
             const int d = tp->digit;
-            if (d >= 0 && (d == 1023 - 2 * tid || d == 1022 - 2 * tid)) {
-                const unsigned T = tp->cnt[DP_HB(d)];
-                const u64 m = tp->hsel / (u64)T;                          // all ties share one pattern, hence one mass
-                u64 nk = (tau - tp->S) / m + 1ull;
-                if (nk > (u64)T) nk = T;
-                tp->ties = T;
-                tp->nkeep = nk;
-                tp->zk = tp->S + nk * m;
-            }
+            if (d >= 0 && (d == 1023 - 2 * tid || d == 1022 - 2 * tid)) tp->ties = tp->cnt[DP_HB(d)];
             __syncthreads();
             tp->cnt[bA] = 0u;
             tp->cnt[bB] = 0u;
         }
     };
-    if (d1 == -2) {                                                      // (kept exact; unreachable for the cut of part (a)): all entries
-        row_round([](unsigned) { return true; }, [](unsigned b) { return (int)(b >> 20); }, false);
-        finish_round(false);
+    auto tie_round = [&](auto sel, auto dig, u64 base, u64 want) {
+        for_each([&](u64 e) {
+            if (sel(e)) atomicAdd(&tp->hist[DP_HB(1023 - dig(e))], 1ull);
+        });
+        __syncthreads();
+        const int bA = DP_HB(1023 - 2 * tid), bB = DP_HB(1022 - 2 * tid);
+        const u64 hA = tp->hist[bA], hB = tp->hist[bB];
+        tp->hist[bA] = 0ull;
+        tp->hist[bB] = 0ull;
+        if (tid == 0) tp->digit = -1;
+        dp_scan512(tp, hA, hB, base, want, tid, lane, wave);
+    };
+    int d1 = -1;
+    unsigned ustar = 0u, ties = 0u;
+    u64 nkeep = 0ull, zk = Zall;
+    long long istar = -1;
+    if (tau < Zall) {                                                    // (tau >= Z: top_p >= 1 keeps everything)
+        round([](unsigned) { return true; }, [](unsigned bb) { return (int)(bb >> 20); }, true);
         d1 = tp->digit;
-    }
-    unsigned ustar = 0u, ties = 0u, nlist_k = 0u;
-    bool tp_list_ok = false;
-    u64 nkeep = 0ull;
-    if (d1 >= 0) {
-        // file the boundary bin's entries (pattern, index) from the registers, in index-free but deterministic order, WITHOUT
-        // atomics: per-thread count -> DPP prefix in the wave -> wave totals through LDS.  (One LDS counter bumped per entry
-        // serialised 32 000 same-address atomics on a flat row: 12.6 us, and 2 us on a peaked one.)
-        unsigned mycnt = 0u;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned b = __float_as_uint(ev[it][j]);
-                mycnt += ((int)(b >> 20) == d1) ? 1u : 0u;                // (a bin fixes the exponent: its entries all have a mass, or none has)
+        if (d1 < 0) {                                                    // cannot happen: the cut holds the crossing among the candidates
+            if (tid == 0) {
+                unsigned expected = 0u;
+                __hip_atomic_compare_exchange_strong(&P.ctl->error, &expected, 99u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-        const unsigned incl = dp_wave_prefix_u32(mycnt);
-        if (lane == 63) tp->red_i[wave] = (int)incl;
-        __syncthreads();
-        unsigned at = incl - mycnt, total = 0u;
-#pragma unroll
-        for (int k = 0; k < DP_WAVES; ++k) {
-            const unsigned t = (unsigned)tp->red_i[k];
-            if (k < wave) at += t;
-            total += t;
+            poison();
+            return;
         }
-        const unsigned nlist = total;
-        if (nlist <= (unsigned)LIST_CAP && mycnt != 0u) {
-#pragma unroll
-            for (int it = 0; it < NIT; ++it)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned b = __float_as_uint(ev[it][j]);
-                    if ((int)(b >> 20) == d1)
-                        list[at++] = ((u64)b << 32) | (unsigned)(4 * (tid + DP_THREADS * it) + j);
-                }
-        }
-        __syncthreads();
-        const bool use_list = nlist <= (unsigned)LIST_CAP;
-        nlist_k = nlist;
-        tp_list_ok = use_list;
         dp_stamp(c);
-        // ---- round 2: bits 19..10 inside the boundary bin ----
-        if (use_list) {
-            for (unsigned i = tid; i < nlist; i += DP_THREADS) {
-                const unsigned b = (unsigned)(list[i] >> 32);
-                atomicAdd(&tp->hist[DP_HB((int)((b >> 10) & 1023u))], dp_fix(__uint_as_float(b)));
+        const int dd1 = d1;
+        const unsigned nbin = tp->ties;                                  // entries of the boundary bin (an eighth of an octave of e)
+        if (nbin <= 64u) {
+            // The usual row: the boundary bin holds a handful of entries.  They are gathered (any order) and every WAVE finishes by
+            // itself, lane i holding entry i: mass above it, its tie group and its rank by index inside the group come from one
+            // pass over the <= 64 entries — the same boundary the two remaining radix rounds and the tie ranking would name
+            // (integers throughout), without their eight barriers.
+            for_each([&](u64 e) {
+                if ((int)((unsigned)(e >> 32) >> 20) == dd1) fin[atomicAdd(&tp->nfin, 1u)] = e;
+            });
+            __syncthreads();
+            const u64 mine = (unsigned)lane < nbin ? fin[lane] : 0ull;
+            const unsigned pi = (unsigned)(mine >> 32), ii = (unsigned)mine;
+            const u64 mi = dp_fix(__uint_as_float(pi));
+            u64 above = 0ull;
+            unsigned eq = 0u, lower = 0u;
+            for (unsigned j = 0; j < nbin; ++j) {
+                const u64 ej = fin[j];                                   // (one address for the wave: a broadcast read)
+                const unsigned pj = (unsigned)(ej >> 32), ij = (unsigned)ej;
+                above += pj > pi ? dp_fix(__uint_as_float(pj)) : 0ull;
+                eq += pj == pi ? 1u : 0u;
+                lower += (pj == pi && ij < ii) ? 1u : 0u;
+            }
+            const u64 Sx = tp->S + above;                                // mass of everything above this lane's pattern
+            const bool cross = (unsigned)lane < nbin && Sx <= tau && tau - Sx < (u64)eq * mi;
+            const unsigned long long cm = __ballot(cross);               // the lanes of ONE tie group
+            const int first = (int)__builtin_ctzll(cm);
+            ustar = (unsigned)__shfl((int)pi, first, 64);
+            ties = (unsigned)__shfl((int)eq, first, 64);
+            const u64 Sg = dp_shfl_u64(Sx, first), mg = dp_shfl_u64(mi, first);
+            nkeep = (tau - Sg) / mg + 1ull;
+            if (nkeep > (u64)ties) nkeep = ties;
+            zk = Sg + nkeep * mg;
+            if (nkeep < (u64)ties) {                                     // the tie group is cut: its nkeep lowest indices stay
+                const unsigned long long lm = __ballot(cross && (u64)lower + 1ull == nkeep);
+                istar = (long long)(unsigned)__shfl((int)ii, (int)__builtin_ctzll(lm), 64);
             }
         } else {
-            row_round([d1](unsigned b) { return (int)(b >> 20) == d1; }, [](unsigned b) { return (int)((b >> 10) & 1023u); }, false);
-        }
-        finish_round(false);
-        const unsigned pre = ((unsigned)d1 << 10) | (unsigned)tp->digit;
-        dp_stamp(c);
-        // ---- round 3: bits 9..0, with tie counts ----
-        if (use_list) {
-            for (unsigned i = tid; i < nlist; i += DP_THREADS) {
-                const unsigned b = (unsigned)(list[i] >> 32);
-                if ((b >> 10) == pre) {
-                    atomicAdd(&tp->hist[DP_HB((int)(b & 1023u))], dp_fix(__uint_as_float(b)));
-                    atomicAdd(&tp->cnt[DP_HB((int)(b & 1023u))], 1u);
-                }
+            if (!use_list) {
+                // file the boundary bin's entries (LDS counter: only the matches pay for it); overflow -> the rounds keep streaming
+                stream([&](u64 e, unsigned, bool ok) {
+                    if (ok && (int)((unsigned)(e >> 32) >> 20) == dd1) {
+                        const unsigned at = atomicAdd(&tp->nlist, 1u);
+                        if (at < (unsigned)LIST_CAP) list[at] = e;
+                    }
+                });
+                __syncthreads();
+                nlist = tp->nlist;
+                use_list = nlist <= (unsigned)LIST_CAP;
             }
-        } else {
-            row_round([pre](unsigned b) { return (b >> 10) == pre; }, [](unsigned b) { return (int)(b & 1023u); }, true);
+            round([dd1](unsigned bb) { return (int)(bb >> 20) == dd1; }, [](unsigned bb) { return (int)((bb >> 10) & 1023u); }, false);
+            const unsigned pre = ((unsigned)d1 << 10) | (unsigned)tp->digit;
+            dp_stamp(c);
+            round([pre](unsigned bb) { return (bb >> 10) == pre; }, [](unsigned bb) { return (int)(bb & 1023u); }, true);
+            ustar = (pre << 10) | (unsigned)tp->digit;
+            ties = tp->ties;
+            {
+                const u64 m = tp->hsel / (u64)ties;                      // all ties share one pattern, hence one mass
+                nkeep = (tau - tp->S) / m + 1ull;
+                if (nkeep > (u64)ties) nkeep = ties;
+                zk = tp->S + nkeep * m;
+            }
+            __syncthreads();                                             // (everyone has read tp->S before a tie round moves it)
+            if (nkeep < (u64)ties) {                                     // the tie group is cut: its nkeep lowest indices stay
+                const u64 want = nkeep - 1ull;
+                const unsigned us = ustar;
+                tie_round([us](u64 e) { return (unsigned)(e >> 32) == us; }, [](u64 e) { return (int)(((unsigned)e >> 5) & 1023u); }, 0ull, want);
+                const unsigned hi_idx = (unsigned)(1023 - tp->digit);
+                const u64 before = tp->S;
+                __syncthreads();
+                tie_round([us, hi_idx](u64 e) { return (unsigned)(e >> 32) == us && (((unsigned)e >> 5) & 1023u) == hi_idx; },
+                          [](u64 e) { return (int)((unsigned)e & 31u); }, before, want);
+                istar = (long long)((hi_idx << 5) | (unsigned)(1023 - tp->digit));
+            }
         }
-        finish_round(true);
-        ustar = (pre << 10) | (unsigned)tp->digit;
-        __syncthreads();
-        ties = tp->ties;
-        nkeep = tp->nkeep;
     }
     dp_stamp(c);
-    const float Zk = (float)((double)tp->zk * (1.0 / 1099511627776.0));
+    const float Zk = (float)((double)zk * (1.0 / 1099511627776.0));
     const bool rank_ties = d1 >= 0 && nkeep < (u64)ties;
-    long long istar = -1;
-    const bool list_ok = d1 >= 0 && tp_list_ok;
-    if (rank_ties && list_ok) {
-        // The tie group is cut: keep its nkeep lowest indices.  Every tie is in the list, so the nkeep-th smallest index among them is
-        // a two-round radix select on the 15-bit index with the same scan (counts as masses, bins reversed: "from the top" =
-        // ascending index): bits 14..5, then bits 4..0.
-        const u64 want = nkeep - 1ull;
-        if (tid == 0) tp->S = 0ull;
-        for (unsigned i = tid; i < nlist_k; i += DP_THREADS) {
-            const u64 e = list[i];
-            if ((unsigned)(e >> 32) == ustar) atomicAdd(&tp->hist[DP_HB(1023 - (int)(((unsigned)e >> 5) & 1023u))], 1ull);
-        }
-        __syncthreads();
-        {
-            const int bA = DP_HB(1023 - 2 * tid), bB = DP_HB(1022 - 2 * tid);
-            const u64 hA = tp->hist[bA], hB = tp->hist[bB];
-            tp->hist[bA] = 0ull;
-            tp->hist[bB] = 0ull;
-            if (tid == 0) tp->digit = -1;
-            dp_scan512(tp, hA, hB, 0ull, want, tid, lane, wave);
-        }
-        const unsigned hi_idx = (unsigned)(1023 - tp->digit);            // index >> 5 of the nkeep-th tie
-        const u64 before = tp->S;                                        // ties with a smaller index >> 5
-        __syncthreads();
-        for (unsigned i = tid; i < nlist_k; i += DP_THREADS) {
-            const u64 e = list[i];
-            if ((unsigned)(e >> 32) == ustar && (((unsigned)e >> 5) & 1023u) == hi_idx)
-                atomicAdd(&tp->hist[DP_HB(1023 - (int)((unsigned)e & 31u))], 1ull);
-        }
-        __syncthreads();
-        {
-            const int bA = DP_HB(1023 - 2 * tid), bB = DP_HB(1022 - 2 * tid);
-            const u64 hA = tp->hist[bA], hB = tp->hist[bB];
-            tp->hist[bA] = 0ull;
-            tp->hist[bB] = 0ull;
-            if (tid == 0) tp->digit = -1;
-            dp_scan512(tp, hA, hB, before, want, tid, lane, wave);
-        }
-        istar = (long long)((hi_idx << 5) | (unsigned)(1023 - tp->digit));
-        __syncthreads();
-    } else if (rank_ties) {
-        // (list overflowed: flat rows) index of the nkeep-th tie in index order: block-wide exclusive scan per entry block of the parked row
-        int basecnt = 0;
-        if (tid == 0) tp->istar = -1;
-        __syncthreads();
-#pragma unroll 1
-        for (int it = 0; it < NIT; ++it) {
-            const f32x4 x = mine[DP_THREADS * it];
-            int cc = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) cc += (__float_as_uint(x[j]) == ustar) ? 1 : 0;
-            int inc = cc;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int nn = __shfl_up(inc, o, 64);
-                if (lane >= o) inc += nn;
-            }
-            __syncthreads();
-            if (lane == 63) tp->red_i[wave] = inc;
-            __syncthreads();
-            int rank = basecnt + inc - cc, total = 0;
-#pragma unroll
-            for (int k = 0; k < DP_WAVES; ++k) {
-                const int t = tp->red_i[k];
-                if (k < wave) rank += t;
-                total += t;
-            }
-            basecnt += total;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (__float_as_uint(x[j]) == ustar) {
-                    if ((u64)rank + 1ull == nkeep) tp->istar = 4ll * (tid + DP_THREADS * it) + j;
-                    ++rank;
-                }
-        }
-        __syncthreads();
-        istar = tp->istar;
-    }
     if (own) {
         const unsigned ulow = d1 < 0 ? 0u : (rank_ties ? ustar + 1u : ustar);   // patterns >= ulow stay unconditionally
         f32x4 o;
@@ -1133,7 +1117,7 @@ size_t dp_lds_bytes(int kv_len) {
     const size_t kvp = (size_t)((kv_len + 31) & ~31), PS = kvp + DP_KPAD;
     const size_t attn = kvp * (HD + DP_KPAD) * 2 + HD * PS * 2 + 2 * 16 * PS * 2 + 16 * kvp * 4 + 64;
     const size_t gemm = 16384 + 16 * (HID + 8) * 2;                       // merge scratch + normalised rows of lm_head
-    const size_t topp = 16384 + (size_t)32768 * 4 + 1024 * 8;             // select scratch + the parked row + the boundary-bin list
+    const size_t topp = 16384 + (size_t)16384 * 8 + 1088 + 64 * 8;        // select scratch + the candidate list + the segment offsets + the boundary bin
     size_t m = attn > gemm ? attn : gemm;
     if (topp > m) m = topp;
     return 64 + ((m + 15) & ~(size_t)15);
@@ -1145,7 +1129,7 @@ extern "C" int64_t tf_draft_persist_ctl_bytes(void) { return (int64_t)sizeof(DpC
 
 extern "C" int64_t tf_draft_persist_ws_bytes(const TfDraftModel* m) {
     if (!m) return 0;
-    return a256(16 * HID * 2) * 3 + a256(16 * INTER * 2) + a256(SS_PARTS * 32 * 4) + a256(DP_GRID * 4) + a256((int64_t)32768 * 4);
+    return a256(16 * HID * 2) * 3 + a256(16 * INTER * 2) + a256(SS_PARTS * 32 * 4) + a256(DP_GRID * 4) + a256((int64_t)DP_GRID * 128 * 8) + a256(DP_GRID * 8) + a256(DP_GRID * 4);
 }
 
 // 0 when the shape is one the persistent launch takes (the 68M draft, <= 16 rows, <= 384 keys, a device with >= 256 CUs)
@@ -1209,7 +1193,9 @@ extern "C" int tf_draft_forward_68m_persist(const TfDraftModel* m, const TfDraft
     P.act = reinterpret_cast<h16*>(p);    p += a256(16 * INTER * 2);
     P.ss = reinterpret_cast<float*>(p);   p += a256(SS_PARTS * 32 * 4);
     P.wgmax = reinterpret_cast<float*>(p); p += a256(DP_GRID * 4);
-    P.ebuf = reinterpret_cast<float*>(p);
+    P.cand = reinterpret_cast<u64*>(p);   p += a256((int64_t)DP_GRID * 128 * 8);
+    P.zslice = reinterpret_cast<u64*>(p); p += a256(DP_GRID * 8);
+    P.ccount = reinterpret_cast<unsigned*>(p);
     P.ctl = reinterpret_cast<DpCtl*>(ctl);
     P.stamps = g_dp_stamps;
     P.timeout_ticks = (u64)(g_dp_timeout_ms > 0 ? g_dp_timeout_ms : 1) * (DP_WALL_HZ / 1000ull);

@@ -56,6 +56,7 @@ struct DpTopp {                                                          // LDS
     unsigned ties, nlist;
     int digit;                                                           // >= 0 boundary bin, -1 keep everything, -2 below the candidate cut
     long long istar;                                                     // index of the last kept tie (tie ranking)
+    unsigned nfin;                                                       // entries gathered from the boundary bin (in-wave finish)
 };
 // hist[digit] += m for the active lanes of a wave (wave-uniform call); a wave whose active lanes all name one bin adds ONE
 // pre-summed value (degenerate rows: huge tie groups)
