@@ -387,7 +387,8 @@ int tf_middle_accept(const float* p, const float* q_d, int64_t* tokens, const fl
  * the tensor-parallel loop applies RANK 0's broadcast record (utils/decoding.py:452-470) with it in one launch. */
 int tf_mid_record_tokens(const int64_t* rec, int64_t* tokens, int tokens_len, int n, void* stream);
 /* tf_topp_probs_multi (csrc/topp_multi.hip; round 6): tf_topp_probs with every row spread over 16 (8 from 17 rows up) workgroups of
- * ONE launch — the slices of a row meet through two in-launch edges (row maximum; mass sums + compacted candidates), then every
+ * ONE launch — every workgroup takes the row maximum from the whole row (tune key 3 = 0: the slices exchange their maxima through
+ * an in-launch edge instead), the slices of a row meet through an in-launch edge (mass sums + compacted candidates), then every
  * workgroup of the row runs the exact-integer select over the row's candidates and writes its own entries.  Probabilities are
  * BIT-IDENTICAL to tf_topp_probs (utils/sampling.py:5-27,43-60).  rows <= 32, V % 4 == 0, 64 <= V <= 32768, rows x slices <= the
  * device's CU count (TF_ERANGE otherwise: the caller keeps tf_topp_probs).
@@ -395,7 +396,8 @@ int tf_mid_record_tokens(const int64_t* rec, int64_t* tokens, int tokens_len, in
  *              (tf_skinny_gemm_act with out_f32 = 1 and ss_out != NULL): the first edge is skipped
  *   ctl        tf_topp_multi_ctl_bytes() bytes, 64-byte aligned, ZERO-filled once; launches on one ctl must not overlap
  *   ws         >= tf_topp_multi_ws_bytes(rows, V) bytes of device scratch, 256-byte aligned
- * Bounded waits (tf_topp_multi_tune key 0 = ms, default 2000; key 1 = fault injection for tests): a time-out sets the sticky
+ * Bounded waits (tf_topp_multi_tune key 0 = ms, default 2000; key 1 = fault injection for tests; key 2 = entries of the LDS
+ * candidate list; key 3 = where the row maximum comes from): a time-out sets the sticky
  * error word (tf_topp_multi_error) and NaN-fills the rows until tf_topp_multi_reset. */
 int64_t tf_topp_multi_ctl_bytes(void);
 int64_t tf_topp_multi_ws_bytes(int rows, int V);

@@ -580,11 +580,15 @@ def test_topp_multi_workgroup_form_is_bit_identical_to_the_one_workgroup_kernel(
         monkeypatch.setattr(ops, "TOPP_MULTI", False)
         want = ops.topp_probs(lg, T, P)
         monkeypatch.setattr(ops, "TOPP_MULTI", True)
-        for panel in (None, pm):
-            for _ in range(2):
-                got = multi(T, P, panel) if rows > 16 else ops.topp_probs(lg, T, P, panel_max=panel)
-                assert torch.equal(got, want), (kind, T, P, panel is not None, int((got != want).sum()),
-                                                float((got - want).abs().max()))
+        for panel, rowmax in ((None, 1), (None, 0), (pm, 1)):          # row maximum: from the whole row / through edge A / handed over
+            L.tf_topp_multi_tune(3, rowmax)
+            try:
+                for _ in range(2):
+                    got = multi(T, P, panel) if rows > 16 else ops.topp_probs(lg, T, P, panel_max=panel)
+                    assert torch.equal(got, want), (kind, T, P, panel is not None, rowmax, int((got != want).sum()),
+                                                    float((got - want).abs().max()))
+            finally:
+                L.tf_topp_multi_tune(3, 1)
     assert _ops_lib().tf_topp_multi_error(ops._ptr(st[0])) == 0
 
 
@@ -602,6 +606,7 @@ def test_topp_multi_lost_arrival_times_out_poisons_and_recovers(monkeypatch):
     old = L.tf_topp_multi_tune(0, 50)
     try:
         for edge in (0, 1):
+            L.tf_topp_multi_tune(3, 0 if edge == 0 else 1)           # (edge A only exists when the slices exchange their maxima)
             L.tf_topp_multi_tune(1, edge + 1)
             bad = ops.topp_probs(lg, 0.6, 0.9)
             torch.cuda.synchronize()
@@ -616,6 +621,7 @@ def test_topp_multi_lost_arrival_times_out_poisons_and_recovers(monkeypatch):
             assert torch.equal(good, want)
     finally:
         L.tf_topp_multi_tune(1, 0)
+        L.tf_topp_multi_tune(3, 1)
         L.tf_topp_multi_tune(0, old)
 
 

@@ -48,7 +48,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--list-cap", type=int, default=0)
+    ap.add_argument("--rowmax", type=int, default=1, help="1: row maximum from the whole row (default); 0: slice maxima through an in-launch edge")
+    ap.add_argument("--tag", default="")
     a = ap.parse_args()
+    from triforce_amd import hip
+    hip.lib().tf_topp_multi_tune(3, a.rowmax)
     if a.list_cap:
         from triforce_amd import hip
         hip.lib().tf_topp_multi_tune(2, a.list_cap)
@@ -65,7 +69,7 @@ def main():
                     ops.TOPP_MULTI = multi
                     out[name] = round(graph_us(lambda: ops.topp_probs(lg, 0.6, 0.9, panel_max=panel)), 2)
                 kept = int((ops.topp_probs(lg, 0.6, 0.9)[0] > 0).sum())
-                line = {"what": "temperature + top-p + softmax, V = 32000, T 0.6 / top_p 0.9, 50 calls per hipGraph", "rows": rows, "kind": kind, "list_cap": a.list_cap or 8192,
+                line = {"what": "temperature + top-p + softmax, V = 32000, T 0.6 / top_p 0.9, 50 calls per hipGraph", "rows": rows, "kind": kind, "list_cap": a.list_cap or 16384, "rowmax_from_row": a.rowmax, "tag": a.tag,
                         "kept_in_row_0": kept, **out}
                 lines.append(line)
                 print(json.dumps(line), flush=True)

@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(DP_THREADS) void draft_persist_kernel(DpParams P) {
     u64 nkeep = 0ull, zk = Zall;
     long long istar = -1;
     if (tau < Zall) {                                                    // (tau >= Z: top_p >= 1 keeps everything)
-        round([](unsigned) { return true; }, [](unsigned bb) { return (int)(bb >> 20); }, true);
+        round([](unsigned) { return true; }, [](unsigned bb) { return (int)(bb >> 20); }, false);
         d1 = tp->digit;
         if (d1 < 0) {                                                    // cannot happen: the cut holds the crossing among the candidates
             if (tid == 0) {
@@ -1016,16 +1016,26 @@ __global__ __launch_bounds__(DP_THREADS) void draft_persist_kernel(DpParams P) {
         }
         dp_stamp(c);
         const int dd1 = d1;
-        const unsigned nbin = tp->ties;                                  // entries of the boundary bin (an eighth of an octave of e)
+        // the boundary bin's entries (an eighth of an octave of e), gathered in any order — up to 64 of them; one counter bump
+        // per wave and pass (a flat row has thousands of matches)
+        for_each([&](u64 e) {
+            const bool hit = (int)((unsigned)(e >> 32) >> 20) == dd1;
+            const unsigned long long hm = __ballot(hit);                 // (the lanes still in the loop)
+            if (hit) {
+                const int leader = (int)__builtin_ctzll(hm);
+                unsigned at0 = 0u;
+                if (lane == leader) at0 = atomicAdd(&tp->nfin, (unsigned)__popcll(hm));
+                const unsigned at = (unsigned)__shfl((int)at0, leader, 64) + (unsigned)__popcll(hm & ((1ull << lane) - 1ull));
+                if (at < 64u) fin[at] = e;
+            }
+        });
+        __syncthreads();
+        const unsigned nbin = tp->nfin;
         if (nbin <= 64u) {
-            // The usual row: the boundary bin holds a handful of entries.  They are gathered (any order) and every WAVE finishes by
-            // itself, lane i holding entry i: mass above it, its tie group and its rank by index inside the group come from one
-            // pass over the <= 64 entries — the same boundary the two remaining radix rounds and the tie ranking would name
-            // (integers throughout), without their eight barriers.
-            for_each([&](u64 e) {
-                if ((int)((unsigned)(e >> 32) >> 20) == dd1) fin[atomicAdd(&tp->nfin, 1u)] = e;
-            });
-            __syncthreads();
+            // The usual row: the boundary bin holds a handful of entries and every WAVE finishes by itself, lane i holding entry i:
+            // the mass above it, its tie group and its rank by index inside the group come from one pass over the <= 64 entries
+            // — the boundary the two remaining radix rounds and the tie ranking would name (integers throughout), without their
+            // eight barriers.
             const u64 mine = (unsigned)lane < nbin ? fin[lane] : 0ull;
             const unsigned pi = (unsigned)(mine >> 32), ii = (unsigned)mine;
             const u64 mi = dp_fix(__uint_as_float(pi));

@@ -4,17 +4,21 @@
 // tf_topp_probs (csrc/sampling.hip) runs one 1 024-thread workgroup per row: 32 000 correctly rounded divisions (twice) and
 // expf on ONE compute unit — ~13 us of arithmetic before any select, 26-42 us per call for <= 8 rows, while 248 CUs idle.
 // Here grid = rows x S (S = 16 slices of <= 2 048 entries; 8 slices of <= 4 096 from 17 rows up), 512 threads, all resident,
-// and the slices of a row meet through two in-launch edges — the machinery of csrc/draft_persist.hip (arrival counter, the
+// and the slices of a row meet through an in-launch edge — the machinery of csrc/draft_persist.hip (arrival counter, the
 // last arriver publishes the launch epoch in a READY flag, write-through stores / agent-scope loads, no fences):
 //
-//   (a) x = l / T, slice maximum                                  -> edge A[row]   (skipped when the caller hands the per-panel
-//                                                                                   maxima the lm_head GEMM left: panel_max)
+//   (a) x = l / T; the row maximum: every workgroup reads the WHOLE row (128 KB out of L2, 16 float4 loads in flight per thread —
+//       cheaper than an edge; tune key 3 = 0 brings back the slice maxima exchanged through edge A[row]), or takes the per-panel
+//       maxima the lm_head GEMM left (panel_max)
 //   (b) e = exp(x - max), 2^-40 fixed-point masses, the slice's mass sum, and the slice's CANDIDATES — entries at or above the
 //       cut (1 - top_p) / (2 V), which provably contain the top-p crossing — compacted as (pattern, index) pairs
 //                                                                  -> edge B[row]
-//   (c) every workgroup of the row: Z and tau from the 16 slice sums, the row's candidates gathered into LDS (a real row has a few
-//       hundred to a few thousand; beyond 16 384 round 1 streams them and only the boundary bin is kept), the 3-round radix select on exact
-//       integers with 512-thread DPP scans, ties at the boundary ranked by index; own entries: p = keep ? e / Z_kept : 0.
+//   (c) every workgroup of the row: the 16 slice counts / sums AND the first 32 candidates of every slice in one round trip (lanes
+//       past a count drop what they read), Z and tau, the rest of the candidates gathered into LDS (<= 16 384; beyond that round 1
+//       streams them and only the boundary bin is kept), round 1 of the radix select (top 10 pattern bits, exact integers, 512-thread
+//       DPP scan) names the boundary bin — an eighth of an octave of e.  <= 64 entries there (the usual row): every wave finishes by
+//       itself from one pass over them (mass above, tie group, rank by index); more: two more radix rounds and a radix select on the
+//       index for a cut tie group.  Own entries: p = keep ? e / Z_kept : 0.
 //
 // The select is the one of topp_probs_kernel on the same integers (mass = floor(e 2^40), tau = floor(top_p Z), boundary
 // pattern, kept ties = lowest indices, Z_kept): the probabilities are BIT-IDENTICAL to tf_topp_probs (tests/test_gpu_ops.py).
@@ -47,6 +51,7 @@ struct TmParams {
     TmCtl* ctl;
     u64 timeout_ticks;
     int rows, V, S, slice_f4, skip_edge, list_cap;     // slice_f4: float4s per slice; list_cap: entries of the LDS list
+    int rowmax;                              // 1: every workgroup takes the row maximum from the whole row (no edge A)
     float temperature, top_p;
 };
 
@@ -57,6 +62,7 @@ struct TmShared {
     float red[DP_WAVES];
     u64 red64[DP_WAVES];
     unsigned red32[DP_WAVES];
+    u64 fin[64];                             // the boundary bin's entries (in-wave finish)
 };
 
 // An edge of ONE row: its S workgroups add 1 to the row's counter; the last arriver puts the counter back to 0 and advances the
@@ -173,6 +179,20 @@ __global__ __launch_bounds__(TM_THREADS) void topp_multi_kernel(TmParams P) {
         float pm = -INFINITY;
         for (int p = tid; p < V / 16; p += TM_THREADS) pm = fmaxf(pm, P.panel_max[p * 32 + row]);
         mx = tm_block_max(pm, sh, lane, wave) / P.temperature;
+    } else if (P.rowmax) {
+        // every workgroup reads the WHOLE row (128 KB from L2, 16 float4 loads in flight per thread): cheaper than an edge (the
+        // arrival + the flag poll cost ~3 us) and max(l) / T is max(l / T) bit for bit
+        float pm = -INFINITY;
+        f32x4 r[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int f = tid + TM_THREADS * k;
+            r[k] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (f < nf4) r[k] = *reinterpret_cast<const f32x4*>(lr + 4 * f);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) pm = fmaxf(pm, fmaxf(fmaxf(r[k][0], r[k][1]), fmaxf(r[k][2], r[k][3])));
+        mx = tm_block_max(pm, sh, lane, wave) / P.temperature;
     } else {
         const float smax = tm_block_max(lmax, sh, lane, wave);
         if (tid == 0) st4f(P.wgmax + row * S + slice, smax);
@@ -235,6 +255,13 @@ __global__ __launch_bounds__(TM_THREADS) void topp_multi_kernel(TmParams P) {
         return;
     }
     // ---- (c) the select ----
+    // The slice counts / sums AND the first 32 candidates of every slice (half a wave each) are requested together: lanes past a
+    // slice's count read stale workspace and drop it.  One round trip for a sharp row; a slice with more costs a second for the rest.
+    constexpr int SPEC = 32;
+    const int cap = P.slice_f4 * 4;                                      // candidate capacity of a slice
+    const u64* cbase = P.cand + (int64_t)row * S * (int64_t)cap;
+    const int sp_slice = 2 * wave + (lane >> 5), sp_en = lane & 31;
+    u64 spec = 0ull;
     {
         unsigned c = 0u;
         u64 z = 0ull;
@@ -242,6 +269,7 @@ __global__ __launch_bounds__(TM_THREADS) void topp_multi_kernel(TmParams P) {
             c = ld4u(P.ccount + row * S + tid);
             z = ld8(P.zslice + row * S + tid);
         }
+        if (sp_slice < S) spec = ld8(cbase + (int64_t)sp_slice * cap + sp_en);
         if (wave == 0) {
             const unsigned incl = dp_wave_prefix_u32(c);
             const u64 zin = dp_wave_prefix_u64(z);
@@ -256,34 +284,57 @@ __global__ __launch_bounds__(TM_THREADS) void topp_multi_kernel(TmParams P) {
                 tp->digit = -1;
                 tp->ties = 0u;
                 tp->nkeep = 0ull;
+                tp->nlist = 0u;
+                tp->nfin = 0u;
             }
         }
     }
     __syncthreads();
     const unsigned C = sh->off[S];
     const u64 tau = tp->tau, Z = tp->Z;
-    const int cap = P.slice_f4 * 4;                                      // candidate capacity of a slice
-    const u64* cbase = P.cand + (int64_t)row * S * (int64_t)cap;
-    // Walk the row's candidates where they lie (per slice, coalesced; four slices' loads in flight before the first is used).
+    // Walk the row's candidates where they lie (per slice, coalesced; the loads of a batch in flight before the first is used).
     constexpr int NK = 4 * NPT;                                          // a slice holds at most 512 x NK entries
     unsigned maxc = 0u;
 #pragma unroll
     for (int k = 0; k < TM_MAX_SLICES; ++k)
         if (k < S) maxc = max(maxc, sh->off[k + 1] - sh->off[k]);
     auto stream = [&](auto fn) {
-        if (maxc <= (unsigned)TM_THREADS) {
-            // the usual case — no slice holds more than 512 candidates: ONE entry per thread and slice, all S loads in flight
-            // before the first is used (one memory round trip for the whole row; four-slice batches cost four)
+        if (sp_slice < S && (unsigned)sp_en < sh->off[sp_slice + 1] - sh->off[sp_slice]) fn(spec, sh->off[sp_slice] + sp_en);
+        if (maxc <= (unsigned)SPEC) return;
+        if (maxc <= (unsigned)(SPEC + TM_THREADS)) {
+            // no slice holds more than 32 + 512 candidates: ONE more entry per thread and slice, all S loads in flight together
             u64 v[TM_MAX_SLICES];
 #pragma unroll
             for (int q = 0; q < TM_MAX_SLICES; ++q) {
                 const unsigned cn = q < S ? (sh->off[q + 1] - sh->off[q]) : 0u;
-                v[q] = (unsigned)tid < cn ? ld8(cbase + (int64_t)q * cap + tid) : 0ull;
+                v[q] = (unsigned)(SPEC + tid) < cn ? ld8(cbase + (int64_t)q * cap + SPEC + tid) : 0ull;
             }
 #pragma unroll
             for (int q = 0; q < TM_MAX_SLICES; ++q) {
                 const unsigned cn = q < S ? (sh->off[q + 1] - sh->off[q]) : 0u;
-                if ((unsigned)tid < cn) fn(v[q], sh->off[q] + tid);
+                if ((unsigned)(SPEC + tid) < cn) fn(v[q], sh->off[q] + SPEC + tid);
+            }
+            return;
+        }
+        if (maxc <= (unsigned)(SPEC + 2 * TM_THREADS)) {                  // up to 32 + 1 024: two entries per thread and slice, still one trip
+            u64 v[TM_MAX_SLICES][2];
+#pragma unroll
+            for (int q = 0; q < TM_MAX_SLICES; ++q) {
+                const unsigned cn = q < S ? (sh->off[q + 1] - sh->off[q]) : 0u;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const unsigned j = SPEC + tid + TM_THREADS * k;
+                    v[q][k] = j < cn ? ld8(cbase + (int64_t)q * cap + j) : 0ull;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < TM_MAX_SLICES; ++q) {
+                const unsigned cn = q < S ? (sh->off[q + 1] - sh->off[q]) : 0u;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const unsigned j = SPEC + tid + TM_THREADS * k;
+                    if (j < cn) fn(v[q][k], sh->off[q] + j);
+                }
             }
             return;
         }
@@ -295,7 +346,7 @@ __global__ __launch_bounds__(TM_THREADS) void topp_multi_kernel(TmParams P) {
                 cn[q] = (s0 + q < S) ? (sh->off[s0 + q + 1] - sh->off[s0 + q]) : 0u;
 #pragma unroll
                 for (int k = 0; k < NK; ++k) {
-                    const unsigned j = tid + TM_THREADS * k;
+                    const unsigned j = SPEC + tid + TM_THREADS * k;
                     v[q][k] = j < cn[q] ? ld8(cbase + (int64_t)(s0 + q) * cap + j) : 0ull;
                 }
             }
@@ -303,7 +354,7 @@ __global__ __launch_bounds__(TM_THREADS) void topp_multi_kernel(TmParams P) {
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int k = 0; k < NK; ++k) {
-                    const unsigned j = tid + TM_THREADS * k;
+                    const unsigned j = SPEC + tid + TM_THREADS * k;
                     if (j < cn[q]) fn(v[q][k], sh->off[s0 + q] + j);
                 }
         }
@@ -325,14 +376,15 @@ __global__ __launch_bounds__(TM_THREADS) void topp_multi_kernel(TmParams P) {
             stream([&](u64 e, unsigned) { fn(e); });
         }
     };
-    // one round: bins dig(pattern) of the candidates with sel(pattern); then the 512-thread scan from base tp->S
-    auto round = [&](auto sel, auto dig, bool last) {
+    // one round: bins dig(pattern) of the candidates with sel(pattern) (+ how many fell in each when `count`); then the 512-thread
+    // scan from base tp->S; tp->ties = the entries of the bin the scan names (count rounds only)
+    auto round = [&](auto sel, auto dig, bool count) {
         for_each([&](u64 e) {
             const unsigned b = (unsigned)(e >> 32);
             if (sel(b)) {
                 const int d = dig(b);
                 atomicAdd(&tp->hist[DP_HB(d)], dp_fix(__uint_as_float(b)));
-                if (last) atomicAdd(&tp->cnt[DP_HB(d)], 1u);
+                if (count) atomicAdd(&tp->cnt[DP_HB(d)], 1u);
             }
         });
         __syncthreads();
@@ -343,20 +395,12 @@ __global__ __launch_bounds__(TM_THREADS) void topp_multi_kernel(TmParams P) {
         const u64 base = tp->S;
         if (tid == 0) tp->digit = -1;
         dp_scan512(tp, hA, hB, base, tau, tid, lane, wave);
-        if (last) {
+        if (count) {
             const int d = tp->digit;
-            if (d >= 0 && (d == 1023 - 2 * tid || d == 1022 - 2 * tid)) {
-                const unsigned T = tp->cnt[DP_HB(d)];
-                const u64 m = tp->hsel / (u64)T;
-                u64 nk = (tau - tp->S) / m + 1ull;
-                if (nk > (u64)T) nk = T;
-                tp->ties = T;
-                tp->nkeep = nk;
-                tp->zk = tp->S + nk * m;
-            }
+            if (d >= 0 && (d == 1023 - 2 * tid || d == 1022 - 2 * tid)) tp->ties = tp->cnt[DP_HB(d)];
             __syncthreads();
-            tp->cnt[bA] = 0u;
-            tp->cnt[bB] = 0u;
+            tp->cnt[DP_HB(1023 - 2 * tid)] = 0u;
+            tp->cnt[DP_HB(1022 - 2 * tid)] = 0u;
         }
     };
     // index of the nkeep-th tie by a two-round radix select on the 15-bit index (bins reversed: "from the top" = ascending index)
@@ -374,7 +418,7 @@ __global__ __launch_bounds__(TM_THREADS) void topp_multi_kernel(TmParams P) {
     };
     int d1 = -1;
     unsigned ustar = 0u, ties = 0u;
-    u64 nkeep = 0ull;
+    u64 nkeep = 0ull, zk = Z;
     long long istar = -1;
     if (tau < Z) {                                                       // (tau >= Z: top_p >= 1 keeps everything)
         round([](unsigned) { return true; }, [](unsigned b) { return (int)(b >> 20); }, false);
@@ -388,40 +432,92 @@ __global__ __launch_bounds__(TM_THREADS) void topp_multi_kernel(TmParams P) {
             return;
         }
         const int dd1 = d1;
-        if (!use_list) {
-            // file the boundary bin's entries (LDS counter: only the matches pay for it); overflow -> the rounds keep streaming
-            if (tid == 0) tp->nlist = 0u;
-            __syncthreads();
-            stream([&](u64 e, unsigned) {
-                if ((int)((unsigned)(e >> 32) >> 20) == dd1) {
-                    const unsigned at = atomicAdd(&tp->nlist, 1u);
-                    if (at < (unsigned)P.list_cap) list[at] = e;
-                }
-            });
-            __syncthreads();
-            nlist = tp->nlist;
-            use_list = nlist <= (unsigned)P.list_cap;
-        }
-        round([dd1](unsigned b) { return (int)(b >> 20) == dd1; }, [](unsigned b) { return (int)((b >> 10) & 1023u); }, false);
-        const unsigned pre = ((unsigned)d1 << 10) | (unsigned)tp->digit;
-        round([pre](unsigned b) { return (b >> 10) == pre; }, [](unsigned b) { return (int)(b & 1023u); }, true);
-        ustar = (pre << 10) | (unsigned)tp->digit;
+        // the boundary bin's entries (an eighth of an octave of e), gathered in any order — up to 64 of them; one counter bump
+        // per wave and pass (a flat row has thousands of matches)
+        u64* fin = sh->fin;
+        for_each([&](u64 e) {
+            const bool hit = (int)((unsigned)(e >> 32) >> 20) == dd1;
+            const unsigned long long hm = __ballot(hit);                 // (the lanes still in the loop)
+            if (hit) {
+                const int leader = (int)__builtin_ctzll(hm);
+                unsigned at0 = 0u;
+                if (lane == leader) at0 = atomicAdd(&tp->nfin, (unsigned)__popcll(hm));
+                const unsigned at = (unsigned)__shfl((int)at0, leader, 64) + (unsigned)__popcll(hm & ((1ull << lane) - 1ull));
+                if (at < 64u) fin[at] = e;
+            }
+        });
         __syncthreads();
-        ties = tp->ties;
-        nkeep = tp->nkeep;
-        if (nkeep < (u64)ties) {                                         // the tie group is cut: its nkeep lowest indices stay
-            const u64 want = nkeep - 1ull;
-            const unsigned us = ustar;
-            tie_round([us](u64 e) { return (unsigned)(e >> 32) == us; }, [](u64 e) { return (int)(((unsigned)e >> 5) & 1023u); }, 0ull, want);
-            const unsigned hi_idx = (unsigned)(1023 - tp->digit);
-            const u64 before = tp->S;
-            __syncthreads();
-            tie_round([us, hi_idx](u64 e) { return (unsigned)(e >> 32) == us && (((unsigned)e >> 5) & 1023u) == hi_idx; },
-                      [](u64 e) { return (int)((unsigned)e & 31u); }, before, want);
-            istar = (long long)((hi_idx << 5) | (unsigned)(1023 - tp->digit));
+        const unsigned nbin = tp->nfin;
+        if (nbin <= 64u) {
+            // The usual row: the boundary bin holds a handful of entries and every WAVE finishes by itself, lane i holding entry i:
+            // the mass above it, its tie group and its rank by index inside the group come from one pass over the <= 64 entries
+            // — the boundary the two remaining radix rounds and the tie ranking would name (integers throughout), without their
+            // eight barriers.
+            const u64 mine = (unsigned)lane < nbin ? fin[lane] : 0ull;
+            const unsigned pi = (unsigned)(mine >> 32), ii = (unsigned)mine;
+            const u64 mi = dp_fix(__uint_as_float(pi));
+            u64 above = 0ull;
+            unsigned eq = 0u, lower = 0u;
+            for (unsigned j = 0; j < nbin; ++j) {
+                const u64 ej = fin[j];                                   // (one address for the wave: a broadcast read)
+                const unsigned pj = (unsigned)(ej >> 32), ij = (unsigned)ej;
+                above += pj > pi ? dp_fix(__uint_as_float(pj)) : 0ull;
+                eq += pj == pi ? 1u : 0u;
+                lower += (pj == pi && ij < ii) ? 1u : 0u;
+            }
+            const u64 Sx = tp->S + above;                                // mass of everything above this lane's pattern
+            const bool cross = (unsigned)lane < nbin && Sx <= tau && tau - Sx < (u64)eq * mi;
+            const unsigned long long cm = __ballot(cross);               // the lanes of ONE tie group
+            const int first = (int)__builtin_ctzll(cm);
+            ustar = (unsigned)__shfl((int)pi, first, 64);
+            ties = (unsigned)__shfl((int)eq, first, 64);
+            const u64 Sg = dp_shfl_u64(Sx, first), mg = dp_shfl_u64(mi, first);
+            nkeep = (tau - Sg) / mg + 1ull;
+            if (nkeep > (u64)ties) nkeep = ties;
+            zk = Sg + nkeep * mg;
+            if (nkeep < (u64)ties) {                                     // the tie group is cut: its nkeep lowest indices stay
+                const unsigned long long lm = __ballot(cross && (u64)lower + 1ull == nkeep);
+                istar = (long long)(unsigned)__shfl((int)ii, (int)__builtin_ctzll(lm), 64);
+            }
+        } else {
+            if (!use_list) {
+                // file the boundary bin's entries (LDS counter: only the matches pay for it); overflow -> the rounds keep streaming
+                stream([&](u64 e, unsigned) {
+                    if ((int)((unsigned)(e >> 32) >> 20) == dd1) {
+                        const unsigned at = atomicAdd(&tp->nlist, 1u);
+                        if (at < (unsigned)P.list_cap) list[at] = e;
+                    }
+                });
+                __syncthreads();
+                nlist = tp->nlist;
+                use_list = nlist <= (unsigned)P.list_cap;
+            }
+            round([dd1](unsigned b) { return (int)(b >> 20) == dd1; }, [](unsigned b) { return (int)((b >> 10) & 1023u); }, false);
+            const unsigned pre = ((unsigned)d1 << 10) | (unsigned)tp->digit;
+            round([pre](unsigned b) { return (b >> 10) == pre; }, [](unsigned b) { return (int)(b & 1023u); }, true);
+            ustar = (pre << 10) | (unsigned)tp->digit;
+            ties = tp->ties;
+            {
+                const u64 m = tp->hsel / (u64)ties;                      // all ties share one pattern, hence one mass
+                nkeep = (tau - tp->S) / m + 1ull;
+                if (nkeep > (u64)ties) nkeep = ties;
+                zk = tp->S + nkeep * m;
+            }
+            __syncthreads();                                             // (everyone has read tp->S before a tie round moves it)
+            if (nkeep < (u64)ties) {                                     // the tie group is cut: its nkeep lowest indices stay
+                const u64 want = nkeep - 1ull;
+                const unsigned us = ustar;
+                tie_round([us](u64 e) { return (unsigned)(e >> 32) == us; }, [](u64 e) { return (int)(((unsigned)e >> 5) & 1023u); }, 0ull, want);
+                const unsigned hi_idx = (unsigned)(1023 - tp->digit);
+                const u64 before = tp->S;
+                __syncthreads();
+                tie_round([us, hi_idx](u64 e) { return (unsigned)(e >> 32) == us && (((unsigned)e >> 5) & 1023u) == hi_idx; },
+                          [](u64 e) { return (int)((unsigned)e & 31u); }, before, want);
+                istar = (long long)((hi_idx << 5) | (unsigned)(1023 - tp->digit));
+            }
         }
     }
-    const float Zk = (float)((double)tp->zk * (1.0 / 1099511627776.0));
+    const float Zk = (float)((double)zk * (1.0 / 1099511627776.0));
     const bool rank_ties = d1 >= 0 && nkeep < (u64)ties;
     const unsigned ulow = d1 < 0 ? 0u : (rank_ties ? ustar + 1u : ustar);
 #pragma unroll
@@ -442,7 +538,8 @@ __global__ __launch_bounds__(TM_THREADS) void topp_multi_kernel(TmParams P) {
 int g_tm_timeout_ms = 2000;
 int g_tm_skip_edge = 0;
 inline int64_t tm_a256(int64_t v) { return (v + 255) & ~(int64_t)255; }
-int g_tm_list_cap = 8192;                  // candidates the rounds keep in LDS (tf_topp_multi_tune key 2; <= TM_LIST_CAP)
+int g_tm_rowmax = 1;                       // 1: the row maximum from the whole row, no edge A (tf_topp_multi_tune key 3)
+int g_tm_list_cap = 16384;                 // candidates the rounds keep in LDS (tf_topp_multi_tune key 2; <= TM_LIST_CAP)
 inline size_t tm_lds_bytes(int cap) { return ((sizeof(TmShared) + 15) & ~(size_t)15) + (size_t)cap * 8; }
 }  // namespace
 
@@ -495,6 +592,7 @@ extern "C" int tf_topp_probs_multi(const float* logits, const float* panel_max, 
     P.ctl = reinterpret_cast<TmCtl*>(ctl);
     P.timeout_ticks = (u64)(g_tm_timeout_ms > 0 ? g_tm_timeout_ms : 1) * (TM_WALL_HZ / 1000ull);
     P.rows = rows, P.V = V, P.S = S, P.slice_f4 = per, P.skip_edge = g_tm_skip_edge, P.list_cap = g_tm_list_cap;
+    P.rowmax = (g_tm_rowmax != 0 && V <= 32768) ? 1 : 0;
     P.temperature = temperature, P.top_p = top_p;
     static bool attr_set = false;
     if (!attr_set) {
@@ -514,14 +612,16 @@ extern "C" int tf_topp_probs_multi(const float* logits, const float* panel_max, 
 }
 
 // key 0: wall-clock limit of one wait in ms (default 2000); key 1: fault injection (edge + 1 whose first arrival of row 0 is lost);
-// key 2: entries of the LDS candidate list (512 .. 16384; default 8192 = 64 KiB: two workgroups fit a CU)
+// key 2: entries of the LDS candidate list (512 .. 16384 = the default: the launch is one workgroup per CU for <= 16 rows);
+// key 3: 1 (default) every workgroup takes the row maximum from the whole row, 0 slice maxima through edge A
 extern "C" int tf_topp_multi_tune(int key, int value) {
-    int* slot = key == 0 ? &g_tm_timeout_ms : key == 1 ? &g_tm_skip_edge : key == 2 ? &g_tm_list_cap : nullptr;
+    int* slot = key == 0 ? &g_tm_timeout_ms : key == 1 ? &g_tm_skip_edge : key == 2 ? &g_tm_list_cap : key == 3 ? &g_tm_rowmax : nullptr;
     if (!slot) return -1;
     const int old = *slot;
     if (key == 0 && value < 1) return old;
     if (key == 1 && (value < 0 || value > 2)) return old;
     if (key == 2 && (value < 512 || value > TM_LIST_CAP)) return old;
+    if (key == 3 && (value < 0 || value > 1)) return old;
     *slot = value;
     return old;
 }
