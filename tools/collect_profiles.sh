@@ -14,6 +14,7 @@ cp $V/parity_notes.txt $P/${R}_parity_notes.txt
 [ -s $V/parity_table.md ] && cp $V/parity_table.md $P/${R}_parity_table.md && cp $V/parity_table.json $P/${R}_parity_table.json
 [ -s $V/bench_200.json ] && cp $V/bench_200.json $P/${R}_bench_default_200_steps.json
 [ -s $V/draft_persist.jsonl ] && cp $V/draft_persist.jsonl $P/${R}_draft_persist_chain_vs_one_launch.jsonl
+[ -s $V/topp_bench.jsonl ] && cp $V/topp_bench.jsonl $P/${R}_topp_one_workgroup_vs_multi.jsonl
 [ -s $V/bench_eager_comparator.json ] && cp $V/bench_eager_comparator.json $P/${R}_bench_eager_comparator_n1.json
 [ -s $V/acceptance_sweep.json ] && cp $V/acceptance_sweep.json $P/${R}_acceptance_sweep.json
 # provenance: the commit these figures were measured on (the GPU box has no .git: stamped here, at collection time)

@@ -55,6 +55,8 @@ python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "ben
 python bench.py --steps 200 --warmup 5 --no-cpu-baseline --random-steps 0 --roofline-every 0 > $O/bench_200.json 2> $O/bench_200.err; echo "bench200 rc=$?"; python -c "import json;j=json.loads([l for l in open('$O/bench_200.json') if l.startswith('{')][-1]);print(j['value'],j['ms_per_step'],j.get('ms_per_step_blocks'))"
 # the draft step: 13-launch chain against the one-launch form (hipGraph replays), with the per-role timeline
 python tools/draft_persist_bench.py --rows 1 3 7 --stamps --tag validate --out $O/draft_persist.jsonl > $O/draft_persist.log 2>&1; echo "draft persist rc=$?"; grep -c "" $O/draft_persist.jsonl
+# temperature + top-p + softmax: one workgroup per row against the multi-workgroup launch
+rm -f $O/topp_bench.jsonl; python tools/topp_bench.py --tag validate --out $O/topp_bench.jsonl > $O/topp_bench.log 2>&1; echo "topp bench rc=$?"; grep -c "" $O/topp_bench.jsonl
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --random-steps 0 > $R/$O/bench_prof.json 2> $R/$O/bench_prof.err; echo "rocprof rc=$?"
 # target-verify / retrieval-verify launches of the split-KV kernel separated by duration cluster + priced (tracked copy -> profiles/)
