@@ -230,3 +230,16 @@ def test_parity_table_folds_recorded_checks_into_the_tolerance_table(tmp_path):
     assert table["test_x.py::test_a"]["cases"] == 2 and abs(table["test_x.py::test_a"]["used"] - 0.6) < 1e-9
     assert table["test_x.py::test_b — rows"]["slack"] == 10.0 and table["test_x.py::test_c — logits"]["slack"] == 1.33
     assert "1 with >= 4x slack: test_x.py::test_b — rows (10.0x)" in dst.read_text()
+
+
+@pytest.mark.parametrize("probe", sorted(p for p in os.listdir(os.path.join(ROOT, "tools", "probes")) if p.endswith(".hip")))
+def test_stand_alone_probes_still_compile_for_gfx950(probe, tmp_path):
+    """tools/probes/*.hip are the stand-alone measurements DESIGN cites (seams, hardware transpose reads): they must keep building."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", os.path.join(ROOT, "tools", "probes", probe),
+                          "-o", str(tmp_path / "probe.o")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
