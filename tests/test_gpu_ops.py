@@ -550,15 +550,19 @@ def _topp_rows(rows, V, kind, seed):
         lg = (lg * 0.01).half().float()
     elif kind == "equal":
         lg = torch.zeros_like(lg)
+    elif kind == "ties20":                             # 20 equal dominant logits: top_p cuts the group inside a boundary bin of <= 64 entries
+        lg = lg.half().float()
+        lg[:, 100:120] = lg.max(-1, keepdim=True).values + 6.0
     return lg
 
 
 @pytest.mark.parametrize("rows,V", [(1, 32000), (7, 32000), (8, 32768), (18, 32000), (3, 1024), (32, 4096)])
-@pytest.mark.parametrize("kind", ["fp16", "peaked", "ties", "flat", "equal"])
+@pytest.mark.parametrize("kind", ["fp16", "peaked", "ties", "ties20", "flat", "equal"])
 def test_topp_multi_workgroup_form_is_bit_identical_to_the_one_workgroup_kernel(rows, V, kind, monkeypatch):
     """tf_topp_probs_multi (every row over 16 / 8 workgroups of one launch, two in-launch hand-offs, candidates compacted per
     slice) against tf_topp_probs (one workgroup per row, itself pinned to the oracle above): torch.equal for fp16-valued rows,
-    sharp rows, rows of 16 distinct values (2 000-entry tie groups cut at the boundary), near-flat rows (every entry a candidate:
+    sharp rows, rows of 16 distinct values (2 000-entry tie groups cut at the boundary: radix tie ranking), 20 equal dominant logits (a cut tie
+    group ranked by the in-wave finish), near-flat rows (every entry a candidate:
     the rounds walk global memory) and all-equal rows, at four (T, top_p) settings incl. top_p = 1 and the greedy emulation; with and
     without the per-panel maxima an lm_head epilogue hands over; twice in a row on the same control block."""
     ops = _ops()
