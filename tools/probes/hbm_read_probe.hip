@@ -1,0 +1,127 @@
+// What does a plain streaming read reach on this MI355X?  The roofline fractions of DESIGN are quoted against the 8 TB/s
+// datasheet peak; this probe measures the ceiling a kernel that does nothing but read can reach, so that "0.75 of peak" can be
+// read against it.  A 2 GiB buffer (far beyond L2 / Infinity Cache) is read once per launch by a grid-stride loop of 16-byte
+// non-temporal loads, U loads in flight per thread, summed into one value per thread (kept alive by a never-true store);
+// variants: workgroups per CU x threads x U.  Median of 10 launches each, HIP events.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/hbm_read_probe.hip -o /tmp/hbm_read && /tmp/hbm_read
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %d at line %d\n", (int)e_, __LINE__); exit(1); } } while (0)
+
+template <int U>
+__global__ void read_kernel(const f32x4* __restrict__ src, size_t n16, float* sink) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u];
+    }
+    for (; i < n16; i += stride) acc += __builtin_nontemporal_load(src + i);
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 123456.789f) sink[0] = acc[0];      // never true for the zero-filled buffer
+}
+
+// The decode attention's pattern on the reference's [token][head][128] cache: workgroup (split, head) walks ITS head's 256-byte rows of a
+// contiguous token range — rows 8 KiB apart (32 heads) — 16 lanes per row, 4 rows per wave load, U loads in flight per wave, 4 waves.
+// All 32 heads of a split move through the same tokens at the same time, so the chip as a whole still sweeps the buffer once.
+template <int U>
+__global__ void read_rows_kernel(const f32x4* __restrict__ src, int tokens, int heads, int nsplit, float* sink) {
+    const int split = blockIdx.x % nsplit, head = blockIdx.x / nsplit;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const int t0 = (int)((long long)tokens * split / nsplit), t1 = (int)((long long)tokens * (split + 1) / nsplit);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int rows_per_step = 4 * U * waves;
+    for (int t = t0 + 4 * U * wave; t < t1; t += rows_per_step) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = t + 4 * u + (lane >> 4);
+            v[u] = row < t1 ? __builtin_nontemporal_load(src + ((size_t)row * heads + head) * 16 + (lane & 15)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u];
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 123456.789f) sink[0] = acc[0];
+}
+
+template <int U>
+static void run_rows(const f32x4* src, size_t n16, float* sink, int heads, int nsplit, int threads, hipStream_t st) {
+    const int tokens = (int)(n16 / 16 / heads);
+    std::vector<float> ts;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int r = 0; r < 12; ++r) {
+        CK(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(read_rows_kernel<U>, dim3(heads * nsplit), dim3(threads), 0, st, src, tokens, heads, nsplit, sink);
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 2) ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    const double bytes = (double)tokens * heads * 256.0;
+    printf("{\"pattern\": \"256-byte rows of one head per workgroup, [token][%d heads][128 halfs]\", \"splits\": %d, \"workgroups\": %d, \"threads\": %d, "
+           "\"loads_in_flight_per_wave\": %d, \"ms_median\": %.3f, \"GBps_median\": %.0f, \"GBps_best\": %.0f, \"frac_of_8TBps\": %.3f}\n", heads, nsplit,
+           heads * nsplit, threads, U, ts[ts.size() / 2], bytes / ts[ts.size() / 2] / 1e6, bytes / ts[0] / 1e6, bytes / ts[ts.size() / 2] / 1e6 / 8000.0);
+    fflush(stdout);
+}
+
+template <int U>
+static void run(const f32x4* src, size_t n16, float* sink, int cus, int wg_per_cu, int threads, hipStream_t st) {
+    std::vector<float> ts;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int r = 0; r < 12; ++r) {
+        CK(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(read_kernel<U>, dim3(cus * wg_per_cu), dim3(threads), 0, st, src, n16, sink);
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 2) ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    const double bytes = (double)n16 * 16.0;
+    printf("{\"workgroups_per_cu\": %d, \"threads\": %d, \"loads_in_flight_per_thread\": %d, \"ms_median\": %.3f, \"GBps_median\": %.0f, \"GBps_best\": %.0f, "
+           "\"frac_of_8TBps\": %.3f}\n", wg_per_cu, threads, U, ts[ts.size() / 2], bytes / ts[ts.size() / 2] / 1e6, bytes / ts[0] / 1e6,
+           bytes / ts[ts.size() / 2] / 1e6 / 8000.0);
+    fflush(stdout);
+}
+
+int main() {
+    const size_t bytes = (size_t)2 << 30, n16 = bytes / 16;
+    f32x4* src;
+    float* sink;
+    CK(hipMalloc(&src, bytes)); CK(hipMalloc(&sink, 4));
+    CK(hipMemset(src, 0, bytes));
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    printf("{\"probe\": \"streaming read of a 2 GiB buffer, 16-byte non-temporal loads, grid-stride\", \"device\": \"%s\", \"compute_units\": %d}\n", prop.name, cus);
+    for (int wg : {1, 2, 4, 8}) {
+        run<4>(src, n16, sink, cus, wg, 256, st);
+        run<8>(src, n16, sink, cus, wg, 256, st);
+        run<16>(src, n16, sink, cus, wg, 256, st);
+    }
+    run<8>(src, n16, sink, cus, 2, 512, st);
+    run<8>(src, n16, sink, cus, 2, 1024, st);
+    run<16>(src, n16, sink, cus, 1, 1024, st);
+    for (int nsplit : {8, 16}) {
+        run_rows<4>(src, n16, sink, 32, nsplit, 256, st);
+        run_rows<8>(src, n16, sink, 32, nsplit, 256, st);
+        run_rows<16>(src, n16, sink, 32, nsplit, 256, st);
+    }
+    run_rows<8>(src, n16, sink, 4, 64, 256, st);         // a TP-8 rank: 4 heads, 64 splits
+    return 0;
+}
