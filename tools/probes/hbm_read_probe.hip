@@ -52,6 +52,55 @@ __global__ void read_rows_kernel(const f32x4* __restrict__ src, int tokens, int 
     if (acc[0] + acc[1] + acc[2] + acc[3] == 123456.789f) sink[0] = acc[0];
 }
 
+// The same walk over TWO buffers (K rows and V rows of the same tokens, as the attention kernel reads them): U / 2 loads of either
+// per wave in flight, 16-key tiles
+template <int U>
+__global__ void read_rows_kv_kernel(const f32x4* __restrict__ ksrc, const f32x4* __restrict__ vsrc, int tokens, int heads, int nsplit, float* sink) {
+    const int split = blockIdx.x % nsplit, head = blockIdx.x / nsplit;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const int t0 = (int)((long long)tokens * split / nsplit), t1 = (int)((long long)tokens * (split + 1) / nsplit);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int H2 = U / 2;
+    const int rows_per_step = 4 * H2 * waves;
+    for (int t = t0 + 4 * H2 * wave; t < t1; t += rows_per_step) {
+        f32x4 a[H2], b[H2];
+#pragma unroll
+        for (int u = 0; u < H2; ++u) {
+            const int row = t + 4 * u + (lane >> 4);
+            const size_t at = ((size_t)row * heads + head) * 16 + (lane & 15);
+            a[u] = row < t1 ? __builtin_nontemporal_load(ksrc + at) : f32x4{0.f, 0.f, 0.f, 0.f};
+            b[u] = row < t1 ? __builtin_nontemporal_load(vsrc + at) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < H2; ++u) acc += a[u] + b[u];
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 123456.789f) sink[0] = acc[0];
+}
+
+template <int U>
+static void run_rows_kv(const f32x4* src, size_t n16, float* sink, int heads, int nsplit, int threads, hipStream_t st) {
+    const int tokens = (int)(n16 / 2 / 16 / heads);                     // K in the first half of the buffer, V in the second
+    const f32x4* vsrc = src + (size_t)tokens * heads * 16;
+    std::vector<float> ts;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int r = 0; r < 12; ++r) {
+        CK(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(read_rows_kv_kernel<U>, dim3(heads * nsplit), dim3(threads), 0, st, src, vsrc, tokens, heads, nsplit, sink);
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 2) ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    const double bytes = 2.0 * tokens * heads * 256.0;
+    printf("{\"pattern\": \"K rows + V rows of one head per workgroup (two buffers), [token][%d heads][128 halfs]\", \"splits\": %d, \"workgroups\": %d, \"threads\": %d, "
+           "\"loads_in_flight_per_wave\": %d, \"ms_median\": %.3f, \"GBps_median\": %.0f, \"GBps_best\": %.0f, \"frac_of_8TBps\": %.3f}\n", heads, nsplit,
+           heads * nsplit, threads, U, ts[ts.size() / 2], bytes / ts[ts.size() / 2] / 1e6, bytes / ts[0] / 1e6, bytes / ts[ts.size() / 2] / 1e6 / 8000.0);
+    fflush(stdout);
+}
+
 template <int U>
 static void run_rows(const f32x4* src, size_t n16, float* sink, int heads, int nsplit, int threads, hipStream_t st) {
     const int tokens = (int)(n16 / 16 / heads);
@@ -123,5 +172,9 @@ int main() {
         run_rows<16>(src, n16, sink, 32, nsplit, 256, st);
     }
     run_rows<8>(src, n16, sink, 4, 64, 256, st);         // a TP-8 rank: 4 heads, 64 splits
+    run_rows_kv<4>(src, n16, sink, 32, 8, 256, st);
+    run_rows_kv<8>(src, n16, sink, 32, 8, 256, st);
+    run_rows_kv<16>(src, n16, sink, 32, 8, 256, st);
+    run_rows_kv<8>(src, n16, sink, 32, 16, 256, st);
     return 0;
 }
