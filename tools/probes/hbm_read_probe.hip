@@ -77,6 +77,59 @@ __global__ void read_rows_kv_kernel(const f32x4* __restrict__ ksrc, const f32x4*
     if (acc[0] + acc[1] + acc[2] + acc[3] == 123456.789f) sink[0] = acc[0];
 }
 
+// The attention kernel's ACTUAL mapping (csrc/attn.hip load_kv_tile): a load instruction is an MFMA A-operand fragment — lane (li, g)
+// reads 16 bytes of key 16 tile + li at dims 32 c + 8 g: SIXTEEN rows x 64 bytes per instruction, four instructions (c) per 256-byte
+// row set, K and V; wave w owns tiles w, w + 4, ...; TILES tiles (8 loads each) in flight per wave.
+template <int TILES>
+__global__ void read_frag_kv_kernel(const f32x4* __restrict__ ksrc, const f32x4* __restrict__ vsrc, int tokens, int heads, int nsplit, float* sink) {
+    const int split = blockIdx.x % nsplit, head = blockIdx.x / nsplit;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6, li = lane & 15, g = lane >> 4;
+    const int ntiles = tokens / 16, tl0 = (int)((long long)ntiles * split / nsplit), tl1 = (int)((long long)ntiles * (split + 1) / nsplit);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = tl0 + wave; t < tl1; t += waves * TILES) {
+        f32x4 a[TILES][4], b[TILES][4];
+#pragma unroll
+        for (int i = 0; i < TILES; ++i) {
+            const int tt = min(t + waves * i, tl1 - 1);
+            const size_t at = ((size_t)(tt * 16 + li) * heads + head) * 16 + g;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                a[i][c] = __builtin_nontemporal_load(ksrc + at + 4 * c);
+                b[i][c] = __builtin_nontemporal_load(vsrc + at + 4 * c);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TILES; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc += a[i][c] + b[i][c];
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 123456.789f) sink[0] = acc[0];
+}
+
+template <int TILES>
+static void run_frag_kv(const f32x4* src, size_t n16, float* sink, int heads, int nsplit, int threads, hipStream_t st) {
+    const int tokens = (int)(n16 / 2 / 16 / heads) & ~15;
+    const f32x4* vsrc = src + (size_t)tokens * heads * 16;
+    std::vector<float> ts;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int r = 0; r < 12; ++r) {
+        CK(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(read_frag_kv_kernel<TILES>, dim3(heads * nsplit), dim3(threads), 0, st, src, vsrc, tokens, heads, nsplit, sink);
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 2) ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    const double bytes = 2.0 * tokens * heads * 256.0;
+    printf("{\"pattern\": \"MFMA-fragment loads as csrc/attn.hip issues them: 16 rows x 64 bytes per instruction, K + V, [token][%d heads][128 halfs]\", \"splits\": %d, \"workgroups\": %d, "
+           "\"threads\": %d, \"tiles_in_flight_per_wave\": %d, \"loads_in_flight_per_wave\": %d, \"ms_median\": %.3f, \"GBps_median\": %.0f, \"GBps_best\": %.0f, \"frac_of_8TBps\": %.3f}\n",
+           heads, nsplit, heads * nsplit, threads, TILES, 8 * TILES, ts[ts.size() / 2], bytes / ts[ts.size() / 2] / 1e6, bytes / ts[0] / 1e6, bytes / ts[ts.size() / 2] / 1e6 / 8000.0);
+    fflush(stdout);
+}
+
 template <int U>
 static void run_rows_kv(const f32x4* src, size_t n16, float* sink, int heads, int nsplit, int threads, hipStream_t st) {
     const int tokens = (int)(n16 / 2 / 16 / heads);                     // K in the first half of the buffer, V in the second
@@ -176,5 +229,8 @@ int main() {
     run_rows_kv<8>(src, n16, sink, 32, 8, 256, st);
     run_rows_kv<16>(src, n16, sink, 32, 8, 256, st);
     run_rows_kv<8>(src, n16, sink, 32, 16, 256, st);
+    run_frag_kv<1>(src, n16, sink, 32, 8, 256, st);
+    run_frag_kv<2>(src, n16, sink, 32, 8, 256, st);
+    run_frag_kv<1>(src, n16, sink, 32, 16, 256, st);
     return 0;
 }

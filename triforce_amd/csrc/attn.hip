@@ -169,6 +169,48 @@ __device__ __forceinline__ void load_kv_tile(const h16* __restrict__ kbase, cons
     }
 }
 
+// Round 6: the same tile fetched as FULL ROWS.  load_kv_tile above issues MFMA A-operand fragments straight from memory: every
+// load instruction touches sixteen rows x 64 bytes (lane (li, g): key li, dims 32 c + 8 g), and a kernel that only reads with that
+// pattern reaches 5.1 TB/s where 256-byte rows, four per instruction, reach 7.0 (tools/probes/hbm_read_probe.hip,
+// profiles/r06_hbm_read_probe.jsonl).  Here lane l of instruction j reads 16 bytes of row RPI j + l / LPR at piece l % LPR
+// (LPR = D / 8 lanes per row, RPI = 64 / LPR rows per instruction; as many instructions as before), and the consumer turns the
+// rows into the fragments load_kv_tile would have produced through a wave-private LDS tile (rows padded by 16 bytes: the
+// fragment reads of a 16-lane group then cover all banks).  Same values in the same registers: the kernel's output bits do not change.
+#ifndef TF_ATTN_ROW_LOADS
+#define TF_ATTN_ROW_LOADS 1
+#endif
+template <int D>
+__device__ __forceinline__ void load_kv_rows(const h16* __restrict__ kbase, const h16* __restrict__ vbase, int64_t stride_t, int tile,
+                                             int sk, int lane, half8 (&kr)[D / 32], half8 (&vr)[D / 32]) {
+    constexpr int LPR = D / 8, RPI = 64 / LPR;
+    const int rl = lane / LPR, q = lane % LPR;
+#pragma unroll
+    for (int j = 0; j < D / 32; ++j) {
+        int key = tile * 16 + RPI * j + rl;
+        key = key < sk ? key : sk - 1;                 // clamp: masked below, but must stay in-bounds
+        const int64_t off = (int64_t)key * stride_t + 8 * q;
+        kr[j] = load_half8_stream(kbase + off);
+        vr[j] = load_half8_stream(vbase + off);
+    }
+}
+// stage: this wave's [2][16][D + 8] halfs of LDS.  One wave writes and reads it (LDS serves a wave's operations in order): no barrier.
+template <int D>
+__device__ __forceinline__ void rows_to_frags(const half8 (&kr)[D / 32], const half8 (&vr)[D / 32], h16* stage, int lane, int li, int g,
+                                              half8 (&kf)[D / 32], half8 (&vf)[D / 32]) {
+    constexpr int LPR = D / 8, RPI = 64 / LPR, LDR = D + 8;
+    const int rl = lane / LPR, q = lane % LPR;
+#pragma unroll
+    for (int j = 0; j < D / 32; ++j) {
+        *reinterpret_cast<half8*>(stage + (RPI * j + rl) * LDR + 8 * q) = kr[j];
+        *reinterpret_cast<half8*>(stage + (16 + RPI * j + rl) * LDR + 8 * q) = vr[j];
+    }
+#pragma unroll
+    for (int c = 0; c < D / 32; ++c) {
+        kf[c] = *reinterpret_cast<const half8*>(stage + li * LDR + 32 * c + 8 * g);
+        vf[c] = *reinterpret_cast<const half8*>(stage + (16 + li) * LDR + 32 * c + 8 * g);
+    }
+}
+
 struct TreeMask {                      // tree-attention visibility bits (block kernel, TREE = true)
     const uint32_t* rows;              // [n_rows][words] uint32, bit j of a row = tree key j visible
     int words, row0, start;            // words per row, first row of this launch, key index of tree key 0
@@ -305,11 +347,36 @@ __device__ __forceinline__ void attn_split_body(
     const h16* kbase = k + (int64_t)h * stride_h;
     const h16* vbase = v + (int64_t)h * stride_h;
 
+    // One block of LDS: the row -> fragment staging tiles of the stream loop (TF_ATTN_ROW_LOADS, 4-wave forms), then — behind a
+    // barrier — the merge of the waves' partial results
+    constexpr int HALVES = NW > 4 ? 2 : 1, DH = D / HALVES, NTH = NT / HALVES;
+    constexpr bool ROWS = TF_ATTN_ROW_LOADS > 0 && NW == 4;
+    constexpr size_t MERGE_BYTES = sizeof(float) * ((size_t)NW * 16 * (DH + 1) + 2 * NW * 16);
+    constexpr size_t STAGE_BYTES = ROWS ? (size_t)NW * 2 * 16 * (D + 8) * sizeof(h16) : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char sm_raw[MERGE_BYTES > STAGE_BYTES ? MERGE_BYTES : STAGE_BYTES];
+    h16* stage = reinterpret_cast<h16*>(sm_raw) + (size_t)wave * 2 * 16 * (D + 8);
+
     // tiles whose 16 keys are all <= sk - sq are visible to every row: no mask arithmetic
-#define ATTN_TILE_AUTO(KF, VF, T)                                                                     \
+#define ATTN_TILE_FRAGS(KF, VF, T)                                                                    \
     do {                                                                                                \
         if ((T) * 16 + 15 <= sk - sq) attn_tile<D, QT, false, false>(st, KF, VF, sel0, sel1, (T), sk, sq, scale, li, g); \
         else attn_tile<D, QT, false, true>(st, KF, VF, sel0, sel1, (T), sk, sq, scale, li, g);        \
+    } while (0)
+    // (ROWS: what was loaded are rows; the fragments are made here, right before their use)
+#define ATTN_TILE_AUTO(KX, VX, T)                                                                     \
+    do {                                                                                                \
+        if constexpr (ROWS) {                                                                           \
+            half8 kf_[NC], vf_[NC];                                                                     \
+            rows_to_frags<D>(KX, VX, stage, lane, li, g, kf_, vf_);                                     \
+            ATTN_TILE_FRAGS(kf_, vf_, T);                                                               \
+        } else {                                                                                        \
+            ATTN_TILE_FRAGS(KX, VX, T);                                                                 \
+        }                                                                                               \
+    } while (0)
+#define ATTN_LOAD_TILE(T, KX, VX)                                                                     \
+    do {                                                                                                \
+        if constexpr (ROWS) load_kv_rows<D>(kbase, vbase, stride_t, (T), sk, lane, KX, VX);             \
+        else load_kv_tile<D>(kbase, vbase, stride_t, (T), sk, li, g, KX, VX);                           \
     } while (0)
     // Two forms of the same two-tiles-deep loop.  A load under `if (t1 < t_end)` makes the compiler assume the worst
     // case at the use of the OLDER tile — "no younger load was issued" — so it waits vmcnt(7..0) there, i.e. for the
@@ -328,7 +395,7 @@ __device__ __forceinline__ void attn_split_body(
         half8 kd[N][NC], vd[N][NC];                                                                            \
         const int tl = t_end - 1;                                                                              \
         _Pragma("unroll") for (int i = 0; i < (N); ++i)                                                        \
-            load_kv_tile<D>(kbase, vbase, stride_t, min(t + 4 * i, tl), sk, li, g, kd[i], vd[i]);              \
+            ATTN_LOAD_TILE(min(t + 4 * i, tl), kd[i], vd[i]);                        \
         _Pragma("unroll") for (int i = 0; i < (N); ++i) {                                                      \
             const int ti = t + 4 * i;                                                                          \
             if (ti < t_end) ATTN_TILE_AUTO(kd[i], vd[i], ti);                                                  \
@@ -348,28 +415,28 @@ __device__ __forceinline__ void attn_split_body(
             half8 kr[RING][NC], vr[RING][NC];
             const int tl = t_end - 1;
 #pragma unroll
-            for (int s = 0; s < RING; ++s) load_kv_tile<D>(kbase, vbase, stride_t, min(t + 4 * s, tl), sk, li, g, kr[s], vr[s]);
+            for (int s = 0; s < RING; ++s) ATTN_LOAD_TILE(min(t + 4 * s, tl), kr[s], vr[s]);
             while (t < t_end) {
 #pragma unroll
                 for (int s = 0; s < RING; ++s) {
                     const int ti = t + 4 * s;
                     if (ti < t_end) ATTN_TILE_AUTO(kr[s], vr[s], ti);
-                    load_kv_tile<D>(kbase, vbase, stride_t, min(ti + 4 * RING, tl), sk, li, g, kr[s], vr[s]);
+                    ATTN_LOAD_TILE(min(ti + 4 * RING, tl), kr[s], vr[s]);
                 }
                 t += 4 * RING;
             }
         }
     } else if (t < t_end) {
         half8 ka[NC], va_[NC], kb[NC], vb[NC];
-        load_kv_tile<D>(kbase, vbase, stride_t, t, sk, li, g, ka, va_);
+        ATTN_LOAD_TILE(t, ka, va_);
         // (one-q-tile form only: with both loops the two-q-tile form no longer fits its 2-waves-per-SIMD register budget)
         if (TF_ATTN_EAGER_TILES > 0 && QT == 1 && t_end - t_begin <= NW * TF_ATTN_EAGER_TILES) {
             const int tl = t_end - 1;
             while (true) {
-                load_kv_tile<D>(kbase, vbase, stride_t, min(t + NW, tl), sk, li, g, kb, vb);
+                ATTN_LOAD_TILE(min(t + NW, tl), kb, vb);
                 ATTN_TILE_AUTO(ka, va_, t);
                 if (t + NW >= t_end) break;
-                load_kv_tile<D>(kbase, vbase, stride_t, min(t + 2 * NW, tl), sk, li, g, ka, va_);
+                ATTN_LOAD_TILE(min(t + 2 * NW, tl), ka, va_);
                 ATTN_TILE_AUTO(kb, vb, t + NW);
                 if (t + 2 * NW >= t_end) break;
                 t += 2 * NW;
@@ -377,11 +444,11 @@ __device__ __forceinline__ void attn_split_body(
         } else {
             while (t < t_end) {
                 const int t1 = t + NW;
-                if (t1 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t1, sk, li, g, kb, vb);
+                if (t1 < t_end) ATTN_LOAD_TILE(t1, kb, vb);
                 ATTN_TILE_AUTO(ka, va_, t);
                 if (t1 >= t_end) break;
                 const int t2 = t1 + NW;
-                if (t2 < t_end) load_kv_tile<D>(kbase, vbase, stride_t, t2, sk, li, g, ka, va_);
+                if (t2 < t_end) ATTN_LOAD_TILE(t2, ka, va_);
                 ATTN_TILE_AUTO(kb, vb, t1);
                 t = t2;
             }
@@ -389,12 +456,14 @@ __device__ __forceinline__ void attn_split_body(
     }
 
 #undef ATTN_TILE_AUTO
+#undef ATTN_TILE_FRAGS
+#undef ATTN_LOAD_TILE
     // ---- merge the NW waves of this split through LDS, one q-tile at a time (8 waves: one half of D at a time, so the
     // staging stays under the 64 KiB static limit) ----
-    constexpr int HALVES = NW > 4 ? 2 : 1, DH = D / HALVES, NTH = NT / HALVES;
-    __shared__ float sm_o[NW][16][DH + 1];
-    __shared__ float sm_m[NW][16];
-    __shared__ float sm_l[NW][16];
+    float (*sm_o)[16][DH + 1] = reinterpret_cast<float (*)[16][DH + 1]>(sm_raw);
+    float (*sm_m)[16] = reinterpret_cast<float (*)[16]>(sm_raw + sizeof(float) * (size_t)NW * 16 * (DH + 1));
+    float (*sm_l)[16] = sm_m + NW;
+    if constexpr (ROWS) __syncthreads();               // another wave may still be reading its staging tile where this one is about to write
     float* ws_o = ws;
     float* ws_m = ws + (int64_t)H * nsplit * QR * D;
     float* ws_l = ws_m + (int64_t)H * nsplit * QR;
