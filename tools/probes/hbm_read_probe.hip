@@ -130,6 +130,101 @@ static void run_frag_kv(const f32x4* src, size_t n16, float* sink, int heads, in
     fflush(stdout);
 }
 
+// The skinny GEMMs' weight stream (csrc/gemv.hip): packed panels [panel][K / 32 chunks][64 lanes] x 16 bytes — a wave-load is 1 KiB
+// contiguous; a workgroup of 4 waves takes a (gate, up) panel pair of K = 4096 (2 x 128 KiB), wave w the chunks 32 w .. 32 w + 31 of
+// either; U loads per wave in flight; the grid is the 688 pairs of the 7B gate|up GEMM, or fewer workgroups striding over them.
+template <int U>
+__global__ void read_panels_kernel(const f32x4* __restrict__ src, int pairs, float* sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int p = blockIdx.x; p < pairs; p += gridDim.x) {
+        const f32x4* g = src + ((size_t)(2 * p) * 128 + 32 * wave) * 64 + lane;
+        const f32x4* u = src + ((size_t)(2 * p + 1) * 128 + 32 * wave) * 64 + lane;
+        for (int c = 0; c < 32; c += U / 2) {
+            f32x4 a[U / 2], b[U / 2];
+#pragma unroll
+            for (int i = 0; i < U / 2; ++i) {
+                a[i] = __builtin_nontemporal_load(g + (size_t)(c + i) * 64);
+                b[i] = __builtin_nontemporal_load(u + (size_t)(c + i) * 64);
+            }
+#pragma unroll
+            for (int i = 0; i < U / 2; ++i) acc += a[i] + b[i];
+        }
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 123456.789f) sink[0] = acc[0];
+}
+
+// The same work with the weights laid out CHUNK-major ([K / 32 chunks][panel][64 lanes]): workgroups that run side by side read
+// neighbouring KiBs at every step — one moving window across the chip instead of thousands of private 32 KiB streams.
+template <int U>
+__global__ void read_panels_tm_kernel(const f32x4* __restrict__ src, int pairs, int group, float* sink) {
+    // `group` consecutive pairs form one chunk-major block (a GEMM of that many panel pairs): block stride = group * 2 * 128 KiB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int p = blockIdx.x; p < pairs; p += gridDim.x) {
+        const int blk = p / group, pl = p % group, np = 2 * group;
+        const f32x4* base = src + (size_t)blk * np * 128 * 64 + lane;
+        for (int c = 0; c < 32; c += U / 2) {
+            f32x4 a[U / 2], b[U / 2];
+#pragma unroll
+            for (int i = 0; i < U / 2; ++i) {
+                const size_t ch = (size_t)(32 * wave + c + i) * np;
+                a[i] = __builtin_nontemporal_load(base + (ch + 2 * pl) * 64);
+                b[i] = __builtin_nontemporal_load(base + (ch + 2 * pl + 1) * 64);
+            }
+#pragma unroll
+            for (int i = 0; i < U / 2; ++i) acc += a[i] + b[i];
+        }
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 123456.789f) sink[0] = acc[0];
+}
+
+template <int U>
+static void run_panels_tm(const f32x4* src, float* sink, int grid, hipStream_t st) {
+    const int pairs = 688 * 8;
+    std::vector<float> ts;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int r = 0; r < 12; ++r) {
+        CK(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(read_panels_tm_kernel<U>, dim3(grid), dim3(256), 0, st, src, pairs, 688, sink);
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 2) ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    const double bytes = (double)pairs * 2 * 128 * 1024;
+    printf("{\"pattern\": \"the same panels laid out chunk-major ([chunk][panel][lane]: neighbours read neighbouring KiBs)\", \"workgroups\": %d, \"panel_pairs\": %d, "
+           "\"loads_in_flight_per_wave\": %d, \"ms_median\": %.3f, \"GBps_median\": %.0f, \"GBps_best\": %.0f, \"frac_of_8TBps\": %.3f}\n", grid, pairs, U,
+           ts[ts.size() / 2], bytes / ts[ts.size() / 2] / 1e6, bytes / ts[0] / 1e6, bytes / ts[ts.size() / 2] / 1e6 / 8000.0);
+    fflush(stdout);
+}
+
+template <int U>
+static void run_panels(const f32x4* src, float* sink, int grid, hipStream_t st) {
+    const int pairs = 688 * 8;                           // eight different copies of the 180 MB stream per launch: 1.44 GB, cold
+    std::vector<float> ts;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int r = 0; r < 12; ++r) {
+        CK(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(read_panels_kernel<U>, dim3(grid), dim3(256), 0, st, src, pairs, sink);
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 2) ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    const double bytes = (double)pairs * 2 * 128 * 1024;
+    printf("{\"pattern\": \"packed GEMM panels (1 KiB per wave-load, a 2 x 128 KiB panel pair per workgroup, 4 waves split K)\", \"workgroups\": %d, \"panel_pairs\": %d, "
+           "\"loads_in_flight_per_wave\": %d, \"ms_median\": %.3f, \"GBps_median\": %.0f, \"GBps_best\": %.0f, \"frac_of_8TBps\": %.3f}\n", grid, pairs, U,
+           ts[ts.size() / 2], bytes / ts[ts.size() / 2] / 1e6, bytes / ts[0] / 1e6, bytes / ts[ts.size() / 2] / 1e6 / 8000.0);
+    fflush(stdout);
+}
+
 template <int U>
 static void run_rows_kv(const f32x4* src, size_t n16, float* sink, int heads, int nsplit, int threads, hipStream_t st) {
     const int tokens = (int)(n16 / 2 / 16 / heads);                     // K in the first half of the buffer, V in the second
@@ -232,5 +327,15 @@ int main() {
     run_frag_kv<1>(src, n16, sink, 32, 8, 256, st);
     run_frag_kv<2>(src, n16, sink, 32, 8, 256, st);
     run_frag_kv<1>(src, n16, sink, 32, 16, 256, st);
+    for (int grid : {5504, 1024, 768, 512, 256}) {
+        run_panels<4>(src, sink, grid, st);
+        run_panels<8>(src, sink, grid, st);
+        run_panels<16>(src, sink, grid, st);
+    }
+    for (int grid : {5504, 768, 512, 256}) {
+        run_panels_tm<4>(src, sink, grid, st);
+        run_panels_tm<8>(src, sink, grid, st);
+        run_panels_tm<16>(src, sink, grid, st);
+    }
     return 0;
 }
