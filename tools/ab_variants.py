@@ -41,7 +41,12 @@ VARIANTS = {"q2occ1": ["TF_ATTN_QT2_OCC=0"],
             "lnpre": ["SG_LN_PRE=1"],                # the first batch's norm weights prefetched with the prologue (+16 registers)
             "epilate0": ["SG_EPI_LATE=0"],           # plain GEMMs fetch their epilogue operands in front of the first weight batch
             "nopreload": ["!kernarg-preload"],       # built without -mllvm -amdgpu-kernarg-preload-count=14
-            "ring4ps1": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_RING_Q1=4", "TF_ATTN_RING_Q2=4", "TF_ATTN_QT2_OCC=1", "TF_ATTN_P_SPLIT=1"]}
+            "ring4ps1": ["TF_ATTN_DEEP_TILES=8", "TF_ATTN_RING_Q1=4", "TF_ATTN_RING_Q2=4", "TF_ATTN_QT2_OCC=1", "TF_ATTN_P_SPLIT=1"],
+            # round 6: the decode attention's K / V tiles loaded as MFMA fragments straight from memory (rounds 1-5: 16 rows x 64 bytes
+            # per instruction, 5.9 TB/s) instead of full rows through a wave-private LDS tile (6.6 TB/s); and the fully two-deep
+            # load loop forced onto the long streams (tools/verify_bench.py <tag> with TRIFORCE_HIP_LIB set)
+            "fragloads": ["TF_ATTN_ROW_LOADS=0"],
+            "eagerall": ["TF_ATTN_EAGER_TILES=1000000"]}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(VARIANTS)
